@@ -1,0 +1,182 @@
+/*
+ * oc_amd.h — C-ABI of liboc_amd.so, the MI355X (gfx950) batched Overcooked hot path.
+ *
+ * The reference (HumanCompatibleAI/overcooked_ai) is pure Python and has no FFI; the
+ * boundary this library sits under is the Python class API
+ *     OvercookedGridworld.get_state_transition   src/overcooked_ai_py/mdp/overcooked_mdp.py:1375
+ *     OvercookedGridworld.lossless_state_encoding src/overcooked_ai_py/mdp/overcooked_mdp.py:2385
+ *     OvercookedEnv.step / reset / is_done        src/overcooked_ai_py/mdp/overcooked_env.py:244,288,321
+ * Each entry point below names the reference function(s) it replaces.  INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer whose name starts with d_ is a DEVICE pointer (HBM) owned by the caller;
+ *    the library never allocates, frees or synchronises.
+ *  - all launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *  - return value: 0 on success, negative OC_E* on error; oc_last_error() gives a message.
+ *  - thread-safe per (device, stream); the library keeps no global mutable state except the
+ *    thread-local error string.
+ *
+ * Wire format of one environment ("env") — see DESIGN.md §3.
+ *  State is struct-of-arrays over 16-byte words ("planes"): plane p of env e lives at
+ *      ((oc_u128*)d_state)[p * n_envs + e]
+ *  so a wavefront reading plane p for 64 consecutive envs issues one 1 KiB coalesced load.
+ *  Plane 0 (header), byte offsets:
+ *      0  player0 cell index (y*W + x)      3  player1 cell index (0xFF = absent, 1-player layouts)
+ *      1  player0 orientation (0..3)        4  player1 orientation
+ *      2  player0 held object code          5  player1 held object code
+ *      6..7  timestep, u16 little endian
+ *      8..15 pot slot k: cooking_tick + 1   (0 = idle, i.e. reference _cooking_tick == -1)
+ *  Planes 1..n_obj_planes: one object code per grid cell; cell c is byte (c & 15) of plane 1 + (c >> 4).
+ *  Object code: 0 none, 1 onion, 2 tomato, 3 dish,
+ *               0x80 | (n_ingredients << 3) | tomato_bits   for a soup, where bit i of tomato_bits
+ *               says ingredient i (insertion order, SoupState._ingredients, mdp.py:453) is a tomato.
+ *  A soup that is held or lies on a counter is always cooked (it left its pot through the
+ *  dish pickup at mdp.py:1525-1539); its tick is implied (= the recipe's cook time).
+ */
+#ifndef OC_AMD_H
+#define OC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OC_ABI_VERSION 1
+
+#define OC_MAX_CELLS 128
+#define OC_MAX_POTS 8
+#define OC_NUM_LAYERS 26 /* lossless_state_encoding layers, mdp.py:2393-2442 */
+#define OC_NUM_ACTIONS 6
+
+/* terrain codes = the reference's own TYPE_TO_CODE table (layout_generator.py:18-27) */
+#define OC_T_FLOOR 0
+#define OC_T_COUNTER 1
+#define OC_T_ONION_DISP 2
+#define OC_T_TOMATO_DISP 3
+#define OC_T_POT 4
+#define OC_T_DISH_DISP 5
+#define OC_T_SERVE 6
+
+/* action indices = Action.INDEX_TO_ACTION (actions.py:49-52); orientation = Direction index (actions.py:16) */
+#define OC_A_NORTH 0
+#define OC_A_SOUTH 1
+#define OC_A_EAST 2
+#define OC_A_WEST 3
+#define OC_A_STAY 4
+#define OC_A_INTERACT 5
+
+/* object codes */
+#define OC_O_NONE 0
+#define OC_O_ONION 1
+#define OC_O_TOMATO 2
+#define OC_O_DISH 3
+#define OC_O_SOUP 0x80
+
+/* per-env flag byte written by oc_step / oc_rollout_random */
+#define OC_F_DONE 0x01       /* timestep >= horizon after this step (env.py:321-325) */
+#define OC_F_BAD_ACTION 0x02 /* action index >= 6: state left untouched (mdp.py:1394-1398 raises) */
+#define OC_F_RESET 0x04      /* env was auto-reset to its start state after this step */
+
+/* option bits for oc_step / oc_rollout_random */
+#define OC_OPT_AUTO_RESET 0x1u /* reset a done env to its layout's start state inside the kernel */
+
+/* obs dtypes of oc_encode_lossless */
+#define OC_OBS_U8 0
+#define OC_OBS_F32 1
+
+/* error codes */
+#define OC_OK 0
+#define OC_EINVAL (-1)
+#define OC_ELAUNCH (-2)
+
+/*
+ * One compiled layout: terrain + the recipe/reward configuration of one OvercookedGridworld
+ * (mdp.py:1090-1148) flattened to look-up tables.  256 bytes, 16-byte aligned.  The table is
+ * built on the host by overcooked_ai_amd.layouts.compile_layout and uploaded once.
+ *   cook_time[n_onion + 4*n_tomato]      = Recipe.time  (mdp.py:163-188)
+ *   delivery_value[n_onion + 4*n_tomato] = get_recipe_value, non-discounted branch (mdp.py:1595-1602):
+ *        0 if the recipe is not in all_orders, order_bonus*value if it is a bonus order, else value.
+ *   terrain[c] = terrain code | (pot slot << 3) for cell c = y*W + x  (terrain_mtx[y][x], mdp.py:1783)
+ */
+typedef struct OcLayout {
+    uint8_t width, height, n_cells, n_pots;
+    uint8_t n_players, old_dynamics, n_obj_planes, reserved0;
+    uint8_t start_pos[2];
+    uint8_t start_or[2];
+    uint8_t reserved1[4];
+    uint8_t pot_cell[OC_MAX_POTS];
+    uint8_t reserved2[8];
+    float rew_placement_in_pot; /* PLACEMENT_IN_POT_REW, mdp.py:1019 */
+    float rew_dish_pickup;      /* DISH_PICKUP_REWARD */
+    float rew_soup_pickup;      /* SOUP_PICKUP_REWARD */
+    float reserved3;
+    uint8_t cook_time[16];
+    float delivery_value[16];
+    uint8_t terrain[OC_MAX_CELLS];
+} OcLayout;
+
+int oc_abi_version(void);
+size_t oc_layout_size(void); /* == sizeof(OcLayout) == 256 */
+const char* oc_last_error(void);
+
+/*
+ * oc_step — one joint transition for n_envs independent envs.
+ * Replaces OvercookedGridworld.get_state_transition (mdp.py:1375-1430) = resolve_interacts (1432)
+ * -> resolve_movement (1644) -> step_environment_effects (1691), plus OvercookedEnv.step's
+ * done/bookkeeping (env.py:244-274, 321-325, 382-392).
+ *   d_layouts      n_layouts compiled layouts; all must share width/height/n_obj_planes
+ *   d_layout_id    [n_envs] layout index per env, or NULL when n_layouts == 1
+ *   d_state_in/out [(1+n_obj_planes) * n_envs] 16-byte words; may alias (in-place step)
+ *   d_actions      [n_envs][2] action indices 0..5 (player 0, player 1)
+ *   d_rewards      [n_envs][4] float: sparse_reward_by_agent[0..1], shaped_reward_by_agent[0..1]
+ *   d_flags        [n_envs] OC_F_* bits
+ *   d_ep_returns   [n_envs][4] float running sums of d_rewards over the episode
+ *                  (game_stats cumulative_*_rewards_by_agent, env.py:387-392), or NULL
+ *   horizon        done when timestep >= horizon (1..65535)
+ */
+int oc_step(const OcLayout* d_layouts, int n_layouts, const uint16_t* d_layout_id,
+            const void* d_state_in, void* d_state_out, const uint8_t* d_actions,
+            float* d_rewards, uint8_t* d_flags, float* d_ep_returns,
+            int64_t n_envs, int horizon, uint32_t options, void* stream);
+
+/*
+ * oc_rollout_random — n_steps transitions per launch under the uniform random policy
+ * (the reference's RandomAgent(all_actions=True) pair, agents/agent.py:223), actions drawn
+ * in-kernel: action of player p of global env g at global step t is
+ *      philox4x32_10(counter = {t, g_lo, g_hi, 0}, key = {seed_lo, seed_hi})[p] % 6.
+ * Same transition function as oc_step; state stays on chip between the fused steps.
+ *   d_rewards  [n_steps][n_envs][4] or NULL;  d_flags [n_steps][n_envs] or NULL
+ *   env_offset global index of local env 0 (multi-GPU shards draw disjoint streams)
+ *   t0         global step index of the first fused step
+ */
+int oc_rollout_random(const OcLayout* d_layouts, int n_layouts, const uint16_t* d_layout_id,
+                      void* d_state, float* d_rewards, uint8_t* d_flags, float* d_ep_returns,
+                      int64_t n_envs, int horizon, uint32_t options, uint64_t seed,
+                      int64_t env_offset, int64_t t0, int n_steps, void* stream);
+
+/*
+ * oc_encode_lossless — the 26-layer observation of both players.
+ * Replaces OvercookedGridworld.lossless_state_encoding (mdp.py:2385-2561) as called through
+ * OvercookedEnv.lossless_state_encoding_mdp (env.py:276-280).
+ *   d_obs  [n_envs][2][W][H][26] of u8 or f32 (index [x][y][layer], mdp.py:2415-2418, 2550)
+ */
+int oc_encode_lossless(const OcLayout* d_layouts, int n_layouts, const uint16_t* d_layout_id,
+                       const void* d_state, void* d_obs, int obs_dtype, int64_t n_envs,
+                       int horizon, void* stream);
+
+/*
+ * oc_reset — write the standard start state (OvercookedGridworld.get_standard_start_state,
+ * mdp.py:1297-1305: players at start positions facing NORTH, no objects, timestep 0) into every
+ * env whose d_mask byte is non-zero (all envs when d_mask is NULL).  Replaces OvercookedEnv.reset
+ * (env.py:288-319) for the default start_state_fn.  d_ep_returns (nullable) is zeroed for reset envs.
+ */
+int oc_reset(const OcLayout* d_layouts, int n_layouts, const uint16_t* d_layout_id, void* d_state,
+             const uint8_t* d_mask, float* d_ep_returns, int64_t n_envs, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OC_AMD_H */

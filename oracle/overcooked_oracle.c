@@ -1,0 +1,629 @@
+/*
+ * overcooked_oracle.c — CPU restatement of the Overcooked hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the checker, never the product: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg load it.  The shipped package (overcooked_ai_amd) never imports oracle/.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this code against fixtures under
+ * tests/golden/ that were produced by running the real reference (imported from /root/reference
+ * by oracle/gen_golden.py): the reference's own 1500-step golden trajectory
+ * (data/testing/test_mdp_dynamics/expected.json), its one-transition fixture, start-state fixture,
+ * ~10^5 randomized transitions over 8 layouts (incl. old_dynamics, tomato/bonus layouts), the
+ * K1..K11 micro cases of SURVEY.md §8c and lossless encodings of visited states.
+ *
+ * It deliberately mirrors the *structure* of the reference (objects keyed by position, players
+ * processed in index order, the helper predicates of the reference) rather than the structure of
+ * the HIP kernels, so that kernel-vs-oracle agreement is a real cross-check.  All file:line
+ * citations are into /root/reference/src/overcooked_ai_py/mdp/overcooked_mdp.py ("mdp.py") unless
+ * stated otherwise.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAX_CELLS 128
+#define MAX_POTS 8
+#define MAX_RECIPES 9 /* multisets of 1..3 items over {onion, tomato}: 2+3+4 */
+#define NUM_LAYERS 26
+
+enum { NAME_NONE = 0, NAME_ONION = 1, NAME_TOMATO = 2, NAME_DISH = 3, NAME_SOUP = 4 };
+enum { A_NORTH = 0, A_SOUTH, A_EAST, A_WEST, A_STAY, A_INTERACT };
+
+/* Direction.INDEX_TO_DIRECTION, actions.py:12-16 ; STAY = (0,0), actions.py:47 */
+static const int DIR_DX[5] = {0, 0, 1, -1, 0};
+static const int DIR_DY[5] = {-1, 1, 0, 0, 0};
+
+/* ------------------------------------------------------------------------------------------
+ * Layout / recipe configuration, in the reference's own terms (the kwargs of
+ * OvercookedGridworld.__init__, mdp.py:1090-1148, and Recipe.configure, mdp.py:221-336).
+ * Filled from Python (oracle/oracle.py) via ctypes.  A recipe is identified by its ingredient
+ * multiset (Recipe.ingredients is sorted, mdp.py:126-128) -> (n_onion, n_tomato).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct OracleMdp {
+    int32_t width, height;
+    int32_t n_players;
+    int32_t start_x[2], start_y[2];
+    int32_t old_dynamics;
+    int32_t max_num_ingredients; /* Recipe.MAX_NUM_INGREDIENTS, mdp.py:19,225 */
+    int32_t n_all_orders;        /* 0 => every recipe is an order (OvercookedState.all_orders, mdp.py:881-887) */
+    int32_t all_orders[MAX_RECIPES][2];
+    int32_t n_bonus_orders;
+    int32_t bonus_orders[MAX_RECIPES][2];
+    int32_t has_cook_time, has_delivery_reward, has_recipe_values, has_recipe_times;
+    int32_t has_ingredient_value, has_ingredient_time;
+    double cook_time, delivery_reward;
+    double recipe_values[MAX_RECIPES]; /* aligned with all_orders (Recipe.configure zip, mdp.py:310-316) */
+    double recipe_times[MAX_RECIPES];
+    double onion_value, tomato_value, onion_time, tomato_time;
+    double order_bonus;
+    double rew_placement_in_pot, rew_dish_pickup, rew_soup_pickup; /* mdp.py:1018-1025 */
+    char terrain[MAX_CELLS]; /* terrain_mtx[y][x] at y*width+x, player digits already replaced by ' ' (mdp.py:1193-1206) */
+} OracleMdp;
+
+typedef struct Obj {
+    int name;
+    int n_ing;
+    int ing[3]; /* NAME_ONION / NAME_TOMATO in insertion order (SoupState._ingredients, mdp.py:453) */
+    int tick;   /* SoupState._cooking_tick, -1 idle (mdp.py:454,543-544) */
+} Obj;
+
+typedef struct Player {
+    int present;
+    int x, y;
+    int o; /* Direction index */
+    Obj held;
+} Player;
+
+typedef struct State {
+    Player players[2];
+    Obj objects[MAX_CELLS]; /* OvercookedState.objects: dict pos -> obj (mdp.py:798-811); name==NONE => key absent */
+    int timestep;
+} State;
+
+/* ---------------------------------- Recipe ----------------------------------------------- */
+
+static void count_ing(const Obj* soup, int* n_o, int* n_t) {
+    int o = 0, t = 0;
+    for (int i = 0; i < soup->n_ing; ++i) {
+        if (soup->ing[i] == NAME_ONION) ++o;
+        else ++t;
+    }
+    *n_o = o;
+    *n_t = t;
+}
+
+static int find_order(const int32_t (*orders)[2], int n, int n_o, int n_t) {
+    for (int i = 0; i < n; ++i)
+        if (orders[i][0] == n_o && orders[i][1] == n_t) return i;
+    return -1;
+}
+
+/* Recipe.value, mdp.py:136-161.  Python truthiness is restated literally: a configured value of 0
+ * falls through to the next rule (`if self._delivery_reward:` / `if self._onion_value and self._tomato_value`). */
+static double recipe_value(const OracleMdp* m, int n_o, int n_t) {
+    if (m->has_delivery_reward && m->delivery_reward != 0.0) return m->delivery_reward;
+    if (m->has_recipe_values && m->n_all_orders > 0) {
+        int i = find_order(m->all_orders, m->n_all_orders, n_o, n_t);
+        if (i >= 0) return m->recipe_values[i];
+    }
+    if (m->has_ingredient_value && m->onion_value != 0.0 && m->tomato_value != 0.0)
+        return m->tomato_value * n_t + m->onion_value * n_o;
+    return 20.0;
+}
+
+/* Recipe.time, mdp.py:163-188 */
+static double recipe_time(const OracleMdp* m, int n_o, int n_t) {
+    if (m->has_cook_time && m->cook_time != 0.0) return m->cook_time;
+    if (m->has_recipe_times && m->n_all_orders > 0) {
+        int i = find_order(m->all_orders, m->n_all_orders, n_o, n_t);
+        if (i >= 0) return m->recipe_times[i];
+    }
+    if (m->has_ingredient_time && m->onion_time != 0.0 && m->tomato_time != 0.0)
+        return m->onion_time * n_o + m->tomato_time * n_t;
+    return 20.0;
+}
+
+/* get_recipe_value, non-discounted branch, mdp.py:1595-1602 */
+static double get_recipe_value(const OracleMdp* m, int n_o, int n_t) {
+    int in_all = (m->n_all_orders == 0) ? 1 : (find_order(m->all_orders, m->n_all_orders, n_o, n_t) >= 0);
+    if (!in_all) return 0.0;
+    if (find_order(m->bonus_orders, m->n_bonus_orders, n_o, n_t) < 0) return recipe_value(m, n_o, n_t);
+    return m->order_bonus * recipe_value(m, n_o, n_t);
+}
+
+/* ---------------------------------- SoupState -------------------------------------------- */
+
+static int soup_is_idle(const Obj* s) { return s->tick < 0; } /* mdp.py:543-544 */
+static double soup_cook_time(const OracleMdp* m, const Obj* s) { /* mdp.py:525-530 -> recipe.time */
+    int n_o, n_t;
+    count_ing(s, &n_o, &n_t);
+    return recipe_time(m, n_o, n_t);
+}
+static int soup_is_ready(const OracleMdp* m, const Obj* s) { /* mdp.py:537-540 */
+    if (soup_is_idle(s)) return 0;
+    return (double)s->tick >= soup_cook_time(m, s);
+}
+static int soup_is_cooking(const OracleMdp* m, const Obj* s) { /* mdp.py:507-508 */
+    return !soup_is_idle(s) && !soup_is_ready(m, s);
+}
+static int soup_is_full(const OracleMdp* m, const Obj* s) { /* mdp.py:547-551 */
+    return !soup_is_idle(s) || s->n_ing == m->max_num_ingredients;
+}
+
+/* ---------------------------------- helpers ---------------------------------------------- */
+
+static char terrain_at(const OracleMdp* m, int x, int y) { return m->terrain[y * m->width + x]; } /* mdp.py:1783-1785 */
+static int cell_of(const OracleMdp* m, int x, int y) { return y * m->width + x; }
+
+enum { POT_EMPTY = 0, POT_1 = 1, POT_2 = 2, POT_3 = 3, POT_COOKING = 4, POT_READY = 5 };
+
+typedef struct PotStates {
+    int n_pots;
+    int cls[MAX_CELLS]; /* class per pot, in get_pot_locations order */
+} PotStates;
+
+/* get_pot_states, mdp.py:1809-1838 */
+static void get_pot_states(const OracleMdp* m, const State* s, PotStates* ps) {
+    ps->n_pots = 0;
+    for (int c = 0; c < m->width * m->height; ++c) {
+        if (m->terrain[c] != 'P') continue;
+        const Obj* soup = &s->objects[c];
+        int cls;
+        if (soup->name == NAME_NONE) cls = POT_EMPTY;
+        else if (soup_is_ready(m, soup)) cls = POT_READY;
+        else if (soup_is_cooking(m, soup)) cls = POT_COOKING;
+        else cls = soup->n_ing; /* "{}_items" */
+        ps->cls[ps->n_pots++] = cls;
+    }
+}
+
+/* is_dish_pickup_useful, mdp.py:2180-2204 */
+static int is_dish_pickup_useful(const OracleMdp* m, const State* s, const PotStates* ps) {
+    if (m->n_players != 2) return 0;
+    int dishes_on_counters = 0; /* get_counter_objects_dict(state)["dish"], mdp.py:1840-1851 */
+    for (int c = 0; c < m->width * m->height; ++c)
+        if (m->terrain[c] == 'X' && s->objects[c].name == NAME_DISH) ++dishes_on_counters;
+    int num_player_dishes = 0; /* player_objects_by_type["dish"], mdp.py:851-862 */
+    for (int p = 0; p < 2; ++p)
+        if (s->players[p].present && s->players[p].held.name == NAME_DISH) ++num_player_dishes;
+    int non_empty_pots = 0; /* ready + cooking + partially full (range(1, MAX), mdp.py:1882-1890) */
+    for (int i = 0; i < ps->n_pots; ++i) {
+        int c = ps->cls[i];
+        if (c == POT_READY || c == POT_COOKING || (c >= 1 && c < m->max_num_ingredients)) ++non_empty_pots;
+    }
+    return dishes_on_counters == 0 && num_player_dishes < non_empty_pots;
+}
+
+/* ---------------------------------- resolve_interacts, mdp.py:1432-1579 ------------------- */
+
+static void resolve_interacts(const OracleMdp* m, State* ns, const int* joint_action, double* sparse, double* shaped) {
+    PotStates pot_states;
+    get_pot_states(m, ns, &pot_states); /* once, before any interact: mdp.py:1439 */
+    sparse[0] = sparse[1] = 0.0;
+    shaped[0] = shaped[1] = 0.0;
+
+    for (int player_idx = 0; player_idx < m->n_players; ++player_idx) {
+        Player* player = &ns->players[player_idx];
+        if (joint_action[player_idx] != A_INTERACT) continue;
+
+        int ix = player->x + DIR_DX[player->o], iy = player->y + DIR_DY[player->o]; /* mdp.py:1452-1453 */
+        char terrain_type = terrain_at(m, ix, iy);
+        int i_pos = cell_of(m, ix, iy);
+        Obj* at = &ns->objects[i_pos];
+        int has_obj = player->held.name != NAME_NONE;
+
+        if (terrain_type == 'X') {
+            if (has_obj && at->name == NAME_NONE) { /* drop on counter, mdp.py:1459-1471 */
+                *at = player->held;
+                player->held.name = NAME_NONE;
+            } else if (!has_obj && at->name != NAME_NONE) { /* pick up from counter, mdp.py:1473-1485 */
+                player->held = *at;
+                at->name = NAME_NONE;
+            }
+        } else if (terrain_type == 'O' && !has_obj) { /* mdp.py:1487-1494 */
+            memset(&player->held, 0, sizeof(Obj));
+            player->held.name = NAME_ONION;
+        } else if (terrain_type == 'T' && !has_obj) { /* mdp.py:1496-1498 */
+            memset(&player->held, 0, sizeof(Obj));
+            player->held.name = NAME_TOMATO;
+        } else if (terrain_type == 'D' && !has_obj) { /* mdp.py:1500-1513 */
+            if (is_dish_pickup_useful(m, ns, &pot_states)) shaped[player_idx] += m->rew_dish_pickup;
+            memset(&player->held, 0, sizeof(Obj));
+            player->held.name = NAME_DISH;
+        } else if (terrain_type == 'P' && !has_obj) { /* mdp.py:1515-1522 */
+            /* soup_to_be_cooked_at_location, mdp.py:1899-1908 */
+            if (!m->old_dynamics && at->name == NAME_SOUP && !soup_is_cooking(m, at) && !soup_is_ready(m, at) &&
+                at->n_ing > 0)
+                at->tick = 0; /* begin_cooking, mdp.py:592-599 */
+        } else if (terrain_type == 'P' && has_obj) {
+            if (player->held.name == NAME_DISH && at->name == NAME_SOUP && soup_is_ready(m, at)) {
+                /* soup pickup, mdp.py:1525-1539 */
+                player->held = *at;
+                at->name = NAME_NONE;
+                shaped[player_idx] += m->rew_soup_pickup;
+            } else if (player->held.name == NAME_ONION || player->held.name == NAME_TOMATO) {
+                /* mdp.py:1541-1568 */
+                if (at->name == NAME_NONE) {
+                    memset(at, 0, sizeof(Obj));
+                    at->name = NAME_SOUP;
+                    at->tick = -1;
+                }
+                if (!soup_is_full(m, at)) {
+                    at->ing[at->n_ing++] = player->held.name; /* add_ingredient, mdp.py:571-577 */
+                    player->held.name = NAME_NONE;
+                    shaped[player_idx] += m->rew_placement_in_pot;
+                }
+            }
+        } else if (terrain_type == 'S' && has_obj) { /* mdp.py:1570-1577 */
+            if (player->held.name == NAME_SOUP) {
+                int n_o, n_t;
+                count_ing(&player->held, &n_o, &n_t);
+                player->held.name = NAME_NONE;                /* deliver_soup, mdp.py:1631-1642 */
+                sparse[player_idx] += get_recipe_value(m, n_o, n_t);
+            }
+        }
+    }
+}
+
+/* ---------------------------------- resolve_movement, mdp.py:1644-1727 -------------------- */
+
+static void resolve_movement(const OracleMdp* m, State* s, const int* joint_action) {
+    int old_x[2], old_y[2], new_x[2], new_y[2], new_o[2];
+    int np = m->n_players;
+    for (int i = 0; i < np; ++i) {
+        const Player* p = &s->players[i];
+        int a = joint_action[i];
+        old_x[i] = p->x;
+        old_y[i] = p->y;
+        /* _move_if_direction, mdp.py:1718-1727 */
+        if (a == A_INTERACT) {
+            new_x[i] = p->x; new_y[i] = p->y; new_o[i] = p->o;
+        } else {
+            int nx = p->x + DIR_DX[a], ny = p->y + DIR_DY[a];
+            new_o[i] = (a == A_STAY) ? p->o : a;
+            if (terrain_at(m, nx, ny) != ' ') { nx = p->x; ny = p->y; }
+            new_x[i] = nx; new_y[i] = ny;
+        }
+    }
+    /* is_transition_collision, mdp.py:1673-1683 */
+    int collision = 0;
+    if (np == 2) {
+        if (new_x[0] == new_x[1] && new_y[0] == new_y[1]) collision = 1;
+        if (new_x[0] == old_x[1] && new_y[0] == old_y[1] && old_x[0] == new_x[1] && old_y[0] == new_y[1]) collision = 1;
+    }
+    for (int i = 0; i < np; ++i) {
+        Player* p = &s->players[i];
+        if (!collision) { p->x = new_x[i]; p->y = new_y[i]; } /* _handle_collisions, mdp.py:1705-1709 */
+        p->o = new_o[i];                                       /* orientation always updated, mdp.py:1652-1655 */
+    }
+}
+
+/* ---------------------------------- step_environment_effects, mdp.py:1691-1703 ------------ */
+
+static void step_environment_effects(const OracleMdp* m, State* s) {
+    s->timestep += 1;
+    for (int c = 0; c < m->width * m->height; ++c) {
+        Obj* obj = &s->objects[c];
+        if (obj->name != NAME_SOUP) continue;
+        if (m->old_dynamics && !soup_is_cooking(m, obj) && !soup_is_ready(m, obj) && obj->n_ing == 3) obj->tick = 0;
+        if (soup_is_cooking(m, obj)) obj->tick += 1;
+    }
+}
+
+/* get_state_transition, mdp.py:1375-1430 */
+static void state_transition(const OracleMdp* m, State* ns, const int* joint_action, double* sparse, double* shaped) {
+    resolve_interacts(m, ns, joint_action, sparse, shaped);
+    resolve_movement(m, ns, joint_action);
+    step_environment_effects(m, ns);
+}
+
+/* get_standard_start_state, mdp.py:1297-1305 + from_player_positions 939-950 */
+static void standard_start_state(const OracleMdp* m, State* s) {
+    memset(s, 0, sizeof(State));
+    for (int i = 0; i < m->n_players; ++i) {
+        s->players[i].present = 1;
+        s->players[i].x = m->start_x[i];
+        s->players[i].y = m->start_y[i];
+        s->players[i].o = A_NORTH;
+    }
+}
+
+/* ---------------------------------- wire format (include/oc_amd.h) ------------------------ */
+
+static int obj_to_code(const Obj* o) {
+    switch (o->name) {
+        case NAME_NONE: return 0;
+        case NAME_ONION: return 1;
+        case NAME_TOMATO: return 2;
+        case NAME_DISH: return 3;
+        default: {
+            int bits = 0;
+            for (int i = 0; i < o->n_ing; ++i)
+                if (o->ing[i] == NAME_TOMATO) bits |= 1 << i;
+            return 0x80 | (o->n_ing << 3) | bits;
+        }
+    }
+}
+
+static void code_to_obj(int code, Obj* o) {
+    memset(o, 0, sizeof(Obj));
+    if (code == 0) return;
+    if (code < 0x80) { o->name = code; return; }
+    o->name = NAME_SOUP;
+    o->n_ing = (code >> 3) & 3;
+    for (int i = 0; i < o->n_ing; ++i) o->ing[i] = ((code >> i) & 1) ? NAME_TOMATO : NAME_ONION;
+    o->tick = -1;
+}
+
+static int n_obj_planes(const OracleMdp* m) { return (m->width * m->height + 15) / 16; }
+
+static void unpack_state(const OracleMdp* m, const uint8_t* planes, int64_t n_envs, int64_t e, State* s) {
+    const uint8_t* hdr = planes + 16 * e;
+    memset(s, 0, sizeof(State));
+    int ncells = m->width * m->height;
+    for (int c = 0; c < ncells; ++c) {
+        const uint8_t* pl = planes + 16 * ((int64_t)(1 + (c >> 4)) * n_envs + e);
+        code_to_obj(pl[c & 15], &s->objects[c]);
+    }
+    /* pot ticks: slot k = k-th 'P' cell in row-major order (get_pot_locations order, mdp.py:1711-1716,1799) */
+    int slot = 0;
+    for (int c = 0; c < ncells; ++c) {
+        if (m->terrain[c] != 'P') continue;
+        if (s->objects[c].name == NAME_SOUP && slot < MAX_POTS) s->objects[c].tick = (int)hdr[8 + slot] - 1;
+        ++slot;
+    }
+    for (int c = 0; c < ncells; ++c) { /* soups outside pots are cooked: tick = cook time */
+        Obj* o = &s->objects[c];
+        if (o->name == NAME_SOUP && m->terrain[c] != 'P') o->tick = (int)soup_cook_time(m, o);
+    }
+    for (int p = 0; p < 2; ++p) {
+        Player* pl = &s->players[p];
+        int pos = hdr[3 * p];
+        if (pos == 0xFF) { pl->present = 0; continue; }
+        pl->present = 1;
+        pl->x = pos % m->width;
+        pl->y = pos / m->width;
+        pl->o = hdr[3 * p + 1];
+        code_to_obj(hdr[3 * p + 2], &pl->held);
+        if (pl->held.name == NAME_SOUP) pl->held.tick = (int)soup_cook_time(m, &pl->held);
+    }
+    s->timestep = hdr[6] | (hdr[7] << 8);
+}
+
+static void pack_state(const OracleMdp* m, const State* s, uint8_t* planes, int64_t n_envs, int64_t e) {
+    uint8_t* hdr = planes + 16 * e;
+    memset(hdr, 0, 16);
+    int ncells = m->width * m->height;
+    for (int pl = 0; pl < n_obj_planes(m); ++pl) memset(planes + 16 * ((int64_t)(1 + pl) * n_envs + e), 0, 16);
+    for (int c = 0; c < ncells; ++c) {
+        uint8_t* pl = planes + 16 * ((int64_t)(1 + (c >> 4)) * n_envs + e);
+        pl[c & 15] = (uint8_t)obj_to_code(&s->objects[c]);
+    }
+    int slot = 0;
+    for (int c = 0; c < ncells; ++c) {
+        if (m->terrain[c] != 'P') continue;
+        if (s->objects[c].name == NAME_SOUP && slot < MAX_POTS) hdr[8 + slot] = (uint8_t)(s->objects[c].tick + 1);
+        ++slot;
+    }
+    for (int p = 0; p < 2; ++p) {
+        const Player* pl = &s->players[p];
+        if (!pl->present) { hdr[3 * p] = 0xFF; continue; }
+        hdr[3 * p] = (uint8_t)(pl->y * m->width + pl->x);
+        hdr[3 * p + 1] = (uint8_t)pl->o;
+        hdr[3 * p + 2] = (uint8_t)obj_to_code(&pl->held);
+    }
+    hdr[6] = (uint8_t)(s->timestep & 0xFF);
+    hdr[7] = (uint8_t)((s->timestep >> 8) & 0xFF);
+}
+
+/* ---------------------------------- batch entry points ------------------------------------ */
+
+#define F_DONE 0x01
+#define F_BAD_ACTION 0x02
+#define F_RESET 0x04
+#define OPT_AUTO_RESET 0x1u
+
+static void env_step_one(const OracleMdp* m, State* s, const int* ja, float* rew4, uint8_t* flag, float* ep4,
+                         int horizon, uint32_t options) {
+    double sparse[2], shaped[2];
+    uint8_t f = 0;
+    if (ja[0] < 0 || ja[0] > 5 || ja[1] < 0 || ja[1] > 5) { /* mdp.py:1394-1398 raises ValueError */
+        if (rew4) rew4[0] = rew4[1] = rew4[2] = rew4[3] = 0.f;
+        if (flag) *flag = F_BAD_ACTION;
+        return;
+    }
+    state_transition(m, s, ja, sparse, shaped);
+    if (rew4) {
+        rew4[0] = (float)sparse[0]; rew4[1] = (float)sparse[1];
+        rew4[2] = (float)shaped[0]; rew4[3] = (float)shaped[1];
+    }
+    if (ep4) { /* _update_game_stats, env.py:387-392 */
+        ep4[0] += (float)sparse[0]; ep4[1] += (float)sparse[1];
+        ep4[2] += (float)shaped[0]; ep4[3] += (float)shaped[1];
+    }
+    if (s->timestep >= horizon) { /* is_done, env.py:321-325 */
+        f |= F_DONE;
+        if (options & OPT_AUTO_RESET) {
+            standard_start_state(m, s);
+            if (ep4) ep4[0] = ep4[1] = ep4[2] = ep4[3] = 0.f;
+            f |= F_RESET;
+        }
+    }
+    if (flag) *flag = f;
+}
+
+int oracle_step(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, const uint8_t* state_in,
+                uint8_t* state_out, const uint8_t* actions, float* rewards, uint8_t* flags, float* ep_returns,
+                int64_t n_envs, int horizon, uint32_t options) {
+    (void)n_mdps;
+    for (int64_t e = 0; e < n_envs; ++e) {
+        const OracleMdp* m = &mdps[layout_id ? layout_id[e] : 0];
+        State s;
+        unpack_state(m, state_in, n_envs, e, &s);
+        int ja[2] = {actions[2 * e], actions[2 * e + 1]};
+        env_step_one(m, &s, ja, rewards ? rewards + 4 * e : 0, flags ? flags + e : 0, ep_returns ? ep_returns + 4 * e : 0,
+                     horizon, options);
+        pack_state(m, &s, state_out, n_envs, e);
+    }
+    return 0;
+}
+
+int oracle_reset(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, uint8_t* state, const uint8_t* mask,
+                 float* ep_returns, int64_t n_envs) {
+    (void)n_mdps;
+    for (int64_t e = 0; e < n_envs; ++e) {
+        if (mask && !mask[e]) continue;
+        const OracleMdp* m = &mdps[layout_id ? layout_id[e] : 0];
+        State s;
+        standard_start_state(m, &s);
+        pack_state(m, &s, state, n_envs, e);
+        if (ep_returns) memset(ep_returns + 4 * e, 0, 4 * sizeof(float));
+    }
+    return 0;
+}
+
+/* Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123).
+ * Not part of the reference: it stands in for the reference's RandomAgent(all_actions=True)
+ * (agents/agent.py:223-260, np.random.choice over the 6 actions) so that rollouts are reproducible
+ * on both sides.  Checked against the Random123 known-answer vectors in tests/test_oracle_golden.py. */
+void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void oracle_random_actions(uint64_t seed, int64_t env_offset, int64_t t, int64_t n_envs, uint8_t* actions) {
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int64_t e = 0; e < n_envs; ++e) {
+        uint64_t g = (uint64_t)(env_offset + e);
+        uint32_t ctr[4] = {(uint32_t)(uint64_t)t, (uint32_t)g, (uint32_t)(g >> 32), (uint32_t)((uint64_t)t >> 32)};
+        uint32_t r[4];
+        oracle_philox4x32_10(ctr, key, r);
+        actions[2 * e] = (uint8_t)(r[0] % 6u);
+        actions[2 * e + 1] = (uint8_t)(r[1] % 6u);
+    }
+}
+
+int oracle_rollout_random(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, uint8_t* state, float* rewards,
+                          uint8_t* flags, float* ep_returns, int64_t n_envs, int horizon, uint32_t options,
+                          uint64_t seed, int64_t env_offset, int64_t t0, int n_steps) {
+    (void)n_mdps;
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int64_t e = 0; e < n_envs; ++e) {
+        const OracleMdp* m = &mdps[layout_id ? layout_id[e] : 0];
+        State s;
+        unpack_state(m, state, n_envs, e, &s);
+        uint64_t g = (uint64_t)(env_offset + e);
+        for (int k = 0; k < n_steps; ++k) {
+            uint64_t t = (uint64_t)(t0 + k);
+            uint32_t ctr[4] = {(uint32_t)t, (uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(t >> 32)};
+            uint32_t r[4];
+            oracle_philox4x32_10(ctr, key, r);
+            int ja[2] = {(int)(r[0] % 6u), (int)(r[1] % 6u)};
+            env_step_one(m, &s, ja, rewards ? rewards + 4 * ((int64_t)k * n_envs + e) : 0,
+                         flags ? flags + ((int64_t)k * n_envs + e) : 0, ep_returns ? ep_returns + 4 * e : 0, horizon,
+                         options);
+        }
+        pack_state(m, &s, state, n_envs, e);
+    }
+    return 0;
+}
+
+/* ---------------------------------- lossless_state_encoding, mdp.py:2385-2561 ------------- */
+
+/* obs: [n_envs][2][W][H][26] int32 here (the reference emits int64 via astype(int), mdp.py:2554). */
+static void encode_one(const OracleMdp* m, const State* st, int horizon, int32_t* obs) {
+    int W = m->width, H = m->height;
+    size_t per_player = (size_t)W * H * NUM_LAYERS;
+    memset(obs, 0, 2 * per_player * sizeof(int32_t));
+#define LAYER(base, x, y, l) (base)[((size_t)(x) * H + (y)) * NUM_LAYERS + (l)]
+    for (int primary = 0; primary < 2; ++primary) {
+        int32_t* o = obs + primary * per_player;
+        int other = 1 - primary;
+        /* urgency, mdp.py:2446-2447 */
+        if (horizon - st->timestep < 40)
+            for (int x = 0; x < W; ++x)
+                for (int y = 0; y < H; ++y) LAYER(o, x, y, 25) = 1;
+        /* base map layers 10..15, mdp.py:2449-2465 */
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                char t = terrain_at(m, x, y);
+                if (t == 'P') LAYER(o, x, y, 10) = 1;
+                if (t == 'X') LAYER(o, x, y, 11) = 1;
+                if (t == 'O') LAYER(o, x, y, 12) = 1;
+                if (t == 'T') LAYER(o, x, y, 13) = 1;
+                if (t == 'D') LAYER(o, x, y, 14) = 1;
+                if (t == 'S') LAYER(o, x, y, 15) = 1;
+            }
+        /* player layers, mdp.py:2468-2479 with the ordering of 2423-2434 */
+        int order[2] = {primary, other};
+        for (int k = 0; k < 2; ++k) {
+            const Player* p = &st->players[order[k]];
+            LAYER(o, p->x, p->y, k) = 1;
+            LAYER(o, p->x, p->y, 2 + 4 * k + p->o) = 1;
+        }
+        /* object layers, mdp.py:2482-2534; all_objects_list includes held objects (876-879) */
+        for (int idx = 0; idx < W * H + 2; ++idx) {
+            const Obj* ob;
+            int x, y;
+            if (idx < W * H) {
+                ob = &st->objects[idx];
+                x = idx % W;
+                y = idx / W;
+            } else {
+                const Player* p = &st->players[idx - W * H];
+                ob = &p->held;
+                x = p->x;
+                y = p->y;
+            }
+            if (ob->name == NAME_NONE) continue;
+            if (ob->name == NAME_SOUP) {
+                int n_o, n_t;
+                count_ing(ob, &n_o, &n_t);
+                if (terrain_at(m, x, y) == 'P' && idx < W * H) {
+                    if (soup_is_idle(ob)) {
+                        LAYER(o, x, y, 16) += n_o;
+                        LAYER(o, x, y, 17) += n_t;
+                    } else {
+                        LAYER(o, x, y, 18) += n_o;
+                        LAYER(o, x, y, 19) += n_t;
+                        LAYER(o, x, y, 20) += (int32_t)(soup_cook_time(m, ob) - ob->tick);
+                        if (soup_is_ready(m, ob)) LAYER(o, x, y, 21) += 1;
+                    }
+                } else {
+                    LAYER(o, x, y, 18) += n_o;
+                    LAYER(o, x, y, 19) += n_t;
+                    LAYER(o, x, y, 21) += 1;
+                }
+            } else if (ob->name == NAME_DISH) LAYER(o, x, y, 22) += 1;
+            else if (ob->name == NAME_ONION) LAYER(o, x, y, 23) += 1;
+            else if (ob->name == NAME_TOMATO) LAYER(o, x, y, 24) += 1;
+        }
+    }
+#undef LAYER
+}
+
+int oracle_encode_lossless(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, const uint8_t* state,
+                           int32_t* obs, int64_t n_envs, int horizon) {
+    (void)n_mdps;
+    for (int64_t e = 0; e < n_envs; ++e) {
+        const OracleMdp* m = &mdps[layout_id ? layout_id[e] : 0];
+        State s;
+        unpack_state(m, state, n_envs, e, &s);
+        if (m->n_players != 2) return -1; /* assert, mdp.py:2389-2391 */
+        encode_one(m, &s, horizon, obs + (size_t)e * 2 * m->width * m->height * NUM_LAYERS);
+    }
+    return 0;
+}
+
+size_t oracle_mdp_size(void) { return sizeof(OracleMdp); }
