@@ -118,18 +118,31 @@ typedef struct OcLayout {
     uint8_t terrain[OC_MAX_CELLS];
 } OcLayout;
 
+/*
+ * A batch of envs: which layouts they use and how many there are.  Host-side POD; the two d_ members
+ * are device pointers.  All layouts of one table share width/height (pad smaller grids with counters,
+ * as the reference's LayoutGenerator.embed_grid does, layout_generator.py:309-329).
+ */
+typedef struct OcBatch {
+    const OcLayout* d_layouts;   /* [n_layouts] compiled layouts in HBM */
+    const uint16_t* d_layout_id; /* [n_envs] layout index per env, or NULL when n_layouts == 1 */
+    int64_t n_envs;
+    int32_t n_layouts;
+    int32_t width, height;       /* grid shape shared by every layout of the table */
+} OcBatch;
+
 int oc_abi_version(void);
 size_t oc_layout_size(void); /* == sizeof(OcLayout) == 256 */
 const char* oc_last_error(void);
+/* number of 16-byte planes per env for a width x height grid: 1 + ceil(width*height/16) */
+int oc_state_planes(int width, int height);
 
 /*
  * oc_step — one joint transition for n_envs independent envs.
  * Replaces OvercookedGridworld.get_state_transition (mdp.py:1375-1430) = resolve_interacts (1432)
  * -> resolve_movement (1644) -> step_environment_effects (1691), plus OvercookedEnv.step's
  * done/bookkeeping (env.py:244-274, 321-325, 382-392).
- *   d_layouts      n_layouts compiled layouts; all must share width/height/n_obj_planes
- *   d_layout_id    [n_envs] layout index per env, or NULL when n_layouts == 1
- *   d_state_in/out [(1+n_obj_planes) * n_envs] 16-byte words; may alias (in-place step)
+ *   d_state_in/out [oc_state_planes * n_envs] 16-byte words; may alias (in-place step)
  *   d_actions      [n_envs][2] action indices 0..5 (player 0, player 1)
  *   d_rewards      [n_envs][4] float: sparse_reward_by_agent[0..1], shaped_reward_by_agent[0..1]
  *   d_flags        [n_envs] OC_F_* bits
@@ -137,35 +150,32 @@ const char* oc_last_error(void);
  *                  (game_stats cumulative_*_rewards_by_agent, env.py:387-392), or NULL
  *   horizon        done when timestep >= horizon (1..65535)
  */
-int oc_step(const OcLayout* d_layouts, int n_layouts, const uint16_t* d_layout_id,
-            const void* d_state_in, void* d_state_out, const uint8_t* d_actions,
-            float* d_rewards, uint8_t* d_flags, float* d_ep_returns,
-            int64_t n_envs, int horizon, uint32_t options, void* stream);
+int oc_step(const OcBatch* batch, const void* d_state_in, void* d_state_out, const uint8_t* d_actions,
+            float* d_rewards, uint8_t* d_flags, float* d_ep_returns, int horizon, uint32_t options,
+            void* stream);
 
 /*
  * oc_rollout_random — n_steps transitions per launch under the uniform random policy
  * (the reference's RandomAgent(all_actions=True) pair, agents/agent.py:223), actions drawn
- * in-kernel: action of player p of global env g at global step t is
- *      philox4x32_10(counter = {t, g_lo, g_hi, 0}, key = {seed_lo, seed_hi})[p] % 6.
+ * in-kernel: the action of player p of global env g at global step t is
+ *      philox4x32_10(counter = {t_lo, g_lo, g_hi, t_hi}, key = {seed_lo, seed_hi})[p] % 6.
  * Same transition function as oc_step; state stays on chip between the fused steps.
  *   d_rewards  [n_steps][n_envs][4] or NULL;  d_flags [n_steps][n_envs] or NULL
  *   env_offset global index of local env 0 (multi-GPU shards draw disjoint streams)
  *   t0         global step index of the first fused step
  */
-int oc_rollout_random(const OcLayout* d_layouts, int n_layouts, const uint16_t* d_layout_id,
-                      void* d_state, float* d_rewards, uint8_t* d_flags, float* d_ep_returns,
-                      int64_t n_envs, int horizon, uint32_t options, uint64_t seed,
+int oc_rollout_random(const OcBatch* batch, void* d_state, float* d_rewards, uint8_t* d_flags,
+                      float* d_ep_returns, int horizon, uint32_t options, uint64_t seed,
                       int64_t env_offset, int64_t t0, int n_steps, void* stream);
 
 /*
  * oc_encode_lossless — the 26-layer observation of both players.
  * Replaces OvercookedGridworld.lossless_state_encoding (mdp.py:2385-2561) as called through
  * OvercookedEnv.lossless_state_encoding_mdp (env.py:276-280).
- *   d_obs  [n_envs][2][W][H][26] of u8 or f32 (index [x][y][layer], mdp.py:2415-2418, 2550)
+ *   d_obs  [n_envs][2][W][H][26] of u8 or f32 (index [x][y][layer], mdp.py:2415-2418, 2550); 16-byte aligned
  */
-int oc_encode_lossless(const OcLayout* d_layouts, int n_layouts, const uint16_t* d_layout_id,
-                       const void* d_state, void* d_obs, int obs_dtype, int64_t n_envs,
-                       int horizon, void* stream);
+int oc_encode_lossless(const OcBatch* batch, const void* d_state, void* d_obs, int obs_dtype, int horizon,
+                       void* stream);
 
 /*
  * oc_reset — write the standard start state (OvercookedGridworld.get_standard_start_state,
@@ -173,8 +183,7 @@ int oc_encode_lossless(const OcLayout* d_layouts, int n_layouts, const uint16_t*
  * env whose d_mask byte is non-zero (all envs when d_mask is NULL).  Replaces OvercookedEnv.reset
  * (env.py:288-319) for the default start_state_fn.  d_ep_returns (nullable) is zeroed for reset envs.
  */
-int oc_reset(const OcLayout* d_layouts, int n_layouts, const uint16_t* d_layout_id, void* d_state,
-             const uint8_t* d_mask, float* d_ep_returns, int64_t n_envs, void* stream);
+int oc_reset(const OcBatch* batch, void* d_state, const uint8_t* d_mask, float* d_ep_returns, void* stream);
 
 #ifdef __cplusplus
 }

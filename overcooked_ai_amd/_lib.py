@@ -1,0 +1,78 @@
+"""ctypes binding of liboc_amd.so (include/oc_amd.h).  There is no CPU fallback: if the HIP library is
+missing or fails to load, every entry point raises."""
+import ctypes
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "liboc_amd.so")
+
+ABI_VERSION = 1
+F_DONE, F_BAD_ACTION, F_RESET = 0x01, 0x02, 0x04
+OPT_AUTO_RESET = 0x1
+OBS_U8, OBS_F32 = 0, 1
+
+EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_step", "oc_rollout_random",
+           "oc_encode_lossless", "oc_reset")
+
+
+class OcBatch(ctypes.Structure):
+    _fields_ = [
+        ("d_layouts", ctypes.c_void_p),
+        ("d_layout_id", ctypes.c_void_p),
+        ("n_envs", ctypes.c_int64),
+        ("n_layouts", ctypes.c_int32),
+        ("width", ctypes.c_int32),
+        ("height", ctypes.c_int32),
+    ]
+
+
+class OcAmdError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load liboc_amd.so and declare prototypes. Raises OcAmdError when the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OcAmdError(
+            "liboc_amd.so not found at %s — build it with `python -m overcooked_ai_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise OcAmdError("failed to load %s: %s" % (LIB_PATH, e))
+    vp, i32, i64, u32, u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
+    bp = ctypes.POINTER(OcBatch)
+    L.oc_abi_version.restype = i32
+    L.oc_abi_version.argtypes = []
+    L.oc_layout_size.restype = ctypes.c_size_t
+    L.oc_layout_size.argtypes = []
+    L.oc_last_error.restype = ctypes.c_char_p
+    L.oc_last_error.argtypes = []
+    L.oc_state_planes.restype = i32
+    L.oc_state_planes.argtypes = [i32, i32]
+    L.oc_step.restype = i32
+    L.oc_step.argtypes = [bp, vp, vp, vp, vp, vp, vp, i32, u32, vp]
+    L.oc_rollout_random.restype = i32
+    L.oc_rollout_random.argtypes = [bp, vp, vp, vp, vp, i32, u32, u64, i64, i64, i32, vp]
+    L.oc_encode_lossless.restype = i32
+    L.oc_encode_lossless.argtypes = [bp, vp, vp, i32, i32, vp]
+    L.oc_reset.restype = i32
+    L.oc_reset.argtypes = [bp, vp, vp, vp, vp]
+    if L.oc_abi_version() != ABI_VERSION:
+        raise OcAmdError("liboc_amd.so ABI version %d != expected %d; rebuild" % (L.oc_abi_version(), ABI_VERSION))
+    if L.oc_layout_size() != 256:
+        raise OcAmdError("OcLayout size mismatch")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().oc_last_error().decode(errors="replace")
+        raise OcAmdError("%s failed (%d): %s" % (what, rc, msg))

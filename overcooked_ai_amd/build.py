@@ -1,0 +1,45 @@
+"""Build liboc_amd.so (HIP kernels + C-ABI) in-tree for gfx950 with hipcc.
+
+    python -m overcooked_ai_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The .so is written next to this package so that it travels with
+a source snapshot (and is git-ignored)."""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(PKG, "csrc", "oc_amd.hip")
+HDR = os.path.join(os.path.dirname(PKG), "include", "oc_amd.h")
+LIB = os.path.join(PKG, "liboc_amd.so")
+ARCH = "gfx950"
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.sep not in cand or os.path.exists(cand)):
+            return cand
+    return "hipcc"
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in (SRC, HDR))
+
+
+def build_extension(force=False, verbose=False):
+    if not force and not is_stale():
+        return LIB
+    tmp = LIB + ".%d.tmp" % os.getpid()
+    cmd = [hipcc_path(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC", "-o", tmp, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_extension(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,162 @@
+"""VecOvercookedEnv — N independent Overcooked envs resident in HBM, stepped by the HIP kernels.
+
+This is the batched form of the reference's `OvercookedEnv` (overcooked_env.py:33-325): `reset` ~ env.py:288,
+`step` ~ env.py:244 (get_state_transition mdp.py:1375 + done/`game_stats` bookkeeping), `encode_lossless` ~
+`lossless_state_encoding_mdp` env.py:276.  PyTorch is used only for device memory and streams; all game logic
+is in liboc_amd.so, called through its C-ABI (include/oc_amd.h).  There is no CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .layouts import LayoutSpec, LayoutTable, spec_from_name
+from .state import pack_states, unpack_states
+
+
+def as_layout_table(layouts, pad_to=None):
+    if isinstance(layouts, LayoutTable):
+        return layouts
+    if isinstance(layouts, (str, LayoutSpec)):
+        layouts = [layouts]
+    specs = [spec_from_name(l) if isinstance(l, str) else l for l in layouts]
+    return LayoutTable(specs, pad_to=pad_to)
+
+
+class VecOvercookedEnv:
+    def __init__(self, layouts, n_envs, horizon=400, device="cuda", layout_id=None, auto_reset=False, seed=0,
+                 env_offset=0, pad_to=None, track_returns=True):
+        self.lib = _lib.load()
+        self.table = as_layout_table(layouts, pad_to)
+        self.n_envs = int(n_envs)
+        self.horizon = int(horizon)
+        if not 1 <= self.horizon <= 65535:
+            raise ValueError("horizon must be in 1..65535 (timestep is a u16 in the packed state)")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.OcAmdError("VecOvercookedEnv needs a ROCm GPU device (got %r); there is no CPU fallback" % device)
+        self.auto_reset = bool(auto_reset)
+        self.seed = int(seed)
+        self.env_offset = int(env_offset)
+        self.t_global = 0  # global step counter feeding the Philox counter of rollout_random
+        self.width, self.height = self.table.width, self.table.height
+        self.n_planes = self.table.n_planes
+        assert self.lib.oc_state_planes(self.width, self.height) == self.n_planes
+        dev = self.device
+        self.d_layouts = torch.from_numpy(self.table.records.copy()).to(dev)
+        if layout_id is None:
+            if len(self.table) != 1:
+                raise ValueError("layout_id is required when the table holds more than one layout")
+            self.layout_id = None
+        else:
+            lid = np.ascontiguousarray(np.asarray(layout_id), dtype=np.int64)
+            if lid.shape != (self.n_envs,) or lid.min() < 0 or lid.max() >= len(self.table):
+                raise ValueError("layout_id must be [n_envs] with values in [0, %d)" % len(self.table))
+            self.layout_id_host = lid.astype(np.uint16)
+            # torch has no uint16 arithmetic, but we only need the bytes on the device
+            self.layout_id = torch.from_numpy(self.layout_id_host.view(np.int16).copy()).to(dev)
+        self.state = torch.zeros((self.n_planes, self.n_envs, 16), dtype=torch.uint8, device=dev)
+        self.rewards = torch.zeros((self.n_envs, 4), dtype=torch.float32, device=dev)
+        self.flags = torch.zeros((self.n_envs,), dtype=torch.uint8, device=dev)
+        self.ep_returns = torch.zeros((self.n_envs, 4), dtype=torch.float32, device=dev) if track_returns else None
+        self._batch = _lib.OcBatch(
+            d_layouts=self.d_layouts.data_ptr(),
+            d_layout_id=self.layout_id.data_ptr() if self.layout_id is not None else None,
+            n_envs=self.n_envs, n_layouts=len(self.table), width=self.width, height=self.height)
+        self._bref = ctypes.byref(self._batch)
+        self.reset()
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    @property
+    def options(self):
+        return _lib.OPT_AUTO_RESET if self.auto_reset else 0
+
+    def spec_of(self, e):
+        return self.table.specs[0 if self.layout_id is None else int(self.layout_id_host[e])]
+
+    # ------------------------------------------------------------------ env API
+    def reset(self, mask=None):
+        """Standard start state (mdp.py:1297) for all envs, or those with mask != 0 (u8/bool tensor [n_envs])."""
+        d_mask = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            d_mask = mask.data_ptr()
+        with torch.cuda.device(self.device):
+            rc = self.lib.oc_reset(self._bref, self.state.data_ptr(), d_mask,
+                                   self.ep_returns.data_ptr() if self.ep_returns is not None else None, self._stream())
+        _lib.check(rc, "oc_reset")
+
+    def step(self, actions, state_out=None):
+        """actions: uint8 tensor [n_envs, 2] of action indices (Action.INDEX_TO_ACTION order).
+        Returns (rewards [n_envs,4] = sparse0, sparse1, shaped0, shaped1; flags [n_envs] OC_F_* bits).
+        The returned tensors are reused by the next call."""
+        if actions.dtype != torch.uint8 or actions.shape != (self.n_envs, 2) or not actions.is_contiguous() \
+                or actions.device != self.state.device:
+            raise ValueError("actions must be a contiguous uint8 [n_envs, 2] tensor on %s" % self.device)
+        out = self.state if state_out is None else state_out
+        with torch.cuda.device(self.device):
+            rc = self.lib.oc_step(self._bref, self.state.data_ptr(), out.data_ptr(), actions.data_ptr(),
+                                  self.rewards.data_ptr(), self.flags.data_ptr(),
+                                  self.ep_returns.data_ptr() if self.ep_returns is not None else None,
+                                  self.horizon, self.options, self._stream())
+        _lib.check(rc, "oc_step")
+        return self.rewards, self.flags
+
+    def rollout_random(self, n_steps, rewards_out=None, flags_out=None):
+        """n_steps fused random-policy transitions in one launch (Philox actions, see include/oc_amd.h).
+        rewards_out: float32 [n_steps, n_envs, 4] or None; flags_out: uint8 [n_steps, n_envs] or None."""
+        if rewards_out is not None:
+            assert rewards_out.dtype == torch.float32 and rewards_out.shape == (n_steps, self.n_envs, 4) \
+                and rewards_out.is_contiguous()
+        if flags_out is not None:
+            assert flags_out.dtype == torch.uint8 and flags_out.shape == (n_steps, self.n_envs) \
+                and flags_out.is_contiguous()
+        with torch.cuda.device(self.device):
+            rc = self.lib.oc_rollout_random(
+                self._bref, self.state.data_ptr(),
+                rewards_out.data_ptr() if rewards_out is not None else None,
+                flags_out.data_ptr() if flags_out is not None else None,
+                self.ep_returns.data_ptr() if self.ep_returns is not None else None,
+                self.horizon, self.options, self.seed, self.env_offset, self.t_global, int(n_steps), self._stream())
+        _lib.check(rc, "oc_rollout_random")
+        self.t_global += int(n_steps)
+        return rewards_out, flags_out
+
+    def encode_lossless(self, dtype=torch.uint8, out=None, state=None):
+        """[n_envs, 2, W, H, 26] observation (mdp.py:2385); out[:, i] is the encoding for player i."""
+        code = {torch.uint8: _lib.OBS_U8, torch.float32: _lib.OBS_F32}[dtype]
+        if out is None:
+            out = torch.empty((self.n_envs, 2, self.width, self.height, 26), dtype=dtype, device=self.device)
+        else:
+            assert out.dtype == dtype and out.is_contiguous() \
+                and out.numel() == self.n_envs * 2 * self.width * self.height * 26
+        st = self.state if state is None else state
+        with torch.cuda.device(self.device):
+            rc = self.lib.oc_encode_lossless(self._bref, st.data_ptr(), out.data_ptr(), code, self.horizon,
+                                             self._stream())
+        _lib.check(rc, "oc_encode_lossless")
+        return out
+
+    # ------------------------------------------------------------------ host <-> device state
+    def set_packed_state(self, packed):
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        assert packed.shape == (self.n_planes, self.n_envs, 16)
+        self.state.copy_(torch.from_numpy(packed))
+
+    def get_packed_state(self):
+        return self.state.cpu().numpy()
+
+    def set_states(self, states):
+        assert len(states) == self.n_envs
+        out = np.zeros((self.n_planes, self.n_envs, 16), np.uint8)
+        for e, s in enumerate(states):
+            out[:, e:e + 1] = pack_states(self.spec_of(e), [s], self.n_planes)
+        self.set_packed_state(out)
+
+    def get_states(self, as_dict=False):
+        packed = self.get_packed_state()
+        return [unpack_states(self.spec_of(e), packed[:, e:e + 1], as_dict=as_dict)[0] for e in range(self.n_envs)]

@@ -1,0 +1,378 @@
+"""Parity of the HIP kernels (through the C-ABI of liboc_amd.so) against (a) fixtures generated from the real
+reference and (b) the C oracle on seeded random inputs.  Integer state: bit-exact; rewards: |diff| <= 1e-6."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from helpers import CANONICAL_5, random_packed_states
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+TRANSITION_CONFIGS = [
+    "cramped_room", "asymmetric_advantages", "coordination_ring", "forced_coordination", "counter_circuit",
+    "mdp_test", "cramped_room_old_dynamics", "bonus_order_test", "cramped_room_tomato", "cramped_room_single",
+    "cramped_room_padded_9x5",
+]
+ROLLOUT_CONFIGS = ["cramped_room", "asymmetric_advantages", "counter_circuit", "mdp_test", "cramped_room_old_dynamics"]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    from overcooked_ai_amd import _lib
+
+    _lib.load()  # fail loudly if the HIP extension is missing
+    return torch.device("cuda:0")
+
+
+def make_env(layouts, n, gpu, **kw):
+    from overcooked_ai_amd.vec_env import VecOvercookedEnv
+
+    return VecOvercookedEnv(layouts, n, device=gpu, **kw)
+
+
+def oracle_for(specs):
+    from oracle import oracle as O
+
+    if not isinstance(specs, (list, tuple)):
+        specs = [specs]
+    return O.Oracle([O.mdp_from_layout_dict(s.to_layout_dict()) for s in specs])
+
+
+def u8(t):
+    return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", TRANSITION_CONFIGS)
+def test_golden_transitions(name, manifest, gpu):
+    from overcooked_ai_amd.layouts import LayoutSpec
+
+    cfg = manifest["configs"][name]["transitions"]
+    spec = LayoutSpec(cfg["layout"])
+    d = np.load(os.path.join(GOLDEN, "transitions_%s.npz" % name))
+    n = d["actions"].shape[0]
+    env = make_env(spec, n, gpu, horizon=65535)
+    env.set_packed_state(d["state_in"])
+    rew, flags = env.step(torch.from_numpy(d["actions"]).to(gpu))
+    assert np.array_equal(env.get_packed_state(), d["state_out"])
+    assert np.max(np.abs(u8(rew).astype(np.float64) - d["rewards"])) <= 1e-6
+    assert not u8(flags).any()
+    # pure-function form: separate output buffer leaves the input untouched (mdp.py:1400 deep-copies)
+    env.set_packed_state(d["state_in"])
+    out = torch.zeros_like(env.state)
+    env.step(torch.from_numpy(d["actions"]).to(gpu), state_out=out)
+    assert np.array_equal(u8(env.state), d["state_in"]) and np.array_equal(u8(out), d["state_out"])
+
+
+@pytest.mark.parametrize("name", [n for n in TRANSITION_CONFIGS if n != "cramped_room_single"])
+def test_golden_lossless_encoding(name, manifest, gpu):
+    from overcooked_ai_amd.layouts import LayoutSpec
+
+    cfg = manifest["configs"][name]["transitions"]
+    spec = LayoutSpec(cfg["layout"])
+    d = np.load(os.path.join(GOLDEN, "transitions_%s.npz" % name))
+    st = np.ascontiguousarray(d["state_in"][:, d["enc_index"], :])
+    for n in (st.shape[1], 1, 5, 63):  # ragged tails of the encode kernel's env groups
+        env = make_env(spec, n, gpu, horizon=int(d["enc_horizon"]))
+        env.set_packed_state(st[:, :n])
+        a = u8(env.encode_lossless(torch.uint8))
+        b = u8(env.encode_lossless(torch.float32))
+        assert a.shape == (n, 2, spec.width, spec.height, 26)
+        assert np.array_equal(a.astype(np.int16), d["enc"][:n])
+        assert np.array_equal(b, d["enc"][:n].astype(np.float32))
+
+
+def test_reference_golden_trajectory(manifest, gpu):
+    from overcooked_ai_amd.layouts import LayoutSpec
+
+    cfg = manifest["ref_mdp_dynamics"]
+    spec = LayoutSpec(cfg["layout"])
+    d = np.load(os.path.join(GOLDEN, "ref_mdp_dynamics.npz"))
+    states, actions = d["states"], d["actions"]
+    n = states.shape[1]
+    env = make_env(spec, n, gpu, horizon=65535)
+    env.set_packed_state(states)
+    rew, _ = env.step(torch.from_numpy(actions).to(gpu))
+    out = env.get_packed_state()
+    assert np.array_equal(out[:, : n - 1], states[:, 1:])
+    r = u8(rew)
+    assert np.array_equal(r[:, 0] + r[:, 1], d["ep_rewards"]) and np.array_equal(r[:, 2:], d["shaped"])
+    # sequential replay of the 1499 transitions on one env
+    env1 = make_env(spec, 1, gpu, horizon=65535)
+    env1.set_packed_state(states[:, :1])
+    acts = torch.from_numpy(actions).to(gpu)
+    total = 0.0
+    for t in range(n - 1):
+        r1, _ = env1.step(acts[t:t + 1])
+        total += float(r1[0, 0] + r1[0, 1])
+    assert np.array_equal(env1.get_packed_state()[:, 0], states[:, n - 1])
+    assert total == d["ep_rewards"][: n - 1].sum()
+
+
+@pytest.mark.parametrize("name", ROLLOUT_CONFIGS)
+def test_golden_rollouts_fused(name, manifest, gpu):
+    """The fused Philox rollout kernel against episodes run through the reference's OvercookedEnv.step."""
+    from overcooked_ai_amd.layouts import LayoutSpec
+
+    cfg = manifest["configs"][name]["rollouts"]
+    spec = LayoutSpec(cfg["layout"])
+    d = np.load(os.path.join(GOLDEN, "rollouts_%s.npz" % name))
+    n, seed, horizon = cfg["n_envs"], int(d["seed"]), int(d["horizon"])
+    env = make_env(spec, n, gpu, horizon=horizon, seed=seed)
+    for k in range(4):
+        rew = torch.zeros((100, n, 4), dtype=torch.float32, device=gpu)
+        fl = torch.zeros((100, n), dtype=torch.uint8, device=gpu)
+        env.rollout_random(100, rew, fl)
+        assert np.array_equal(u8(rew).astype(np.float64), d["rewards"][100 * k:100 * (k + 1)])
+        assert np.array_equal(env.get_packed_state(), d["checkpoints"][k])
+        f = u8(fl)
+        assert f[:-1].sum() == 0 and (f[-1] == (1 if k == 3 else 0)).all()
+    assert np.array_equal(u8(env.ep_returns).astype(np.float64), d["rewards"].sum(axis=0))
+
+
+def test_small_fixtures_and_micro_cases(small_fixtures, gpu):
+    from overcooked_ai_amd import state as S
+    from overcooked_ai_amd.layouts import LayoutSpec
+
+    cases = list(small_fixtures["micro"])
+    for key in ("old_dynamics_cook_test_old0", "old_dynamics_cook_test_old1", "old_dynamics_put_test_old0",
+                "old_dynamics_put_test_old1"):
+        c = dict(small_fixtures[key])
+        c["label"] = key
+        cases.append(c)
+    for case in cases:
+        spec = LayoutSpec(case["layout"])
+        env = make_env(spec, 1, gpu, horizon=65535)
+        env.set_states([case["state"]])
+        rew, _ = env.step(torch.tensor([case["actions"]], dtype=torch.uint8, device=gpu))
+        got = env.get_states(as_dict=True)[0]
+        assert S.canonical_state_dict(got) == S.canonical_state_dict(case["expected_state"]), case["label"]
+        if "sparse" in case:
+            r = u8(rew)[0]
+            assert list(r[:2]) == case["sparse"] and list(r[2:]) == case["shaped"], case["label"]
+        if "after_more_stay" in case:
+            stay = torch.tensor([[4, 4]], dtype=torch.uint8, device=gpu)
+            for _ in range(case["n_more_stay"]):
+                env.step(stay)
+            assert S.canonical_state_dict(env.get_states(as_dict=True)[0]) == S.canonical_state_dict(
+                case["after_more_stay"])
+        if "encoding_layer_sums_p0" in case:
+            env.set_states([case["state"]])
+            env.horizon = 400
+            enc = u8(env.encode_lossless(torch.uint8)).astype(np.int64)
+            assert [int(v) for v in enc[0, 0].sum(axis=(0, 1))] == case["encoding_layer_sums_p0"]
+            assert [int(v) for v in enc[0, 1].sum(axis=(0, 1))] == case["encoding_layer_sums_p1"]
+    # scripted bonus-order episode: total sparse reward 50 (overcooked_test.py:994-998)
+    ep = small_fixtures["mdp_test_bonus_episode"]
+    spec = LayoutSpec(ep["layout"])
+    env = make_env(spec, 1, gpu, horizon=65535)
+    env.set_states([ep["start_state"]])
+    total = 0.0
+    for step in ep["steps"]:
+        rew, _ = env.step(torch.tensor([step["actions"]], dtype=torch.uint8, device=gpu))
+        r = u8(rew)[0]
+        assert list(r[:2]) == step["sparse"] and list(r[2:]) == step["shaped"]
+        total += r[:2].sum()
+    assert total == 50
+    assert S.canonical_state_dict(env.get_states(as_dict=True)[0]) == S.canonical_state_dict(
+        ep["steps"][-1]["next_state"])
+
+
+@pytest.mark.parametrize("n_envs", [1, 63, 257, 4096])
+def test_step_vs_oracle_random_states(n_envs, gpu):
+    """Ragged batch sizes, every canonical layout, explicit actions incl. illegal ones and auto-reset."""
+    from overcooked_ai_amd.layouts import spec_from_name
+
+    rng = np.random.default_rng(n_envs)
+    for name in CANONICAL_5 + ["mdp_test"]:
+        spec = spec_from_name(name)
+        orc = oracle_for(spec)
+        st = random_packed_states(spec, n_envs, rng)
+        acts = rng.integers(0, 6, size=(n_envs, 2)).astype(np.uint8)
+        acts[rng.random(n_envs) < 0.02, 0] = 6 + rng.integers(0, 200)
+        if n_envs > 1:
+            acts[1, 1] = 9
+        horizon = 200
+        env = make_env(spec, n_envs, gpu, horizon=horizon, auto_reset=True)
+        env.set_packed_state(st)
+        ep0 = rng.integers(0, 50, size=(n_envs, 4)).astype(np.float32)
+        env.ep_returns.copy_(torch.from_numpy(ep0))
+        rew, flags = env.step(torch.from_numpy(acts).to(gpu))
+        ep_o = ep0.copy()
+        out_o, rew_o, fl_o = orc.step(st, acts, horizon=horizon, options=1, ep_returns=ep_o)
+        assert np.array_equal(env.get_packed_state(), out_o), name
+        assert np.array_equal(u8(rew), rew_o) and np.array_equal(u8(flags), fl_o)
+        assert np.array_equal(u8(env.ep_returns), ep_o)
+        assert (fl_o & 2).any() or n_envs == 1
+
+
+def test_full_size_rollout_vs_oracle(gpu):
+    """BASELINE config 2 at full size: 65 536 cramped_room envs, random policy, horizon 400 with auto-reset."""
+    from overcooked_ai_amd.layouts import spec_from_name
+
+    n = 65536
+    spec = spec_from_name("cramped_room")
+    orc = oracle_for(spec)
+    env = make_env(spec, n, gpu, horizon=400, auto_reset=True, seed=1234)
+    st_o = orc.reset(orc.new_state(n))
+    ep_o = np.zeros((n, 4), np.float32)
+    t0 = 0
+    for chunk in (7, 64, 129, 200, 100):  # crosses the 400-step reset boundary
+        rew = torch.zeros((chunk, n, 4), dtype=torch.float32, device=gpu)
+        fl = torch.zeros((chunk, n), dtype=torch.uint8, device=gpu)
+        env.rollout_random(chunk, rew, fl)
+        rew_o, fl_o = orc.rollout_random(st_o, chunk, horizon=400, options=1, seed=1234, t0=t0, ep_returns=ep_o)
+        t0 += chunk
+        assert np.array_equal(env.get_packed_state(), st_o)
+        assert np.array_equal(u8(rew), rew_o) and np.array_equal(u8(fl), fl_o)
+        assert np.array_equal(u8(env.ep_returns), ep_o)
+    # step-by-step API with the same Philox actions reaches the same state as the fused kernel
+    from oracle import oracle as O
+
+    env2 = make_env(spec, n, gpu, horizon=400, auto_reset=True)
+    for t in range(20):
+        env2.step(torch.from_numpy(O.random_actions(1234, 0, t, n)).to(gpu))
+    env3 = make_env(spec, n, gpu, horizon=400, auto_reset=True, seed=1234)
+    env3.rollout_random(20)
+    assert torch.equal(env2.state, env3.state)
+    # sharding property: a shard that owns envs [a, b) reproduces exactly that slice
+    a, b = 12345, 12345 + 777
+    shard = make_env(spec, b - a, gpu, horizon=400, auto_reset=True, seed=1234, env_offset=a)
+    shard.rollout_random(20)
+    assert torch.equal(shard.state, env3.state[:, a:b])
+
+
+def test_mixed_layout_batch_vs_oracle(gpu):
+    """BASELINE config 4 (one GPU's shard): env e uses canonical layout e % 5, all padded to 9x5."""
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    n = 20000
+    table = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+    lid = (np.arange(n) % 5).astype(np.uint16)
+    orc = oracle_for(table.specs)
+    env = make_env(table, n, gpu, horizon=400, auto_reset=True, seed=99, layout_id=lid)
+    rng = np.random.default_rng(5)
+    st = np.zeros((table.n_planes, n, 16), np.uint8)
+    for l in range(5):
+        idx = np.nonzero(lid == l)[0]
+        st[:, idx] = random_packed_states(table.specs[l], len(idx), rng)
+    env.set_packed_state(st)
+    st_o = st.copy()
+    ep_o = np.zeros((n, 4), np.float32)
+    rew = torch.zeros((150, n, 4), dtype=torch.float32, device=gpu)
+    fl = torch.zeros((150, n), dtype=torch.uint8, device=gpu)
+    env.rollout_random(150, rew, fl)
+    rew_o, fl_o = orc.rollout_random(st_o, 150, horizon=400, options=1, seed=99, layout_id=lid, ep_returns=ep_o)
+    assert np.array_equal(env.get_packed_state(), st_o)
+    assert np.array_equal(u8(rew), rew_o) and np.array_equal(u8(fl), fl_o)
+    assert np.abs(rew_o).sum() > 0
+    enc = u8(env.encode_lossless(torch.uint8))
+    assert np.array_equal(enc.astype(np.int32), orc.encode_lossless(st_o, horizon=400, layout_id=lid))
+
+
+def test_large_layout_table_global_path(gpu):
+    """More than 32 layouts: the table is read from HBM/L2 instead of LDS."""
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    names = ["cramped_room", "cramped_room_tomato", "bonus_order_test", "mdp_test", "simple_o", "simple_o_t",
+             "simple_tomato", "m_shaped_s", "cramped_room_o_3orders"]
+    specs = [spec_from_name(nm) for nm in names] * 5  # 45 entries
+    table = LayoutTable(specs)
+    n = 9000
+    lid = (np.arange(n) * 7 % len(specs)).astype(np.uint16)
+    orc = oracle_for(table.specs)
+    env = make_env(table, n, gpu, horizon=100, auto_reset=True, seed=5, layout_id=lid)
+    rng = np.random.default_rng(11)
+    st = np.zeros((table.n_planes, n, 16), np.uint8)
+    for l in range(len(specs)):
+        idx = np.nonzero(lid == l)[0]
+        st[:, idx] = random_packed_states(table.specs[l], len(idx), rng, timestep_max=99)
+    env.set_packed_state(st)
+    st_o = st.copy()
+    env.rollout_random(120)
+    orc.rollout_random(st_o, 120, horizon=100, options=1, seed=5, layout_id=lid, want_outputs=False)
+    assert np.array_equal(env.get_packed_state(), st_o)
+    acts = rng.integers(0, 6, size=(n, 2)).astype(np.uint8)
+    env.step(torch.from_numpy(acts).to(gpu))
+    st_o2, _, _ = orc.step(st_o, acts, horizon=100, options=1, layout_id=lid)
+    assert np.array_equal(env.get_packed_state(), st_o2)
+    enc = u8(env.encode_lossless(torch.float32))
+    assert np.array_equal(enc, orc.encode_lossless(st_o2, horizon=100, layout_id=lid).astype(np.float32))
+
+
+def test_every_registry_layout_vs_oracle(gpu):
+    """All 1- and 2-player layouts shipped by the reference (grids up to 14x9 = 8 object planes)."""
+    from overcooked_ai_amd.layouts import layout_names, spec_from_name
+
+    rng = np.random.default_rng(2024)
+    n = 1500
+    for name in layout_names():
+        if name == "multiplayer_schelling":
+            continue
+        spec = spec_from_name(name)
+        orc = oracle_for(spec)
+        st = random_packed_states(spec, n, rng)
+        env = make_env(spec, n, gpu, horizon=400, auto_reset=True, seed=3)
+        env.set_packed_state(st)
+        st_o = st.copy()
+        rew = torch.zeros((60, n, 4), dtype=torch.float32, device=gpu)
+        env.rollout_random(60, rew, None)
+        rew_o, _ = orc.rollout_random(st_o, 60, horizon=400, options=1, seed=3)
+        assert np.array_equal(env.get_packed_state(), st_o), name
+        assert np.array_equal(u8(rew), rew_o), name
+        if spec.num_players == 2:
+            enc = u8(env.encode_lossless(torch.uint8))
+            assert np.array_equal(enc.astype(np.int32), orc.encode_lossless(st_o, horizon=400)), name
+
+
+def test_full_size_encoding_properties(gpu):
+    """BASELINE config 3 at full size: 65 536 asymmetric_advantages envs. Size-independent properties:
+    f32 == u8, player-swap symmetry (overcooked_test.py:1112-1128), static-layer checksums; oracle on a slice."""
+    from overcooked_ai_amd.layouts import spec_from_name
+
+    n = 65536
+    spec = spec_from_name("asymmetric_advantages")
+    env = make_env(spec, n, gpu, horizon=400, auto_reset=True, seed=8)
+    rng = np.random.default_rng(0)
+    st = random_packed_states(spec, 4096, rng)
+    env.set_packed_state(np.tile(st, (1, n // 4096, 1)))
+    env.rollout_random(37)
+    a = env.encode_lossless(torch.uint8)
+    b = env.encode_lossless(torch.float32)
+    assert torch.equal(a.float(), b)
+    sw = env.state.clone()
+    sw[0, :, 0:3], sw[0, :, 3:6] = env.state[0, :, 3:6], env.state[0, :, 0:3]
+    c = env.encode_lossless(torch.uint8, state=sw)
+    assert torch.equal(a[:, 0], c[:, 1]) and torch.equal(a[:, 1], c[:, 0])
+    sums = a.sum(dim=(2, 3), dtype=torch.int64)  # [n, 2, 26]
+    assert (sums[:, :, 0] == 1).all() and (sums[:, :, 1] == 1).all()
+    assert (sums[:, :, 2:6].sum(-1) == 1).all() and (sums[:, :, 6:10].sum(-1) == 1).all()
+    static = torch.tensor([2, 23, 2, 0, 2, 2], device=gpu)  # P, X, O, T, D, S cells of asymmetric_advantages
+    assert (sums[:, :, 10:16] == static).all()
+    orc = oracle_for(spec)
+    host = env.get_packed_state()[:, :3000]
+    assert np.array_equal(u8(a[:3000]).astype(np.int32), orc.encode_lossless(np.ascontiguousarray(host), horizon=400))
+
+
+def test_abi_argument_errors(gpu):
+    import ctypes
+
+    from overcooked_ai_amd import _lib
+
+    env = make_env("cramped_room", 8, gpu)
+    L = _lib.load()
+    rc = L.oc_step(env._bref, None, None, None, None, None, None, 400, 0, None)
+    assert rc == -1 and b"NULL" in L.oc_last_error()
+    rc = L.oc_step(env._bref, env.state.data_ptr(), env.state.data_ptr(), env.flags.data_ptr(),
+                   env.rewards.data_ptr(), env.flags.data_ptr(), None, 0, 0, None)
+    assert rc == -1 and b"horizon" in L.oc_last_error()
+    bad = _lib.OcBatch(d_layouts=env.d_layouts.data_ptr(), d_layout_id=None, n_envs=8, n_layouts=2, width=5, height=4)
+    rc = L.oc_reset(ctypes.byref(bad), env.state.data_ptr(), None, None, None)
+    assert rc == -1 and b"layout_id" in L.oc_last_error()
+    with pytest.raises(ValueError):
+        env.step(torch.zeros((8, 2), dtype=torch.int64, device=gpu))
