@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""bench.py — env steps/s of the MI355X Overcooked hot path on BASELINE.json's metric.
+
+Workload (BASELINE.json configs[1] / SURVEY.md §8d-2): 65 536 parallel cramped_room envs PER GPU, uniform random
+policy drawn in-kernel with Philox, horizon 400 with auto-reset to the standard start state, outputs written
+every step (4 x f32 rewards + 1 flag byte per env-step).  A "step" is one batched transition of all envs of a
+GPU.  The timed region launches oc_rollout_random with --fuse steps per launch; `value` is whole-job env-steps/s
+over all ranks (weak scaling: every rank owns 65 536 envs, disjoint Philox streams via env_offset).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see DESIGN.md §6 for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+N_ENVS_PER_GPU = 65536
+HORIZON = 400
+
+# SURVEY.md §8d algorithmic bytes.  S = minimal state of cramped_room (2 players x 3 B + 14 non-floor cells
+# + 1 pot tick + 2 B timestep -> 24 B), outputs 17 B per env-step, actions generated in-kernel (0 B).
+S_CRAMPED = 24
+OUT_BYTES = 17
+S_ASYM = 44
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--fuse", type=int, default=100, help="env steps fused per oc_rollout_random launch")
+    ap.add_argument("--envs", type=int, default=N_ENVS_PER_GPU, help="envs per GPU")
+    ap.add_argument("--layout", default="cramped_room")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the step-API and encode side measurements")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+def run_fused(env, n_steps, fuse, rew, fl):
+    """n_steps batched steps as ceil(n_steps / fuse) launches; returns number of launches."""
+    launches = 0
+    left = n_steps
+    while left > 0:
+        k = min(fuse, left)
+        env.rollout_random(k, rew[:k], fl[:k])
+        left -= k
+        launches += 1
+    return launches
+
+
+def cpu_baseline(layout, seconds):
+    """The C oracle (a scalar port of the reference's algorithm) on ONE host core: a bounded sample of the same
+    workload (same layout, random policy, horizon 400 with auto-reset, outputs written every step)."""
+    import numpy as np
+
+    from oracle import oracle as O
+    from overcooked_ai_amd.layouts import spec_from_name
+
+    spec = spec_from_name(layout)
+    orc = O.Oracle(O.mdp_from_layout_dict(spec.to_layout_dict()))
+    n, T = 4096, 100
+    st = orc.reset(orc.new_state(n))
+    ep = np.zeros((n, 4), np.float32)
+    orc.rollout_random(st, 10, horizon=HORIZON, options=1, seed=0, t0=0, ep_returns=ep)  # warm
+    t0 = time.perf_counter()
+    orc.rollout_random(st, T, horizon=HORIZON, options=1, seed=0, t0=10, ep_returns=ep)
+    probe = time.perf_counter() - t0
+    reps = max(1, int(seconds / max(probe, 1e-6)))
+    t0 = time.perf_counter()
+    tg = 110
+    for _ in range(reps):
+        orc.rollout_random(st, T, horizon=HORIZON, options=1, seed=0, t0=tg, ep_returns=ep)
+        tg += T
+    dt = time.perf_counter() - t0
+    steps = reps * n * T
+    return {
+        "value": steps / dt, "unit": "env steps/s", "cores": 1, "kind": "port",
+        "sample": "%d envs x %d steps of %s (C oracle, 1 thread, %.1f s)" % (n, reps * T, layout, dt),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+
+    from overcooked_ai_amd import sharding
+    from overcooked_ai_amd.vec_env import VecOvercookedEnv
+
+    rank, local_rank, world = sharding.init_process_group()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    n = args.envs
+    env = VecOvercookedEnv(args.layout, n, horizon=HORIZON, device=dev, auto_reset=True, seed=0,
+                           env_offset=rank * n)
+    fuse = max(1, min(args.fuse, args.steps))
+    rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
+    fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
+
+    run_fused(env, args.warmup, fuse, rew, fl)
+    torch.cuda.synchronize(dev)
+    sharding.barrier()
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    launches = run_fused(env, args.steps, fuse, rew, fl)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    sharding.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+    sharding.allreduce_max(tmax)
+    wall_max = float(tmax.item())
+    # aggregate-return metric: the only collective, outside the hot path (RCCL all-reduce of 6 scalars)
+    done_eps = (fl[-1] & 1).sum().to(torch.float64) if args.steps >= fuse else torch.zeros((), dtype=torch.float64, device=dev)
+    metrics = torch.stack([rew[..., 0:2].sum().to(torch.float64), rew[..., 2:4].sum().to(torch.float64), done_eps])
+    sharding.allreduce_metrics(metrics)
+
+    total_env_steps = float(world) * n * args.steps
+    value = total_env_steps / wall_max
+
+    # roofline of the dominant kernel (k_rollout): algorithmic HBM bytes per launch / mean launch duration
+    state_bytes = S_CRAMPED if args.layout == "cramped_room" else 4 * ((env.n_planes * 16) // 4)
+    bytes_per_launch = n * (2 * state_bytes + OUT_BYTES * fuse)
+    full_launches = args.steps // fuse
+    launch_ms = dev_ms / launches
+    if args.steps % fuse:
+        # mean over equal-size launches only; the ragged tail launch is excluded pro rata
+        launch_ms = dev_ms * (fuse / float(args.steps))
+    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    out = {
+        "metric": "env steps/sec (whole node), 65k parallel cramped_room envs",
+        "value": value, "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall_max * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "%s x %d envs/GPU, in-kernel Philox random policy, horizon %d auto-reset, outputs every step"
+                               % (args.layout, n, HORIZON),
+                   "envs_per_gpu": n, "fused_steps_per_launch": fuse, "launches": launches, "parallelism": "env-shard x%d" % world},
+        "roofline": {"bound": "hbm", "kernel": "k_rollout", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_launch": bytes_per_launch, "launch_ms": launch_ms,
+                     "bytes_model": "n_envs*(2*S + 17*T): S=%d B state in+out once per launch, 17 B outputs per env-step, actions in-kernel" % state_bytes,
+                     "survey_8d_per_step_model_GBs": n * (2 * state_bytes + OUT_BYTES) * fuse / (launch_ms * 1e-3) / 1e9},
+        "device_ms_timed_region": dev_ms,
+        "aggregate": {"sparse_return_last_launch": float(metrics[0]), "shaped_return_last_launch": float(metrics[1]),
+                      "episodes_done_last_step": float(metrics[2])},
+    }
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        out["step_api"] = bench_step_api(env, dev, torch)
+        out["encode"] = bench_encode(dev, torch, VecOvercookedEnv)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.layout, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    sharding.barrier()
+
+
+def bench_step_api(env, dev, torch, iters=2000):
+    """The one-launch-per-step API (actions supplied by the caller, resident in HBM): oc_step per batched step."""
+    n = env.n_envs
+    acts = torch.randint(0, 6, (16, n, 2), dtype=torch.uint8, device=dev)
+    for i in range(50):
+        env.step(acts[i % 16])
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(iters):
+        env.step(acts[i % 16])
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    ms = ev0.elapsed_time(ev1) / iters
+    b = n * (2 * S_CRAMPED + 2 + OUT_BYTES)
+    return {"value": n * iters / wall, "unit": "env steps/s", "launch_ms": ms, "bytes_per_launch": b,
+            "achieved_GBs": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "oc_step, one launch per batched step incl. Python/ctypes launch overhead; SURVEY 8d: 67 B/env-step"}
+
+
+def bench_encode(dev, torch, VecOvercookedEnv, iters=200):
+    """BASELINE configs[2] kernel: lossless_state_encoding of 65 536 asymmetric_advantages envs."""
+    n = N_ENVS_PER_GPU
+    env = VecOvercookedEnv("asymmetric_advantages", n, horizon=HORIZON, device=dev, auto_reset=True, seed=1)
+    env.rollout_random(150)
+    res = {}
+    for name, dt, elem in (("u8", torch.uint8, 1), ("f32", torch.float32, 4)):
+        obs = torch.empty((n, 2, env.width, env.height, 26), dtype=dt, device=dev)
+        for _ in range(5):
+            env.encode_lossless(dt, out=obs)
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(iters):
+            env.encode_lossless(dt, out=obs)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        ms = ev0.elapsed_time(ev1) / iters
+        b = n * (S_ASYM + 2 * env.width * env.height * 26 * elem)
+        res[name] = {"launch_ms": ms, "bytes_per_launch": b, "achieved_GBs": b / (ms * 1e-3) / 1e9,
+                     "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "env_encodes_per_s": n / (ms * 1e-3)}
+    res["note"] = "k_encode on asymmetric_advantages x 65536; SURVEY 8d: 2384 B (u8) / 9404 B (f32) per env"
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -437,7 +437,44 @@ def _micro_cases():
     return cases
 
 
+def gen_layout_luts():
+    """For every 1-/2-player layout of the reference: the quantities overcooked_ai_amd.layouts.compile_layout
+    flattens, taken from the live reference objects (Recipe.time mdp.py:163, get_recipe_value mdp.py:1595,
+    terrain_mtx, start_player_positions, get_pot_locations)."""
+    import itertools
+    out = {}
+    for name in L.layout_names():
+        spec = L.spec_from_name(name)
+        if spec.num_players not in (1, 2):
+            continue
+        mdp = R.OvercookedGridworld.from_layout_name(name)
+        activate(mdp)
+        st = mdp.get_standard_start_state() if not mdp.start_state else mdp.start_state
+        ct, val = [0] * 16, [0.0] * 16
+        for n in (1, 2, 3):
+            for ings in itertools.combinations_with_replacement(["onion", "tomato"], n):
+                r = R.Recipe(list(ings))
+                n_t = ings.count("tomato")
+                idx = (n - n_t) + 4 * n_t
+                ct[idx] = r.time
+                val[idx] = mdp.get_recipe_value(st, r)
+        out[name] = {
+            "terrain": ["".join(row) for row in mdp.terrain_mtx],
+            "start_player_positions": [list(p) for p in mdp.start_player_positions],
+            "pot_locations": [list(p) for p in mdp.get_pot_locations()],
+            "cook_time": ct, "delivery_value": val,
+            "rew": [mdp.reward_shaping_params[k] for k in ("PLACEMENT_IN_POT_REW", "DISH_PICKUP_REWARD", "SOUP_PICKUP_REWARD")],
+        }
+    with open(os.path.join(GOLDEN, "layout_luts.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("layout_luts", len(out))
+
+
 def main():
+    if "--luts-only" in sys.argv:
+        os.makedirs(GOLDEN, exist_ok=True)
+        gen_layout_luts()
+        return
     os.makedirs(GOLDEN, exist_ok=True)
     manifest = {"generator": "oracle/gen_golden.py", "reference": "HumanCompatibleAI/overcooked_ai @ /root/reference",
                 "event_types": EVENT_TYPES, "configs": {}}
@@ -456,6 +493,7 @@ def main():
         if name in ("cramped_room", "asymmetric_advantages", "counter_circuit", "mdp_test", "cramped_room_old_dynamics"):
             manifest["configs"][name]["rollouts"] = gen_rollouts(name, lname, ov, n_envs=24, seed=77 + i)
             print("rollouts", name)
+    gen_layout_luts()
     with open(os.path.join(GOLDEN, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
     print("done")

@@ -1,0 +1,76 @@
+"""The C-ABI library builds for gfx950, loads without a GPU and exports every symbol include/oc_amd.h declares.
+No compute calls here (those need a GPU: tests/test_gpu_parity.py)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "oc_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(oc_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from overcooked_ai_amd import _lib, build
+
+    path = build.build_extension()
+    assert os.path.exists(path)
+    L = _lib.load()
+    syms = _declared_symbols()
+    assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
+    for s in syms:
+        assert getattr(L, s) is not None
+    assert L.oc_abi_version() == 1
+    assert L.oc_layout_size() == 256
+    assert L.oc_state_planes(5, 4) == 3 and L.oc_state_planes(9, 5) == 4 and L.oc_state_planes(14, 9) == 9
+
+
+def test_batch_struct_layout_matches_header():
+    from overcooked_ai_amd import _lib
+
+    # OcBatch: two pointers, int64, three int32 (+4 padding) = 40 bytes on LP64
+    assert ctypes.sizeof(_lib.OcBatch) == 40
+    assert _lib.OcBatch.n_envs.offset == 16 and _lib.OcBatch.n_layouts.offset == 24
+    assert _lib.OcBatch.width.offset == 28 and _lib.OcBatch.height.offset == 32
+
+
+def test_argument_validation_without_gpu():
+    """Argument errors are detected on the host before any launch, so they are testable without a GPU."""
+    from overcooked_ai_amd import _lib
+
+    L = _lib.load()
+    assert L.oc_step(None, None, None, None, None, None, None, 400, 0, None) == -1
+    assert b"batch is NULL" in L.oc_last_error()
+    b = _lib.OcBatch(d_layouts=None, d_layout_id=None, n_envs=4, n_layouts=1, width=5, height=4)
+    assert L.oc_reset(ctypes.byref(b), None, None, None, None) == -1
+    assert b"d_layouts" in L.oc_last_error()
+    b = _lib.OcBatch(d_layouts=4096, d_layout_id=None, n_envs=4, n_layouts=1, width=40, height=40)
+    assert L.oc_reset(ctypes.byref(b), 4096, None, None, None) == -1
+    assert b"grid shape" in L.oc_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under overcooked_ai_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "overcooked_ai_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "liboracle" not in text, f
+
+
+def test_vec_env_fails_loudly_without_gpu():
+    import pytest
+    import torch
+
+    from overcooked_ai_amd import _lib
+    from overcooked_ai_amd.vec_env import VecOvercookedEnv
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.OcAmdError):
+        VecOvercookedEnv("cramped_room", 4, device="cpu")

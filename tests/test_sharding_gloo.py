@@ -1,0 +1,87 @@
+"""Multi-GPU path on CPU: world_size-2 gloo process group.  The envs shard as contiguous ranges with no
+data-path collective; each rank steps its shard (here with the CPU oracle standing in for the GPU) using its
+global env offset for the Philox streams, and only the aggregate metrics are all-reduced."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from overcooked_ai_amd.sharding import shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 65536, 524288, 1000003):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_global, steps, seed, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch
+
+    from oracle import oracle as O
+    from overcooked_ai_amd import sharding
+    from overcooked_ai_amd.layouts import spec_from_name
+
+    r, lr, w = sharding.init_process_group(backend="gloo")
+    assert (r, w) == (rank, world)
+    a, b = sharding.shard_range(n_global, r, w)
+    orc = O.Oracle(O.mdp_from_layout_dict(spec_from_name("cramped_room").to_layout_dict()))
+    st = orc.reset(orc.new_state(b - a))
+    ep = np.zeros((b - a, 4), np.float32)
+    rew, fl = orc.rollout_random(st, steps, horizon=50, options=1, seed=seed, env_offset=a, ep_returns=ep)
+    metrics = torch.tensor([rew[..., :2].sum(), rew[..., 2:].sum(), float((fl & 1).sum()), float((b - a) * steps)],
+                           dtype=torch.float64)
+    sharding.allreduce_metrics(metrics)
+    tmax = torch.tensor([float(rank)], dtype=torch.float64)
+    sharding.allreduce_max(tmax)
+    sharding.barrier()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), state=st, metrics=metrics.numpy(), span=np.array([a, b]),
+             tmax=tmax.numpy())
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_shards_reproduce_the_unsharded_batch(tmp_path):
+    import torch.multiprocessing as mp
+
+    from oracle import oracle as O
+    from overcooked_ai_amd.layouts import spec_from_name
+
+    n_global, steps, seed, world = 1001, 120, 42, 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_global, steps, seed, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    orc = O.Oracle(O.mdp_from_layout_dict(spec_from_name("cramped_room").to_layout_dict()))
+    st = orc.reset(orc.new_state(n_global))
+    rew, fl = orc.rollout_random(st, steps, horizon=50, options=1, seed=seed)
+    expect = np.array([rew[..., :2].sum(), rew[..., 2:].sum(), float((fl & 1).sum()), float(n_global * steps)])
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        a, b = d["span"]
+        assert np.array_equal(d["state"], st[:, a:b])          # shard == slice of the unsharded run
+        assert np.allclose(d["metrics"], expect)                # all-reduced aggregate metrics
+        assert d["tmax"][0] == world - 1

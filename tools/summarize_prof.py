@@ -1,0 +1,67 @@
+"""Summarise rocprofv3 (rocpd sqlite) outputs of tools/profile_round.sh into a small text file for profiles/.
+
+    python tools/summarize_prof.py gpurun_out/prof_r01 profiles/r01_bench_rocprof.txt
+
+Per kernel: calls, mean/min/max duration (kernel-trace pass) and mean FETCH_SIZE / WRITE_SIZE per dispatch (two
+separate --pmc passes).  FETCH_SIZE/WRITE_SIZE are reported by rocprofv3 in KiB; per MI355X_MICROARCH.md §HBM
+FETCH_SIZE on gfx950 counts wide coalesced reads at half their bytes, so the "corrected" column doubles it.
+"""
+import glob
+import os
+import sqlite3
+import sys
+
+
+def q(dbpath, sql):
+    db = sqlite3.connect(dbpath)
+    try:
+        return db.execute(sql).fetchall()
+    finally:
+        db.close()
+
+
+def main(src, dst):
+    lines = []
+    trace = glob.glob(os.path.join(src, "trace", "*.db"))
+    kern = {}
+    if trace:
+        rows = q(trace[0], "select name, count(*), avg(duration), min(duration), max(duration), sum(duration), "
+                           "max(vgpr_count), max(sgpr_count), max(lds_size), max(grid_x), max(workgroup_x) "
+                           "from kernels group by name order by sum(duration) desc")
+        lines.append("== rocprofv3 --kernel-trace --stats : per-kernel durations (ns) ==")
+        lines.append("%-70s %7s %12s %10s %10s %14s %5s %5s %7s %9s %5s" % (
+            "kernel", "calls", "mean_ns", "min_ns", "max_ns", "total_ns", "vgpr", "sgpr", "lds", "grid", "wg"))
+        for r in rows:
+            name = r[0].replace("void (anonymous namespace)::", "")
+            name = name.split("(")[0]
+            kern[r[0]] = r
+            lines.append("%-70s %7d %12.1f %10d %10d %14d %5s %5s %7s %9s %5s" % (name[:70], r[1], r[2], r[3], r[4], r[5],
+                                                                           r[6], r[7], r[8], r[9], r[10]))
+    for label, sub, counter in (("FETCH_SIZE", "pmc_fetch", "FETCH_SIZE"), ("WRITE_SIZE", "pmc_write", "WRITE_SIZE")):
+        dbs = glob.glob(os.path.join(src, sub, "*.db"))
+        if not dbs:
+            continue
+        rows = q(dbs[0], "select name, count(*), avg(counter_value), min(counter_value), max(counter_value) "
+                         "from pmc_events where counter_name='%s' group by name order by sum(counter_value) desc" % counter)
+        lines.append("")
+        lines.append("== rocprofv3 --pmc %s : KiB per dispatch (separate pass) ==" % counter)
+        lines.append("%-70s %7s %14s %12s %12s %s" % ("kernel", "calls", "mean_KiB", "min_KiB", "max_KiB",
+                                                      "mean_bytes_corrected" if counter == "FETCH_SIZE" else "mean_bytes"))
+        for r in rows:
+            name = r[0].replace("void (anonymous namespace)::", "").split("(")[0]
+            b = r[2] * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
+            lines.append("%-70s %7d %14.2f %12.2f %12.2f %.0f" % (name[:70], r[1], r[2], r[3], r[4], b))
+    for log in sorted(glob.glob(os.path.join(src, "bench_*.log"))):
+        for l in open(log, errors="replace"):
+            if l.startswith("{\"metric\""):
+                lines.append("")
+                lines.append("== bench.py JSON line under %s ==" % os.path.basename(log))
+                lines.append(l.strip())
+    os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+    with open(dst, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines[:40]))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
