@@ -108,7 +108,9 @@ typedef struct OcLayout {
     uint8_t start_or[2];
     uint8_t reserved1[4];
     uint8_t pot_cell[OC_MAX_POTS];
-    uint8_t reserved2[8];
+    uint8_t potting_class[8];   /* [n_onion + 3*n_tomato of the soup BEFORE the potting], low nibble: an onion is
+                                   added, high nibble: a tomato; bit 0 optimal, 1 viable, 2 catastrophic, 3 useless
+                                   (is_potting_*, mdp.py:2256-2308) */
     float rew_placement_in_pot; /* PLACEMENT_IN_POT_REW, mdp.py:1019 */
     float rew_dish_pickup;      /* DISH_PICKUP_REWARD */
     float rew_soup_pickup;      /* SOUP_PICKUP_REWARD */
@@ -129,6 +131,8 @@ typedef struct OcBatch {
     int64_t n_envs;
     int32_t n_layouts;
     int32_t width, height;       /* grid shape shared by every layout of the table */
+    int32_t max_pots;            /* max n_pots over the table (1..8), or 0 if unknown: selects how many pot slots
+                                    the step kernels keep in registers */
 } OcBatch;
 
 int oc_abi_version(void);
@@ -148,17 +152,22 @@ int oc_state_planes(int width, int height);
  *   d_flags        [n_envs] OC_F_* bits
  *   d_ep_returns   [n_envs][4] float running sums of d_rewards over the episode
  *                  (game_stats cumulative_*_rewards_by_agent, env.py:387-392), or NULL
+ *   d_events       [n_envs] u64 event_infos of this step (EVENT_TYPES, mdp.py:1027-1058): bit 2*k + p is
+ *                  event_infos[EVENT_TYPES[k]][p]; or NULL to skip event logging
  *   horizon        done when timestep >= horizon (1..65535)
  */
 int oc_step(const OcBatch* batch, const void* d_state_in, void* d_state_out, const uint8_t* d_actions,
-            float* d_rewards, uint8_t* d_flags, float* d_ep_returns, int horizon, uint32_t options,
-            void* stream);
+            float* d_rewards, uint8_t* d_flags, float* d_ep_returns, uint64_t* d_events, int horizon,
+            uint32_t options, void* stream);
 
 /*
  * oc_rollout_random — n_steps transitions per launch under the uniform random policy
  * (the reference's RandomAgent(all_actions=True) pair, agents/agent.py:223), actions drawn
- * in-kernel: the action of player p of global env g at global step t is
- *      philox4x32_10(counter = {t_lo, g_lo, g_hi, t_hi}, key = {seed_lo, seed_hi})[p] % 6.
+ * in-kernel.  One Philox4x32-10 block feeds 8 consecutive steps: with b = t >> 3, s = t & 7,
+ *      r[0..3] = philox4x32_10(counter = {b_lo, g_lo, g_hi, b_hi}, key = {seed_lo, seed_hi}),
+ *      x = r[s >> 1] * (s & 1 ? 36 : 1)  (mod 2^32),
+ *      action of player 0 = mulhi32(x, 6),  action of player 1 = mulhi32(x * 6 mod 2^32, 6)
+ * for global env g at global step t (base-6 digits of the 32-bit word; bias < 6^4 / 2^32).
  * Same transition function as oc_step; state stays on chip between the fused steps.
  *   d_rewards  [n_steps][n_envs][4] or NULL;  d_flags [n_steps][n_envs] or NULL
  *   env_offset global index of local env 0 (multi-GPU shards draw disjoint streams)

@@ -204,9 +204,11 @@ class Oracle:
         out = np.empty_like(state)
         rewards = np.zeros((n, 4), dtype=np.float32)
         flags = np.zeros((n,), dtype=np.uint8)
+        self.last_events = np.zeros((n,), dtype=np.uint64)  # EVENT_TYPES bit mask, bit 2*k + player
         rc = lib().oracle_step(self.arr, self.n, _ptr(lid, ctypes.c_uint16), _ptr(np.ascontiguousarray(state), ctypes.c_uint8),
                                _ptr(out, ctypes.c_uint8), _ptr(actions, ctypes.c_uint8), _ptr(rewards, ctypes.c_float),
-                               _ptr(flags, ctypes.c_uint8), _ptr(ep_returns, ctypes.c_float), ctypes.c_int64(n),
+                               _ptr(flags, ctypes.c_uint8), _ptr(ep_returns, ctypes.c_float),
+                               _ptr(self.last_events, ctypes.c_uint64), ctypes.c_int64(n),
                                int(horizon), ctypes.c_uint32(options))
         assert rc == 0
         return out, rewards, flags

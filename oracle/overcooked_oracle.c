@@ -194,9 +194,110 @@ static int is_dish_pickup_useful(const OracleMdp* m, const State* s, const PotSt
     return dishes_on_counters == 0 && num_player_dishes < non_empty_pots;
 }
 
+/* ---------------------------------- event logging, mdp.py:1027-1058, 2121-2308 ------------- */
+
+/* EVENT_TYPES order, mdp.py:1027-1058; bit index of (event k, player p) in the mask is 2*k + p */
+enum {
+    EV_TOMATO_PICKUP = 0, EV_USEFUL_TOMATO_PICKUP, EV_TOMATO_DROP, EV_USEFUL_TOMATO_DROP, EV_POTTING_TOMATO,
+    EV_ONION_PICKUP, EV_USEFUL_ONION_PICKUP, EV_ONION_DROP, EV_USEFUL_ONION_DROP, EV_POTTING_ONION,
+    EV_DISH_PICKUP, EV_USEFUL_DISH_PICKUP, EV_DISH_DROP, EV_USEFUL_DISH_DROP,
+    EV_SOUP_PICKUP, EV_SOUP_DELIVERY, EV_SOUP_DROP,
+    EV_OPTIMAL_ONION_POTTING, EV_OPTIMAL_TOMATO_POTTING, EV_VIABLE_ONION_POTTING, EV_VIABLE_TOMATO_POTTING,
+    EV_CATASTROPHIC_ONION_POTTING, EV_CATASTROPHIC_TOMATO_POTTING, EV_USELESS_ONION_POTTING, EV_USELESS_TOMATO_POTTING
+};
+
+static void set_event(uint64_t* ev, int k, int player) { *ev |= (uint64_t)1 << (2 * k + player); }
+
+/* get_full_pots: cooking + ready + "3_items", mdp.py:1872-1880 */
+static int num_full_pots(const OracleMdp* m, const PotStates* ps) {
+    int n = 0;
+    for (int i = 0; i < ps->n_pots; ++i)
+        if (ps->cls[i] == POT_COOKING || ps->cls[i] == POT_READY || ps->cls[i] == m->max_num_ingredients) ++n;
+    return n;
+}
+
+static int other_holds(const State* s, int player_index, int name) {
+    const Player* o = &s->players[1 - player_index];
+    return o->present && o->held.name == name;
+}
+
+/* mdp.py:2223-2237 */
+static int is_ingredient_pickup_useful(const OracleMdp* m, const State* s, const PotStates* ps, int player_index) {
+    if (m->n_players != 2) return 0;
+    int all_pots_full = ps->n_pots == num_full_pots(m, ps);
+    return !(all_pots_full && !other_holds(s, player_index, NAME_DISH));
+}
+/* mdp.py:2239-2254 */
+static int is_ingredient_drop_useful(const OracleMdp* m, const State* s, const PotStates* ps, int player_index) {
+    if (m->n_players != 2) return 0;
+    int all_pots_full = num_full_pots(m, ps) == ps->n_pots;
+    return all_pots_full && !other_holds(s, player_index, NAME_DISH);
+}
+/* mdp.py:2206-2221 */
+static int is_dish_drop_useful(const OracleMdp* m, const State* s, const PotStates* ps, int player_index) {
+    if (m->n_players != 2) return 0;
+    int all_non_full = num_full_pots(m, ps) == 0;
+    return all_non_full && !other_holds(s, player_index, NAME_ONION);
+}
+
+/* log_object_pickup, mdp.py:2142-2159 */
+static void log_object_pickup(const OracleMdp* m, uint64_t* ev, const State* s, int name, const PotStates* ps, int pi) {
+    static const int key[5] = {-1, EV_ONION_PICKUP, EV_TOMATO_PICKUP, EV_DISH_PICKUP, EV_SOUP_PICKUP};
+    static const int useful_key[5] = {-1, EV_USEFUL_ONION_PICKUP, EV_USEFUL_TOMATO_PICKUP, EV_USEFUL_DISH_PICKUP, -1};
+    set_event(ev, key[name], pi);
+    int useful = 0;
+    if (name == NAME_ONION || name == NAME_TOMATO) useful = is_ingredient_pickup_useful(m, s, ps, pi);
+    else if (name == NAME_DISH) useful = is_dish_pickup_useful(m, s, ps);
+    if (useful) set_event(ev, useful_key[name], pi);
+}
+
+/* log_object_drop, mdp.py:2161-2178 */
+static void log_object_drop(const OracleMdp* m, uint64_t* ev, const State* s, int name, const PotStates* ps, int pi) {
+    static const int key[5] = {-1, EV_ONION_DROP, EV_TOMATO_DROP, EV_DISH_DROP, EV_SOUP_DROP};
+    static const int useful_key[5] = {-1, EV_USEFUL_ONION_DROP, EV_USEFUL_TOMATO_DROP, EV_USEFUL_DISH_DROP, -1};
+    set_event(ev, key[name], pi);
+    int useful = 0;
+    if (name == NAME_ONION || name == NAME_TOMATO) useful = is_ingredient_drop_useful(m, s, ps, pi);
+    else if (name == NAME_DISH) useful = is_dish_drop_useful(m, s, ps, pi);
+    if (useful) set_event(ev, useful_key[name], pi);
+}
+
+/* Value of the best recipe reachable from (n_o, n_t) by adding ingredients: the DFS of
+ * _get_optimal_possible_recipe (mdp.py:1976-2016) followed by get_recipe_value of its result.  (0,0) stands
+ * for the empty recipe (recipe == None). */
+static double optimal_possible_value(const OracleMdp* m, int n_o, int n_t) {
+    double best = 0.0;
+    if (n_o + n_t >= 1) {
+        double v = get_recipe_value(m, n_o, n_t);
+        if (v > best) best = v;
+    }
+    if (n_o + n_t < m->max_num_ingredients) { /* Recipe.neighbors, mdp.py:193-205 */
+        double a = optimal_possible_value(m, n_o + 1, n_t), b = optimal_possible_value(m, n_o, n_t + 1);
+        if (a > best) best = a;
+        if (b > best) best = b;
+    }
+    return best;
+}
+
+/* log_object_potting, mdp.py:2121-2140 with is_potting_{optimal,viable,catastrophic,useless} 2256-2308 */
+static void log_object_potting(const OracleMdp* m, uint64_t* ev, const Obj* old_soup, const Obj* new_soup, int name, int pi) {
+    int tomato = name == NAME_TOMATO;
+    set_event(ev, tomato ? EV_POTTING_TOMATO : EV_POTTING_ONION, pi);
+    int o_o, o_t, n_o, n_t;
+    count_ing(old_soup, &o_o, &o_t);
+    count_ing(new_soup, &n_o, &n_t);
+    double old_val = optimal_possible_value(m, o_o, o_t);
+    double new_val = optimal_possible_value(m, n_o, n_t);
+    if (old_val == new_val) set_event(ev, EV_OPTIMAL_ONION_POTTING + tomato, pi);
+    if (old_val > 0 && new_val == 0) set_event(ev, EV_CATASTROPHIC_ONION_POTTING + tomato, pi);
+    if (new_val > 0) set_event(ev, EV_VIABLE_ONION_POTTING + tomato, pi);
+    if (old_val == 0) set_event(ev, EV_USELESS_ONION_POTTING + tomato, pi);
+}
+
 /* ---------------------------------- resolve_interacts, mdp.py:1432-1579 ------------------- */
 
-static void resolve_interacts(const OracleMdp* m, State* ns, const int* joint_action, double* sparse, double* shaped) {
+static void resolve_interacts(const OracleMdp* m, State* ns, const int* joint_action, double* sparse, double* shaped,
+                              uint64_t* ev) {
     PotStates pot_states;
     get_pot_states(m, ns, &pot_states); /* once, before any interact: mdp.py:1439 */
     sparse[0] = sparse[1] = 0.0;
@@ -214,19 +315,23 @@ static void resolve_interacts(const OracleMdp* m, State* ns, const int* joint_ac
 
         if (terrain_type == 'X') {
             if (has_obj && at->name == NAME_NONE) { /* drop on counter, mdp.py:1459-1471 */
+                log_object_drop(m, ev, ns, player->held.name, &pot_states, player_idx);
                 *at = player->held;
                 player->held.name = NAME_NONE;
             } else if (!has_obj && at->name != NAME_NONE) { /* pick up from counter, mdp.py:1473-1485 */
+                log_object_pickup(m, ev, ns, at->name, &pot_states, player_idx);
                 player->held = *at;
                 at->name = NAME_NONE;
             }
         } else if (terrain_type == 'O' && !has_obj) { /* mdp.py:1487-1494 */
+            log_object_pickup(m, ev, ns, NAME_ONION, &pot_states, player_idx);
             memset(&player->held, 0, sizeof(Obj));
             player->held.name = NAME_ONION;
         } else if (terrain_type == 'T' && !has_obj) { /* mdp.py:1496-1498 */
             memset(&player->held, 0, sizeof(Obj));
             player->held.name = NAME_TOMATO;
         } else if (terrain_type == 'D' && !has_obj) { /* mdp.py:1500-1513 */
+            log_object_pickup(m, ev, ns, NAME_DISH, &pot_states, player_idx);
             if (is_dish_pickup_useful(m, ns, &pot_states)) shaped[player_idx] += m->rew_dish_pickup;
             memset(&player->held, 0, sizeof(Obj));
             player->held.name = NAME_DISH;
@@ -238,6 +343,7 @@ static void resolve_interacts(const OracleMdp* m, State* ns, const int* joint_ac
         } else if (terrain_type == 'P' && has_obj) {
             if (player->held.name == NAME_DISH && at->name == NAME_SOUP && soup_is_ready(m, at)) {
                 /* soup pickup, mdp.py:1525-1539 */
+                log_object_pickup(m, ev, ns, NAME_SOUP, &pot_states, player_idx);
                 player->held = *at;
                 at->name = NAME_NONE;
                 shaped[player_idx] += m->rew_soup_pickup;
@@ -249,9 +355,12 @@ static void resolve_interacts(const OracleMdp* m, State* ns, const int* joint_ac
                     at->tick = -1;
                 }
                 if (!soup_is_full(m, at)) {
-                    at->ing[at->n_ing++] = player->held.name; /* add_ingredient, mdp.py:571-577 */
+                    Obj old_soup = *at; /* soup.deepcopy(), mdp.py:1551 */
+                    int ing_name = player->held.name;
+                    at->ing[at->n_ing++] = ing_name; /* add_ingredient, mdp.py:571-577 */
                     player->held.name = NAME_NONE;
                     shaped[player_idx] += m->rew_placement_in_pot;
+                    log_object_potting(m, ev, &old_soup, at, ing_name, player_idx);
                 }
             }
         } else if (terrain_type == 'S' && has_obj) { /* mdp.py:1570-1577 */
@@ -260,6 +369,7 @@ static void resolve_interacts(const OracleMdp* m, State* ns, const int* joint_ac
                 count_ing(&player->held, &n_o, &n_t);
                 player->held.name = NAME_NONE;                /* deliver_soup, mdp.py:1631-1642 */
                 sparse[player_idx] += get_recipe_value(m, n_o, n_t);
+                set_event(ev, EV_SOUP_DELIVERY, player_idx);
             }
         }
     }
@@ -311,8 +421,9 @@ static void step_environment_effects(const OracleMdp* m, State* s) {
 }
 
 /* get_state_transition, mdp.py:1375-1430 */
-static void state_transition(const OracleMdp* m, State* ns, const int* joint_action, double* sparse, double* shaped) {
-    resolve_interacts(m, ns, joint_action, sparse, shaped);
+static void state_transition(const OracleMdp* m, State* ns, const int* joint_action, double* sparse, double* shaped,
+                             uint64_t* ev) {
+    resolve_interacts(m, ns, joint_action, sparse, shaped, ev);
     resolve_movement(m, ns, joint_action);
     step_environment_effects(m, ns);
 }
@@ -424,15 +535,18 @@ static void pack_state(const OracleMdp* m, const State* s, uint8_t* planes, int6
 #define OPT_AUTO_RESET 0x1u
 
 static void env_step_one(const OracleMdp* m, State* s, const int* ja, float* rew4, uint8_t* flag, float* ep4,
-                         int horizon, uint32_t options) {
+                         int horizon, uint32_t options, uint64_t* events) {
     double sparse[2], shaped[2];
     uint8_t f = 0;
+    uint64_t ev = 0;
+    if (events) *events = 0;
     if (ja[0] < 0 || ja[0] > 5 || ja[1] < 0 || ja[1] > 5) { /* mdp.py:1394-1398 raises ValueError */
         if (rew4) rew4[0] = rew4[1] = rew4[2] = rew4[3] = 0.f;
         if (flag) *flag = F_BAD_ACTION;
         return;
     }
-    state_transition(m, s, ja, sparse, shaped);
+    state_transition(m, s, ja, sparse, shaped, &ev);
+    if (events) *events = ev;
     if (rew4) {
         rew4[0] = (float)sparse[0]; rew4[1] = (float)sparse[1];
         rew4[2] = (float)shaped[0]; rew4[3] = (float)shaped[1];
@@ -454,7 +568,7 @@ static void env_step_one(const OracleMdp* m, State* s, const int* ja, float* rew
 
 int oracle_step(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, const uint8_t* state_in,
                 uint8_t* state_out, const uint8_t* actions, float* rewards, uint8_t* flags, float* ep_returns,
-                int64_t n_envs, int horizon, uint32_t options) {
+                uint64_t* events, int64_t n_envs, int horizon, uint32_t options) {
     (void)n_mdps;
     for (int64_t e = 0; e < n_envs; ++e) {
         const OracleMdp* m = &mdps[layout_id ? layout_id[e] : 0];
@@ -462,7 +576,7 @@ int oracle_step(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, co
         unpack_state(m, state_in, n_envs, e, &s);
         int ja[2] = {actions[2 * e], actions[2 * e + 1]};
         env_step_one(m, &s, ja, rewards ? rewards + 4 * e : 0, flags ? flags + e : 0, ep_returns ? ep_returns + 4 * e : 0,
-                     horizon, options);
+                     horizon, options, events ? events + e : 0);
         pack_state(m, &s, state_out, n_envs, e);
     }
     return 0;
@@ -502,15 +616,28 @@ void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-void oracle_random_actions(uint64_t seed, int64_t env_offset, int64_t t, int64_t n_envs, uint8_t* actions) {
+/* Action stream of oc_rollout_random (include/oc_amd.h): one Philox block feeds 8 consecutive steps; word s/2
+ * of block t/8 is expanded into base-6 digits by multiply-high, two digits (player 0, player 1) per step. */
+static void draw_actions(uint64_t seed, uint64_t g, uint64_t t, int* a0, int* a1) {
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint64_t blk = t >> 3;
+    uint32_t s8 = (uint32_t)(t & 7u);
+    uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(blk >> 32)};
+    uint32_t r[4];
+    oracle_philox4x32_10(ctr, key, r);
+    uint32_t x = r[s8 >> 1];
+    if (s8 & 1u) x *= 36u;
+    *a0 = (int)(((uint64_t)x * 6u) >> 32);
+    x *= 6u;
+    *a1 = (int)(((uint64_t)x * 6u) >> 32);
+}
+
+void oracle_random_actions(uint64_t seed, int64_t env_offset, int64_t t, int64_t n_envs, uint8_t* actions) {
     for (int64_t e = 0; e < n_envs; ++e) {
-        uint64_t g = (uint64_t)(env_offset + e);
-        uint32_t ctr[4] = {(uint32_t)(uint64_t)t, (uint32_t)g, (uint32_t)(g >> 32), (uint32_t)((uint64_t)t >> 32)};
-        uint32_t r[4];
-        oracle_philox4x32_10(ctr, key, r);
-        actions[2 * e] = (uint8_t)(r[0] % 6u);
-        actions[2 * e + 1] = (uint8_t)(r[1] % 6u);
+        int a0, a1;
+        draw_actions(seed, (uint64_t)(env_offset + e), (uint64_t)t, &a0, &a1);
+        actions[2 * e] = (uint8_t)a0;
+        actions[2 * e + 1] = (uint8_t)a1;
     }
 }
 
@@ -518,21 +645,17 @@ int oracle_rollout_random(const OracleMdp* mdps, int n_mdps, const uint16_t* lay
                           uint8_t* flags, float* ep_returns, int64_t n_envs, int horizon, uint32_t options,
                           uint64_t seed, int64_t env_offset, int64_t t0, int n_steps) {
     (void)n_mdps;
-    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     for (int64_t e = 0; e < n_envs; ++e) {
         const OracleMdp* m = &mdps[layout_id ? layout_id[e] : 0];
         State s;
         unpack_state(m, state, n_envs, e, &s);
         uint64_t g = (uint64_t)(env_offset + e);
         for (int k = 0; k < n_steps; ++k) {
-            uint64_t t = (uint64_t)(t0 + k);
-            uint32_t ctr[4] = {(uint32_t)t, (uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(t >> 32)};
-            uint32_t r[4];
-            oracle_philox4x32_10(ctr, key, r);
-            int ja[2] = {(int)(r[0] % 6u), (int)(r[1] % 6u)};
+            int ja[2];
+            draw_actions(seed, g, (uint64_t)(t0 + k), &ja[0], &ja[1]);
             env_step_one(m, &s, ja, rewards ? rewards + 4 * ((int64_t)k * n_envs + e) : 0,
                          flags ? flags + ((int64_t)k * n_envs + e) : 0, ep_returns ? ep_returns + 4 * e : 0, horizon,
-                         options);
+                         options, 0);
         }
         pack_state(m, &s, state, n_envs, e);
     }

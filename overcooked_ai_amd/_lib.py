@@ -23,6 +23,7 @@ class OcBatch(ctypes.Structure):
         ("n_layouts", ctypes.c_int32),
         ("width", ctypes.c_int32),
         ("height", ctypes.c_int32),
+        ("max_pots", ctypes.c_int32),
     ]
 
 
@@ -57,7 +58,7 @@ def load():
     L.oc_state_planes.restype = i32
     L.oc_state_planes.argtypes = [i32, i32]
     L.oc_step.restype = i32
-    L.oc_step.argtypes = [bp, vp, vp, vp, vp, vp, vp, i32, u32, vp]
+    L.oc_step.argtypes = [bp, vp, vp, vp, vp, vp, vp, vp, i32, u32, vp]
     L.oc_rollout_random.restype = i32
     L.oc_rollout_random.argtypes = [bp, vp, vp, vp, vp, i32, u32, u64, i64, i64, i32, vp]
     L.oc_encode_lossless.restype = i32

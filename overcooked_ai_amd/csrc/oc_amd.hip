@@ -26,7 +26,7 @@ constexpr int LDS_LAYOUT_MAX = 32;  // layout tables up to this many entries are
 
 // byte offsets inside OcLayout (include/oc_amd.h)
 constexpr int L_NPOTS = 3, L_NPLAYERS = 4, L_OLDDYN = 5, L_START_POS = 8, L_START_OR = 10, L_POT_CELL = 16,
-              L_REW = 32, L_COOK = 48, L_VALUE = 64, L_TERRAIN = 128;
+              L_PCLASS = 24, L_REW = 32, L_COOK = 48, L_VALUE = 64, L_TERRAIN = 128;
 static_assert(sizeof(OcLayout) == 256, "OcLayout must be 256 bytes");
 
 thread_local char g_err[256] = "";
@@ -38,6 +38,7 @@ thread_local char g_err[256] = "";
 struct Lay {
     const uint8_t* base;
     __device__ __forceinline__ uint32_t u8(int off) const { return base[off]; }
+    __device__ __forceinline__ uint32_t u32(int off) const { return *reinterpret_cast<const uint32_t*>(base + off); }
     __device__ __forceinline__ uint32_t n_pots() const { return u8(L_NPOTS); }
     __device__ __forceinline__ uint32_t n_players() const { return u8(L_NPLAYERS); }
     __device__ __forceinline__ bool old_dynamics() const { return u8(L_OLDDYN) != 0; }
@@ -51,194 +52,337 @@ struct Lay {
     __device__ __forceinline__ float rew_soup() const { return f32(L_REW + 8); }
 };
 
-// Per-lane view of the object bytes of one env, living in LDS as words[dword][lane].
-template <int NOBJ>
-struct ObjLds {
-    uint32_t* col;  // &s_obj[0][tid]; dword w of this lane is col[w * BLOCK]
-    __device__ __forceinline__ uint32_t get(uint32_t c) const {
-        return reinterpret_cast<const uint8_t*>(col + (c >> 2) * BLOCK)[c & 3];
-    }
-    __device__ __forceinline__ void set(uint32_t c, uint32_t v) {
-        reinterpret_cast<uint8_t*>(col + (c >> 2) * BLOCK)[c & 3] = (uint8_t)v;
-    }
-    __device__ __forceinline__ uint32_t word(int w) const { return col[w * BLOCK]; }
-    __device__ __forceinline__ void set_word(int w, uint32_t v) { col[w * BLOCK] = v; }
-    // any byte == OC_O_DISH in the grid?  Only counters can hold a loose dish (pots hold soups,
-    // floor cells nothing), so this is get_counter_objects_dict(state)["dish"] != [] (mdp.py:2195).
-    __device__ __forceinline__ bool any_dish() const {
-        uint32_t acc = 0;
-#pragma unroll
-        for (int w = 0; w < NOBJ * 4; ++w) {
-            uint32_t x = word(w) ^ 0x03030303u;                      // dish bytes become 0
-            acc |= (x - 0x01010101u) & ~x & 0x80808080u;             // classic zero-byte detector
-        }
-        return acc != 0;
-    }
+// ------------------------------------------------------------------------------------------
+// Working representation of one env inside the step / rollout kernels.
+//
+//  * registers: both players, the timestep, and — per pot slot — the soup code and cooking tick
+//    (pots are the only cells whose content is needed every step: stale pot_states, env effects);
+//    the number of loose dishes on counters (is_dish_pickup_useful needs "no dish on any counter");
+//  * LDS: one 16-bit word per grid cell = object code (low byte, wire format) | terrain byte (high
+//    byte: type | pot slot << 3), stored as dwords[cell / 2][lane].  One ds_read_u16 answers "what
+//    terrain is there and what lies on it"; bank = lane % 32 for every cell, so the divergent
+//    per-lane cell indices of a wavefront never conflict.  Per-env (divergent) terrain costs nothing
+//    extra in the step loop.  The object bytes of pot cells are stale while the kernel runs (the
+//    registers are authoritative) and are written back before the planes are stored.
+// ------------------------------------------------------------------------------------------
+template <int MAXP>
+struct EnvW {
+    uint32_t pos0, or0, held0, pos1, or1, held1, t;
+    uint32_t tk[MAXP];  // cooking_tick + 1 per pot slot (0 = idle)
+    uint32_t ps[MAXP];  // soup code per pot slot (0 = empty pot)
+    int32_t dcount;     // loose dishes lying on counters
 };
 
-struct Env {
-    uint32_t pos0, or0, held0, pos1, or1, held1, t;
-    uint32_t tk_lo, tk_hi;  // pot slots 0-3 / 4-7: cooking_tick + 1 per byte
-    __device__ __forceinline__ uint32_t tick1(uint32_t slot) const {
-        uint32_t w = slot < 4 ? tk_lo : tk_hi;
-        return (w >> ((slot & 3) * 8)) & 0xFFu;
-    }
-    __device__ __forceinline__ void set_tick1(uint32_t slot, uint32_t v) {
-        uint32_t sh = (slot & 3) * 8;
-        uint32_t m = ~(0xFFu << sh);
-        if (slot < 4) tk_lo = (tk_lo & m) | (v << sh);
-        else tk_hi = (tk_hi & m) | (v << sh);
-    }
-    __device__ __forceinline__ void unpack(const uint4& h) {
-        pos0 = h.x & 0xFF; or0 = (h.x >> 8) & 0xFF; held0 = (h.x >> 16) & 0xFF; pos1 = h.x >> 24;
-        or1 = h.y & 0xFF; held1 = (h.y >> 8) & 0xFF; t = h.y >> 16;
-        tk_lo = h.z; tk_hi = h.w;
-    }
-    __device__ __forceinline__ uint4 pack() const {
-        uint4 h;
-        h.x = pos0 | (or0 << 8) | (held0 << 16) | (pos1 << 24);
-        h.y = or1 | (held1 << 8) | (t << 16);
-        h.z = tk_lo; h.w = tk_hi;
-        return h;
-    }
+// Per-layout constants the step loop needs every iteration.  With a single layout for the whole batch
+// they are made wave-uniform (SGPRs) via readfirstlane.
+struct LayC {
+    uint32_t old_dyn, n_pots;
+    float rew_place, rew_dish, rew_soup;
+    uint32_t cook[4];    // cook_time[n_onion + 4*n_tomato] as 4 dwords: dword n_tomato, byte n_onion
+    uint32_t pclass[2];  // potting class nibbles (events only)
 };
+
+template <bool UNIFORM>
+__device__ __forceinline__ uint32_t uni(uint32_t v) {
+    return UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v) : v;
+}
+template <bool UNIFORM>
+__device__ __forceinline__ float unif(float v) {
+    return UNIFORM ? __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))) : v;
+}
+
+template <bool UNIFORM>
+__device__ __forceinline__ LayC load_consts(const Lay L) {
+    LayC C;
+    C.old_dyn = uni<UNIFORM>(L.u8(L_OLDDYN));
+    C.n_pots = uni<UNIFORM>(L.u8(L_NPOTS));
+    C.rew_place = unif<UNIFORM>(L.rew_placement());
+    C.rew_dish = unif<UNIFORM>(L.rew_dish());
+    C.rew_soup = unif<UNIFORM>(L.rew_soup());
+#pragma unroll
+    for (int i = 0; i < 4; ++i) C.cook[i] = uni<UNIFORM>(L.u32(L_COOK + 4 * i));
+    C.pclass[0] = uni<UNIFORM>(L.u32(L_PCLASS));
+    C.pclass[1] = uni<UNIFORM>(L.u32(L_PCLASS + 4));
+    return C;
+}
+
+__device__ __forceinline__ uint32_t rd_cell16(const uint32_t* cellw, uint32_t c) {
+    return reinterpret_cast<const uint16_t*>(cellw + (c >> 1) * BLOCK)[c & 1];
+}
+__device__ __forceinline__ void wr_cell_obj(uint32_t* cellw, uint32_t c, uint32_t v) {
+    reinterpret_cast<uint8_t*>(cellw + (c >> 1) * BLOCK)[(c & 1) * 2] = (uint8_t)v;
+}
 
 // recipe index n_onion + 4*n_tomato of a soup code
 __device__ __forceinline__ uint32_t recipe_idx(uint32_t soup) {
-    uint32_t n = (soup >> 3) & 3u;
-    uint32_t nt = __popc(soup & 7u);
+    const uint32_t n = (soup >> 3) & 3u, nt = __popc(soup & 7u);
     return (n - nt) + 4u * nt;
 }
 
-// orientation / motion action 0..3 (N,S,E,W) -> cell index delta for row-major cells (actions.py:12-16)
-__device__ __forceinline__ int dir_delta(uint32_t d, int W) {
-    return d == 0 ? -W : d == 1 ? W : d == 2 ? 1 : -1;
+// Recipe.time of a soup code through the 16-byte LUT held in 4 registers
+__device__ __forceinline__ uint32_t cook_of(const LayC& C, uint32_t soup) {
+    const uint32_t n = (soup >> 3) & 3u, nt = __popc(soup & 7u), no = n - nt;
+    const uint32_t w = nt == 0u ? C.cook[0] : nt == 1u ? C.cook[1] : nt == 2u ? C.cook[2] : C.cook[3];
+    return (w >> (8u * no)) & 0xFFu;
+}
+
+// cell-index delta of direction d (0..3 = N,S,E,W) from a packed table of 4 signed bytes
+__device__ __forceinline__ uint32_t step_cell(uint32_t c, uint32_t d, uint32_t delta4) {
+    return c + (uint32_t)__builtin_amdgcn_sbfe((int)delta4, 8u * d, 8u);
+}
+
+// EVENT_TYPES bit helpers (mdp.py:1027-1058): bit 2*k + player
+enum {
+    EV_TOMATO_PICKUP = 0, EV_USEFUL_TOMATO_PICKUP, EV_TOMATO_DROP, EV_USEFUL_TOMATO_DROP, EV_POTTING_TOMATO,
+    EV_ONION_PICKUP, EV_USEFUL_ONION_PICKUP, EV_ONION_DROP, EV_USEFUL_ONION_DROP, EV_POTTING_ONION,
+    EV_DISH_PICKUP, EV_USEFUL_DISH_PICKUP, EV_DISH_DROP, EV_USEFUL_DISH_DROP,
+    EV_SOUP_PICKUP, EV_SOUP_DELIVERY, EV_SOUP_DROP,
+    EV_OPTIMAL_ONION_POTTING, EV_OPTIMAL_TOMATO_POTTING, EV_VIABLE_ONION_POTTING, EV_VIABLE_TOMATO_POTTING,
+    EV_CATASTROPHIC_ONION_POTTING, EV_CATASTROPHIC_TOMATO_POTTING, EV_USELESS_ONION_POTTING, EV_USELESS_TOMATO_POTTING
+};
+__device__ __forceinline__ uint64_t evbit(bool cond, int k, int p) { return cond ? (1ull << (2 * k + p)) : 0ull; }
+
+// ------------------------------------------------------------------------------------------
+// INTERACT of player P (resolve_interacts, mdp.py:1432-1579), written without data-dependent
+// branches: every outcome is a predicate, the new hand / cell / tick are selects.  `cell16` is the
+// LDS word of the faced cell, `fwd_*` forwards player 0's counter write when both face one cell.
+// ------------------------------------------------------------------------------------------
+template <int MAXP, bool EVENTS, int P>
+__device__ __forceinline__ void interact(const LayC& C, const Lay L, EnvW<MAXP>& s, bool act, uint32_t f,
+                                         uint32_t cell16, uint32_t useful_pots, uint32_t n_full, bool two,
+                                         bool& wr, uint32_t& wr_val, float& sparse, float& shaped, uint64_t& ev) {
+    uint32_t h = P ? s.held1 : s.held0;
+    const uint32_t other_h = P ? s.held0 : s.held1;
+    const uint32_t tc = cell16 >> 8;
+    const uint32_t type = act ? (tc & 7u) : 7u;  // 7 matches no terrain: a lane that does not interact falls through
+    const uint32_t slot = tc >> 3;
+    const bool isP = type == OC_T_POT;
+    uint32_t tkv = 0, pso = 0;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const bool sel = slot == (uint32_t)k;
+        tkv = sel ? s.tk[k] : tkv;
+        pso = sel ? s.ps[k] : pso;
+    }
+    const uint32_t o = isP ? pso : (cell16 & 0xFFu);
+    const uint32_t tk = isP ? tkv : 0u;
+    const bool hz = h == 0u, oz = o == 0u;
+    const uint32_t n = (o >> 3) & 3u;
+    // counter: drop (mdp.py:1459-1471) or pick up (1473-1485) = swap hand and cell when exactly one is empty
+    const bool swapX = (type == OC_T_COUNTER) & (hz != oz);
+    // dispensers (mdp.py:1487-1513)
+    const bool isD = type == OC_T_DISH_DISP;
+    const bool take = hz & ((type == OC_T_ONION_DISP) | (type == OC_T_TOMATO_DISP) | isD);
+    const uint32_t disp_obj = type == OC_T_ONION_DISP ? (uint32_t)OC_O_ONION
+                              : type == OC_T_TOMATO_DISP ? (uint32_t)OC_O_TOMATO : (uint32_t)OC_O_DISH;
+    // is_dish_pickup_useful (mdp.py:2180-2204): live hands and counters, stale pot_states
+    const bool dish_useful = two & (((other_h == OC_O_DISH) ? 1u : 0u) < useful_pots) & (s.dcount == 0);
+    // pot (mdp.py:1515-1568)
+    const bool idle = tk == 0u;
+    const bool start = isP & hz & (C.old_dyn == 0u) & (!oz) & idle & (n > 0u);       // begin_cooking -> tick 0
+    const uint32_t ct = cook_of(C, o);
+    const bool ready = (!idle) & ((tk - 1u) >= ct);
+    const bool plate = isP & (h == OC_O_DISH) & (!oz) & ready;                       // soup pickup
+    const bool is_ing = (h == OC_O_ONION) | (h == OC_O_TOMATO);
+    const bool place = isP & is_ing & idle & (n < 3u);                               // not is_full (mdp.py:547-551)
+    const uint32_t soup_new = OC_O_SOUP | ((n + 1u) << 3) | (o & 7u) | ((h == OC_O_TOMATO ? 1u : 0u) << n);
+    // serving (mdp.py:1570-1577)
+    const bool serve = (type == OC_T_SERVE) & ((h & OC_O_SOUP) != 0u);
+
+    const uint32_t new_h = swapX ? o : take ? disp_obj : plate ? o : (place | serve) ? 0u : h;
+    const uint32_t new_o = swapX ? h : plate ? 0u : place ? soup_new : o;
+    const uint32_t new_tk = start ? 1u : plate ? 0u : tk;
+    const bool pot_upd = start | plate | place;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const bool upd = pot_upd & (slot == (uint32_t)k);
+        s.ps[k] = upd ? new_o : s.ps[k];
+        s.tk[k] = upd ? new_tk : s.tk[k];
+    }
+    s.dcount += swapX ? ((h == OC_O_DISH ? 1 : 0) - (o == OC_O_DISH ? 1 : 0)) : 0;
+    if (P) s.held1 = new_h; else s.held0 = new_h;
+    wr = swapX;
+    wr_val = new_o;
+    shaped = (place ? C.rew_place : 0.f) + (plate ? C.rew_soup : 0.f) + ((take & isD & dish_useful) ? C.rew_dish : 0.f);
+    sparse = 0.f;
+    if (serve) sparse = L.value(recipe_idx(h));  // deliver_soup / get_recipe_value (mdp.py:1631-1642, 1595-1602); rare
+
+    if (EVENTS) {
+        // log_object_pickup / drop / potting and their usefulness predicates (mdp.py:2121-2308)
+        const bool all_full = C.n_pots == n_full;
+        const bool other_dish = other_h == OC_O_DISH, other_onion = other_h == OC_O_ONION;
+        const bool ing_pick_useful = two & !(all_full & !other_dish);
+        const bool ing_drop_useful = two & all_full & !other_dish;
+        const bool dish_drop_useful = two & (n_full == 0u) & !other_onion;
+        const bool pickX = swapX & hz, dropX = swapX & !hz;
+        const bool takeO = take & (type == OC_T_ONION_DISP), takeD = take & isD;
+        uint64_t e = 0;
+        const bool pk_on = (pickX & (o == OC_O_ONION)) | takeO, pk_to = pickX & (o == OC_O_TOMATO);
+        const bool pk_di = (pickX & (o == OC_O_DISH)) | takeD;
+        e |= evbit(pk_on, EV_ONION_PICKUP, P) | evbit(pk_on & ing_pick_useful, EV_USEFUL_ONION_PICKUP, P);
+        e |= evbit(pk_to, EV_TOMATO_PICKUP, P) | evbit(pk_to & ing_pick_useful, EV_USEFUL_TOMATO_PICKUP, P);
+        e |= evbit(pk_di, EV_DISH_PICKUP, P) | evbit(pk_di & dish_useful, EV_USEFUL_DISH_PICKUP, P);
+        e |= evbit((pickX & ((o & OC_O_SOUP) != 0u)) | plate, EV_SOUP_PICKUP, P);
+        e |= evbit(dropX & (h == OC_O_ONION), EV_ONION_DROP, P) | evbit(dropX & (h == OC_O_ONION) & ing_drop_useful, EV_USEFUL_ONION_DROP, P);
+        e |= evbit(dropX & (h == OC_O_TOMATO), EV_TOMATO_DROP, P) | evbit(dropX & (h == OC_O_TOMATO) & ing_drop_useful, EV_USEFUL_TOMATO_DROP, P);
+        e |= evbit(dropX & (h == OC_O_DISH), EV_DISH_DROP, P) | evbit(dropX & (h == OC_O_DISH) & dish_drop_useful, EV_USEFUL_DISH_DROP, P);
+        e |= evbit(dropX & ((h & OC_O_SOUP) != 0u), EV_SOUP_DROP, P);
+        e |= evbit(serve, EV_SOUP_DELIVERY, P);
+        // potting: class nibble of (old soup, ingredient): 1 optimal, 2 viable, 4 catastrophic, 8 useless
+        const uint32_t nt = __popc(o & 7u), no = n - nt, pi = no + 3u * nt;  // old soup has <= 2 ingredients here
+        const uint32_t pw = pi < 4u ? C.pclass[0] : C.pclass[1];
+        const uint32_t tom = h == OC_O_TOMATO ? 1u : 0u;
+        const uint32_t nib = (pw >> (8u * (pi & 3u) + 4u * tom)) & 0xFu;
+        e |= evbit(place, tom ? EV_POTTING_TOMATO : EV_POTTING_ONION, P);
+        e |= evbit(place & ((nib & 1u) != 0u), EV_OPTIMAL_ONION_POTTING + (int)0, P) << (2 * tom);
+        e |= evbit(place & ((nib & 2u) != 0u), EV_VIABLE_ONION_POTTING, P) << (2 * tom);
+        e |= evbit(place & ((nib & 4u) != 0u), EV_CATASTROPHIC_ONION_POTTING, P) << (2 * tom);
+        e |= evbit(place & ((nib & 8u) != 0u), EV_USELESS_ONION_POTTING, P) << (2 * tom);
+        ev |= e;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
-// One joint transition of one env.  a0/a1 in 0..5.  Rewards are accumulated into sp*/sh*.
+// One joint transition: get_state_transition (mdp.py:1375-1430).
 // ------------------------------------------------------------------------------------------
-template <int NOBJ>
-__device__ __forceinline__ void env_step(const Lay L, ObjLds<NOBJ> obj, Env& s, int W, uint32_t a0, uint32_t a1,
-                                         float& sp0, float& sp1, float& sh0, float& sh1) {
+template <int MAXP, bool EVENTS>
+__device__ __forceinline__ void env_step(const LayC& C, const Lay L, uint32_t* cellw, EnvW<MAXP>& s, uint32_t delta4,
+                                         uint32_t a0, uint32_t a1, float4& r, uint64_t& ev) {
     const bool two = s.pos1 != 0xFFu;
-    const uint32_t n_pots = L.n_pots();
-    const bool old_dyn = L.old_dynamics();
+    // cells this step looks at: the two faced cells (pre-move pose, mdp.py:1452-1454) and the two move targets
+    const uint32_t f0 = step_cell(s.pos0, s.or0, delta4);
+    const uint32_t f1 = two ? step_cell(s.pos1, s.or1, delta4) : f0;
+    const uint32_t m0 = a0 < 4u ? step_cell(s.pos0, a0, delta4) : s.pos0;
+    const uint32_t m1 = (two & (a1 < 4u)) ? step_cell(s.pos1, a1, delta4) : (two ? s.pos1 : s.pos0);
+    const uint32_t c_f0 = rd_cell16(cellw, f0), c_f1 = rd_cell16(cellw, f1);
+    const uint32_t c_m0 = rd_cell16(cellw, m0), c_m1 = rd_cell16(cellw, m1);
 
-    // pot_states, computed once before any interact (mdp.py:1439): the number of pots that are
-    // ready, cooking or hold 1..2 idle ingredients (mdp.py:2199-2203; 3 idle items do not count).
-    uint32_t useful_pots = 0;
-    for (uint32_t k = 0; k < n_pots; ++k) {
-        uint32_t o = obj.get(L.pot_cell(k));
-        if (o) {
-            uint32_t n = (o >> 3) & 3u;
-            useful_pots += (s.tick1(k) != 0u || (n >= 1u && n < 3u)) ? 1u : 0u;
-        }
-    }
-
-    // ---- resolve_interacts: player 0 fully, then player 1 (mdp.py:1446) ----
+    // pot_states, once before any interact (mdp.py:1439): pots that are ready / cooking / hold 1..2 idle items
+    uint32_t useful_pots = 0, n_full = 0;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const uint32_t a = p ? a1 : a0;
-        if (a != OC_A_INTERACT || (p == 1 && !two)) continue;
-        const uint32_t pos = p ? s.pos1 : s.pos0;
-        const uint32_t ori = p ? s.or1 : s.or0;
-        uint32_t h = p ? s.held1 : s.held0;
-        const uint32_t f = pos + dir_delta(ori, W);  // facing cell; borders are never floor (mdp.py:2082-2088)
-        const uint32_t tc = L.terrain(f);
-        const uint32_t type = tc & 7u, slot = tc >> 3;
-        const uint32_t o = obj.get(f);
-        float shaped = 0.f, sparse = 0.f;
-        if (type == OC_T_COUNTER) {
-            if (h && !o) { obj.set(f, h); h = 0; }             // drop, mdp.py:1459-1471
-            else if (!h && o) { h = o; obj.set(f, 0); }        // pick up, mdp.py:1473-1485
-        } else if (type == OC_T_ONION_DISP) {
-            if (!h) h = OC_O_ONION;                            // mdp.py:1487-1494
-        } else if (type == OC_T_TOMATO_DISP) {
-            if (!h) h = OC_O_TOMATO;                           // mdp.py:1496-1498
-        } else if (type == OC_T_DISH_DISP) {
-            if (!h) {                                          // mdp.py:1500-1513
-                // is_dish_pickup_useful (mdp.py:2180-2204) sees the live hands (before this pickup)
-                // and counters, but the stale pot_states.
-                const uint32_t other_h = p ? s.held0 : s.held1;
-                const uint32_t dishes_held = (two && other_h == OC_O_DISH) ? 1u : 0u;
-                if (two && dishes_held < useful_pots && !obj.any_dish()) shaped += L.rew_dish();
-                h = OC_O_DISH;
-            }
-        } else if (type == OC_T_POT) {
-            const uint32_t tk = s.tick1(slot);
-            if (!h) {
-                // soup_to_be_cooked_at_location (mdp.py:1899-1908): idle soup with >= 1 ingredient
-                if (!old_dyn && o && tk == 0u && ((o >> 3) & 3u) > 0u) s.set_tick1(slot, 1u);  // begin_cooking: tick 0
-            } else if (h == OC_O_DISH) {
-                if (o && tk != 0u && (tk - 1u) >= L.cook_time(recipe_idx(o))) {  // soup ready, mdp.py:1525-1539
-                    h = o;
-                    obj.set(f, 0);
-                    s.set_tick1(slot, 0u);
-                    shaped += L.rew_soup();
-                }
-            } else if (h == OC_O_ONION || h == OC_O_TOMATO) {  // mdp.py:1541-1568
-                const uint32_t soup = o ? o : (uint32_t)OC_O_SOUP;
-                const uint32_t n = (soup >> 3) & 3u;
-                if (tk == 0u && n < 3u) {                      // not is_full (mdp.py:547-551)
-                    const uint32_t bit = (h == OC_O_TOMATO) ? (1u << n) : 0u;
-                    obj.set(f, OC_O_SOUP | ((n + 1u) << 3) | (soup & 7u) | bit);
-                    h = 0;
-                    shaped += L.rew_placement();
-                }
-            }
-        } else if (type == OC_T_SERVE) {
-            if (h & OC_O_SOUP) {                               // deliver_soup, mdp.py:1570-1577, 1631-1642
-                sparse += L.value(recipe_idx(h));
-                h = 0;
-            }
-        }
-        if (p) { s.held1 = h; sp1 += sparse; sh1 += shaped; }
-        else { s.held0 = h; sp0 += sparse; sh0 += shaped; }
+    for (int k = 0; k < MAXP; ++k) {
+        const uint32_t o = s.ps[k], n = (o >> 3) & 3u;
+        const bool nz = o != 0u, hot = s.tk[k] != 0u;
+        useful_pots += (nz & (hot | ((n - 1u) < 2u))) ? 1u : 0u;
+        if (EVENTS) n_full += (nz & (hot | (n == 3u))) ? 1u : 0u;
     }
 
-    // ---- resolve_movement (mdp.py:1644-1727) ----
-    uint32_t np0 = s.pos0, np1 = s.pos1;
-    if (a0 < 4u) {
-        s.or0 = a0;                                            // orientation follows the action even when blocked
-        const uint32_t c = s.pos0 + dir_delta(a0, W);
-        if ((L.terrain(c) & 7u) == OC_T_FLOOR) np0 = c;
-    }
-    if (two && a1 < 4u) {
-        s.or1 = a1;
-        const uint32_t c = s.pos1 + dir_delta(a1, W);
-        if ((L.terrain(c) & 7u) == OC_T_FLOOR) np1 = c;
-    }
-    // is_transition_collision (mdp.py:1673-1683): same target cell, or swapped cells -> nobody moves
-    const bool collide = two && (np0 == np1 || (np0 == s.pos1 && np1 == s.pos0));
-    if (!collide) { s.pos0 = np0; s.pos1 = np1; }
+    // resolve_interacts: player 0 fully, then player 1 (mdp.py:1446)
+    bool wr0, wr1;
+    uint32_t v0, v1;
+    float sp0, sh0, sp1, sh1;
+    interact<MAXP, EVENTS, 0>(C, L, s, a0 == OC_A_INTERACT, f0, c_f0, useful_pots, n_full, two, wr0, v0, sp0, sh0, ev);
+    // player 1 sees player 0's counter write when both face the same cell
+    const uint32_t c_f1_live = (wr0 & (f1 == f0)) ? ((c_f1 & 0xFF00u) | v0) : c_f1;
+    interact<MAXP, EVENTS, 1>(C, L, s, two & (a1 == OC_A_INTERACT), f1, c_f1_live, useful_pots, n_full, two, wr1, v1, sp1,
+                              sh1, ev);
+    if (wr0) wr_cell_obj(cellw, f0, v0);
+    if (wr1) wr_cell_obj(cellw, f1, v1);
+    r = make_float4(sp0, sp1, sh0, sh1);
 
-    // ---- step_environment_effects (mdp.py:1691-1703) ----
+    // resolve_movement (mdp.py:1644-1727): orientation follows the action even when blocked;
+    // same target cell or swapped cells -> nobody moves (is_transition_collision, 1673-1683)
+    const bool mv0 = a0 < 4u, mv1 = two & (a1 < 4u);
+    const uint32_t np0 = (mv0 & (((c_m0 >> 8) & 7u) == OC_T_FLOOR)) ? m0 : s.pos0;
+    const uint32_t np1 = (mv1 & (((c_m1 >> 8) & 7u) == OC_T_FLOOR)) ? m1 : s.pos1;
+    s.or0 = mv0 ? a0 : s.or0;
+    s.or1 = mv1 ? a1 : s.or1;
+    const bool collide = two & ((np0 == np1) | ((np0 == s.pos1) & (np1 == s.pos0)));
+    s.pos0 = collide ? s.pos0 : np0;
+    s.pos1 = collide ? s.pos1 : np1;
+
+    // step_environment_effects (mdp.py:1691-1703)
     s.t += 1u;
-    for (uint32_t k = 0; k < n_pots; ++k) {
-        const uint32_t o = obj.get(L.pot_cell(k));
-        if (!o) continue;
-        uint32_t tk = s.tick1(k);
-        if (old_dyn && tk == 0u && ((o >> 3) & 3u) == 3u) tk = 1u;            // auto begin_cooking (old dynamics)
-        if (tk != 0u && (tk - 1u) < L.cook_time(recipe_idx(o))) tk += 1u;     // is_cooking -> cook()
-        s.set_tick1(k, tk);
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const uint32_t o = s.ps[k], n = (o >> 3) & 3u;
+        uint32_t tk = s.tk[k];
+        const bool nz = o != 0u;
+        tk = ((C.old_dyn != 0u) & nz & (tk == 0u) & (n == 3u)) ? 1u : tk;       // auto begin_cooking (old dynamics)
+        const bool cooking = nz & (tk != 0u) & ((tk - 1u) < cook_of(C, o));      // is_cooking -> cook()
+        s.tk[k] = tk + (cooking ? 1u : 0u);
+    }
+}
+
+// exact count of bytes equal to OC_O_DISH in a dword
+__device__ __forceinline__ uint32_t count_dish_bytes(uint32_t w) {
+    const uint32_t x = w ^ 0x03030303u;  // dish bytes -> 0
+    const uint32_t t = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu;
+    return __popc(~t);
+}
+
+// load one env from its HBM planes into registers + the LDS cell words
+template <int MAXP>
+__device__ __forceinline__ void load_env(const Lay L, const uint4* __restrict__ st, int64_t n, int64_t e, int n_obj,
+                                         uint32_t n_pots, EnvW<MAXP>& s, uint32_t* cellw) {
+    const uint4 h = st[e];
+    s.pos0 = h.x & 0xFF; s.or0 = (h.x >> 8) & 0xFF; s.held0 = (h.x >> 16) & 0xFF; s.pos1 = h.x >> 24;
+    s.or1 = h.y & 0xFF; s.held1 = (h.y >> 8) & 0xFF; s.t = h.y >> 16;
+    int32_t dishes = 0;
+    for (int p = 0; p < n_obj; ++p) {
+        const uint4 v = st[(int64_t)(1 + p) * n + e];
+        const uint32_t ow[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t T = L.u32(L_TERRAIN + 16 * p + 4 * q);
+            dishes += (int32_t)count_dish_bytes(ow[q]);
+            // interleave object and terrain bytes: cells 4q..4q+3 of this plane -> two dwords of (obj | terrain << 8)
+            cellw[(8 * p + 2 * q) * BLOCK] = __builtin_amdgcn_perm(T, ow[q], 0x05010400u);
+            cellw[(8 * p + 2 * q + 1) * BLOCK] = __builtin_amdgcn_perm(T, ow[q], 0x07030602u);
+        }
+    }
+    s.dcount = dishes;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        s.ps[k] = 0; s.tk[k] = 0;
+        if ((uint32_t)k < n_pots) {
+            s.ps[k] = rd_cell16(cellw, L.pot_cell(k)) & 0xFFu;
+            s.tk[k] = ((k < 4 ? h.z : h.w) >> (8 * (k & 3))) & 0xFFu;
+        }
+    }
+}
+
+template <int MAXP>
+__device__ __forceinline__ void store_env(const Lay L, uint4* __restrict__ st, int64_t n, int64_t e, int n_obj,
+                                          uint32_t n_pots, const EnvW<MAXP>& s, uint32_t* cellw) {
+    uint4 h;
+    h.x = s.pos0 | (s.or0 << 8) | (s.held0 << 16) | (s.pos1 << 24);
+    h.y = s.or1 | (s.held1 << 8) | (s.t << 16);
+    h.z = 0; h.w = 0;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        if ((uint32_t)k < n_pots) {
+            wr_cell_obj(cellw, L.pot_cell(k), s.ps[k]);
+            if (k < 4) h.z |= s.tk[k] << (8 * (k & 3));
+            else h.w |= s.tk[k] << (8 * (k & 3));
+        }
+    }
+    st[e] = h;
+    for (int p = 0; p < n_obj; ++p) {
+        uint32_t ow[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t lo = cellw[(8 * p + 2 * q) * BLOCK], hi = cellw[(8 * p + 2 * q + 1) * BLOCK];
+            ow[q] = __builtin_amdgcn_perm(hi, lo, 0x06040200u);  // object bytes of 4 cells
+        }
+        st[(int64_t)(1 + p) * n + e] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
     }
 }
 
 // start state of a layout (mdp.py:1297-1305, 939-950)
-template <int NOBJ>
-__device__ __forceinline__ void env_reset(const Lay L, ObjLds<NOBJ> obj, Env& s) {
+template <int MAXP>
+__device__ __forceinline__ void env_reset(const Lay L, int n_obj, EnvW<MAXP>& s, uint32_t* cellw) {
     s.pos0 = L.u8(L_START_POS); s.pos1 = L.u8(L_START_POS + 1);
-    s.or0 = L.u8(L_START_OR); s.or1 = L.u8(L_START_OR + 1);
-    s.held0 = s.held1 = 0; s.t = 0; s.tk_lo = s.tk_hi = 0;
-    if (s.pos1 == 0xFFu) s.or1 = 0;
+    s.or0 = L.u8(L_START_OR); s.or1 = s.pos1 == 0xFFu ? 0u : L.u8(L_START_OR + 1);
+    s.held0 = s.held1 = 0; s.t = 0; s.dcount = 0;
 #pragma unroll
-    for (int w = 0; w < NOBJ * 4; ++w) obj.set_word(w, 0);
+    for (int k = 0; k < MAXP; ++k) { s.ps[k] = 0; s.tk[k] = 0; }
+    for (int d = 0; d < n_obj * 8; ++d) cellw[d * BLOCK] &= 0xFF00FF00u;  // clear objects, keep terrain
 }
 
 // Philox4x32-10 (Salmon et al., SC'11).  Same constants/rounds as oracle_philox4x32_10.
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                              uint32_t k1, uint32_t& r0, uint32_t& r1) {
+                                              uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
@@ -247,7 +391,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    r0 = c0; r1 = c1;
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -270,41 +414,21 @@ __device__ __forceinline__ Lay stage_layouts(const OcLayout* __restrict__ g_layo
     }
 }
 
-template <int NOBJ>
-__device__ __forceinline__ void load_env(const uint4* __restrict__ st, int64_t n, int64_t e, Env& s, ObjLds<NOBJ> obj) {
-    uint4 h = st[e];
-    uint4 v[NOBJ];
-#pragma unroll
-    for (int p = 0; p < NOBJ; ++p) v[p] = st[(int64_t)(1 + p) * n + e];
-    s.unpack(h);
-#pragma unroll
-    for (int p = 0; p < NOBJ; ++p) {
-        obj.set_word(4 * p + 0, v[p].x); obj.set_word(4 * p + 1, v[p].y);
-        obj.set_word(4 * p + 2, v[p].z); obj.set_word(4 * p + 3, v[p].w);
-    }
-}
-
-template <int NOBJ>
-__device__ __forceinline__ void store_env(uint4* __restrict__ st, int64_t n, int64_t e, const Env& s, ObjLds<NOBJ> obj) {
-    st[e] = s.pack();
-#pragma unroll
-    for (int p = 0; p < NOBJ; ++p) {
-        uint4 v;
-        v.x = obj.word(4 * p + 0); v.y = obj.word(4 * p + 1); v.z = obj.word(4 * p + 2); v.w = obj.word(4 * p + 3);
-        st[(int64_t)(1 + p) * n + e] = v;
-    }
+__device__ __forceinline__ uint32_t make_delta4(int W) {
+    // signed byte deltas of N, S, E, W for row-major cells (actions.py:12-16)
+    return ((uint32_t)(-W) & 0xFFu) | (((uint32_t)W & 0xFFu) << 8) | (1u << 16) | (0xFFu << 24);
 }
 
 // post-transition bookkeeping shared by k_step and k_rollout (env.py:266-267, 321-325, 387-392)
-template <int NOBJ>
-__device__ __forceinline__ uint32_t finish_step(const Lay L, ObjLds<NOBJ> obj, Env& s, int horizon, uint32_t options,
-                                                float4 r, float4& ep) {
+template <int MAXP>
+__device__ __forceinline__ uint32_t finish_step(const Lay L, int n_obj, uint32_t* cellw, EnvW<MAXP>& s, int horizon,
+                                                uint32_t options, const float4& r, float4& ep) {
     ep.x += r.x; ep.y += r.y; ep.z += r.z; ep.w += r.w;
     uint32_t fl = 0;
     if ((int)s.t >= horizon) {
         fl |= OC_F_DONE;
         if (options & OC_OPT_AUTO_RESET) {
-            env_reset<NOBJ>(L, obj, s);
+            env_reset<MAXP>(L, n_obj, s, cellw);
             ep = make_float4(0.f, 0.f, 0.f, 0.f);
             fl |= OC_F_RESET;
         }
@@ -315,73 +439,96 @@ __device__ __forceinline__ uint32_t finish_step(const Lay L, ObjLds<NOBJ> obj, E
 // ------------------------------------------------------------------------------------------
 // k_step: one transition per launch, actions supplied by the caller.
 // ------------------------------------------------------------------------------------------
-template <int NOBJ, bool LAY_LDS>
+template <bool UNIFORM, int MAXP, bool LAY_LDS, bool EVENTS>
 __global__ __launch_bounds__(BLOCK) void k_step(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                 const uint16_t* __restrict__ layout_id, const uint4* st_in,
                                                 uint4* st_out, const uint8_t* __restrict__ actions,
                                                 float4* __restrict__ rewards, uint8_t* __restrict__ flags,
-                                                float4* __restrict__ ep_returns, int64_t n, int W, int horizon,
-                                                uint32_t options) {
-    __shared__ uint32_t s_obj[NOBJ * 4][BLOCK];
+                                                float4* __restrict__ ep_returns, uint64_t* __restrict__ events,
+                                                int64_t n, int W, int n_obj, int horizon, uint32_t options) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_cells[];  // [n_obj * 8][BLOCK]
     __shared__ uint4 s_lay[LAY_LDS ? LDS_LAYOUT_MAX * 16 : 1];
     const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool active = e < n;
     const Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);
     if (!active) return;
-    ObjLds<NOBJ> obj{&s_obj[0][threadIdx.x]};
-    Env s;
-    load_env<NOBJ>(st_in, n, e, s, obj);
+    uint32_t* cellw = s_cells + threadIdx.x;
+    const LayC C = load_consts<UNIFORM>(L);
+    const uint32_t delta4 = make_delta4(W);
+    EnvW<MAXP> s;
+    load_env<MAXP>(L, st_in, n, e, n_obj, C.n_pots, s, cellw);
     const uint32_t a01 = reinterpret_cast<const uint16_t*>(actions)[e];
     const uint32_t a0 = a01 & 0xFFu, a1 = a01 >> 8;
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint64_t ev = 0;
     uint32_t fl;
     float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (a0 > 5u || a1 > 5u) {
         fl = OC_F_BAD_ACTION;  // get_state_transition raises ValueError (mdp.py:1394-1398): leave the env untouched
     } else {
-        env_step<NOBJ>(L, obj, s, W, a0, a1, r.x, r.y, r.z, r.w);
-        fl = finish_step<NOBJ>(L, obj, s, horizon, options, r, ep);
+        env_step<MAXP, EVENTS>(C, L, cellw, s, delta4, a0, a1, r, ev);
+        fl = finish_step<MAXP>(L, n_obj, cellw, s, horizon, options, r, ep);
     }
-    store_env<NOBJ>(st_out, n, e, s, obj);
+    store_env<MAXP>(L, st_out, n, e, n_obj, C.n_pots, s, cellw);
     rewards[e] = r;
     flags[e] = (uint8_t)fl;
     if (ep_returns) ep_returns[e] = ep;
+    if (EVENTS) events[e] = ev;
 }
 
 // ------------------------------------------------------------------------------------------
-// k_rollout: n_steps fused transitions, actions from Philox; state stays in registers/LDS.
+// k_rollout: n_steps fused transitions per launch under the uniform random policy; the env lives in
+// registers + LDS between steps and only the per-step outputs (17 B per env-step) go to HBM.
+// Action stream: one Philox4x32-10 block feeds 8 consecutive steps — word s/2 of block t/8 is
+// expanded into base-6 digits by multiply-high (digit = mulhi(x, 6), x <- x * 6), two digits (player
+// 0, player 1) per step.  oracle_random_actions restates the same mapping.
 // ------------------------------------------------------------------------------------------
-template <int NOBJ, bool LAY_LDS>
+__device__ __forceinline__ void draw_actions(const uint32_t (&rnd)[4], uint32_t s8, uint32_t& a0, uint32_t& a1) {
+    const uint32_t w = s8 < 2u ? rnd[0] : s8 < 4u ? rnd[1] : s8 < 6u ? rnd[2] : rnd[3];  // s8 is wave-uniform
+    const uint32_t x = (s8 & 1u) ? w * 36u : w;
+    a0 = __umulhi(x, 6u);
+    a1 = __umulhi(x * 6u, 6u);
+}
+
+template <bool UNIFORM, int MAXP, bool LAY_LDS>
 __global__ __launch_bounds__(BLOCK) void k_rollout(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                    const uint16_t* __restrict__ layout_id, uint4* st,
                                                    float4* __restrict__ rewards, uint8_t* __restrict__ flags,
-                                                   float4* __restrict__ ep_returns, int64_t n, int W, int horizon,
-                                                   uint32_t options, uint32_t seed_lo, uint32_t seed_hi,
+                                                   float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,
+                                                   int horizon, uint32_t options, uint32_t seed_lo, uint32_t seed_hi,
                                                    int64_t env_offset, int64_t t0, int n_steps) {
-    __shared__ uint32_t s_obj[NOBJ * 4][BLOCK];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_cells[];
     __shared__ uint4 s_lay[LAY_LDS ? LDS_LAYOUT_MAX * 16 : 1];
     const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool active = e < n;
     const Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);
     if (!active) return;
-    ObjLds<NOBJ> obj{&s_obj[0][threadIdx.x]};
-    Env s;
-    load_env<NOBJ>(st, n, e, s, obj);
+    uint32_t* cellw = s_cells + threadIdx.x;
+    const LayC C = load_consts<UNIFORM>(L);
+    const uint32_t delta4 = make_delta4(W);
+    EnvW<MAXP> s;
+    load_env<MAXP>(L, st, n, e, n_obj, C.n_pots, s, cellw);
     float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     const uint64_t g = (uint64_t)(env_offset + e);
     const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
+    uint32_t rnd[4] = {0, 0, 0, 0};
     for (int k = 0; k < n_steps; ++k) {
         const uint64_t t = (uint64_t)(t0 + k);
-        uint32_t r0, r1;
-        philox4x32_10((uint32_t)t, g_lo, g_hi, (uint32_t)(t >> 32), seed_lo, seed_hi, r0, r1);
-        const uint32_t a0 = r0 % 6u, a1 = r1 % 6u;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        env_step<NOBJ>(L, obj, s, W, a0, a1, r.x, r.y, r.z, r.w);
-        const uint32_t fl = finish_step<NOBJ>(L, obj, s, horizon, options, r, ep);
+        const uint32_t s8 = (uint32_t)t & 7u;
+        if (k == 0 || s8 == 0u) {
+            const uint64_t blk = t >> 3;
+            philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, rnd);
+        }
+        uint32_t a0, a1;
+        draw_actions(rnd, s8, a0, a1);
+        float4 r;
+        uint64_t ev = 0;
+        env_step<MAXP, false>(C, L, cellw, s, delta4, a0, a1, r, ev);
+        const uint32_t fl = finish_step<MAXP>(L, n_obj, cellw, s, horizon, options, r, ep);
         if (rewards) rewards[(int64_t)k * n + e] = r;
         if (flags) flags[(int64_t)k * n + e] = (uint8_t)fl;
     }
-    store_env<NOBJ>(st, n, e, s, obj);
+    store_env<MAXP>(L, st, n, e, n_obj, C.n_pots, s, cellw);
     if (ep_returns) ep_returns[e] = ep;
 }
 
@@ -398,11 +545,9 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const OcLayout* __restrict__ g_
     if (mask && !mask[e]) return;
     const uint32_t lid = layout_id ? layout_id[e] : 0u;
     const uint8_t* base = reinterpret_cast<const uint8_t*>(g_layouts) + (size_t)lid * 256u;
-    Env s;
-    s.pos0 = base[L_START_POS]; s.pos1 = base[L_START_POS + 1];
-    s.or0 = base[L_START_OR]; s.or1 = s.pos1 == 0xFFu ? 0u : base[L_START_OR + 1];
-    s.held0 = s.held1 = 0; s.t = 0; s.tk_lo = s.tk_hi = 0;
-    st[e] = s.pack();
+    const uint32_t pos0 = base[L_START_POS], pos1 = base[L_START_POS + 1];
+    const uint32_t or0 = base[L_START_OR], or1 = pos1 == 0xFFu ? 0u : base[L_START_OR + 1];
+    st[e] = make_uint4(pos0 | (or0 << 8) | (pos1 << 24), or1, 0u, 0u);
     const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int p = 0; p < NOBJ; ++p) st[(int64_t)(1 + p) * n + e] = z;
@@ -582,6 +727,25 @@ inline unsigned grid_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK)
         default: { constexpr int NOBJ = 8; __VA_ARGS__; } break;        \
     }
 
+// kernel variant selection: UNIFORM (one layout for the whole batch -> layout constants in SGPRs),
+// MAXP (pot slots kept in registers: 2 covers every canonical layout, 8 is the format's maximum),
+// LAY_LDS (layout table staged in LDS vs read from HBM/L2 for tables of more than 32 layouts)
+template <bool EVENTS>
+void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_state_out, const uint8_t* d_actions,
+                 float* d_rewards, uint8_t* d_flags, float* d_ep_returns, uint64_t* d_events, int horizon,
+                 uint32_t options, hipStream_t s) {
+    const bool uniform = b->n_layouts == 1;
+    const bool lds = b->n_layouts <= LDS_LAYOUT_MAX;
+    const bool small = b->max_pots >= 1 && b->max_pots <= 2;
+    const size_t smem = (size_t)n_obj * 8 * BLOCK * sizeof(uint32_t);
+    const dim3 grid(grid_for(b->n_envs)), block(BLOCK);
+#define GO(U, MP, LL)                                                                                                    do {                                                                                                                     if (smem > 48 * 1024)                                                                                                    (void)hipFuncSetAttribute((const void*)k_step<U, MP, LL, EVENTS>,                                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                hipLaunchKernelGGL((k_step<U, MP, LL, EVENTS>), grid, block, smem, s, b->d_layouts, b->n_layouts,                                       b->d_layout_id, (const uint4*)d_state_in, (uint4*)d_state_out, d_actions,                                            (float4*)d_rewards, d_flags, (float4*)d_ep_returns, d_events, b->n_envs, b->width, n_obj,                            horizon, options);                                                                            } while (0)
+    if (uniform) { if (small) GO(true, 2, true); else GO(true, 8, true); }
+    else if (lds) { if (small) GO(false, 2, true); else GO(false, 8, true); }
+    else { if (small) GO(false, 2, false); else GO(false, 8, false); }
+#undef GO
+}
+
 }  // namespace
 
 extern "C" {
@@ -592,7 +756,7 @@ const char* oc_last_error(void) { return g_err; }
 int oc_state_planes(int width, int height) { return 1 + (width * height + 15) / 16; }
 
 int oc_step(const OcBatch* b, const void* d_state_in, void* d_state_out, const uint8_t* d_actions, float* d_rewards,
-            uint8_t* d_flags, float* d_ep_returns, int horizon, uint32_t options, void* stream) {
+            uint8_t* d_flags, float* d_ep_returns, uint64_t* d_events, int horizon, uint32_t options, void* stream) {
     int n_obj = 0;
     if (int rc = check_batch(b, &n_obj)) return rc;
     if (!d_state_in || !d_state_out || !d_actions || !d_rewards || !d_flags)
@@ -600,19 +764,12 @@ int oc_step(const OcBatch* b, const void* d_state_in, void* d_state_out, const u
     if (horizon < 1 || horizon > 65535) return fail(OC_EINVAL, "oc_step: horizon must be in 1..65535");
     if (b->n_envs == 0) return OC_OK;
     hipStream_t s = (hipStream_t)stream;
-    const bool lds = b->n_layouts <= LDS_LAYOUT_MAX;
-    DISPATCH_NOBJ(n_obj, {
-        if (lds)
-            hipLaunchKernelGGL((k_step<NOBJ, true>), dim3(grid_for(b->n_envs)), dim3(BLOCK), 0, s, b->d_layouts,
-                               b->n_layouts, b->d_layout_id, (const uint4*)d_state_in, (uint4*)d_state_out, d_actions,
-                               (float4*)d_rewards, d_flags, (float4*)d_ep_returns, b->n_envs, b->width, horizon,
-                               options);
-        else
-            hipLaunchKernelGGL((k_step<NOBJ, false>), dim3(grid_for(b->n_envs)), dim3(BLOCK), 0, s, b->d_layouts,
-                               b->n_layouts, b->d_layout_id, (const uint4*)d_state_in, (uint4*)d_state_out, d_actions,
-                               (float4*)d_rewards, d_flags, (float4*)d_ep_returns, b->n_envs, b->width, horizon,
-                               options);
-    });
+    if (d_events)
+        launch_step<true>(b, n_obj, d_state_in, d_state_out, d_actions, d_rewards, d_flags, d_ep_returns, d_events,
+                          horizon, options, s);
+    else
+        launch_step<false>(b, n_obj, d_state_in, d_state_out, d_actions, d_rewards, d_flags, d_ep_returns, nullptr,
+                           horizon, options, s);
     return check_launch("oc_step");
 }
 
@@ -626,19 +783,16 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
     if (n_steps < 0) return fail(OC_EINVAL, "oc_rollout_random: n_steps < 0");
     if (b->n_envs == 0 || n_steps == 0) return OC_OK;
     hipStream_t s = (hipStream_t)stream;
+    const bool uniform = b->n_layouts == 1;
     const bool lds = b->n_layouts <= LDS_LAYOUT_MAX;
-    DISPATCH_NOBJ(n_obj, {
-        if (lds)
-            hipLaunchKernelGGL((k_rollout<NOBJ, true>), dim3(grid_for(b->n_envs)), dim3(BLOCK), 0, s, b->d_layouts,
-                               b->n_layouts, b->d_layout_id, (uint4*)d_state, (float4*)d_rewards, d_flags,
-                               (float4*)d_ep_returns, b->n_envs, b->width, horizon, options, (uint32_t)seed,
-                               (uint32_t)(seed >> 32), env_offset, t0, n_steps);
-        else
-            hipLaunchKernelGGL((k_rollout<NOBJ, false>), dim3(grid_for(b->n_envs)), dim3(BLOCK), 0, s, b->d_layouts,
-                               b->n_layouts, b->d_layout_id, (uint4*)d_state, (float4*)d_rewards, d_flags,
-                               (float4*)d_ep_returns, b->n_envs, b->width, horizon, options, (uint32_t)seed,
-                               (uint32_t)(seed >> 32), env_offset, t0, n_steps);
-    });
+    const bool small = b->max_pots >= 1 && b->max_pots <= 2;
+    const size_t smem = (size_t)n_obj * 8 * BLOCK * sizeof(uint32_t);
+    const dim3 grid(grid_for(b->n_envs)), block(BLOCK);
+#define GO(U, MP, LL)                                                                                                    do {                                                                                                                     if (smem > 48 * 1024)                                                                                                    (void)hipFuncSetAttribute((const void*)k_rollout<U, MP, LL>, hipFuncAttributeMaxDynamicSharedMemorySize,                                       (int)smem);                                                                            hipLaunchKernelGGL((k_rollout<U, MP, LL>), grid, block, smem, s, b->d_layouts, b->n_layouts, b->d_layout_id,                            (uint4*)d_state, (float4*)d_rewards, d_flags, (float4*)d_ep_returns, b->n_envs, b->width,                            n_obj, horizon, options, (uint32_t)seed, (uint32_t)(seed >> 32), env_offset, t0, n_steps);     } while (0)
+    if (uniform) { if (small) GO(true, 2, true); else GO(true, 8, true); }
+    else if (lds) { if (small) GO(false, 2, true); else GO(false, 8, true); }
+    else { if (small) GO(false, 2, false); else GO(false, 8, false); }
+#undef GO
     return check_launch("oc_rollout_random");
 }
 

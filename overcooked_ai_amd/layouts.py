@@ -191,6 +191,23 @@ class LayoutSpec:
             return self.order_bonus * self.recipe_value(key)
         return self.recipe_value(key)
 
+    def optimal_possible_value(self, key):
+        """Value of the best recipe reachable from `key` (n_onion, n_tomato; (0, 0) = empty pot) by adding
+        ingredients: _get_optimal_possible_recipe's DFS (mdp.py:1976-2016) + get_recipe_value of its result."""
+        best = self.delivery_value(key) if sum(key) >= 1 else 0
+        if sum(key) < MAX_NUM_INGREDIENTS:
+            best = max(best, self.optimal_possible_value((key[0] + 1, key[1])),
+                       self.optimal_possible_value((key[0], key[1] + 1)))
+        return best
+
+    def potting_class(self, key, ingredient):
+        """Bit mask of the potting events logged when `ingredient` is added to a soup with multiset `key`
+        (is_potting_optimal / viable / catastrophic / useless, mdp.py:2256-2308): 1, 2, 4, 8."""
+        new = (key[0] + 1, key[1]) if ingredient == "onion" else (key[0], key[1] + 1)
+        old_val, new_val = self.optimal_possible_value(key), self.optimal_possible_value(new)
+        return ((1 if old_val == new_val else 0) | (2 if new_val > 0 else 0)
+                | (4 if (old_val > 0 and new_val == 0) else 0) | (8 if old_val == 0 else 0))
+
     @property
     def shape(self):
         return (self.width, self.height)
@@ -262,6 +279,9 @@ def compile_layout(spec):
         buf[10 + i] = 0  # NORTH, mdp.py:947
     for k in range(MAX_POTS):
         buf[16 + k] = (pots[k][1] * W + pots[k][0]) if k < len(pots) else 0xFF
+    for n_o in range(3):
+        for n_t in range(3 - n_o):
+            buf[24 + n_o + 3 * n_t] = spec.potting_class((n_o, n_t), "onion") | (spec.potting_class((n_o, n_t), "tomato") << 4)
     rew = spec.rew_shaping_params
     struct.pack_into("<4f", buf, 32, float(rew["PLACEMENT_IN_POT_REW"]), float(rew["DISH_PICKUP_REWARD"]),
                      float(rew["SOUP_PICKUP_REWARD"]), 0.0)
@@ -303,6 +323,7 @@ class LayoutTable:
         self.n_obj_planes = (self.n_cells + 15) // 16
         self.n_planes = 1 + self.n_obj_planes
         self.records = np.stack([compile_layout(s) for s in specs])  # [L, 256] u8
+        self.max_pots = max(len(s.cells_of("P")) for s in specs)
 
     def __len__(self):
         return len(self.specs)

@@ -63,7 +63,8 @@ class VecOvercookedEnv:
         self._batch = _lib.OcBatch(
             d_layouts=self.d_layouts.data_ptr(),
             d_layout_id=self.layout_id.data_ptr() if self.layout_id is not None else None,
-            n_envs=self.n_envs, n_layouts=len(self.table), width=self.width, height=self.height)
+            n_envs=self.n_envs, n_layouts=len(self.table), width=self.width, height=self.height,
+            max_pots=self.table.max_pots)
         self._bref = ctypes.byref(self._batch)
         self.reset()
 
@@ -90,10 +91,13 @@ class VecOvercookedEnv:
                                    self.ep_returns.data_ptr() if self.ep_returns is not None else None, self._stream())
         _lib.check(rc, "oc_reset")
 
-    def step(self, actions, state_out=None):
+    def step(self, actions, state_out=None, events_out=None):
         """actions: uint8 tensor [n_envs, 2] of action indices (Action.INDEX_TO_ACTION order).
         Returns (rewards [n_envs,4] = sparse0, sparse1, shaped0, shaped1; flags [n_envs] OC_F_* bits).
-        The returned tensors are reused by the next call."""
+        The returned tensors are reused by the next call.  events_out: optional int64 tensor [n_envs] that
+        receives the event_infos bit mask of the step (bit 2*k + p = EVENT_TYPES[k] for player p)."""
+        if events_out is not None:
+            assert events_out.dtype == torch.int64 and events_out.shape == (self.n_envs,) and events_out.is_contiguous()
         if actions.dtype != torch.uint8 or actions.shape != (self.n_envs, 2) or not actions.is_contiguous() \
                 or actions.device != self.state.device:
             raise ValueError("actions must be a contiguous uint8 [n_envs, 2] tensor on %s" % self.device)
@@ -102,6 +106,7 @@ class VecOvercookedEnv:
             rc = self.lib.oc_step(self._bref, self.state.data_ptr(), out.data_ptr(), actions.data_ptr(),
                                   self.rewards.data_ptr(), self.flags.data_ptr(),
                                   self.ep_returns.data_ptr() if self.ep_returns is not None else None,
+                                  events_out.data_ptr() if events_out is not None else None,
                                   self.horizon, self.options, self._stream())
         _lib.check(rc, "oc_step")
         return self.rewards, self.flags

@@ -31,10 +31,10 @@ def test_library_builds_and_exports_every_declared_symbol():
 def test_batch_struct_layout_matches_header():
     from overcooked_ai_amd import _lib
 
-    # OcBatch: two pointers, int64, three int32 (+4 padding) = 40 bytes on LP64
+    # OcBatch: two pointers, int64, four int32 = 40 bytes on LP64
     assert ctypes.sizeof(_lib.OcBatch) == 40
     assert _lib.OcBatch.n_envs.offset == 16 and _lib.OcBatch.n_layouts.offset == 24
-    assert _lib.OcBatch.width.offset == 28 and _lib.OcBatch.height.offset == 32
+    assert _lib.OcBatch.width.offset == 28 and _lib.OcBatch.height.offset == 32 and _lib.OcBatch.max_pots.offset == 36
 
 
 def test_argument_validation_without_gpu():
@@ -42,7 +42,7 @@ def test_argument_validation_without_gpu():
     from overcooked_ai_amd import _lib
 
     L = _lib.load()
-    assert L.oc_step(None, None, None, None, None, None, None, 400, 0, None) == -1
+    assert L.oc_step(None, None, None, None, None, None, None, None, 400, 0, None) == -1
     assert b"batch is NULL" in L.oc_last_error()
     b = _lib.OcBatch(d_layouts=None, d_layout_id=None, n_envs=4, n_layouts=1, width=5, height=4)
     assert L.oc_reset(ctypes.byref(b), None, None, None, None) == -1

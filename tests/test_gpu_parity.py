@@ -58,10 +58,12 @@ def test_golden_transitions(name, manifest, gpu):
     n = d["actions"].shape[0]
     env = make_env(spec, n, gpu, horizon=65535)
     env.set_packed_state(d["state_in"])
-    rew, flags = env.step(torch.from_numpy(d["actions"]).to(gpu))
+    ev = torch.zeros((n,), dtype=torch.int64, device=gpu)
+    rew, flags = env.step(torch.from_numpy(d["actions"]).to(gpu), events_out=ev)
     assert np.array_equal(env.get_packed_state(), d["state_out"])
     assert np.max(np.abs(u8(rew).astype(np.float64) - d["rewards"])) <= 1e-6
     assert not u8(flags).any()
+    assert np.array_equal(u8(ev).view(np.uint64), d["events"])  # event_infos bit masks of the reference
     # pure-function form: separate output buffer leaves the input untouched (mdp.py:1400 deep-copies)
     env.set_packed_state(d["state_in"])
     out = torch.zeros_like(env.state)
@@ -202,10 +204,12 @@ def test_step_vs_oracle_random_states(n_envs, gpu):
         env.set_packed_state(st)
         ep0 = rng.integers(0, 50, size=(n_envs, 4)).astype(np.float32)
         env.ep_returns.copy_(torch.from_numpy(ep0))
-        rew, flags = env.step(torch.from_numpy(acts).to(gpu))
+        ev = torch.zeros((n_envs,), dtype=torch.int64, device=gpu)
+        rew, flags = env.step(torch.from_numpy(acts).to(gpu), events_out=ev)
         ep_o = ep0.copy()
         out_o, rew_o, fl_o = orc.step(st, acts, horizon=horizon, options=1, ep_returns=ep_o)
         assert np.array_equal(env.get_packed_state(), out_o), name
+        assert np.array_equal(u8(ev).view(np.uint64), orc.last_events), name
         assert np.array_equal(u8(rew), rew_o) and np.array_equal(u8(flags), fl_o)
         assert np.array_equal(u8(env.ep_returns), ep_o)
         assert (fl_o & 2).any() or n_envs == 1
@@ -366,12 +370,13 @@ def test_abi_argument_errors(gpu):
 
     env = make_env("cramped_room", 8, gpu)
     L = _lib.load()
-    rc = L.oc_step(env._bref, None, None, None, None, None, None, 400, 0, None)
+    rc = L.oc_step(env._bref, None, None, None, None, None, None, None, 400, 0, None)
     assert rc == -1 and b"NULL" in L.oc_last_error()
     rc = L.oc_step(env._bref, env.state.data_ptr(), env.state.data_ptr(), env.flags.data_ptr(),
-                   env.rewards.data_ptr(), env.flags.data_ptr(), None, 0, 0, None)
+                   env.rewards.data_ptr(), env.flags.data_ptr(), None, None, 0, 0, None)
     assert rc == -1 and b"horizon" in L.oc_last_error()
-    bad = _lib.OcBatch(d_layouts=env.d_layouts.data_ptr(), d_layout_id=None, n_envs=8, n_layouts=2, width=5, height=4)
+    bad = _lib.OcBatch(d_layouts=env.d_layouts.data_ptr(), d_layout_id=None, n_envs=8, n_layouts=2, width=5, height=4,
+                       max_pots=1)
     rc = L.oc_reset(ctypes.byref(bad), env.state.data_ptr(), None, None, None)
     assert rc == -1 and b"layout_id" in L.oc_last_error()
     with pytest.raises(ValueError):
