@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--fuse", type=int, default=100, help="env steps fused per oc_rollout_random launch")
     ap.add_argument("--envs", type=int, default=N_ENVS_PER_GPU, help="envs per GPU")
     ap.add_argument("--layout", default="cramped_room")
+    ap.add_argument("--lane-per-env", action="store_true", help="force the one-lane-per-env rollout kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the step-API and encode side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -111,6 +112,7 @@ def main():
     n = args.envs
     env = VecOvercookedEnv(args.layout, n, horizon=HORIZON, device=dev, auto_reset=True, seed=0,
                            env_offset=rank * n)
+    env.lane_per_env = args.lane_per_env
     fuse = max(1, min(args.fuse, args.steps))
     rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)

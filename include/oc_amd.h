@@ -83,6 +83,13 @@ extern "C" {
 /* option bits for oc_step / oc_rollout_random */
 #define OC_OPT_AUTO_RESET 0x1u /* reset a done env to its layout's start state inside the kernel */
 
+#define OC_OPT_LANE_PER_ENV 0x2u /* oc_rollout_random: force the one-lane-per-env kernel */
+#define OC_OPT_LANE_PAIR 0x4u    /* oc_rollout_random: force the lane-pair-per-env kernel where the table allows it
+                                   (2-player layouts, <= 2 pots); default: pairs iff n_envs <= 64 * #SIMDs */
+
+/* OcBatch.batch_flags */
+#define OC_BATCH_TWO_PLAYERS 0x1u /* every layout of the table has exactly 2 players */
+
 /* obs dtypes of oc_encode_lossless */
 #define OC_OBS_U8 0
 #define OC_OBS_F32 1
@@ -133,6 +140,8 @@ typedef struct OcBatch {
     int32_t width, height;       /* grid shape shared by every layout of the table */
     int32_t max_pots;            /* max n_pots over the table (1..8), or 0 if unknown: selects how many pot slots
                                     the step kernels keep in registers */
+    uint32_t batch_flags;        /* OC_BATCH_* hints about the table */
+    uint32_t reserved;
 } OcBatch;
 
 int oc_abi_version(void);

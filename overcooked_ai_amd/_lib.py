@@ -4,11 +4,14 @@ import ctypes
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "liboc_amd.so")
+LIB_PATH = os.environ.get("OC_AMD_LIB") or os.path.join(PKG, "liboc_amd.so")  # OC_AMD_LIB: developer override
 
 ABI_VERSION = 1
 F_DONE, F_BAD_ACTION, F_RESET = 0x01, 0x02, 0x04
 OPT_AUTO_RESET = 0x1
+OPT_LANE_PER_ENV = 0x2
+OPT_LANE_PAIR = 0x4
+BATCH_TWO_PLAYERS = 0x1
 OBS_U8, OBS_F32 = 0, 1
 
 EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_step", "oc_rollout_random",
@@ -24,6 +27,8 @@ class OcBatch(ctypes.Structure):
         ("width", ctypes.c_int32),
         ("height", ctypes.c_int32),
         ("max_pots", ctypes.c_int32),
+        ("batch_flags", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
     ]
 
 

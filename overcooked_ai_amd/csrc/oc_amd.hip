@@ -106,11 +106,13 @@ __device__ __forceinline__ LayC load_consts(const Lay L) {
     return C;
 }
 
+template <int STRIDE = BLOCK>
 __device__ __forceinline__ uint32_t rd_cell16(const uint32_t* cellw, uint32_t c) {
-    return reinterpret_cast<const uint16_t*>(cellw + (c >> 1) * BLOCK)[c & 1];
+    return reinterpret_cast<const uint16_t*>(cellw + (c >> 1) * STRIDE)[c & 1];
 }
+template <int STRIDE = BLOCK>
 __device__ __forceinline__ void wr_cell_obj(uint32_t* cellw, uint32_t c, uint32_t v) {
-    reinterpret_cast<uint8_t*>(cellw + (c >> 1) * BLOCK)[(c & 1) * 2] = (uint8_t)v;
+    reinterpret_cast<uint8_t*>(cellw + (c >> 1) * STRIDE)[(c & 1) * 2] = (uint8_t)v;
 }
 
 // recipe index n_onion + 4*n_tomato of a soup code
@@ -122,8 +124,12 @@ __device__ __forceinline__ uint32_t recipe_idx(uint32_t soup) {
 // Recipe.time of a soup code through the 16-byte LUT held in 4 registers
 __device__ __forceinline__ uint32_t cook_of(const LayC& C, uint32_t soup) {
     const uint32_t n = (soup >> 3) & 3u, nt = __popc(soup & 7u), no = n - nt;
-    const uint32_t w = nt == 0u ? C.cook[0] : nt == 1u ? C.cook[1] : nt == 2u ? C.cook[2] : C.cook[3];
-    return (w >> (8u * no)) & 0xFFu;
+    // byte (n_onion + 4*(n_tomato & 1)) of the dword pair {cook[2j+1], cook[2j]}: v_perm_b32 with selector
+    // 0x0C (constant 0) in the upper lanes picks it in one instruction per pair
+    const uint32_t sel = 0x0C0C0C00u | no | ((nt & 1u) << 2);
+    const uint32_t lo = __builtin_amdgcn_perm(C.cook[1], C.cook[0], sel);
+    const uint32_t hi = __builtin_amdgcn_perm(C.cook[3], C.cook[2], sel);
+    return nt >= 2u ? hi : lo;
 }
 
 // cell-index delta of direction d (0..3 = N,S,E,W) from a packed table of 4 signed bytes
@@ -143,16 +149,29 @@ enum {
 __device__ __forceinline__ uint64_t evbit(bool cond, int k, int p) { return cond ? (1ull << (2 * k + p)) : 0ull; }
 
 // ------------------------------------------------------------------------------------------
-// INTERACT of player P (resolve_interacts, mdp.py:1432-1579), written without data-dependent
-// branches: every outcome is a predicate, the new hand / cell / tick are selects.  `cell16` is the
-// LDS word of the faced cell, `fwd_*` forwards player 0's counter write when both face one cell.
+// INTERACT of player P (resolve_interacts, mdp.py:1432-1579) as a pure function of its inputs, written
+// without data-dependent branches: every outcome is a predicate, the new hand / cell / tick are selects.
+//   h, other_h   this player's hand and the other player's LIVE hand
+//   dcount       live number of loose dishes on counters
+//   cell16       LDS word of the faced cell (object | terrain << 8)
+//   ps, tk       pot registers the player sees
 // ------------------------------------------------------------------------------------------
-template <int MAXP, bool EVENTS, int P>
-__device__ __forceinline__ void interact(const LayC& C, const Lay L, EnvW<MAXP>& s, bool act, uint32_t f,
-                                         uint32_t cell16, uint32_t useful_pots, uint32_t n_full, bool two,
-                                         bool& wr, uint32_t& wr_val, float& sparse, float& shaped, uint64_t& ev) {
-    uint32_t h = P ? s.held1 : s.held0;
-    const uint32_t other_h = P ? s.held0 : s.held1;
+struct IOut {
+    uint32_t new_h;    // hand after the interact
+    uint32_t cell_obj; // object byte the faced cell holds afterwards (unchanged unless swapX)
+    uint32_t slot, new_o, new_tk;  // pot slot touched and its registers afterwards (valid when pot_upd)
+    bool swapX, pot_upd;
+    bool take_dish;    // a dish was taken from a dispenser (its shaped reward may be added by the caller)
+    int32_t ddelta;    // change of the loose-dish count
+    float sparse, shaped;
+    uint64_t ev;
+};
+
+template <int MAXP, bool EVENTS, int P, bool DEFER_DISH = false>
+__device__ __forceinline__ IOut interact(const LayC& C, const Lay L, bool act, uint32_t h, uint32_t other_h,
+                                         int32_t dcount, uint32_t cell16, const uint32_t (&ps)[MAXP],
+                                         const uint32_t (&tkr)[MAXP], uint32_t useful_pots, uint32_t n_full, bool two) {
+    IOut r;
     const uint32_t tc = cell16 >> 8;
     const uint32_t type = act ? (tc & 7u) : 7u;  // 7 matches no terrain: a lane that does not interact falls through
     const uint32_t slot = tc >> 3;
@@ -161,10 +180,11 @@ __device__ __forceinline__ void interact(const LayC& C, const Lay L, EnvW<MAXP>&
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
         const bool sel = slot == (uint32_t)k;
-        tkv = sel ? s.tk[k] : tkv;
-        pso = sel ? s.ps[k] : pso;
+        tkv = sel ? tkr[k] : tkv;
+        pso = sel ? ps[k] : pso;
     }
-    const uint32_t o = isP ? pso : (cell16 & 0xFFu);
+    const uint32_t o_cell = cell16 & 0xFFu;
+    const uint32_t o = isP ? pso : o_cell;
     const uint32_t tk = isP ? tkv : 0u;
     const bool hz = h == 0u, oz = o == 0u;
     const uint32_t n = (o >> 3) & 3u;
@@ -176,7 +196,7 @@ __device__ __forceinline__ void interact(const LayC& C, const Lay L, EnvW<MAXP>&
     const uint32_t disp_obj = type == OC_T_ONION_DISP ? (uint32_t)OC_O_ONION
                               : type == OC_T_TOMATO_DISP ? (uint32_t)OC_O_TOMATO : (uint32_t)OC_O_DISH;
     // is_dish_pickup_useful (mdp.py:2180-2204): live hands and counters, stale pot_states
-    const bool dish_useful = two & (((other_h == OC_O_DISH) ? 1u : 0u) < useful_pots) & (s.dcount == 0);
+    const bool dish_useful = two & (((other_h == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dcount == 0);
     // pot (mdp.py:1515-1568)
     const bool idle = tk == 0u;
     const bool start = isP & hz & (C.old_dyn == 0u) & (!oz) & idle & (n > 0u);       // begin_cooking -> tick 0
@@ -186,27 +206,23 @@ __device__ __forceinline__ void interact(const LayC& C, const Lay L, EnvW<MAXP>&
     const bool is_ing = (h == OC_O_ONION) | (h == OC_O_TOMATO);
     const bool place = isP & is_ing & idle & (n < 3u);                               // not is_full (mdp.py:547-551)
     const uint32_t soup_new = OC_O_SOUP | ((n + 1u) << 3) | (o & 7u) | ((h == OC_O_TOMATO ? 1u : 0u) << n);
-    // serving (mdp.py:1570-1577)
+    // serving (mdp.py:1570-1577); deliver_soup / get_recipe_value (1631-1642, 1595-1602)
     const bool serve = (type == OC_T_SERVE) & ((h & OC_O_SOUP) != 0u);
+    const float value = L.value(recipe_idx(h) & 15u);  // unconditional LUT read keeps the step straight-line
 
-    const uint32_t new_h = swapX ? o : take ? disp_obj : plate ? o : (place | serve) ? 0u : h;
-    const uint32_t new_o = swapX ? h : plate ? 0u : place ? soup_new : o;
-    const uint32_t new_tk = start ? 1u : plate ? 0u : tk;
-    const bool pot_upd = start | plate | place;
-#pragma unroll
-    for (int k = 0; k < MAXP; ++k) {
-        const bool upd = pot_upd & (slot == (uint32_t)k);
-        s.ps[k] = upd ? new_o : s.ps[k];
-        s.tk[k] = upd ? new_tk : s.tk[k];
-    }
-    s.dcount += swapX ? ((h == OC_O_DISH ? 1 : 0) - (o == OC_O_DISH ? 1 : 0)) : 0;
-    if (P) s.held1 = new_h; else s.held0 = new_h;
-    wr = swapX;
-    wr_val = new_o;
-    shaped = (place ? C.rew_place : 0.f) + (plate ? C.rew_soup : 0.f) + ((take & isD & dish_useful) ? C.rew_dish : 0.f);
-    sparse = 0.f;
-    if (serve) sparse = L.value(recipe_idx(h));  // deliver_soup / get_recipe_value (mdp.py:1631-1642, 1595-1602); rare
-
+    r.new_h = swapX ? o : take ? disp_obj : plate ? o : (place | serve) ? 0u : h;
+    r.cell_obj = swapX ? h : o_cell;
+    r.slot = slot;
+    r.new_o = plate ? 0u : place ? soup_new : o;
+    r.new_tk = start ? 1u : plate ? 0u : tk;
+    r.pot_upd = start | plate | place;
+    r.swapX = swapX;
+    r.ddelta = swapX ? ((h == OC_O_DISH ? 1 : 0) - (o == OC_O_DISH ? 1 : 0)) : 0;
+    r.take_dish = take & isD;
+    r.shaped = (place ? C.rew_place : 0.f) + (plate ? C.rew_soup : 0.f) +
+               ((!DEFER_DISH & r.take_dish & dish_useful) ? C.rew_dish : 0.f);
+    r.sparse = serve ? value : 0.f;
+    r.ev = 0;
     if (EVENTS) {
         // log_object_pickup / drop / potting and their usefulness predicates (mdp.py:2121-2308)
         const bool all_full = C.n_pots == n_full;
@@ -233,17 +249,24 @@ __device__ __forceinline__ void interact(const LayC& C, const Lay L, EnvW<MAXP>&
         const uint32_t pw = pi < 4u ? C.pclass[0] : C.pclass[1];
         const uint32_t tom = h == OC_O_TOMATO ? 1u : 0u;
         const uint32_t nib = (pw >> (8u * (pi & 3u) + 4u * tom)) & 0xFu;
-        e |= evbit(place, tom ? EV_POTTING_TOMATO : EV_POTTING_ONION, P);
-        e |= evbit(place & ((nib & 1u) != 0u), EV_OPTIMAL_ONION_POTTING + (int)0, P) << (2 * tom);
-        e |= evbit(place & ((nib & 2u) != 0u), EV_VIABLE_ONION_POTTING, P) << (2 * tom);
-        e |= evbit(place & ((nib & 4u) != 0u), EV_CATASTROPHIC_ONION_POTTING, P) << (2 * tom);
-        e |= evbit(place & ((nib & 8u) != 0u), EV_USELESS_ONION_POTTING, P) << (2 * tom);
-        ev |= e;
+        e |= evbit(place, EV_POTTING_ONION, P) >> (10u * tom);  // EV_POTTING_TOMATO = EV_POTTING_ONION - 5
+        e |= evbit(place & ((nib & 1u) != 0u), EV_OPTIMAL_ONION_POTTING, P) << (2u * tom);
+        e |= evbit(place & ((nib & 2u) != 0u), EV_VIABLE_ONION_POTTING, P) << (2u * tom);
+        e |= evbit(place & ((nib & 4u) != 0u), EV_CATASTROPHIC_ONION_POTTING, P) << (2u * tom);
+        e |= evbit(place & ((nib & 8u) != 0u), EV_USELESS_ONION_POTTING, P) << (2u * tom);
+        r.ev = e;
     }
+    return r;
 }
 
 // ------------------------------------------------------------------------------------------
 // One joint transition: get_state_transition (mdp.py:1375-1430).
+//
+// The reference applies player 0's interact before player 1's (mdp.py:1446).  Here both are computed from the
+// pre-step pots and cells, which gives the scheduler two independent dependency chains to interleave (one
+// wavefront per SIMD has nobody else to hide latency behind); the only ways player 0 can change what player 1
+// sees are the same counter cell or the same pot, and those lanes (well under 1 % of env-steps) replay player
+// 1's interact on the live state.  Hands and the loose-dish count flow from player 0 to player 1 as plain data.
 // ------------------------------------------------------------------------------------------
 template <int MAXP, bool EVENTS>
 __device__ __forceinline__ void env_step(const LayC& C, const Lay L, uint32_t* cellw, EnvW<MAXP>& s, uint32_t delta4,
@@ -267,18 +290,43 @@ __device__ __forceinline__ void env_step(const LayC& C, const Lay L, uint32_t* c
         if (EVENTS) n_full += (nz & (hot | (n == 3u))) ? 1u : 0u;
     }
 
-    // resolve_interacts: player 0 fully, then player 1 (mdp.py:1446)
-    bool wr0, wr1;
-    uint32_t v0, v1;
-    float sp0, sh0, sp1, sh1;
-    interact<MAXP, EVENTS, 0>(C, L, s, a0 == OC_A_INTERACT, f0, c_f0, useful_pots, n_full, two, wr0, v0, sp0, sh0, ev);
-    // player 1 sees player 0's counter write when both face the same cell
-    const uint32_t c_f1_live = (wr0 & (f1 == f0)) ? ((c_f1 & 0xFF00u) | v0) : c_f1;
-    interact<MAXP, EVENTS, 1>(C, L, s, two & (a1 == OC_A_INTERACT), f1, c_f1_live, useful_pots, n_full, two, wr1, v1, sp1,
-                              sh1, ev);
-    if (wr0) wr_cell_obj(cellw, f0, v0);
-    if (wr1) wr_cell_obj(cellw, f1, v1);
-    r = make_float4(sp0, sp1, sh0, sh1);
+    const bool act0 = a0 == OC_A_INTERACT, act1 = two & (a1 == OC_A_INTERACT);
+    const IOut r0 = interact<MAXP, EVENTS, 0>(C, L, act0, s.held0, s.held1, s.dcount, c_f0, s.ps, s.tk, useful_pots,
+                                              n_full, two);
+    IOut r1 = interact<MAXP, EVENTS, 1>(C, L, act1, s.held1, r0.new_h, s.dcount + r0.ddelta, c_f1, s.ps, s.tk,
+                                        useful_pots, n_full, two);
+    // apply player 0
+    s.held0 = r0.new_h;
+    s.dcount += r0.ddelta;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const bool upd = r0.pot_upd & (r0.slot == (uint32_t)k);
+        s.ps[k] = upd ? r0.new_o : s.ps[k];
+        s.tk[k] = upd ? r0.new_tk : s.tk[k];
+    }
+    // what player 1 faces after player 0's turn
+    const bool same_cell = f1 == f0;
+    const uint32_t c_f1_live = (same_cell & r0.swapX) ? ((c_f1 & 0xFF00u) | r0.cell_obj) : c_f1;
+    const bool conflict = act1 & ((same_cell & r0.swapX) | (r0.pot_upd & (((c_f1 >> 8) & 7u) == OC_T_POT) &
+                                                            ((c_f1 >> 11) == r0.slot)));
+    if (__builtin_expect(conflict, 0)) {
+        r1 = interact<MAXP, EVENTS, 1>(C, L, act1, s.held1, r0.new_h, s.dcount, c_f1_live, s.ps, s.tk, useful_pots, n_full,
+                                       two);
+    }
+    // apply player 1
+    s.held1 = r1.new_h;
+    s.dcount += r1.ddelta;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const bool upd = r1.pot_upd & (r1.slot == (uint32_t)k);
+        s.ps[k] = upd ? r1.new_o : s.ps[k];
+        s.tk[k] = upd ? r1.new_tk : s.tk[k];
+    }
+    // counter cells: unconditional byte stores (unchanged cells rewrite their own value); player 1 after player 0
+    wr_cell_obj(cellw, f0, r0.cell_obj);
+    wr_cell_obj(cellw, f1, r1.swapX ? r1.cell_obj : (c_f1_live & 0xFFu));
+    r = make_float4(r0.sparse, r1.sparse, r0.shaped, r1.shaped);
+    if (EVENTS) ev |= r0.ev | r1.ev;
 
     // resolve_movement (mdp.py:1644-1727): orientation follows the action even when blocked;
     // same target cell or swapped cells -> nobody moves (is_transition_collision, 1673-1683)
@@ -533,6 +581,242 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const OcLayout* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// k_rollout_pair: the fused random-policy rollout with TWO lanes per env (lane parity = player index = pot
+// slot owned).  One wavefront per SIMD issues at most one instruction every four cycles, so with 65 536 envs
+// (1 024 lane-per-env wavefronts on 1 024 SIMDs) the lane-per-env kernel is bound by the length of its own
+// instruction stream.  Splitting each env over a lane pair halves that stream and doubles the wavefronts per
+// SIMD.  The players exchange what the other needs with DPP quad-permutes (v_mov_b32_dpp, no LDS):
+//   - before the interacts: hand, position, faced cell, pot registers;
+//   - after them: the packed result of the interact (new hand, counter byte, pot update, dish-count delta).
+// Interact order (player 0 before player 1, mdp.py:1446) is kept exactly: both lanes evaluate `interact` on the
+// pre-step pots and cells; player 1's inputs that player 0 can change (hand, dish count) arrive as data, and
+// the pairs where player 0 changed the very cell or pot player 1 uses replay player 1's interact on the live
+// state.  Requires 2-player layouts with at most 2 pots (every layout shipped by the reference).
+// ------------------------------------------------------------------------------------------
+constexpr int PAIR_ENVS = BLOCK / 2;
+
+__device__ __forceinline__ uint32_t xchg(uint32_t v) {  // value held by the other lane of the pair
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+
+struct PairW {
+    uint32_t pos, ori, held, t;
+    uint32_t ps, tk;  // the pot slot this lane owns (slot index = lane parity)
+    int32_t dcount;   // loose dishes on counters (kept identical in both lanes)
+};
+
+__device__ __forceinline__ uint32_t pack_res1(const IOut& r) {
+    return r.new_h | (r.cell_obj << 8) | (r.new_o << 16) | (r.new_tk << 24);
+}
+__device__ __forceinline__ uint32_t pack_res2(const IOut& r) {
+    return (r.swapX ? 1u : 0u) | (r.pot_upd ? 2u : 0u) | (r.slot << 2) | ((uint32_t)(r.ddelta + 1) << 5);
+}
+
+__device__ __forceinline__ void pair_step(const LayC& C, const Lay L, uint32_t* cellw, uint32_t p, PairW& s,
+                                          uint32_t delta4, uint32_t a, float& sparse, float& shaped) {
+    const bool lane1 = p != 0u;
+    const bool mv = a < 4u;
+    const uint32_t f = step_cell(s.pos, s.ori, delta4);
+    const uint32_t m = mv ? step_cell(s.pos, a, delta4) : s.pos;
+    const uint32_t c_f = rd_cell16<PAIR_ENVS>(cellw, f), c_m = rd_cell16<PAIR_ENVS>(cellw, m);
+    // the partner's pre-step view
+    const uint32_t held_o = xchg(s.held), pos_o = xchg(s.pos), f_o = xchg(f), ps_o = xchg(s.ps), tk_o = xchg(s.tk);
+    // pot_states before any interact (mdp.py:1439)
+    const uint32_t n_own = (s.ps >> 3) & 3u;
+    const uint32_t u_own = ((s.ps != 0u) & ((s.tk != 0u) | ((n_own - 1u) < 2u))) ? 1u : 0u;
+    const uint32_t useful_pots = u_own + xchg(u_own);
+    uint32_t ps_arr[2] = {lane1 ? ps_o : s.ps, lane1 ? s.ps : ps_o};
+    uint32_t tk_arr[2] = {lane1 ? tk_o : s.tk, lane1 ? s.tk : tk_o};
+    const bool act = a == OC_A_INTERACT;
+    IOut r = interact<2, false, 0, true>(C, L, act, s.held, held_o, s.dcount, c_f, ps_arr, tk_arr, useful_pots, 0u, true);
+    // hand the result to the partner
+    uint32_t o1 = xchg(pack_res1(r)), o2 = xchg(pack_res2(r));
+    const bool same_cell = f == f_o;
+    {
+        // player 1 replays when player 0 changed the counter cell or the pot it uses (player 0's lane follows it
+        // into the branch only to receive the final result)
+        const bool o_swapX = (o2 & 1u) != 0u, o_pot_upd = (o2 & 2u) != 0u;
+        const uint32_t o_slot = (o2 >> 2) & 7u;
+        const bool conflict = lane1 & act & ((same_cell & o_swapX) |
+                                            (o_pot_upd & (((c_f >> 8) & 7u) == OC_T_POT) & ((c_f >> 11) == o_slot)));
+        const bool cpair = conflict | (xchg(conflict ? 1u : 0u) != 0u);
+        if (__builtin_expect(cpair, 0)) {
+            const uint32_t o_new_o = (o1 >> 16) & 0xFFu, o_new_tk = o1 >> 24;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const bool upd = o_pot_upd & (o_slot == (uint32_t)k);
+                ps_arr[k] = upd ? o_new_o : ps_arr[k];
+                tk_arr[k] = upd ? o_new_tk : tk_arr[k];
+            }
+            const uint32_t c_f_live = (same_cell & o_swapX) ? ((c_f & 0xFF00u) | ((o1 >> 8) & 0xFFu)) : c_f;
+            const int32_t o_dd = (int32_t)((o2 >> 5) & 3u) - 1;
+            const IOut r2 = interact<2, false, 0, true>(C, L, act, s.held, o1 & 0xFFu, s.dcount + o_dd, c_f_live, ps_arr,
+                                                        tk_arr, useful_pots, 0u, true);
+            if (lane1) r = r2;
+            const uint32_t n1 = xchg(pack_res1(r)), n2 = xchg(pack_res2(r));
+            if (!lane1) { o1 = n1; o2 = n2; }
+        }
+    }
+    const uint32_t o_new_h = o1 & 0xFFu, o_cell_obj = (o1 >> 8) & 0xFFu, o_new_o = (o1 >> 16) & 0xFFu, o_new_tk = o1 >> 24;
+    const bool o_swapX = (o2 & 1u) != 0u, o_pot_upd = (o2 & 2u) != 0u;
+    const uint32_t o_slot = (o2 >> 2) & 7u;
+    const int32_t o_dd = (int32_t)((o2 >> 5) & 3u) - 1;
+    // is_dish_pickup_useful (mdp.py:2180-2204) on the live hands/counters: player 1 sees player 0's new hand
+    const uint32_t other_live = lane1 ? o_new_h : held_o;
+    const int32_t dcount_live = s.dcount + (lane1 ? o_dd : 0);
+    const bool dish_useful = (((other_live == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dcount_live == 0);
+    sparse = r.sparse;
+    shaped = r.shaped + ((r.take_dish & dish_useful) ? C.rew_dish : 0.f);
+    // apply: hand, dish count, the pot slot this lane owns (player 1's update wins when both hit it: it was replayed)
+    s.held = r.new_h;
+    s.dcount += r.ddelta + o_dd;
+    {
+        const bool mine = r.pot_upd & (r.slot == p), theirs = o_pot_upd & (o_slot == p);
+        const bool hit1 = lane1 ? mine : theirs, hit0 = lane1 ? theirs : mine;
+        const uint32_t o_1 = lane1 ? r.new_o : o_new_o, t_1 = lane1 ? r.new_tk : o_new_tk;
+        const uint32_t o_0 = lane1 ? o_new_o : r.new_o, t_0 = lane1 ? o_new_tk : r.new_tk;
+        s.ps = hit1 ? o_1 : hit0 ? o_0 : s.ps;
+        s.tk = hit1 ? t_1 : hit0 ? t_0 : s.tk;
+    }
+    {
+        // counter byte of the faced cell; when both face one cell both lanes store the same final value
+        const bool sw1 = lane1 ? r.swapX : o_swapX, sw0 = lane1 ? o_swapX : r.swapX;
+        const uint32_t ob1 = lane1 ? r.cell_obj : o_cell_obj, ob0 = lane1 ? o_cell_obj : r.cell_obj;
+        const uint32_t final_same = sw1 ? ob1 : sw0 ? ob0 : (c_f & 0xFFu);
+        wr_cell_obj<PAIR_ENVS>(cellw, f, same_cell ? final_same : r.cell_obj);
+    }
+    // resolve_movement (mdp.py:1644-1727)
+    const uint32_t np = (mv & (((c_m >> 8) & 7u) == OC_T_FLOOR)) ? m : s.pos;
+    const uint32_t np_o = xchg(np);
+    const bool collide = (np == np_o) | ((np == pos_o) & (np_o == s.pos));
+    s.ori = mv ? a : s.ori;
+    s.pos = collide ? s.pos : np;
+    // step_environment_effects (mdp.py:1691-1703) for the pot this lane owns
+    s.t += 1u;
+    {
+        const uint32_t o = s.ps, n = (o >> 3) & 3u;
+        uint32_t tk = s.tk;
+        const bool nz = o != 0u;
+        tk = ((C.old_dyn != 0u) & nz & (tk == 0u) & (n == 3u)) ? 1u : tk;
+        const bool cooking = nz & (tk != 0u) & ((tk - 1u) < cook_of(C, o));
+        s.tk = tk + (cooking ? 1u : 0u);
+    }
+}
+
+template <bool UNIFORM, bool LAY_LDS>
+__global__ __launch_bounds__(BLOCK) void k_rollout_pair(const OcLayout* __restrict__ g_layouts, int n_layouts,
+                                                        const uint16_t* __restrict__ layout_id, uint4* st,
+                                                        float4* __restrict__ rewards, uint8_t* __restrict__ flags,
+                                                        float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,
+                                                        int horizon, uint32_t options, uint32_t seed_lo,
+                                                        uint32_t seed_hi, int64_t env_offset, int64_t t0, int n_steps) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_cells[];  // [n_obj * 8][PAIR_ENVS]
+    __shared__ uint4 s_lay[LAY_LDS ? LDS_LAYOUT_MAX * 16 : 1];
+    const uint32_t p = threadIdx.x & 1u, el = threadIdx.x >> 1;
+    const bool lane1 = p != 0u;
+    const int64_t e = (int64_t)blockIdx.x * PAIR_ENVS + el;
+    const bool active = e < n;
+    const Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);
+    uint32_t* cellw = s_cells + el;
+    const uint32_t delta4 = make_delta4(W);
+    PairW s = {};
+    LayC C = {};
+    float ep_sp = 0.f, ep_sh = 0.f;
+    if (active) {
+        C = load_consts<UNIFORM>(L);
+        const uint4 h = st[e];
+        s.pos = lane1 ? (h.x >> 24) : (h.x & 0xFFu);
+        s.ori = lane1 ? (h.y & 0xFFu) : ((h.x >> 8) & 0xFFu);
+        s.held = lane1 ? ((h.y >> 8) & 0xFFu) : ((h.x >> 16) & 0xFFu);
+        s.t = h.y >> 16;
+        s.tk = (p < C.n_pots) ? ((h.z >> (8u * p)) & 0xFFu) : 0u;
+        // each lane stages half of every object plane (dwords 2p, 2p+1) into the LDS cell words
+        int32_t dishes = 0;
+        for (int pl = 0; pl < n_obj; ++pl) {
+            const uint4 v = st[(int64_t)(1 + pl) * n + e];
+            const uint32_t ow[2] = {lane1 ? v.z : v.x, lane1 ? v.w : v.y};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const uint32_t qq = 2u * p + (uint32_t)q;
+                const uint32_t T = L.u32(L_TERRAIN + 16 * pl + 4 * (int)qq);
+                dishes += (int32_t)count_dish_bytes(ow[q]);
+                cellw[(8 * pl + 2 * (int)qq) * PAIR_ENVS] = __builtin_amdgcn_perm(T, ow[q], 0x05010400u);
+                cellw[(8 * pl + 2 * (int)qq + 1) * PAIR_ENVS] = __builtin_amdgcn_perm(T, ow[q], 0x07030602u);
+            }
+        }
+        s.dcount = dishes + (int32_t)xchg((uint32_t)dishes);
+        if (ep_returns) {
+            const float4 ep = ep_returns[e];
+            ep_sp = lane1 ? ep.y : ep.x;
+            ep_sh = lane1 ? ep.w : ep.z;
+        }
+    }
+    __syncthreads();  // the partner lane staged the other half of the cells
+    if (!active) return;
+    s.ps = (p < C.n_pots) ? (rd_cell16<PAIR_ENVS>(cellw, L.pot_cell((int)p)) & 0xFFu) : 0u;
+    const uint64_t g = (uint64_t)(env_offset + e);
+    const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
+    const uint32_t mul_p = lane1 ? 6u : 1u;  // player 1 reads the next base-6 digit
+    uint32_t rnd[4] = {0, 0, 0, 0};
+    for (int k = 0; k < n_steps; ++k) {
+        const uint64_t t = (uint64_t)(t0 + k);
+        const uint32_t s8 = (uint32_t)t & 7u;
+        if (k == 0 || s8 == 0u) {
+            const uint64_t blk = t >> 3;
+            philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, rnd);
+        }
+        const uint32_t w = s8 < 2u ? rnd[0] : s8 < 4u ? rnd[1] : s8 < 6u ? rnd[2] : rnd[3];
+        const uint32_t x = ((s8 & 1u) ? w * 36u : w) * mul_p;
+        const uint32_t a = __umulhi(x, 6u);
+        float sp, sh;
+        pair_step(C, L, cellw, p, s, delta4, a, sp, sh);
+        ep_sp += sp; ep_sh += sh;
+        uint32_t fl = 0;
+        if ((int)s.t >= horizon) {  // is_done (env.py:321-325); both lanes agree
+            fl |= OC_F_DONE;
+            if (options & OC_OPT_AUTO_RESET) {
+                s.pos = L.u8(L_START_POS + (int)p);
+                s.ori = L.u8(L_START_OR + (int)p);
+                s.held = 0; s.t = 0; s.ps = 0; s.tk = 0; s.dcount = 0;
+                ep_sp = 0.f; ep_sh = 0.f;
+                for (int d = (int)p; d < n_obj * 8; d += 2) cellw[d * PAIR_ENVS] &= 0xFF00FF00u;
+                fl |= OC_F_RESET;
+            }
+        }
+        if (rewards) {
+            float* base = reinterpret_cast<float*>(rewards + ((int64_t)k * n + e));
+            base[p] = sp;       // sparse_reward_by_agent[p]
+            base[2 + p] = sh;   // shaped_reward_by_agent[p]
+        }
+        if (flags) flags[(int64_t)k * n + e] = (uint8_t)fl;  // both lanes store the same byte
+    }
+    // write back: pot soups into their cells, then header (lane 0) and alternating object planes
+    if (p < C.n_pots) wr_cell_obj<PAIR_ENVS>(cellw, L.pot_cell((int)p), s.ps);
+    const uint32_t pos_o = xchg(s.pos), ori_o = xchg(s.ori), held_o = xchg(s.held), tk_o = xchg(s.tk);
+    const float ep_sp_o = __uint_as_float(xchg(__float_as_uint(ep_sp)));
+    const float ep_sh_o = __uint_as_float(xchg(__float_as_uint(ep_sh)));
+    if (!lane1) {
+        uint4 h;
+        h.x = s.pos | (s.ori << 8) | (s.held << 16) | (pos_o << 24);
+        h.y = ori_o | (held_o << 8) | (s.t << 16);
+        h.z = s.tk | (tk_o << 8);
+        h.w = 0;
+        st[e] = h;
+        if (ep_returns) ep_returns[e] = make_float4(ep_sp, ep_sp_o, ep_sh, ep_sh_o);
+    }
+    __syncthreads();
+    for (int pl = (int)p; pl < n_obj; pl += 2) {
+        uint32_t ow[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t lo = cellw[(8 * pl + 2 * q) * PAIR_ENVS], hi = cellw[(8 * pl + 2 * q + 1) * PAIR_ENVS];
+            ow[q] = __builtin_amdgcn_perm(hi, lo, 0x06040200u);
+        }
+        st[(int64_t)(1 + pl) * n + e] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_reset
 // ------------------------------------------------------------------------------------------
 template <int NOBJ>
@@ -715,6 +999,19 @@ int check_batch(const OcBatch* b, int* n_obj) {
 
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
+// SIMDs of the current device (4 per CU); cached per thread
+inline int64_t simd_count() {
+    thread_local int cached_dev = -1;
+    thread_local int64_t cached = 1024;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev != cached_dev) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) cached = 4 * (int64_t)cus;
+        cached_dev = dev;
+    }
+    return cached;
+}
+
 #define DISPATCH_NOBJ(NOBJ_VALUE, ...)                                  \
     switch (NOBJ_VALUE) {                                               \
         case 1: { constexpr int NOBJ = 1; __VA_ARGS__; } break;         \
@@ -786,6 +1083,32 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
     const bool uniform = b->n_layouts == 1;
     const bool lds = b->n_layouts <= LDS_LAYOUT_MAX;
     const bool small = b->max_pots >= 1 && b->max_pots <= 2;
+    // Lane pairs pay ~1.5x the total VALU work of one lane per env but halve the per-wavefront instruction stream:
+    // they win while one lane per env cannot put more than one wavefront on every SIMD (measured on MI355X:
+    // 0.92 vs 1.19 us/step at 32 768 envs, parity at 65 536, 1.93 vs 1.59 at 131 072).
+    const bool pair_ok = small && (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0;
+    const bool want_pair = (options & OC_OPT_LANE_PAIR) || (!(options & OC_OPT_LANE_PER_ENV) && b->n_envs <= 64 * simd_count());
+    if (pair_ok && want_pair) {
+        // two lanes per env (k_rollout_pair)
+        const size_t smem2 = (size_t)n_obj * 8 * PAIR_ENVS * sizeof(uint32_t);
+        const dim3 grid2((unsigned)((b->n_envs + PAIR_ENVS - 1) / PAIR_ENVS)), block2(BLOCK);
+        if (uniform)
+            hipLaunchKernelGGL((k_rollout_pair<true, true>), grid2, block2, smem2, s, b->d_layouts, b->n_layouts,
+                               b->d_layout_id, (uint4*)d_state, (float4*)d_rewards, d_flags, (float4*)d_ep_returns,
+                               b->n_envs, b->width, n_obj, horizon, options, (uint32_t)seed, (uint32_t)(seed >> 32),
+                               env_offset, t0, n_steps);
+        else if (lds)
+            hipLaunchKernelGGL((k_rollout_pair<false, true>), grid2, block2, smem2, s, b->d_layouts, b->n_layouts,
+                               b->d_layout_id, (uint4*)d_state, (float4*)d_rewards, d_flags, (float4*)d_ep_returns,
+                               b->n_envs, b->width, n_obj, horizon, options, (uint32_t)seed, (uint32_t)(seed >> 32),
+                               env_offset, t0, n_steps);
+        else
+            hipLaunchKernelGGL((k_rollout_pair<false, false>), grid2, block2, smem2, s, b->d_layouts, b->n_layouts,
+                               b->d_layout_id, (uint4*)d_state, (float4*)d_rewards, d_flags, (float4*)d_ep_returns,
+                               b->n_envs, b->width, n_obj, horizon, options, (uint32_t)seed, (uint32_t)(seed >> 32),
+                               env_offset, t0, n_steps);
+        return check_launch("oc_rollout_random");
+    }
     const size_t smem = (size_t)n_obj * 8 * BLOCK * sizeof(uint32_t);
     const dim3 grid(grid_for(b->n_envs)), block(BLOCK);
 #define GO(U, MP, LL)                                                                                                    do {                                                                                                                     if (smem > 48 * 1024)                                                                                                    (void)hipFuncSetAttribute((const void*)k_rollout<U, MP, LL>, hipFuncAttributeMaxDynamicSharedMemorySize,                                       (int)smem);                                                                            hipLaunchKernelGGL((k_rollout<U, MP, LL>), grid, block, smem, s, b->d_layouts, b->n_layouts, b->d_layout_id,                            (uint4*)d_state, (float4*)d_rewards, d_flags, (float4*)d_ep_returns, b->n_envs, b->width,                            n_obj, horizon, options, (uint32_t)seed, (uint32_t)(seed >> 32), env_offset, t0, n_steps);     } while (0)

@@ -37,6 +37,8 @@ class VecOvercookedEnv:
         if self.device.type != "cuda":
             raise _lib.OcAmdError("VecOvercookedEnv needs a ROCm GPU device (got %r); there is no CPU fallback" % device)
         self.auto_reset = bool(auto_reset)
+        self.lane_per_env = False  # rollout_random: force the one-lane-per-env kernel (testing / comparison)
+        self.lane_pair = False     # rollout_random: force the lane-pair kernel where the table allows it
         self.seed = int(seed)
         self.env_offset = int(env_offset)
         self.t_global = 0  # global step counter feeding the Philox counter of rollout_random
@@ -64,7 +66,8 @@ class VecOvercookedEnv:
             d_layouts=self.d_layouts.data_ptr(),
             d_layout_id=self.layout_id.data_ptr() if self.layout_id is not None else None,
             n_envs=self.n_envs, n_layouts=len(self.table), width=self.width, height=self.height,
-            max_pots=self.table.max_pots)
+            max_pots=self.table.max_pots,
+            batch_flags=_lib.BATCH_TWO_PLAYERS if all(s.num_players == 2 for s in self.table.specs) else 0)
         self._bref = ctypes.byref(self._batch)
         self.reset()
 
@@ -74,7 +77,8 @@ class VecOvercookedEnv:
 
     @property
     def options(self):
-        return _lib.OPT_AUTO_RESET if self.auto_reset else 0
+        return ((_lib.OPT_AUTO_RESET if self.auto_reset else 0) | (_lib.OPT_LANE_PER_ENV if self.lane_per_env else 0)
+                | (_lib.OPT_LANE_PAIR if self.lane_pair else 0))
 
     def spec_of(self, e):
         return self.table.specs[0 if self.layout_id is None else int(self.layout_id_host[e])]

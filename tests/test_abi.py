@@ -31,8 +31,8 @@ def test_library_builds_and_exports_every_declared_symbol():
 def test_batch_struct_layout_matches_header():
     from overcooked_ai_amd import _lib
 
-    # OcBatch: two pointers, int64, four int32 = 40 bytes on LP64
-    assert ctypes.sizeof(_lib.OcBatch) == 40
+    # OcBatch: two pointers, int64, four int32, two uint32 = 48 bytes on LP64
+    assert ctypes.sizeof(_lib.OcBatch) == 48 and _lib.OcBatch.batch_flags.offset == 40
     assert _lib.OcBatch.n_envs.offset == 16 and _lib.OcBatch.n_layouts.offset == 24
     assert _lib.OcBatch.width.offset == 28 and _lib.OcBatch.height.offset == 32 and _lib.OcBatch.max_pots.offset == 36
 

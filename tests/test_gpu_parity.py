@@ -116,9 +116,10 @@ def test_reference_golden_trajectory(manifest, gpu):
     assert total == d["ep_rewards"][: n - 1].sum()
 
 
+@pytest.mark.parametrize("kernel", ["lane_per_env", "lane_pair"])
 @pytest.mark.parametrize("name", ROLLOUT_CONFIGS)
-def test_golden_rollouts_fused(name, manifest, gpu):
-    """The fused Philox rollout kernel against episodes run through the reference's OvercookedEnv.step."""
+def test_golden_rollouts_fused(name, kernel, manifest, gpu):
+    """Both fused Philox rollout kernels against episodes run through the reference's OvercookedEnv.step."""
     from overcooked_ai_amd.layouts import LayoutSpec
 
     cfg = manifest["configs"][name]["rollouts"]
@@ -126,6 +127,7 @@ def test_golden_rollouts_fused(name, manifest, gpu):
     d = np.load(os.path.join(GOLDEN, "rollouts_%s.npz" % name))
     n, seed, horizon = cfg["n_envs"], int(d["seed"]), int(d["horizon"])
     env = make_env(spec, n, gpu, horizon=horizon, seed=seed)
+    setattr(env, kernel, True)
     for k in range(4):
         rew = torch.zeros((100, n, 4), dtype=torch.float32, device=gpu)
         fl = torch.zeros((100, n), dtype=torch.uint8, device=gpu)
@@ -215,7 +217,8 @@ def test_step_vs_oracle_random_states(n_envs, gpu):
         assert (fl_o & 2).any() or n_envs == 1
 
 
-def test_full_size_rollout_vs_oracle(gpu):
+@pytest.mark.parametrize("kernel", ["lane_per_env", "lane_pair"])
+def test_full_size_rollout_vs_oracle(kernel, gpu):
     """BASELINE config 2 at full size: 65 536 cramped_room envs, random policy, horizon 400 with auto-reset."""
     from overcooked_ai_amd.layouts import spec_from_name
 
@@ -223,6 +226,8 @@ def test_full_size_rollout_vs_oracle(gpu):
     spec = spec_from_name("cramped_room")
     orc = oracle_for(spec)
     env = make_env(spec, n, gpu, horizon=400, auto_reset=True, seed=1234)
+    env.lane_pair = kernel == "lane_pair"
+    env.lane_per_env = kernel == "lane_per_env"
     st_o = orc.reset(orc.new_state(n))
     ep_o = np.zeros((n, 4), np.float32)
     t0 = 0
@@ -251,7 +256,8 @@ def test_full_size_rollout_vs_oracle(gpu):
     assert torch.equal(shard.state, env3.state[:, a:b])
 
 
-def test_mixed_layout_batch_vs_oracle(gpu):
+@pytest.mark.parametrize("kernel", ["lane_per_env", "lane_pair"])
+def test_mixed_layout_batch_vs_oracle(kernel, gpu):
     """BASELINE config 4 (one GPU's shard): env e uses canonical layout e % 5, all padded to 9x5."""
     from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
 
@@ -260,6 +266,8 @@ def test_mixed_layout_batch_vs_oracle(gpu):
     lid = (np.arange(n) % 5).astype(np.uint16)
     orc = oracle_for(table.specs)
     env = make_env(table, n, gpu, horizon=400, auto_reset=True, seed=99, layout_id=lid)
+    env.lane_pair = kernel == "lane_pair"
+    env.lane_per_env = kernel == "lane_per_env"
     rng = np.random.default_rng(5)
     st = np.zeros((table.n_planes, n, 16), np.uint8)
     for l in range(5):
@@ -322,13 +330,16 @@ def test_every_registry_layout_vs_oracle(gpu):
         orc = oracle_for(spec)
         st = random_packed_states(spec, n, rng)
         env = make_env(spec, n, gpu, horizon=400, auto_reset=True, seed=3)
-        env.set_packed_state(st)
         st_o = st.copy()
-        rew = torch.zeros((60, n, 4), dtype=torch.float32, device=gpu)
-        env.rollout_random(60, rew, None)
         rew_o, _ = orc.rollout_random(st_o, 60, horizon=400, options=1, seed=3)
-        assert np.array_equal(env.get_packed_state(), st_o), name
-        assert np.array_equal(u8(rew), rew_o), name
+        for kernel in ("lane_per_env", "lane_pair"):  # lane_pair silently falls back where it does not apply
+            env.lane_per_env, env.lane_pair = kernel == "lane_per_env", kernel == "lane_pair"
+            env.set_packed_state(st)
+            env.t_global = 0
+            rew = torch.zeros((60, n, 4), dtype=torch.float32, device=gpu)
+            env.rollout_random(60, rew, None)
+            assert np.array_equal(env.get_packed_state(), st_o), (name, kernel)
+            assert np.array_equal(u8(rew), rew_o), (name, kernel)
         if spec.num_players == 2:
             enc = u8(env.encode_lossless(torch.uint8))
             assert np.array_equal(enc.astype(np.int32), orc.encode_lossless(st_o, horizon=400)), name
@@ -381,3 +392,52 @@ def test_abi_argument_errors(gpu):
     assert rc == -1 and b"layout_id" in L.oc_last_error()
     with pytest.raises(ValueError):
         env.step(torch.zeros((8, 2), dtype=torch.int64, device=gpu))
+
+
+def test_many_pots_layout_vs_oracle(gpu):
+    """A custom 7-pot layout: exercises the 8-pot-slot kernels (every layout shipped by the reference has <= 2)."""
+    from overcooked_ai_amd.layouts import LayoutSpec, LayoutTable
+
+    spec = LayoutSpec({
+        "grid": "XPPPPPX\nO 1 2 O\nX     X\nXDPSPTX",
+        "start_all_orders": [{"ingredients": ["onion", "onion", "tomato"]}, {"ingredients": ["onion"]},
+                             {"ingredients": ["tomato", "tomato"]}],
+        "start_bonus_orders": [{"ingredients": ["onion"]}],
+        "onion_value": 7, "tomato_value": 4, "onion_time": 3, "tomato_time": 5,
+    })
+    assert len(spec.cells_of("P")) == 7
+    orc = oracle_for(spec)
+    rng = np.random.default_rng(77)
+    n = 6000
+    st = random_packed_states(spec, n, rng)
+    env = make_env(spec, n, gpu, horizon=400, auto_reset=True, seed=21)
+    env.set_packed_state(st)
+    st_o = st.copy()
+    rew = torch.zeros((90, n, 4), dtype=torch.float32, device=gpu)
+    env.rollout_random(90, rew, None)
+    rew_o, _ = orc.rollout_random(st_o, 90, horizon=400, options=1, seed=21)
+    assert np.array_equal(env.get_packed_state(), st_o) and np.array_equal(u8(rew), rew_o)
+    acts = rng.integers(0, 6, size=(n, 2)).astype(np.uint8)
+    acts[rng.random(n) < 0.5] = 5
+    ev = torch.zeros((n,), dtype=torch.int64, device=gpu)
+    env.set_packed_state(st)
+    r, f = env.step(torch.from_numpy(acts).to(gpu), events_out=ev)
+    out_o, r_o, f_o = orc.step(st, acts, horizon=400, options=1)
+    assert np.array_equal(env.get_packed_state(), out_o) and np.array_equal(u8(r), r_o)
+    assert np.array_equal(u8(ev).view(np.uint64), orc.last_events)
+    enc = u8(env.encode_lossless(torch.uint8))
+    assert np.array_equal(enc.astype(np.int32), orc.encode_lossless(out_o, horizon=400))
+    # mixed with a 2-pot layout in one table (per-lane pot counts differ)
+    from overcooked_ai_amd.layouts import spec_from_name
+    table = LayoutTable([spec, spec_from_name("scenario1_s")])
+    lid = (np.arange(n) % 2).astype(np.uint16)
+    orc2 = oracle_for(table.specs)
+    st2 = np.zeros((table.n_planes, n, 16), np.uint8)
+    for l in range(2):
+        idx = np.nonzero(lid == l)[0]
+        st2[:, idx] = random_packed_states(table.specs[l], len(idx), rng)
+    env2 = make_env(table, n, gpu, horizon=400, auto_reset=True, seed=4, layout_id=lid)
+    env2.set_packed_state(st2)
+    env2.rollout_random(70)
+    orc2.rollout_random(st2, 70, horizon=400, options=1, seed=4, layout_id=lid, want_outputs=False)
+    assert np.array_equal(env2.get_packed_state(), st2)
