@@ -470,7 +470,43 @@ def gen_layout_luts():
     print("layout_luts", len(out))
 
 
+def gen_env_episodes():
+    """Whole episodes through the reference's OvercookedEnv.step (env.py:244): per-step returns, the final
+    info["episode"] dict (game_stats with event timesteps, env.py:363-401) and the gym wrapper's observations."""
+    out = {}
+    for name, horizon in (("cramped_room", 150), ("mdp_test", 250), ("counter_circuit", 200)):
+        spec, mdp = make_ref_mdp(name, {})
+        activate(mdp)
+        rng = np.random.default_rng(31337)
+        env = R.OvercookedEnv.from_mdp(mdp, horizon=horizon, info_level=0)
+        env._mp = object()
+        steps = []
+        done = False
+        while not done:
+            ja = [int(rng.choice(6, p=[0.14, 0.14, 0.14, 0.14, 0.04, 0.4])) for _ in range(2)]
+            ns, r, done, info = env.step([Action.INDEX_TO_ACTION[a] for a in ja])
+            steps.append({"actions": ja, "reward": r, "done": bool(done), "sparse_r_by_agent": list(info["sparse_r_by_agent"]),
+                          "shaped_r_by_agent": list(info["shaped_r_by_agent"])})
+        ep = info["episode"]
+        gs = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in ep["ep_game_stats"].items()}
+        enc = env.lossless_state_encoding_mdp(env.state)
+        out[name] = {
+            "layout": spec.to_layout_dict(), "horizon": horizon, "steps": steps, "final_state": env.state.to_dict(),
+            "episode": {"ep_game_stats": gs, "ep_sparse_r": int(ep["ep_sparse_r"]), "ep_shaped_r": int(ep["ep_shaped_r"]),
+                        "ep_sparse_r_by_agent": ep["ep_sparse_r_by_agent"].tolist(),
+                        "ep_shaped_r_by_agent": ep["ep_shaped_r_by_agent"].tolist(), "ep_length": ep["ep_length"]},
+            "final_encoding_nonzero": [[int(i) for i in idx] + [int(np.stack(enc)[tuple(idx)])] for idx in np.argwhere(np.stack(enc))],
+            "encoding_shape": list(np.stack(enc).shape),
+        }
+    with open(os.path.join(GOLDEN, "env_episodes.json"), "w") as f:
+        json.dump(out, f, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
+    print("env_episodes", list(out))
+
+
 def main():
+    if "--env-episodes-only" in sys.argv:
+        gen_env_episodes()
+        return
     if "--luts-only" in sys.argv:
         os.makedirs(GOLDEN, exist_ok=True)
         gen_layout_luts()
@@ -494,6 +530,7 @@ def main():
             manifest["configs"][name]["rollouts"] = gen_rollouts(name, lname, ov, n_envs=24, seed=77 + i)
             print("rollouts", name)
     gen_layout_luts()
+    gen_env_episodes()
     with open(os.path.join(GOLDEN, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
     print("done")

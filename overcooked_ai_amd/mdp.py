@@ -1,0 +1,252 @@
+"""OvercookedGridworld — drop-in mirror of the reference's MDP class for the accelerated path.
+
+Same constructor conventions and method names as `overcooked_ai_py.mdp.overcooked_mdp.OvercookedGridworld`
+(mdp.py:1076-1430, 2382-2561) for the hot path: `from_layout_name`, `from_grid`, `get_standard_start_state`,
+`get_state_transition`, `lossless_state_encoding`, the terrain look-ups.  Every transition / encoding is computed
+by the HIP kernels (a batch of one env for the single-state calls; `get_state_transitions` /
+`lossless_state_encodings` take whole batches).  For throughput use `VecOvercookedEnv` directly: the single-state
+calls pay a host<->device round trip each.
+"""
+import copy
+import os
+
+import numpy as np
+
+from .actions import Action, Direction
+from .layouts import BASE_REW_SHAPING_PARAMS, LayoutSpec, read_layout_dict
+from .state import ObjectState, OvercookedState, PlayerState, SoupState, pack_states, unpack_states  # noqa: F401
+
+EVENT_TYPES = [  # mdp.py:1027-1058
+    "tomato_pickup", "useful_tomato_pickup", "tomato_drop", "useful_tomato_drop", "potting_tomato",
+    "onion_pickup", "useful_onion_pickup", "onion_drop", "useful_onion_drop", "potting_onion",
+    "dish_pickup", "useful_dish_pickup", "dish_drop", "useful_dish_drop",
+    "soup_pickup", "soup_delivery", "soup_drop",
+    "optimal_onion_potting", "optimal_tomato_potting", "viable_onion_potting", "viable_tomato_potting",
+    "catastrophic_onion_potting", "catastrophic_tomato_potting", "useless_onion_potting", "useless_tomato_potting",
+]
+
+
+def events_from_mask(mask, num_players=2):
+    """u64 event mask (bit 2*k + p) -> the reference's event_infos dict {event: [bool] * num_players}."""
+    mask = int(mask)
+    return {name: [bool((mask >> (2 * k + p)) & 1) for p in range(num_players)] for k, name in enumerate(EVENT_TYPES)}
+
+
+def default_device():
+    return os.environ.get("OC_AMD_DEVICE", "cuda:0")
+
+
+class OvercookedGridworld:
+    def __init__(self, terrain, start_player_positions, start_bonus_orders=[], rew_shaping_params=None,
+                 layout_name="unnamed_layout", start_all_orders=[], num_items_for_soup=3, order_bonus=2,
+                 start_state=None, old_dynamics=False, device=None, **kwargs):
+        rows = [list(r) for r in terrain]
+        for i, (x, y) in enumerate(start_player_positions):
+            rows[y][x] = str(i + 1)
+        cfg = dict(kwargs)
+        cfg.update(grid="\n".join("".join(r) for r in rows), layout_name=layout_name,
+                   start_all_orders=start_all_orders, start_bonus_orders=start_bonus_orders,
+                   rew_shaping_params=rew_shaping_params, order_bonus=order_bonus, old_dynamics=old_dynamics,
+                   num_items_for_soup=num_items_for_soup)
+        self._init_from_spec(LayoutSpec(cfg), start_state, device)
+
+    def _init_from_spec(self, spec, start_state=None, device=None):
+        self.spec = spec
+        self.terrain_mtx = spec.terrain_mtx
+        self.height, self.width = spec.height, spec.width
+        self.shape = (self.width, self.height)
+        self.start_player_positions = [tuple(p) for p in spec.start_player_positions]
+        self.num_players = spec.num_players
+        self.start_bonus_orders = spec.start_bonus_orders
+        self.start_all_orders = spec.start_all_orders or [
+            {"ingredients": ["onion"] * a + ["tomato"] * (n - a)} for n in (1, 2, 3) for a in range(n, -1, -1)]
+        self.reward_shaping_params = dict(BASE_REW_SHAPING_PARAMS)
+        self.reward_shaping_params.update(spec.rew_shaping_params)
+        self.layout_name = spec.layout_name
+        self.order_bonus = spec.order_bonus
+        self.old_dynamics = spec.old_dynamics
+        self.recipe_config = dict(spec.recipe_config, num_items_for_soup=spec.num_items_for_soup,
+                                  all_orders=spec.start_all_orders)
+        if isinstance(start_state, dict):
+            start_state = OvercookedState.from_dict(start_state)
+        self.start_state = start_state
+        self.terrain_pos_dict = {c: spec.cells_of(c) for c in " XOTPDS"}
+        self._device = device
+        self._envs = {}
+
+    # ---------------------------------------------------------------- construction (mdp.py:1150-1222)
+    @staticmethod
+    def from_layout_name(layout_name, device=None, **params_to_overwrite):
+        d = read_layout_dict(layout_name)
+        d["layout_name"] = layout_name
+        start_state = d.pop("start_state", None)
+        start_state = params_to_overwrite.pop("start_state", start_state)
+        mdp = OvercookedGridworld.__new__(OvercookedGridworld)
+        mdp._init_from_spec(LayoutSpec(d, **params_to_overwrite), start_state, device)
+        return mdp
+
+    @staticmethod
+    def from_grid(layout_grid, base_layout_params={}, params_to_overwrite={}, debug=False, device=None):
+        cfg = copy.deepcopy(dict(base_layout_params))
+        cfg.update(params_to_overwrite)
+        cfg["grid"] = "\n".join("".join(row) for row in layout_grid)
+        start_state = cfg.pop("start_state", None)
+        mdp = OvercookedGridworld.__new__(OvercookedGridworld)
+        mdp._init_from_spec(LayoutSpec(cfg), start_state, device)
+        return mdp
+
+    @staticmethod
+    def from_spec(spec, device=None):
+        mdp = OvercookedGridworld.__new__(OvercookedGridworld)
+        mdp._init_from_spec(spec, spec.start_state, device)
+        return mdp
+
+    def __eq__(self, other):
+        return (isinstance(other, OvercookedGridworld) and self.terrain_mtx == other.terrain_mtx
+                and self.start_player_positions == other.start_player_positions
+                and self.start_bonus_orders == other.start_bonus_orders
+                and self.start_all_orders == other.start_all_orders
+                and self.reward_shaping_params == other.reward_shaping_params and self.layout_name == other.layout_name)
+
+    @property
+    def mdp_params(self):
+        return {"layout_name": self.layout_name, "terrain": self.terrain_mtx,
+                "start_player_positions": self.start_player_positions, "start_bonus_orders": self.start_bonus_orders,
+                "rew_shaping_params": copy.deepcopy(self.reward_shaping_params),
+                "start_all_orders": self.start_all_orders}
+
+    # ---------------------------------------------------------------- device plumbing
+    def vec_env(self, n_envs, horizon=65535, **kw):
+        """A fresh batched env over this MDP (the fast path)."""
+        from .vec_env import VecOvercookedEnv
+
+        return VecOvercookedEnv(self.spec, n_envs, horizon=horizon, device=self._device or default_device(), **kw)
+
+    def _env(self, n):
+        if n not in self._envs:
+            if len(self._envs) > 8:
+                self._envs.clear()
+            self._envs[n] = self.vec_env(n, track_returns=False)
+        return self._envs[n]
+
+    # ---------------------------------------------------------------- game logic
+    def get_actions(self, state):
+        self._check_valid_state(state)
+        return [Action.ALL_ACTIONS for _ in state.players]
+
+    def _check_valid_state(self, state):
+        """AssertionError for states the reference's _check_valid_state rejects (mdp.py:1910-1949)."""
+        try:
+            pack_states(self.spec, [state])
+        except (ValueError, KeyError) as e:
+            raise AssertionError(str(e))
+
+    def get_standard_start_state(self):
+        if self.start_state:
+            return self.start_state
+        return OvercookedState.from_player_positions(self.start_player_positions, bonus_orders=self.start_bonus_orders,
+                                                     all_orders=self.start_all_orders)
+
+    def is_terminal(self, state):
+        return False
+
+    def get_state_transitions(self, states, joint_actions):
+        """Batched get_state_transition: lists of states / joint actions -> (next_states, infos list)."""
+        import torch
+
+        n = len(states)
+        idx = np.zeros((n, 2), np.uint8)
+        for e, ja in enumerate(joint_actions):
+            if len(ja) != self.num_players:
+                raise ValueError("Illegal joint action %r" % (ja,))
+            for p, a in enumerate(ja):
+                try:
+                    idx[e, p] = Action.to_index(a)
+                except ValueError:
+                    raise ValueError("Illegal action %s in state %s" % (a, states[e]))  # mdp.py:1394-1398
+            if self.num_players == 1:
+                idx[e, 1] = 4
+        try:
+            packed = pack_states(self.spec, states)
+        except (ValueError, KeyError) as e:
+            raise AssertionError(str(e))
+        env = self._env(n)
+        env.horizon = 65535
+        env.set_packed_state(packed)
+        ev = torch.zeros((n,), dtype=torch.int64, device=env.device)
+        rew, flags = env.step(torch.from_numpy(idx).to(env.device), events_out=ev)
+        rew = rew.cpu().numpy()
+        masks = ev.cpu().numpy().view(np.uint64)
+        nxt = unpack_states(self.spec, env.get_packed_state())
+        infos = []
+        for e in range(n):
+            sp = [_num(v) for v in rew[e, 0:self.num_players]]
+            sh = [_num(v) for v in rew[e, 2:2 + self.num_players]]
+            infos.append({"event_infos": events_from_mask(masks[e], self.num_players),
+                          "sparse_reward_by_agent": sp, "shaped_reward_by_agent": sh})
+        return nxt, infos
+
+    def get_state_transition(self, state, joint_action, display_phi=False, motion_planner=None):
+        """(new_state, infos) exactly like mdp.py:1375-1430; the input state is not modified."""
+        if display_phi:
+            raise NotImplementedError("potential_function (display_phi) is outside the accelerated hot path")
+        nxt, infos = self.get_state_transitions([state], [joint_action])
+        return nxt[0], infos[0]
+
+    # ---------------------------------------------------------------- encodings (mdp.py:2382-2561)
+    def get_lossless_state_encoding_shape(self):
+        return np.array(list(self.shape) + [26])
+
+    @property
+    def lossless_state_encoding_shape(self):
+        return self.get_lossless_state_encoding_shape()
+
+    def lossless_state_encodings(self, states, horizon=400):
+        import torch
+
+        assert self.num_players == 2, "Functionality has to be added to support encondings for > 2 players"
+        env = self._env(len(states))
+        env.set_packed_state(pack_states(self.spec, states))
+        env.horizon = int(min(max(horizon, 1), 65535))
+        return env.encode_lossless(torch.uint8).cpu().numpy().astype(np.int64)
+
+    def lossless_state_encoding(self, overcooked_state, horizon=400, debug=False):
+        assert type(debug) is bool
+        enc = self.lossless_state_encodings([overcooked_state], horizon)
+        return tuple(enc[0, i] for i in range(2))
+
+    # ---------------------------------------------------------------- layout info (mdp.py:1733-1807)
+    def get_valid_player_positions(self):
+        return self.terrain_pos_dict[" "]
+
+    def get_terrain_type_at_pos(self, pos):
+        x, y = pos
+        return self.terrain_mtx[y][x]
+
+    def get_dish_dispenser_locations(self):
+        return list(self.terrain_pos_dict["D"])
+
+    def get_onion_dispenser_locations(self):
+        return list(self.terrain_pos_dict["O"])
+
+    def get_tomato_dispenser_locations(self):
+        return list(self.terrain_pos_dict["T"])
+
+    def get_serving_locations(self):
+        return list(self.terrain_pos_dict["S"])
+
+    def get_pot_locations(self):
+        return list(self.terrain_pos_dict["P"])
+
+    def get_counter_locations(self):
+        return list(self.terrain_pos_dict["X"])
+
+    @property
+    def num_pots(self):
+        return len(self.get_pot_locations())
+
+
+def _num(v):
+    """float32 reward -> int when integral (the reference returns Python ints for integer-valued configs)."""
+    v = float(v)
+    return int(v) if v == int(v) and abs(v) < 2 ** 31 else v

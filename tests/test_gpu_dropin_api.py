@@ -1,0 +1,114 @@
+"""The reference-shaped API (OvercookedGridworld / OvercookedEnv / Overcooked) running on the HIP kernels,
+against whole episodes recorded from the reference's own OvercookedEnv (tests/golden/env_episodes.json) and the
+reference's test fixtures.  These tests read like testing/overcooked_test.py on purpose."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def episodes():
+    with open(os.path.join(GOLDEN, "env_episodes.json")) as f:
+        return json.load(f)
+
+
+def test_env_episodes_match_reference(episodes):
+    from overcooked_ai_amd import Action, OvercookedEnv, OvercookedGridworld
+    from overcooked_ai_amd import state as S
+    from overcooked_ai_amd.layouts import LayoutSpec
+
+    for name, ep in episodes.items():
+        mdp = OvercookedGridworld.from_spec(LayoutSpec(ep["layout"]))
+        env = OvercookedEnv.from_mdp(mdp, horizon=ep["horizon"], info_level=0)
+        info = None
+        for t, step in enumerate(ep["steps"]):
+            ja = [Action.INDEX_TO_ACTION[a] for a in step["actions"]]
+            state, reward, done, info = env.step(ja)
+            assert reward == step["reward"] and done == step["done"], (name, t)
+            assert info["sparse_r_by_agent"] == step["sparse_r_by_agent"]
+            assert info["shaped_r_by_agent"] == step["shaped_r_by_agent"]
+        assert S.canonical_state_dict(env.state) == S.canonical_state_dict(ep["final_state"])
+        got, exp = info["episode"], ep["episode"]
+        assert got["ep_length"] == exp["ep_length"] and got["ep_sparse_r"] == exp["ep_sparse_r"]
+        assert got["ep_shaped_r"] == exp["ep_shaped_r"]
+        assert list(got["ep_sparse_r_by_agent"]) == exp["ep_sparse_r_by_agent"]
+        assert list(got["ep_shaped_r_by_agent"]) == exp["ep_shaped_r_by_agent"]
+        for k, v in exp["ep_game_stats"].items():  # event timestep lists per agent + cumulative rewards
+            assert [list(x) if not np.isscalar(x) else x for x in np.asarray(got["ep_game_stats"][k], dtype=object)] == v \
+                or list(got["ep_game_stats"][k]) == v, (name, k)
+        with pytest.raises(AssertionError):
+            env.step([Action.STAY, Action.STAY])  # env.py:255: stepping a done env
+        enc = np.stack(env.lossless_state_encoding_mdp(env.state))
+        assert list(enc.shape) == ep["encoding_shape"] and enc.dtype == np.int64
+        nz = [[int(i) for i in idx] + [int(enc[tuple(idx)])] for idx in np.argwhere(enc)]
+        assert nz == ep["final_encoding_nonzero"]
+
+
+def test_gridworld_api_mirrors_reference(small_fixtures):
+    from overcooked_ai_amd import Action, Direction, OvercookedGridworld, OvercookedState, PlayerState
+    from overcooked_ai_amd import state as S
+
+    mdp = OvercookedGridworld.from_layout_name("mdp_test")
+    assert mdp.shape == (5, 4) and mdp.num_players == 2 and mdp.num_pots == 2
+    assert list(mdp.get_lossless_state_encoding_shape()) == [5, 4, 26]
+    start = mdp.get_standard_start_state()
+    assert S.canonical_state_dict(start) == S.canonical_state_dict(small_fixtures["mdp_test_start_state"]["expected_state"])
+    # test_transitions_and_environment (overcooked_test.py:468-514)
+    bad_state = OvercookedState([PlayerState((0, 0), Direction.SOUTH), PlayerState((3, 1), Direction.SOUTH)], {})
+    with pytest.raises(AssertionError):
+        mdp.get_state_transition(bad_state, [Action.STAY, Action.STAY])
+    with pytest.raises(ValueError):
+        mdp.get_state_transition(start, [Action.STAY, "jump"])
+    case = small_fixtures["mdp_test_one_transition"]
+    before = start.to_dict()
+    new_state, infos = mdp.get_state_transition(start, [Direction.NORTH, Direction.EAST])
+    assert start.to_dict() == before  # input state untouched
+    exp = OvercookedState.from_dict(case["expected_state"])
+    assert new_state.time_independent_equal(exp) and sum(infos["sparse_reward_by_agent"]) == case["expected_reward"]
+    assert set(infos) == {"event_infos", "sparse_reward_by_agent", "shaped_reward_by_agent"}
+    assert len(infos["event_infos"]) == 25 and not any(any(v) for v in infos["event_infos"].values())
+    # old dynamics (overcooked_test.py:527-563)
+    with pytest.raises(AssertionError):
+        OvercookedGridworld.from_layout_name("mdp_test", old_dynamics=True)
+    for lname, new_cooking, old_cooking in (("old_dynamics_cook_test", True, False), ("old_dynamics_put_test", False, True)):
+        new_mdp = OvercookedGridworld.from_layout_name(lname, old_dynamics=False)
+        old_mdp = OvercookedGridworld.from_layout_name(lname, old_dynamics=True)
+        s_new, _ = new_mdp.get_state_transition(new_mdp.start_state, [Action.INTERACT])
+        s_old, _ = old_mdp.get_state_transition(old_mdp.start_state, [Action.INTERACT])
+        assert s_new.get_object((2, 0)).is_cooking == new_cooking
+        assert s_old.get_object((2, 0)).is_cooking == old_cooking
+    # encoding symmetry under player reversal (overcooked_test.py:1112-1128)
+    st = new_state.deepcopy()
+    a = mdp.lossless_state_encoding(st, horizon=400)
+    b = mdp.lossless_state_encoding(st.deepcopy().reverse_players(), horizon=400)
+    assert np.array_equal(a[0], b[1]) and np.array_equal(a[1], b[0]) and a[0].shape == (5, 4, 26)
+
+
+def test_batched_transitions_and_gym_wrapper():
+    from overcooked_ai_amd import Action, Overcooked, OvercookedEnv, OvercookedGridworld
+
+    mdp = OvercookedGridworld.from_layout_name("asymmetric_advantages")
+    start = mdp.get_standard_start_state()
+    states, infos = mdp.get_state_transitions([start] * 6, [[Action.INDEX_TO_ACTION[a], Action.STAY] for a in range(6)])
+    singles = [mdp.get_state_transition(start, [Action.INDEX_TO_ACTION[a], Action.STAY])[0] for a in range(6)]
+    assert states == singles and len(infos) == 6
+    base_env = OvercookedEnv.from_mdp(mdp, horizon=20, info_level=0)
+    env = Overcooked(base_env, base_env.lossless_state_encoding_mdp)
+    assert env.action_space.n == 6 and env.observation_space.shape == (9, 5, 26)
+    np.random.seed(3)
+    obs = env.reset()
+    assert set(obs) == {"both_agent_obs", "overcooked_state", "other_agent_env_idx"}
+    done, n = False, 0
+    while not done:
+        obs, reward, done, info = env.step((np.random.randint(6), np.random.randint(6)))
+        n += 1
+        assert info["policy_agent_idx"] == env.agent_idx
+        ob_main = base_env.lossless_state_encoding_mdp(obs["overcooked_state"])[env.agent_idx]
+        assert np.array_equal(obs["both_agent_obs"][0], ob_main)
+    assert n == 20 and info["episode"]["ep_length"] == 20 and info["episode"]["policy_agent_idx"] == env.agent_idx
