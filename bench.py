@@ -151,6 +151,16 @@ def main():
         # mean over equal-size launches only; the ragged tail launch is excluded pro rata
         launch_ms = dev_ms * (fuse / float(args.steps))
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    kernel = "k_rollout" if (args.lane_per_env or n > 65536) else "k_rollout_pair"
+    traffic = None
+    try:  # PMC HBM bytes per launch measured by tools/profile_round.sh on this same command (profiles/traffic.json)
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            tj = json.load(f)
+        for k, v in tj.items():
+            if k.startswith(kernel + "<") and n == N_ENVS_PER_GPU and fuse == 100 and args.layout == "cramped_room":
+                traffic = v["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     out = {
         "metric": "env steps/sec (whole node), 65k parallel cramped_room envs",
         "value": value, "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -159,8 +169,8 @@ def main():
         "config": {"workload": "%s x %d envs/GPU, in-kernel Philox random policy, horizon %d auto-reset, outputs every step"
                                % (args.layout, n, HORIZON),
                    "envs_per_gpu": n, "fused_steps_per_launch": fuse, "launches": launches, "parallelism": "env-shard x%d" % world},
-        "roofline": {"bound": "hbm", "kernel": "k_rollout", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "bytes_per_launch": bytes_per_launch, "launch_ms": launch_ms,
                      "bytes_model": "n_envs*(2*S + 17*T): S=%d B state in+out once per launch, 17 B outputs per env-step, actions in-kernel" % state_bytes,
                      "survey_8d_per_step_model_GBs": n * (2 * state_bytes + OUT_BYTES) * fuse / (launch_ms * 1e-3) / 1e9},
