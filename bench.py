@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--fuse", type=int, default=100, help="env steps fused per oc_rollout_random launch")
     ap.add_argument("--envs", type=int, default=N_ENVS_PER_GPU, help="envs per GPU")
     ap.add_argument("--layout", default="cramped_room")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE.json config index (1-based): 2 = headline (default); 3 = asymmetric_advantages + "
+                         "lossless encoding every step; 4 = 5-layout mix padded to 9x5; 5 = 4096 generated 9x5 terrains")
     ap.add_argument("--lane-per-env", action="store_true", help="force the one-lane-per-env rollout kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the step-API and encode side measurements")
@@ -110,6 +113,8 @@ def main():
     torch.cuda.set_device(dev)
 
     n = args.envs
+    if args.config != 2:
+        return run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world)
     env = VecOvercookedEnv(args.layout, n, horizon=HORIZON, device=dev, auto_reset=True, seed=0,
                            env_offset=rank * n)
     env.lane_per_env = args.lane_per_env
@@ -184,6 +189,75 @@ def main():
         out["encode"] = bench_encode(dev, torch, VecOvercookedEnv)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.layout, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    sharding.barrier()
+
+
+def run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
+    """Side measurements for BASELINE.json configs 3-5 (same timing protocol; not the headline line)."""
+    import numpy as np
+
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    n = args.envs
+    encode = False
+    if args.config == 3:
+        env = VecOvercookedEnv("asymmetric_advantages", n, horizon=HORIZON, device=dev, auto_reset=True, seed=0,
+                               env_offset=rank * n)
+        encode, workload, sbytes = True, "asymmetric_advantages x %d envs/GPU, random policy + lossless u8 encoding every step" % n, S_ASYM
+    elif args.config == 4:
+        names = ["cramped_room", "asymmetric_advantages", "coordination_ring", "forced_coordination", "counter_circuit"]
+        table = LayoutTable([spec_from_name(nm) for nm in names], pad_to=(9, 5))
+        lid = ((np.arange(n) + rank * n) % 5).astype(np.uint16)
+        env = VecOvercookedEnv(table, n, horizon=HORIZON, device=dev, auto_reset=True, seed=0, env_offset=rank * n,
+                               layout_id=lid)
+        workload, sbytes = "5 canonical layouts padded to 9x5 (env e -> layout e %% 5) x %d envs/GPU, random policy" % n, 34
+    else:
+        from overcooked_ai_amd.layout_gen import generate_layouts
+
+        K = 4096
+        table = LayoutTable(generate_layouts(K, seed=0, inner_shape=(9, 5), prop_empty=0.9, prop_feats=0.1))
+        lid = ((np.arange(n) + rank * n) % K).astype(np.uint16)
+        env = VecOvercookedEnv(table, n, horizon=HORIZON, device=dev, auto_reset=True, seed=0, env_offset=rank * n,
+                               layout_id=lid)
+        workload, sbytes = "%d generated 9x5 terrains (env e -> terrain e %% %d) x %d envs/GPU, random policy" % (K, K, n), 36
+    fuse = 1 if encode else max(1, min(args.fuse, args.steps))
+    rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
+    fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
+    obs = torch.empty((n, 2, env.width, env.height, 26), dtype=torch.uint8, device=dev) if encode else None
+
+    def run(steps):
+        left = steps
+        while left > 0:
+            k = min(fuse, left)
+            env.rollout_random(k, rew[:k], fl[:k])
+            if encode:
+                env.encode_lossless(torch.uint8, out=obs)
+            left -= k
+
+    run(args.warmup)
+    torch.cuda.synchronize(dev)
+    sharding.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize(dev)
+    sharding.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+    sharding.allreduce_max(tmax)
+    wall = float(tmax.item())
+    per_step_bytes = n * ((2 * sbytes + OUT_BYTES) if fuse == 1 else OUT_BYTES) + (n * 2 * env.width * env.height * 26 if encode else 0)
+    out = {"metric": "env steps/sec (whole node)", "value": float(world) * n * args.steps / wall, "unit": "env steps/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": workload, "baseline_config": args.config, "envs_per_gpu": n,
+                      "fused_steps_per_launch": fuse},
+           "roofline": {"bound": "hbm", "achieved": per_step_bytes * args.steps / wall / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": per_step_bytes * args.steps / wall / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "algorithmic bytes per batched step / wall time per step (all kernels of the step)"}}
     if rank == 0:
         print(json.dumps(out))
     sharding.barrier()

@@ -503,7 +503,28 @@ def gen_env_episodes():
     print("env_episodes", list(out))
 
 
+def gen_random_starts():
+    """get_random_start_state_fn (mdp.py:1307-1369) under fixed numpy seeds."""
+    out = {}
+    for name in ("cramped_room", "asymmetric_advantages", "counter_circuit", "mdp_test"):
+        spec, mdp = make_ref_mdp(name, {})
+        activate(mdp)
+        cases = []
+        for seed, (rsp, thresh) in enumerate([(False, 0.0), (True, 0.0), (True, 0.5), (False, 0.9), (True, 0.9), (True, 0.3)]):
+            fn = mdp.get_random_start_state_fn(random_start_pos=rsp, rnd_obj_prob_thresh=thresh)
+            np.random.seed(100 + seed)
+            states = [fn().to_dict() for _ in range(12)]
+            cases.append({"seed": 100 + seed, "random_start_pos": rsp, "rnd_obj_prob_thresh": thresh, "states": states})
+        out[name] = {"layout": spec.to_layout_dict(), "cases": cases}
+    with open(os.path.join(GOLDEN, "random_starts.json"), "w") as f:
+        json.dump(out, f, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
+    print("random_starts", list(out))
+
+
 def main():
+    if "--random-starts-only" in sys.argv:
+        gen_random_starts()
+        return
     if "--env-episodes-only" in sys.argv:
         gen_env_episodes()
         return
@@ -531,6 +552,7 @@ def main():
             print("rollouts", name)
     gen_layout_luts()
     gen_env_episodes()
+    gen_random_starts()
     with open(os.path.join(GOLDEN, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
     print("done")

@@ -1,0 +1,89 @@
+"""Random layout generation (host side) for batches with per-env terrain (BASELINE configs[4]).
+
+Plays the role of the reference's `LayoutGenerator` (layout_generator.py:99-610: dig a connected free region into
+a grid of counters, turn some counters that touch it into pots / dispensers / serving locations, embed the grid in
+an outer shape padded with counters, drop the players on free cells).  This is an independent implementation — a
+randomized region growth instead of the reference's disjoint-set tunnelling — and draws from its own
+`numpy.random.Generator`, so it does not reproduce the reference's layouts draw for draw; every grid it returns
+passes the reference's validity rules (`LayoutSpec._assert_valid_grid` = mdp.py:2064-2115) and can equally be fed
+to the reference via `OvercookedGridworld.from_grid`.  It is tooling around the hot path, not part of it.
+"""
+import numpy as np
+
+from .layouts import LayoutSpec
+
+DEFAULT_FEATURES = ("P", "O", "D", "S")  # like DEFAULT_FEATURE_TYPES (layout_generator.py:90-96): no tomato dispenser
+
+
+def generate_grid(rng, inner_shape=(9, 5), outer_shape=None, prop_empty=0.9, prop_feats=0.1,
+                  feature_types=DEFAULT_FEATURES, n_players=2):
+    """One random grid as a list of row strings (with player digits)."""
+    W, H = inner_shape
+    OW, OH = outer_shape or inner_shape
+    assert W >= 4 and H >= 4 and OW >= W and OH >= H
+    interior = [(x, y) for y in range(1, H - 1) for x in range(1, W - 1)]
+    target = int(round(prop_empty * len(interior)))
+    target = min(len(interior), max(n_players + 1, target))
+    grid = [["X"] * W for _ in range(H)]
+    # grow a connected free region from a random interior cell
+    start = interior[int(rng.integers(len(interior)))]
+    free = {start}
+    frontier = [start]
+    while len(free) < target and frontier:
+        cx, cy = frontier[int(rng.integers(len(frontier)))]
+        nbrs = [(cx + dx, cy + dy) for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1))]
+        nbrs = [p for p in nbrs if 1 <= p[0] < W - 1 and 1 <= p[1] < H - 1 and p not in free]
+        if not nbrs:
+            frontier.remove((cx, cy))
+            continue
+        p = nbrs[int(rng.integers(len(nbrs)))]
+        free.add(p)
+        frontier.append(p)
+    for x, y in free:
+        grid[y][x] = " "
+    # counters that touch the free region can carry a feature
+    touching = [(x, y) for y in range(H) for x in range(W) if grid[y][x] == "X" and any(
+        (x + dx, y + dy) in free for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1)))]
+    order = list(rng.permutation(len(touching)))
+    n_feats = max(len(feature_types), int(round(prop_feats * len(touching))))
+    n_feats = min(n_feats, len(touching))
+    for k in range(n_feats):
+        x, y = touching[order[k]]
+        # one of every required type first, then random extras (at most 2 pots keep the fast kernels applicable)
+        if k < len(feature_types):
+            f = feature_types[k]
+        else:
+            f = feature_types[int(rng.integers(len(feature_types)))]
+            if f == "P" and sum(row.count("P") for row in grid) >= 2:
+                f = "O"
+        grid[y][x] = f
+    cells = sorted(free)
+    picks = rng.choice(len(cells), size=n_players, replace=False)
+    for i, k in enumerate(picks):
+        x, y = cells[int(k)]
+        grid[y][x] = str(i + 1)
+    # embed in the outer shape, padded with counters (layout_generator.py:309-329)
+    ox = int(rng.integers(0, OW - W + 1))
+    oy = int(rng.integers(0, OH - H + 1))
+    outer = [["X"] * OW for _ in range(OH)]
+    for y in range(H):
+        for x in range(W):
+            outer[y + oy][x + ox] = grid[y][x]
+    return ["".join(r) for r in outer]
+
+
+def generate_layouts(n, seed=0, inner_shape=(9, 5), outer_shape=None, prop_empty=0.9, prop_feats=0.1,
+                     feature_types=DEFAULT_FEATURES, base_params=None):
+    """n LayoutSpecs with random terrains; `base_params` are the recipe / order parameters shared by all of them
+    (default: the reference's DEFAULT_MDP_GEN_PARAMS — one 3-onion order worth 20 cooking for 20 steps,
+    layout_generator.py:40-48)."""
+    rng = np.random.default_rng(seed)
+    params = dict(base_params or {"start_all_orders": [{"ingredients": ["onion", "onion", "onion"]}],
+                                  "recipe_values": [20], "recipe_times": [20]})
+    specs = []
+    for _ in range(n):
+        rows = generate_grid(rng, inner_shape, outer_shape, prop_empty, prop_feats, feature_types)
+        d = dict(params)
+        d["grid"] = "\n".join(rows)
+        specs.append(LayoutSpec(d))
+    return specs

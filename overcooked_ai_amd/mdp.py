@@ -150,6 +150,51 @@ class OvercookedGridworld:
     def is_terminal(self, state):
         return False
 
+    def get_valid_joint_player_positions(self):
+        """All joint positions on free cells without overlap, in the reference's order (mdp.py:1736-1747)."""
+        import itertools
+
+        valid = self.get_valid_player_positions()
+        return [jp for jp in itertools.product(valid, repeat=self.num_players) if len(set(jp)) == len(jp)]
+
+    def get_random_start_state_fn(self, random_start_pos=False, rnd_obj_prob_thresh=0.0):
+        """Same start-state distribution AND the same numpy draw sequence as mdp.py:1307-1369, so that with an
+        identical np.random seed this returns exactly the state the reference would."""
+        def start_state_fn():
+            if random_start_pos:
+                valid_positions = self.get_valid_joint_player_positions()
+                start_pos = valid_positions[np.random.choice(len(valid_positions))]
+            else:
+                start_pos = self.start_player_positions
+            start_state = OvercookedState.from_player_positions(start_pos, bonus_orders=self.start_bonus_orders,
+                                                                all_orders=self.start_all_orders)
+            if rnd_obj_prob_thresh == 0:
+                return start_state
+            for pot_loc in self.get_pot_locations():
+                p = np.random.rand()
+                if p < rnd_obj_prob_thresh:
+                    n = int(np.random.randint(low=1, high=4))
+                    m = int(np.random.randint(low=0, high=4 - n))
+                    q = np.random.rand()
+                    cooking_tick = 0 if q < rnd_obj_prob_thresh else -1
+                    ings = ["onion"] * n + ["tomato"] * m
+                    start_state.objects[pot_loc] = SoupState(pot_loc, ings, cooking_tick,
+                                                             self.spec.recipe_time((n, m)))
+            for player in start_state.players:
+                p = np.random.rand()
+                if p < rnd_obj_prob_thresh:
+                    obj = np.random.choice(["dish", "onion", "soup"], p=[0.2, 0.6, 0.2])
+                    n = int(np.random.randint(low=1, high=4))
+                    m = int(np.random.randint(low=0, high=4 - n))
+                    if obj == "soup":
+                        ct = self.spec.recipe_time((n, m))
+                        player.set_object(SoupState(player.position, ["onion"] * n + ["tomato"] * m, ct, ct))
+                    else:
+                        player.set_object(ObjectState(str(obj), player.position))
+            return start_state
+
+        return start_state_fn
+
     def get_state_transitions(self, states, joint_actions):
         """Batched get_state_transition: lists of states / joint actions -> (next_states, infos list)."""
         import torch

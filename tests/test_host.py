@@ -147,3 +147,52 @@ def test_pack_rejects_states_outside_the_domain():
     ok["objects"] = [{"name": "soup", "position": (2, 0), "_ingredients": [{"name": "onion", "position": (2, 0)}],
                       "cooking_tick": 20}]
     assert S.pack_states(spec, [ok])[0, 0, 8] == 21
+
+
+def test_random_start_states_reproduce_reference_draws():
+    """get_random_start_state_fn consumes np.random exactly like mdp.py:1307-1369: same seed -> same states."""
+    from overcooked_ai_amd.mdp import OvercookedGridworld
+
+    with open(os.path.join(GOLDEN, "random_starts.json")) as f:
+        fx = json.load(f)
+    n = 0
+    for name, item in fx.items():
+        spec = L.LayoutSpec(item["layout"])
+        mdp = OvercookedGridworld.from_spec(spec)
+        for case in item["cases"]:
+            fn = mdp.get_random_start_state_fn(random_start_pos=case["random_start_pos"],
+                                               rnd_obj_prob_thresh=case["rnd_obj_prob_thresh"])
+            np.random.seed(case["seed"])
+            for ref in case["states"]:
+                got = fn()
+                assert S.canonical_state_dict(got) == S.canonical_state_dict(ref), (name, case["seed"])
+                S.pack_states(spec, [got])  # every random start lies inside the packed domain
+                n += 1
+    assert n == 4 * 6 * 12
+
+
+def test_generated_layouts_are_valid_and_diverse():
+    from overcooked_ai_amd.layout_gen import generate_layouts
+
+    specs = generate_layouts(200, seed=3, inner_shape=(9, 5), prop_empty=0.9, prop_feats=0.1)
+    grids = set()
+    for s in specs:
+        assert s.shape == (9, 5) and s.num_players == 2
+        flat = "".join("".join(r) for r in s.terrain_mtx)
+        assert 1 <= flat.count("P") <= 2 and flat.count("O") >= 1 and flat.count("D") >= 1 and flat.count("S") >= 1
+        assert 15 <= flat.count(" ") <= 21
+        # the free region is connected
+        free = set(s.cells_of(" "))
+        seen, todo = set(), [next(iter(free))]
+        while todo:
+            x, y = todo.pop()
+            if (x, y) in seen:
+                continue
+            seen.add((x, y))
+            todo += [p for p in ((x + 1, y), (x - 1, y), (x, y + 1), (x, y - 1)) if p in free]
+        assert seen == free
+        L.compile_layout(s)
+        grids.add(flat)
+    assert len(grids) > 190
+    small = generate_layouts(5, seed=1, inner_shape=(5, 4), outer_shape=(9, 5))
+    assert all(s.shape == (9, 5) for s in small)
