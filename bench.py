@@ -310,5 +310,18 @@ def bench_encode(dev, torch, VecOvercookedEnv, iters=200):
     return res
 
 
+def _finish():
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:
+        pass
+
+
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        _finish()
