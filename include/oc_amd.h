@@ -86,6 +86,8 @@ extern "C" {
 #define OC_OPT_LANE_PER_ENV 0x2u /* oc_rollout_random: force the one-lane-per-env kernel */
 #define OC_OPT_LANE_PAIR 0x4u    /* oc_rollout_random: force the lane-pair-per-env kernel where the table allows it
                                    (2-player layouts, <= 2 pots); default: pairs iff n_envs <= 64 * #SIMDs */
+#define OC_OPT_PREDICATE_INTERACT 0x8u /* oc_rollout_random: one-lane-per-env kernel with the predicate-network
+                                         interact instead of the table-driven one (kept for cross-checking) */
 
 /* OcBatch.batch_flags */
 #define OC_BATCH_TWO_PLAYERS 0x1u /* every layout of the table has exactly 2 players */

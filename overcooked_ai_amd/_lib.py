@@ -11,6 +11,7 @@ F_DONE, F_BAD_ACTION, F_RESET = 0x01, 0x02, 0x04
 OPT_AUTO_RESET = 0x1
 OPT_LANE_PER_ENV = 0x2
 OPT_LANE_PAIR = 0x4
+OPT_PREDICATE_INTERACT = 0x8
 BATCH_TWO_PLAYERS = 0x1
 OBS_U8, OBS_F32 = 0, 1
 

@@ -581,6 +581,355 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const OcLayout* __restrict__ 
     if (ep_returns) ep_returns[e] = ep;
 }
 
+// ==========================================================================================
+// v3: table-driven interact.
+//
+// SQ counters show the step kernels are bound by instruction issue (one wavefront per SIMD issues an integer VALU /
+// SALU instruction every ~4-6 cycles), and that INTERACT is more than half of the stream.  v3 replaces the
+// predicate network by one 8-byte look-up per player:
+//     key   = (terrain type of the faced cell or 7 when the player does not interact,
+//              class of the hand        {none, onion, tomato, dish, soup},
+//              class of what is faced   counter: {empty, dish, other};
+//                                       pot: {empty, idle 1, idle 2, idle 3 items, cooking, ready})
+//     entry = three byte selectors into the pool {hand, faced object, soup+ingredient, tick, 1, 2, 3, 0}
+//             (ONE v_perm_b32 yields the new hand, the new faced object and the new tick), event flags,
+//             the pot's new class and the change of the loose-dish count.
+// The table is layout independent (two variants: new / old dynamics) and generated at compile time.  Pot classes
+// are kept in registers and advanced by the env effects, so "ready" costs no cook-time look-up in the interact.
+// Cells live in LDS as u16[cell][lane] (address = cell << 9 | lane << 1: one v_lshl_add per access).
+// ==========================================================================================
+enum { PC_EMPTY = 0, PC_IDLE1 = 1, PC_IDLE2 = 2, PC_IDLE3 = 3, PC_COOKING = 4, PC_READY = 5 };
+enum { LF_SWAP = 1, LF_POT_UPD = 2, LF_SERVE = 4, LF_TAKE_DISH = 8, LF_PLACE = 16, LF_PLATE = 32, LF_START = 64 };
+constexpr int LUT_ENTRIES = 8 * 5 * 6;  // type x hand class x faced class
+
+struct LutEntry { uint32_t lo, hi; };  // lo: sel_h | sel_o << 8 | sel_tk << 16 | 0x0C << 24 ; hi: flags | new_pc << 8 | (dd + 1) << 16
+
+constexpr LutEntry lut_entry(int old_dyn, int type, int hc, int oc) {
+    // pool selectors: 0 hand, 1 faced object, 2 soup + ingredient, 3 tick, 4 const 1 (onion / tick 0), 5 const 2
+    // (tomato), 6 const 3 (dish), 7 const 0
+    int sel_h = 0, sel_o = 1, sel_tk = 3, flags = 0, new_pc = oc, dd = 0;
+    if (type == OC_T_COUNTER) {
+        if (hc == 0 && (oc == 1 || oc == 2)) { sel_h = 1; sel_o = 0; flags = LF_SWAP; dd = (oc == 1) ? -1 : 0; }  // pick up
+        else if (hc != 0 && oc == 0) { sel_h = 1; sel_o = 0; flags = LF_SWAP; dd = (hc == 3) ? 1 : 0; }            // drop
+    } else if (type == OC_T_ONION_DISP) {
+        if (hc == 0) sel_h = 4;
+    } else if (type == OC_T_TOMATO_DISP) {
+        if (hc == 0) sel_h = 5;
+    } else if (type == OC_T_DISH_DISP) {
+        if (hc == 0) { sel_h = 6; flags = LF_TAKE_DISH; }
+    } else if (type == OC_T_POT) {
+        if (hc == 0 && oc >= PC_IDLE1 && oc <= PC_IDLE3 && !old_dyn) {           // begin_cooking (mdp.py:1515-1522)
+            sel_tk = 4; flags = LF_POT_UPD | LF_START; new_pc = PC_COOKING;
+        } else if (hc == 3 && oc == PC_READY) {                                  // soup pickup (mdp.py:1525-1539)
+            sel_h = 1; sel_o = 7; sel_tk = 7; flags = LF_POT_UPD | LF_PLATE; new_pc = PC_EMPTY;
+        } else if ((hc == 1 || hc == 2) && oc <= PC_IDLE2) {                     // add ingredient (mdp.py:1541-1568)
+            sel_h = 7; sel_o = 2; flags = LF_POT_UPD | LF_PLACE; new_pc = oc + 1;
+        }
+    } else if (type == OC_T_SERVE) {
+        if (hc == 4) { sel_h = 7; flags = LF_SERVE; }                            // deliver (mdp.py:1570-1577)
+    }
+    return LutEntry{(uint32_t)(sel_h | (sel_o << 8) | (sel_tk << 16) | (0x0C << 24)),
+                    (uint32_t)(flags | (new_pc << 8) | ((dd + 1) << 16))};
+}
+
+struct LutTable { LutEntry e[2 * LUT_ENTRIES]; };
+constexpr LutTable make_lut() {
+    LutTable t{};
+    for (int od = 0; od < 2; ++od)
+        for (int type = 0; type < 8; ++type)
+            for (int hc = 0; hc < 5; ++hc)
+                for (int oc = 0; oc < 6; ++oc) t.e[od * LUT_ENTRIES + (type * 5 + hc) * 6 + oc] = lut_entry(od, type, hc, oc);
+    return t;
+}
+__device__ const LutTable g_lut = make_lut();
+
+template <int MAXP>
+struct Env3 {
+    uint32_t pos0, or0, held0, pos1, or1, held1, t;
+    uint32_t tk[MAXP], ps[MAXP], pc[MAXP];  // per pot slot: tick + 1, soup code, class
+    int32_t dcount;
+};
+
+__device__ __forceinline__ uint32_t rd_cell3(const uint16_t* cells, uint32_t c) { return cells[c * BLOCK]; }
+__device__ __forceinline__ void wr_obj3(uint16_t* cells, uint32_t c, uint32_t v) {
+    reinterpret_cast<uint8_t*>(cells + c * BLOCK)[0] = (uint8_t)v;
+}
+
+__device__ __forceinline__ uint32_t pot_class(const LayC& C, uint32_t o, uint32_t tk) {
+    const uint32_t n = (o >> 3) & 3u;
+    const uint32_t hot = (tk - 1u) >= cook_of(C, o) ? (uint32_t)PC_READY : (uint32_t)PC_COOKING;
+    return o == 0u ? (uint32_t)PC_EMPTY : (tk == 0u ? n : hot);  // idle with n = 1..3 items (n = 0: an empty soup object)
+}
+
+struct IOut3 {
+    uint32_t new_h, new_o, new_tk, new_pc, slot, flags, cell_obj;
+    int32_t ddelta;
+    float sparse;
+};
+
+// one player's INTERACT through the table; `s_lut` = this lane's table variant in LDS, `c16` the faced cell word
+template <int MAXP>
+__device__ __forceinline__ IOut3 interact3(const Lay L, const uint8_t* s_lut, bool act, uint32_t h, uint32_t c16,
+                                           const uint32_t (&ps)[MAXP], const uint32_t (&tkr)[MAXP],
+                                           const uint32_t (&pcr)[MAXP]) {
+    IOut3 r;
+    const uint32_t tc = c16 >> 8;
+    const uint32_t type = act ? (tc & 7u) : 7u;  // 7 = no interact: every entry of that row is a no-op
+    const uint32_t slot = tc >> 3;
+    uint32_t pso = 0, tkv = 0, pcv = 0;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const bool sel = slot == (uint32_t)k;
+        pso = sel ? ps[k] : pso;
+        tkv = sel ? tkr[k] : tkv;
+        pcv = sel ? pcr[k] : pcv;
+    }
+    const bool isP = type == OC_T_POT;
+    const uint32_t o_cell = c16 & 0xFFu;
+    const uint32_t o = isP ? pso : o_cell;
+    const uint32_t oc = isP ? pcv : (o_cell == 0u ? 0u : o_cell == OC_O_DISH ? 1u : 2u);
+    const uint32_t hc = min(h, 4u);
+    const uint32_t key = (type * 5u + hc) * 6u + oc;
+    const uint2 ent = *reinterpret_cast<const uint2*>(s_lut + key * 8u);
+    // pool {hand, faced object, soup + ingredient, tick | 1, 2, 3, 0}: one v_perm_b32 picks all three results
+    const uint32_t n = (o >> 3) & 3u;
+    const uint32_t soup_new = OC_O_SOUP | ((n + 1u) << 3) | (o & 7u) | ((h == OC_O_TOMATO ? 1u : 0u) << n);
+    const uint32_t pool = h | (o << 8) | (soup_new << 16) | (tkv << 24);
+    const uint32_t res = __builtin_amdgcn_perm(0x00030201u, pool, ent.x);
+    r.new_h = res & 0xFFu;
+    r.new_o = (res >> 8) & 0xFFu;
+    r.new_tk = (res >> 16) & 0xFFu;
+    r.flags = ent.y & 0xFFu;
+    r.new_pc = (ent.y >> 8) & 0xFFu;
+    r.ddelta = (int32_t)((ent.y >> 16) & 3u) - 1;
+    r.slot = slot;
+    r.cell_obj = (r.flags & LF_SWAP) ? r.new_o : o_cell;
+    r.sparse = (r.flags & LF_SERVE) ? L.value(recipe_idx(h) & 15u) : 0.f;  // deliver_soup (mdp.py:1631-1642)
+    return r;
+}
+
+template <int MAXP>
+__device__ __forceinline__ void apply_pot3(Env3<MAXP>& s, const IOut3& r) {
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const bool upd = ((r.flags & LF_POT_UPD) != 0u) & (r.slot == (uint32_t)k);
+        s.ps[k] = upd ? r.new_o : s.ps[k];
+        s.tk[k] = upd ? r.new_tk : s.tk[k];
+        s.pc[k] = upd ? r.new_pc : s.pc[k];
+    }
+}
+
+// get_state_transition (mdp.py:1375-1430), table-driven.  Same sequencing argument as env_step: both interacts are
+// evaluated on the pre-step pots/cells, player 1 replays only when player 0 touched the very cell or pot it uses.
+template <int MAXP>
+__device__ __forceinline__ void env_step3(const LayC& C, const Lay L, const uint8_t* s_lut, uint16_t* cells,
+                                          Env3<MAXP>& s, uint32_t delta4, uint32_t a0, uint32_t a1, float4& r) {
+    const bool two = s.pos1 != 0xFFu;
+    const uint32_t f0 = step_cell(s.pos0, s.or0, delta4);
+    const uint32_t f1 = two ? step_cell(s.pos1, s.or1, delta4) : f0;
+    const bool mv0 = a0 < 4u, mv1 = two & (a1 < 4u);
+    const uint32_t m0 = mv0 ? step_cell(s.pos0, a0, delta4) : s.pos0;
+    const uint32_t m1 = mv1 ? step_cell(s.pos1, a1, delta4) : (two ? s.pos1 : s.pos0);
+    const uint32_t c_f0 = rd_cell3(cells, f0), c_f1 = rd_cell3(cells, f1);
+    const uint32_t c_m0 = rd_cell3(cells, m0), c_m1 = rd_cell3(cells, m1);
+
+    // pot_states before any interact (mdp.py:1439): ready / cooking / 1..2 idle items  <=>  class not in {empty, idle 3}
+    uint32_t useful_pots = 0;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) useful_pots += ((s.pc[k] != PC_EMPTY) & (s.pc[k] != PC_IDLE3)) ? 1u : 0u;
+
+    const bool act0 = a0 == OC_A_INTERACT, act1 = two & (a1 == OC_A_INTERACT);
+    const IOut3 r0 = interact3<MAXP>(L, s_lut, act0, s.held0, c_f0, s.ps, s.tk, s.pc);
+    IOut3 r1 = interact3<MAXP>(L, s_lut, act1, s.held1, c_f1, s.ps, s.tk, s.pc);
+    // shaped rewards; is_dish_pickup_useful (mdp.py:2180-2204) sees the live hands / counters and the stale pots
+    const bool du0 = two & (((s.held1 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (s.dcount == 0);
+    const float sh0 = ((r0.flags & LF_PLACE) ? C.rew_place : 0.f) + ((r0.flags & LF_PLATE) ? C.rew_soup : 0.f) +
+                      (((r0.flags & LF_TAKE_DISH) != 0u) & du0 ? C.rew_dish : 0.f);
+    s.held0 = r0.new_h;
+    s.dcount += r0.ddelta;
+    apply_pot3<MAXP>(s, r0);
+    const bool same_cell = f1 == f0;
+    const bool swap0 = (r0.flags & LF_SWAP) != 0u;
+    const uint32_t c_f1_live = (same_cell & swap0) ? ((c_f1 & 0xFF00u) | r0.cell_obj) : c_f1;
+    const bool conflict = act1 & ((same_cell & swap0) | (((r0.flags & LF_POT_UPD) != 0u) &
+                                                          (((c_f1 >> 8) & 7u) == OC_T_POT) & ((c_f1 >> 11) == r0.slot)));
+    if (__builtin_expect(conflict, 0)) r1 = interact3<MAXP>(L, s_lut, act1, s.held1, c_f1_live, s.ps, s.tk, s.pc);
+    const bool du1 = two & (((s.held0 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (s.dcount == 0);
+    const float sh1 = ((r1.flags & LF_PLACE) ? C.rew_place : 0.f) + ((r1.flags & LF_PLATE) ? C.rew_soup : 0.f) +
+                      (((r1.flags & LF_TAKE_DISH) != 0u) & du1 ? C.rew_dish : 0.f);
+    s.held1 = r1.new_h;
+    s.dcount += r1.ddelta;
+    apply_pot3<MAXP>(s, r1);
+    wr_obj3(cells, f0, r0.cell_obj);
+    wr_obj3(cells, f1, (r1.flags & LF_SWAP) ? r1.cell_obj : (c_f1_live & 0xFFu));
+    r = make_float4(r0.sparse, r1.sparse, sh0, sh1);
+
+    // resolve_movement (mdp.py:1644-1727)
+    const uint32_t np0 = (mv0 & (((c_m0 >> 8) & 7u) == OC_T_FLOOR)) ? m0 : s.pos0;
+    const uint32_t np1 = (mv1 & (((c_m1 >> 8) & 7u) == OC_T_FLOOR)) ? m1 : s.pos1;
+    s.or0 = mv0 ? a0 : s.or0;
+    s.or1 = mv1 ? a1 : s.or1;
+    const bool collide = two & ((np0 == np1) | ((np0 == s.pos1) & (np1 == s.pos0)));
+    s.pos0 = collide ? s.pos0 : np0;
+    s.pos1 = collide ? s.pos1 : np1;
+
+    // step_environment_effects (mdp.py:1691-1703): advance cooking pots, promote them to ready
+    s.t += 1u;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        uint32_t pc = s.pc[k], tk = s.tk[k];
+        const bool autostart = (C.old_dyn != 0u) & (pc == PC_IDLE3);  // old dynamics: 3 idle items start by themselves
+        pc = autostart ? (uint32_t)PC_COOKING : pc;
+        tk = autostart ? 1u : tk;
+        const bool cooking = pc == PC_COOKING;
+        tk += cooking ? 1u : 0u;
+        pc = (cooking & ((tk - 1u) >= cook_of(C, s.ps[k]))) ? (uint32_t)PC_READY : pc;
+        s.pc[k] = pc;
+        s.tk[k] = tk;
+    }
+}
+
+template <int MAXP>
+__device__ __forceinline__ void load_env3(const LayC& C, const Lay L, const uint4* __restrict__ st, int64_t n, int64_t e,
+                                          int n_obj, Env3<MAXP>& s, uint16_t* cells) {
+    const uint4 h = st[e];
+    s.pos0 = h.x & 0xFF; s.or0 = (h.x >> 8) & 0xFF; s.held0 = (h.x >> 16) & 0xFF; s.pos1 = h.x >> 24;
+    s.or1 = h.y & 0xFF; s.held1 = (h.y >> 8) & 0xFF; s.t = h.y >> 16;
+    int32_t dishes = 0;
+    for (int p = 0; p < n_obj; ++p) {
+        const uint4 v = st[(int64_t)(1 + p) * n + e];
+        const uint32_t ow[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t T = L.u32(L_TERRAIN + 16 * p + 4 * q);
+            dishes += (int32_t)count_dish_bytes(ow[q]);
+            const uint32_t lo = __builtin_amdgcn_perm(T, ow[q], 0x05010400u);  // cells 4q, 4q+1: obj | terrain << 8
+            const uint32_t hi = __builtin_amdgcn_perm(T, ow[q], 0x07030602u);  // cells 4q+2, 4q+3
+            const int c = 16 * p + 4 * q;
+            cells[(c + 0) * BLOCK] = (uint16_t)lo;
+            cells[(c + 1) * BLOCK] = (uint16_t)(lo >> 16);
+            cells[(c + 2) * BLOCK] = (uint16_t)hi;
+            cells[(c + 3) * BLOCK] = (uint16_t)(hi >> 16);
+        }
+    }
+    s.dcount = dishes;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        s.ps[k] = 0; s.tk[k] = 0; s.pc[k] = PC_EMPTY;
+        if ((uint32_t)k < C.n_pots) {
+            s.ps[k] = rd_cell3(cells, L.pot_cell(k)) & 0xFFu;
+            s.tk[k] = ((k < 4 ? h.z : h.w) >> (8 * (k & 3))) & 0xFFu;
+            s.pc[k] = pot_class(C, s.ps[k], s.tk[k]);
+        }
+    }
+}
+
+template <int MAXP>
+__device__ __forceinline__ void store_env3(const LayC& C, const Lay L, uint4* __restrict__ st, int64_t n, int64_t e,
+                                           int n_obj, const Env3<MAXP>& s, uint16_t* cells) {
+    uint4 h;
+    h.x = s.pos0 | (s.or0 << 8) | (s.held0 << 16) | (s.pos1 << 24);
+    h.y = s.or1 | (s.held1 << 8) | (s.t << 16);
+    h.z = 0; h.w = 0;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        if ((uint32_t)k < C.n_pots) {
+            wr_obj3(cells, L.pot_cell(k), s.ps[k]);
+            if (k < 4) h.z |= s.tk[k] << (8 * (k & 3));
+            else h.w |= s.tk[k] << (8 * (k & 3));
+        }
+    }
+    st[e] = h;
+    for (int p = 0; p < n_obj; ++p) {
+        uint32_t ow[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 16 * p + 4 * q;
+            const uint32_t b0 = cells[(c + 0) * BLOCK] & 0xFFu, b1 = cells[(c + 1) * BLOCK] & 0xFFu;
+            const uint32_t b2 = cells[(c + 2) * BLOCK] & 0xFFu, b3 = cells[(c + 3) * BLOCK] & 0xFFu;
+            ow[q] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        }
+        st[(int64_t)(1 + p) * n + e] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+}
+
+template <int MAXP>
+__device__ __forceinline__ void env_reset3(const Lay L, int n_obj, Env3<MAXP>& s, uint16_t* cells) {
+    s.pos0 = L.u8(L_START_POS); s.pos1 = L.u8(L_START_POS + 1);
+    s.or0 = L.u8(L_START_OR); s.or1 = s.pos1 == 0xFFu ? 0u : L.u8(L_START_OR + 1);
+    s.held0 = s.held1 = 0; s.t = 0; s.dcount = 0;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) { s.ps[k] = 0; s.tk[k] = 0; s.pc[k] = PC_EMPTY; }
+    for (int c = 0; c < n_obj * 16; ++c) reinterpret_cast<uint8_t*>(cells + c * BLOCK)[0] = 0;  // clear objects, keep terrain
+}
+
+template <int MAXP>
+__device__ __forceinline__ uint32_t finish_step3(const Lay L, int n_obj, uint16_t* cells, Env3<MAXP>& s, int horizon,
+                                                 uint32_t options, const float4& r, float4& ep) {
+    ep.x += r.x; ep.y += r.y; ep.z += r.z; ep.w += r.w;
+    uint32_t fl = 0;
+    if ((int)s.t >= horizon) {
+        fl |= OC_F_DONE;
+        if (options & OC_OPT_AUTO_RESET) {
+            env_reset3<MAXP>(L, n_obj, s, cells);
+            ep = make_float4(0.f, 0.f, 0.f, 0.f);
+            fl |= OC_F_RESET;
+        }
+    }
+    return fl;
+}
+
+// stage the interact table (both variants, 3 840 bytes) in LDS; returns this lane's variant
+__device__ __forceinline__ const uint8_t* stage_lut(uint2* s_lut, uint32_t old_dyn) {
+    const uint2* src = reinterpret_cast<const uint2*>(&g_lut);
+    for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = src[i];
+    return reinterpret_cast<const uint8_t*>(s_lut) + (old_dyn ? LUT_ENTRIES * 8 : 0);
+}
+
+template <bool UNIFORM, int MAXP, bool LAY_LDS>
+__global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__ g_layouts, int n_layouts,
+                                                    const uint16_t* __restrict__ layout_id, uint4* st,
+                                                    float4* __restrict__ rewards, uint8_t* __restrict__ flags,
+                                                    float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,
+                                                    int horizon, uint32_t options, uint32_t seed_lo, uint32_t seed_hi,
+                                                    int64_t env_offset, int64_t t0, int n_steps) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_cells3[];  // [n_obj * 16][BLOCK]
+    __shared__ uint4 s_lay[LAY_LDS ? LDS_LAYOUT_MAX * 16 : 1];
+    __shared__ uint2 s_lut[2 * LUT_ENTRIES];
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = e < n;
+    for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
+    const Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains the barrier
+    if (!active) return;
+    uint16_t* cells = s_cells3 + threadIdx.x;
+    const LayC C = load_consts<UNIFORM>(L);
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut) + (C.old_dyn ? LUT_ENTRIES * 8 : 0);
+    const uint32_t delta4 = make_delta4(W);
+    Env3<MAXP> s;
+    load_env3<MAXP>(C, L, st, n, e, n_obj, s, cells);
+    float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint64_t g = (uint64_t)(env_offset + e);
+    const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
+    uint32_t rnd[4] = {0, 0, 0, 0};
+    for (int k = 0; k < n_steps; ++k) {
+        const uint64_t t = (uint64_t)(t0 + k);
+        const uint32_t s8 = (uint32_t)t & 7u;
+        if (k == 0 || s8 == 0u) {
+            const uint64_t blk = t >> 3;
+            philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, rnd);
+        }
+        uint32_t a0, a1;
+        draw_actions(rnd, s8, a0, a1);
+        float4 r;
+        env_step3<MAXP>(C, L, lut, cells, s, delta4, a0, a1, r);
+        const uint32_t fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);
+        if (rewards) rewards[(int64_t)k * n + e] = r;
+        if (flags) flags[(int64_t)k * n + e] = (uint8_t)fl;
+    }
+    store_env3<MAXP>(C, L, st, n, e, n_obj, s, cells);
+    if (ep_returns) ep_returns[e] = ep;
+}
+
 // ------------------------------------------------------------------------------------------
 // k_rollout_pair: the fused random-policy rollout with TWO lanes per env (lane parity = player index = pot
 // slot owned).  One wavefront per SIMD issues at most one instruction every four cycles, so with 65 536 envs
@@ -602,86 +951,93 @@ __device__ __forceinline__ uint32_t xchg(uint32_t v) {  // value held by the oth
 
 struct PairW {
     uint32_t pos, ori, held, t;
-    uint32_t ps, tk;  // the pot slot this lane owns (slot index = lane parity)
-    int32_t dcount;   // loose dishes on counters (kept identical in both lanes)
+    uint32_t ps, tk, pc;  // the pot slot this lane owns (slot index = lane parity): soup code, tick + 1, class
+    int32_t dcount;       // loose dishes on counters (kept identical in both lanes)
 };
 
-__device__ __forceinline__ uint32_t pack_res1(const IOut& r) {
+// interact result packed for the partner: new hand | counter byte | new pot soup | new tick, and
+// flags | slot << 8 | new class << 12 | (dish delta + 1) << 16
+__device__ __forceinline__ uint32_t pack_res1(const IOut3& r) {
     return r.new_h | (r.cell_obj << 8) | (r.new_o << 16) | (r.new_tk << 24);
 }
-__device__ __forceinline__ uint32_t pack_res2(const IOut& r) {
-    return (r.swapX ? 1u : 0u) | (r.pot_upd ? 2u : 0u) | (r.slot << 2) | ((uint32_t)(r.ddelta + 1) << 5);
+__device__ __forceinline__ uint32_t pack_res2(const IOut3& r) {
+    return r.flags | (r.slot << 8) | (r.new_pc << 12) | ((uint32_t)(r.ddelta + 1) << 16);
 }
 
-__device__ __forceinline__ void pair_step(const LayC& C, const Lay L, uint32_t* cellw, uint32_t p, PairW& s,
-                                          uint32_t delta4, uint32_t a, float& sparse, float& shaped) {
+__device__ __forceinline__ void pair_step(const LayC& C, const Lay L, const uint8_t* s_lut, uint32_t* cellw, uint32_t p,
+                                          PairW& s, uint32_t delta4, uint32_t a, float& sparse, float& shaped) {
     const bool lane1 = p != 0u;
     const bool mv = a < 4u;
     const uint32_t f = step_cell(s.pos, s.ori, delta4);
     const uint32_t m = mv ? step_cell(s.pos, a, delta4) : s.pos;
     const uint32_t c_f = rd_cell16<PAIR_ENVS>(cellw, f), c_m = rd_cell16<PAIR_ENVS>(cellw, m);
     // the partner's pre-step view
-    const uint32_t held_o = xchg(s.held), pos_o = xchg(s.pos), f_o = xchg(f), ps_o = xchg(s.ps), tk_o = xchg(s.tk);
-    // pot_states before any interact (mdp.py:1439)
-    const uint32_t n_own = (s.ps >> 3) & 3u;
-    const uint32_t u_own = ((s.ps != 0u) & ((s.tk != 0u) | ((n_own - 1u) < 2u))) ? 1u : 0u;
+    const uint32_t held_o = xchg(s.held), pos_o = xchg(s.pos), f_o = xchg(f);
+    const uint32_t pot_own = s.ps | (s.tk << 8) | (s.pc << 16);
+    const uint32_t pot_oth = xchg(pot_own);
+    // pot_states before any interact (mdp.py:1439): class not in {empty, idle with 3 items}
+    const uint32_t u_own = ((s.pc != PC_EMPTY) & (s.pc != PC_IDLE3)) ? 1u : 0u;
     const uint32_t useful_pots = u_own + xchg(u_own);
-    uint32_t ps_arr[2] = {lane1 ? ps_o : s.ps, lane1 ? s.ps : ps_o};
-    uint32_t tk_arr[2] = {lane1 ? tk_o : s.tk, lane1 ? s.tk : tk_o};
+    const uint32_t pot0 = lane1 ? pot_oth : pot_own, pot1 = lane1 ? pot_own : pot_oth;  // by slot
+    uint32_t ps_arr[2] = {pot0 & 0xFFu, pot1 & 0xFFu};
+    uint32_t tk_arr[2] = {(pot0 >> 8) & 0xFFu, (pot1 >> 8) & 0xFFu};
+    uint32_t pc_arr[2] = {pot0 >> 16, pot1 >> 16};
     const bool act = a == OC_A_INTERACT;
-    IOut r = interact<2, false, 0, true>(C, L, act, s.held, held_o, s.dcount, c_f, ps_arr, tk_arr, useful_pots, 0u, true);
+    IOut3 r = interact3<2>(L, s_lut, act, s.held, c_f, ps_arr, tk_arr, pc_arr);
     // hand the result to the partner
     uint32_t o1 = xchg(pack_res1(r)), o2 = xchg(pack_res2(r));
     const bool same_cell = f == f_o;
     {
         // player 1 replays when player 0 changed the counter cell or the pot it uses (player 0's lane follows it
         // into the branch only to receive the final result)
-        const bool o_swapX = (o2 & 1u) != 0u, o_pot_upd = (o2 & 2u) != 0u;
-        const uint32_t o_slot = (o2 >> 2) & 7u;
+        const bool o_swapX = (o2 & LF_SWAP) != 0u, o_pot_upd = (o2 & LF_POT_UPD) != 0u;
+        const uint32_t o_slot = (o2 >> 8) & 7u;
         const bool conflict = lane1 & act & ((same_cell & o_swapX) |
                                             (o_pot_upd & (((c_f >> 8) & 7u) == OC_T_POT) & ((c_f >> 11) == o_slot)));
         const bool cpair = conflict | (xchg(conflict ? 1u : 0u) != 0u);
         if (__builtin_expect(cpair, 0)) {
-            const uint32_t o_new_o = (o1 >> 16) & 0xFFu, o_new_tk = o1 >> 24;
+            const uint32_t o_new_o = (o1 >> 16) & 0xFFu, o_new_tk = o1 >> 24, o_new_pc = (o2 >> 12) & 7u;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const bool upd = o_pot_upd & (o_slot == (uint32_t)k);
                 ps_arr[k] = upd ? o_new_o : ps_arr[k];
                 tk_arr[k] = upd ? o_new_tk : tk_arr[k];
+                pc_arr[k] = upd ? o_new_pc : pc_arr[k];
             }
             const uint32_t c_f_live = (same_cell & o_swapX) ? ((c_f & 0xFF00u) | ((o1 >> 8) & 0xFFu)) : c_f;
-            const int32_t o_dd = (int32_t)((o2 >> 5) & 3u) - 1;
-            const IOut r2 = interact<2, false, 0, true>(C, L, act, s.held, o1 & 0xFFu, s.dcount + o_dd, c_f_live, ps_arr,
-                                                        tk_arr, useful_pots, 0u, true);
+            const IOut3 r2 = interact3<2>(L, s_lut, act, s.held, c_f_live, ps_arr, tk_arr, pc_arr);
             if (lane1) r = r2;
             const uint32_t n1 = xchg(pack_res1(r)), n2 = xchg(pack_res2(r));
             if (!lane1) { o1 = n1; o2 = n2; }
         }
     }
     const uint32_t o_new_h = o1 & 0xFFu, o_cell_obj = (o1 >> 8) & 0xFFu, o_new_o = (o1 >> 16) & 0xFFu, o_new_tk = o1 >> 24;
-    const bool o_swapX = (o2 & 1u) != 0u, o_pot_upd = (o2 & 2u) != 0u;
-    const uint32_t o_slot = (o2 >> 2) & 7u;
-    const int32_t o_dd = (int32_t)((o2 >> 5) & 3u) - 1;
+    const bool o_swapX = (o2 & LF_SWAP) != 0u, o_pot_upd = (o2 & LF_POT_UPD) != 0u;
+    const uint32_t o_slot = (o2 >> 8) & 7u, o_new_pc = (o2 >> 12) & 7u;
+    const int32_t o_dd = (int32_t)((o2 >> 16) & 3u) - 1;
     // is_dish_pickup_useful (mdp.py:2180-2204) on the live hands/counters: player 1 sees player 0's new hand
     const uint32_t other_live = lane1 ? o_new_h : held_o;
     const int32_t dcount_live = s.dcount + (lane1 ? o_dd : 0);
     const bool dish_useful = (((other_live == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dcount_live == 0);
     sparse = r.sparse;
-    shaped = r.shaped + ((r.take_dish & dish_useful) ? C.rew_dish : 0.f);
+    shaped = ((r.flags & LF_PLACE) ? C.rew_place : 0.f) + ((r.flags & LF_PLATE) ? C.rew_soup : 0.f) +
+             ((((r.flags & LF_TAKE_DISH) != 0u) & dish_useful) ? C.rew_dish : 0.f);
     // apply: hand, dish count, the pot slot this lane owns (player 1's update wins when both hit it: it was replayed)
     s.held = r.new_h;
     s.dcount += r.ddelta + o_dd;
     {
-        const bool mine = r.pot_upd & (r.slot == p), theirs = o_pot_upd & (o_slot == p);
+        const bool mine = ((r.flags & LF_POT_UPD) != 0u) & (r.slot == p), theirs = o_pot_upd & (o_slot == p);
         const bool hit1 = lane1 ? mine : theirs, hit0 = lane1 ? theirs : mine;
-        const uint32_t o_1 = lane1 ? r.new_o : o_new_o, t_1 = lane1 ? r.new_tk : o_new_tk;
-        const uint32_t o_0 = lane1 ? o_new_o : r.new_o, t_0 = lane1 ? o_new_tk : r.new_tk;
-        s.ps = hit1 ? o_1 : hit0 ? o_0 : s.ps;
-        s.tk = hit1 ? t_1 : hit0 ? t_0 : s.tk;
+        const uint32_t mine_pk = r.new_o | (r.new_tk << 8) | (r.new_pc << 16);
+        const uint32_t theirs_pk = o_new_o | (o_new_tk << 8) | (o_new_pc << 16);
+        const uint32_t pk_1 = lane1 ? mine_pk : theirs_pk, pk_0 = lane1 ? theirs_pk : mine_pk;
+        const uint32_t fin = hit1 ? pk_1 : hit0 ? pk_0 : pot_own;
+        s.ps = fin & 0xFFu; s.tk = (fin >> 8) & 0xFFu; s.pc = fin >> 16;
     }
     {
         // counter byte of the faced cell; when both face one cell both lanes store the same final value
-        const bool sw1 = lane1 ? r.swapX : o_swapX, sw0 = lane1 ? o_swapX : r.swapX;
+        const bool my_swap = (r.flags & LF_SWAP) != 0u;
+        const bool sw1 = lane1 ? my_swap : o_swapX, sw0 = lane1 ? o_swapX : my_swap;
         const uint32_t ob1 = lane1 ? r.cell_obj : o_cell_obj, ob0 = lane1 ? o_cell_obj : r.cell_obj;
         const uint32_t final_same = sw1 ? ob1 : sw0 ? ob0 : (c_f & 0xFFu);
         wr_cell_obj<PAIR_ENVS>(cellw, f, same_cell ? final_same : r.cell_obj);
@@ -695,12 +1051,14 @@ __device__ __forceinline__ void pair_step(const LayC& C, const Lay L, uint32_t* 
     // step_environment_effects (mdp.py:1691-1703) for the pot this lane owns
     s.t += 1u;
     {
-        const uint32_t o = s.ps, n = (o >> 3) & 3u;
-        uint32_t tk = s.tk;
-        const bool nz = o != 0u;
-        tk = ((C.old_dyn != 0u) & nz & (tk == 0u) & (n == 3u)) ? 1u : tk;
-        const bool cooking = nz & (tk != 0u) & ((tk - 1u) < cook_of(C, o));
-        s.tk = tk + (cooking ? 1u : 0u);
+        uint32_t pc = s.pc, tk = s.tk;
+        const bool autostart = (C.old_dyn != 0u) & (pc == PC_IDLE3);
+        pc = autostart ? (uint32_t)PC_COOKING : pc;
+        tk = autostart ? 1u : tk;
+        const bool cooking = pc == PC_COOKING;
+        tk += cooking ? 1u : 0u;
+        pc = (cooking & ((tk - 1u) >= cook_of(C, s.ps))) ? (uint32_t)PC_READY : pc;
+        s.pc = pc; s.tk = tk;
     }
 }
 
@@ -713,6 +1071,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_pair(const OcLayout* __restri
                                                         uint32_t seed_hi, int64_t env_offset, int64_t t0, int n_steps) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_cells[];  // [n_obj * 8][PAIR_ENVS]
     __shared__ uint4 s_lay[LAY_LDS ? LDS_LAYOUT_MAX * 16 : 1];
+    __shared__ uint2 s_lut[2 * LUT_ENTRIES];
+    for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
     const uint32_t p = threadIdx.x & 1u, el = threadIdx.x >> 1;
     const bool lane1 = p != 0u;
     const int64_t e = (int64_t)blockIdx.x * PAIR_ENVS + el;
@@ -755,6 +1115,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_pair(const OcLayout* __restri
     __syncthreads();  // the partner lane staged the other half of the cells
     if (!active) return;
     s.ps = (p < C.n_pots) ? (rd_cell16<PAIR_ENVS>(cellw, L.pot_cell((int)p)) & 0xFFu) : 0u;
+    s.pc = pot_class(C, s.ps, s.tk);
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut) + (C.old_dyn ? LUT_ENTRIES * 8 : 0);
     const uint64_t g = (uint64_t)(env_offset + e);
     const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
     const uint32_t mul_p = lane1 ? 6u : 1u;  // player 1 reads the next base-6 digit
@@ -770,7 +1132,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_pair(const OcLayout* __restri
         const uint32_t x = ((s8 & 1u) ? w * 36u : w) * mul_p;
         const uint32_t a = __umulhi(x, 6u);
         float sp, sh;
-        pair_step(C, L, cellw, p, s, delta4, a, sp, sh);
+        pair_step(C, L, lut, cellw, p, s, delta4, a, sp, sh);
         ep_sp += sp; ep_sh += sh;
         uint32_t fl = 0;
         if ((int)s.t >= horizon) {  // is_done (env.py:321-325); both lanes agree
@@ -778,7 +1140,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_pair(const OcLayout* __restri
             if (options & OC_OPT_AUTO_RESET) {
                 s.pos = L.u8(L_START_POS + (int)p);
                 s.ori = L.u8(L_START_OR + (int)p);
-                s.held = 0; s.t = 0; s.ps = 0; s.tk = 0; s.dcount = 0;
+                s.held = 0; s.t = 0; s.ps = 0; s.tk = 0; s.pc = PC_EMPTY; s.dcount = 0;
                 ep_sp = 0.f; ep_sh = 0.f;
                 for (int d = (int)p; d < n_obj * 8; d += 2) cellw[d * PAIR_ENVS] &= 0xFF00FF00u;
                 fl |= OC_F_RESET;
@@ -1229,10 +1591,11 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
     const bool lds = b->n_layouts <= LDS_LAYOUT_MAX;
     const bool small = b->max_pots >= 1 && b->max_pots <= 2;
     // Lane pairs pay ~1.5x the total VALU work of one lane per env but halve the per-wavefront instruction stream:
-    // they win while one lane per env cannot put more than one wavefront on every SIMD (measured on MI355X:
-    // 0.92 vs 1.19 us/step at 32 768 envs, parity at 65 536, 1.93 vs 1.59 at 131 072).
+    // they win while one lane per env leaves SIMDs without a wavefront (measured on MI355X, us per batched step,
+    // pair vs lane: 0.90 vs 1.09 at 32 768 envs, 1.11 vs 1.10 at 65 536, 1.93 vs 1.44 at 131 072).
     const bool pair_ok = small && (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0;
-    const bool want_pair = (options & OC_OPT_LANE_PAIR) || (!(options & OC_OPT_LANE_PER_ENV) && b->n_envs <= 64 * simd_count());
+    const bool want_pair = (options & OC_OPT_LANE_PAIR) ||
+                           (!(options & (OC_OPT_LANE_PER_ENV | OC_OPT_PREDICATE_INTERACT)) && b->n_envs <= 48 * simd_count());
     if (pair_ok && want_pair) {
         // two lanes per env (k_rollout_pair)
         const size_t smem2 = (size_t)n_obj * 8 * PAIR_ENVS * sizeof(uint32_t);
@@ -1252,6 +1615,25 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
                                b->d_layout_id, (uint4*)d_state, (float4*)d_rewards, d_flags, (float4*)d_ep_returns,
                                b->n_envs, b->width, n_obj, horizon, options, (uint32_t)seed, (uint32_t)(seed >> 32),
                                env_offset, t0, n_steps);
+        return check_launch("oc_rollout_random");
+    }
+    if ((options & OC_OPT_PREDICATE_INTERACT) == 0) {
+        const size_t smem3 = (size_t)n_obj * 16 * BLOCK * sizeof(uint16_t);
+        const dim3 grid3(grid_for(b->n_envs)), block3(BLOCK);
+#define GO3(U, MP, LL)                                                                                               \
+    do {                                                                                                             \
+        if (smem3 > 40 * 1024)                                                                                       \
+            (void)hipFuncSetAttribute((const void*)k_rollout3<U, MP, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)smem3);                                                                   \
+        hipLaunchKernelGGL((k_rollout3<U, MP, LL>), grid3, block3, smem3, s, b->d_layouts, b->n_layouts,             \
+                           b->d_layout_id, (uint4*)d_state, (float4*)d_rewards, d_flags, (float4*)d_ep_returns,     \
+                           b->n_envs, b->width, n_obj, horizon, options, (uint32_t)seed, (uint32_t)(seed >> 32),    \
+                           env_offset, t0, n_steps);                                                                 \
+    } while (0)
+        if (uniform) { if (small) GO3(true, 2, true); else GO3(true, 8, true); }
+        else if (lds) { if (small) GO3(false, 2, true); else GO3(false, 8, true); }
+        else { if (small) GO3(false, 2, false); else GO3(false, 8, false); }
+#undef GO3
         return check_launch("oc_rollout_random");
     }
     const size_t smem = (size_t)n_obj * 8 * BLOCK * sizeof(uint32_t);

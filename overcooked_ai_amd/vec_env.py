@@ -39,6 +39,7 @@ class VecOvercookedEnv:
         self.auto_reset = bool(auto_reset)
         self.lane_per_env = False  # rollout_random: force the one-lane-per-env kernel (testing / comparison)
         self.lane_pair = False     # rollout_random: force the lane-pair kernel where the table allows it
+        self.predicate_interact = False  # rollout_random: lane-per-env kernel with the predicate-network interact
         self.seed = int(seed)
         self.env_offset = int(env_offset)
         self.t_global = 0  # global step counter feeding the Philox counter of rollout_random
@@ -78,7 +79,7 @@ class VecOvercookedEnv:
     @property
     def options(self):
         return ((_lib.OPT_AUTO_RESET if self.auto_reset else 0) | (_lib.OPT_LANE_PER_ENV if self.lane_per_env else 0)
-                | (_lib.OPT_LANE_PAIR if self.lane_pair else 0))
+                | (_lib.OPT_LANE_PAIR if self.lane_pair else 0) | (_lib.OPT_PREDICATE_INTERACT if self.predicate_interact else 0))
 
     def spec_of(self, e):
         return self.table.specs[0 if self.layout_id is None else int(self.layout_id_host[e])]

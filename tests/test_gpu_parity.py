@@ -116,7 +116,7 @@ def test_reference_golden_trajectory(manifest, gpu):
     assert total == d["ep_rewards"][: n - 1].sum()
 
 
-@pytest.mark.parametrize("kernel", ["lane_per_env", "lane_pair"])
+@pytest.mark.parametrize("kernel", ["lane_per_env", "lane_pair", "predicate_interact"])
 @pytest.mark.parametrize("name", ROLLOUT_CONFIGS)
 def test_golden_rollouts_fused(name, kernel, manifest, gpu):
     """Both fused Philox rollout kernels against episodes run through the reference's OvercookedEnv.step."""
@@ -217,7 +217,7 @@ def test_step_vs_oracle_random_states(n_envs, gpu):
         assert (fl_o & 2).any() or n_envs == 1
 
 
-@pytest.mark.parametrize("kernel", ["lane_per_env", "lane_pair"])
+@pytest.mark.parametrize("kernel", ["lane_per_env", "lane_pair", "predicate_interact"])
 def test_full_size_rollout_vs_oracle(kernel, gpu):
     """BASELINE config 2 at full size: 65 536 cramped_room envs, random policy, horizon 400 with auto-reset."""
     from overcooked_ai_amd.layouts import spec_from_name
@@ -226,8 +226,7 @@ def test_full_size_rollout_vs_oracle(kernel, gpu):
     spec = spec_from_name("cramped_room")
     orc = oracle_for(spec)
     env = make_env(spec, n, gpu, horizon=400, auto_reset=True, seed=1234)
-    env.lane_pair = kernel == "lane_pair"
-    env.lane_per_env = kernel == "lane_per_env"
+    setattr(env, kernel, True)
     st_o = orc.reset(orc.new_state(n))
     ep_o = np.zeros((n, 4), np.float32)
     t0 = 0
@@ -256,7 +255,7 @@ def test_full_size_rollout_vs_oracle(kernel, gpu):
     assert torch.equal(shard.state, env3.state[:, a:b])
 
 
-@pytest.mark.parametrize("kernel", ["lane_per_env", "lane_pair"])
+@pytest.mark.parametrize("kernel", ["lane_per_env", "lane_pair", "predicate_interact"])
 def test_mixed_layout_batch_vs_oracle(kernel, gpu):
     """BASELINE config 4 (one GPU's shard): env e uses canonical layout e % 5, all padded to 9x5."""
     from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
@@ -266,8 +265,7 @@ def test_mixed_layout_batch_vs_oracle(kernel, gpu):
     lid = (np.arange(n) % 5).astype(np.uint16)
     orc = oracle_for(table.specs)
     env = make_env(table, n, gpu, horizon=400, auto_reset=True, seed=99, layout_id=lid)
-    env.lane_pair = kernel == "lane_pair"
-    env.lane_per_env = kernel == "lane_per_env"
+    setattr(env, kernel, True)
     rng = np.random.default_rng(5)
     st = np.zeros((table.n_planes, n, 16), np.uint8)
     for l in range(5):
@@ -304,11 +302,14 @@ def test_large_layout_table_global_path(gpu):
     for l in range(len(specs)):
         idx = np.nonzero(lid == l)[0]
         st[:, idx] = random_packed_states(table.specs[l], len(idx), rng, timestep_max=99)
-    env.set_packed_state(st)
     st_o = st.copy()
-    env.rollout_random(120)
     orc.rollout_random(st_o, 120, horizon=100, options=1, seed=5, layout_id=lid, want_outputs=False)
-    assert np.array_equal(env.get_packed_state(), st_o)
+    for table_interact in (True, False):
+        env.predicate_interact = table_interact
+        env.set_packed_state(st)
+        env.t_global = 0
+        env.rollout_random(120)
+        assert np.array_equal(env.get_packed_state(), st_o)
     acts = rng.integers(0, 6, size=(n, 2)).astype(np.uint8)
     env.step(torch.from_numpy(acts).to(gpu))
     st_o2, _, _ = orc.step(st_o, acts, horizon=100, options=1, layout_id=lid)
@@ -332,8 +333,9 @@ def test_every_registry_layout_vs_oracle(gpu):
         env = make_env(spec, n, gpu, horizon=400, auto_reset=True, seed=3)
         st_o = st.copy()
         rew_o, _ = orc.rollout_random(st_o, 60, horizon=400, options=1, seed=3)
-        for kernel in ("lane_per_env", "lane_pair"):  # lane_pair silently falls back where it does not apply
-            env.lane_per_env, env.lane_pair = kernel == "lane_per_env", kernel == "lane_pair"
+        for kernel in ("lane_per_env", "lane_pair", "predicate_interact"):  # lane_pair falls back where it does not apply
+            env.lane_per_env, env.lane_pair, env.predicate_interact = (kernel == "lane_per_env", kernel == "lane_pair",
+                                                                       kernel == "predicate_interact")
             env.set_packed_state(st)
             env.t_global = 0
             rew = torch.zeros((60, n, 4), dtype=torch.float32, device=gpu)
@@ -411,12 +413,16 @@ def test_many_pots_layout_vs_oracle(gpu):
     n = 6000
     st = random_packed_states(spec, n, rng)
     env = make_env(spec, n, gpu, horizon=400, auto_reset=True, seed=21)
-    env.set_packed_state(st)
     st_o = st.copy()
-    rew = torch.zeros((90, n, 4), dtype=torch.float32, device=gpu)
-    env.rollout_random(90, rew, None)
     rew_o, _ = orc.rollout_random(st_o, 90, horizon=400, options=1, seed=21)
-    assert np.array_equal(env.get_packed_state(), st_o) and np.array_equal(u8(rew), rew_o)
+    for table_interact in (False, True):
+        env.predicate_interact = table_interact
+        env.set_packed_state(st)
+        env.t_global = 0
+        rew = torch.zeros((90, n, 4), dtype=torch.float32, device=gpu)
+        env.rollout_random(90, rew, None)
+        assert np.array_equal(env.get_packed_state(), st_o) and np.array_equal(u8(rew), rew_o)
+    env.predicate_interact = False
     acts = rng.integers(0, 6, size=(n, 2)).astype(np.uint8)
     acts[rng.random(n) < 0.5] = 5
     ev = torch.zeros((n,), dtype=torch.int64, device=gpu)
