@@ -282,7 +282,24 @@ def bench_step_api(env, dev, torch, iters=2000):
     wall = time.perf_counter() - t0
     ms = ev0.elapsed_time(ev1) / iters
     b = n * (2 * S_CRAMPED + 2 + OUT_BYTES)
-    return {"value": n * iters / wall, "unit": "env steps/s", "launch_ms": ms, "bytes_per_launch": b,
+    # the same launches enqueued from C (oc_step_many): no Python between steps
+    K = 500
+    acts_k = torch.randint(0, 6, (K, n, 2), dtype=torch.uint8, device=dev)
+    rew_k = torch.zeros((K, n, 4), dtype=torch.float32, device=dev)
+    fl_k = torch.zeros((K, n), dtype=torch.uint8, device=dev)
+    env.step_many(acts_k[:50], rew_k[:50], fl_k[:50])
+    torch.cuda.synchronize(dev)
+    evm0, evm1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tm0 = time.perf_counter()
+    evm0.record()
+    env.step_many(acts_k, rew_k, fl_k)
+    evm1.record()
+    torch.cuda.synchronize(dev)
+    wall_many = time.perf_counter() - tm0
+    ms_many = evm0.elapsed_time(evm1) / K
+    many = {"value": n * K / wall_many, "launch_ms": ms_many, "achieved_GBs": b / (ms_many * 1e-3) / 1e9,
+            "frac": b / (ms_many * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "oc_step_many: the same kernel, launches enqueued from C"}
+    return {"value": n * iters / wall, "step_many": many, "unit": "env steps/s", "launch_ms": ms, "bytes_per_launch": b,
             "achieved_GBs": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "note": "oc_step, one launch per batched step incl. Python/ctypes launch overhead; SURVEY 8d: 67 B/env-step"}
 

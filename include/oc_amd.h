@@ -172,6 +172,14 @@ int oc_step(const OcBatch* batch, const void* d_state_in, void* d_state_out, con
             uint32_t options, void* stream);
 
 /*
+ * oc_step_many — n_steps consecutive oc_step calls (in place) enqueued from C: step k consumes
+ * d_actions[k][n_envs][2] and writes d_rewards[k][n_envs][4], d_flags[k][n_envs].  Same kernel as oc_step; it only
+ * removes the caller's per-step launch overhead (e.g. replaying a pre-sampled action tensor).
+ */
+int oc_step_many(const OcBatch* batch, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
+                 float* d_ep_returns, int n_steps, int horizon, uint32_t options, void* stream);
+
+/*
  * oc_rollout_random — n_steps transitions per launch under the uniform random policy
  * (the reference's RandomAgent(all_actions=True) pair, agents/agent.py:223), actions drawn
  * in-kernel.  One Philox4x32-10 block feeds 8 consecutive steps: with b = t >> 3, s = t & 7,

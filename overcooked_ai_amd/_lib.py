@@ -15,7 +15,8 @@ OPT_PREDICATE_INTERACT = 0x8
 BATCH_TWO_PLAYERS = 0x1
 OBS_U8, OBS_F32 = 0, 1
 
-EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_step", "oc_rollout_random",
+EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_step", "oc_step_many",
+           "oc_rollout_random",
            "oc_encode_lossless", "oc_reset")
 
 
@@ -65,6 +66,8 @@ def load():
     L.oc_state_planes.argtypes = [i32, i32]
     L.oc_step.restype = i32
     L.oc_step.argtypes = [bp, vp, vp, vp, vp, vp, vp, vp, i32, u32, vp]
+    L.oc_step_many.restype = i32
+    L.oc_step_many.argtypes = [bp, vp, vp, vp, vp, vp, i32, i32, u32, vp]
     L.oc_rollout_random.restype = i32
     L.oc_rollout_random.argtypes = [bp, vp, vp, vp, vp, i32, u32, u64, i64, i64, i32, vp]
     L.oc_encode_lossless.restype = i32

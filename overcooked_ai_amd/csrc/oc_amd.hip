@@ -930,6 +930,46 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
     if (ep_returns) ep_returns[e] = ep;
 }
 
+// k_step3: one transition per launch with caller-supplied actions, table-driven interact (no event logging;
+// oc_step with d_events != NULL uses k_step, whose predicate-network interact produces the event bits)
+template <bool UNIFORM, int MAXP, bool LAY_LDS>
+__global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_layouts, int n_layouts,
+                                                 const uint16_t* __restrict__ layout_id, const uint4* st_in,
+                                                 uint4* st_out, const uint8_t* __restrict__ actions,
+                                                 float4* __restrict__ rewards, uint8_t* __restrict__ flags,
+                                                 float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,
+                                                 int horizon, uint32_t options) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_cells3[];  // [n_obj * 16][BLOCK]
+    __shared__ uint4 s_lay[LAY_LDS ? LDS_LAYOUT_MAX * 16 : 1];
+    __shared__ uint2 s_lut[2 * LUT_ENTRIES];
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = e < n;
+    for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
+    const Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains the barrier
+    if (!active) return;
+    uint16_t* cells = s_cells3 + threadIdx.x;
+    const LayC C = load_consts<UNIFORM>(L);
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut) + (C.old_dyn ? LUT_ENTRIES * 8 : 0);
+    const uint32_t delta4 = make_delta4(W);
+    Env3<MAXP> s;
+    load_env3<MAXP>(C, L, st_in, n, e, n_obj, s, cells);
+    const uint32_t a01 = reinterpret_cast<const uint16_t*>(actions)[e];
+    const uint32_t a0 = a01 & 0xFFu, a1 = a01 >> 8;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t fl;
+    float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a0 > 5u || a1 > 5u) {
+        fl = OC_F_BAD_ACTION;  // get_state_transition raises ValueError (mdp.py:1394-1398): leave the env untouched
+    } else {
+        env_step3<MAXP>(C, L, lut, cells, s, delta4, a0, a1, r);
+        fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);
+    }
+    store_env3<MAXP>(C, L, st_out, n, e, n_obj, s, cells);
+    rewards[e] = r;
+    flags[e] = (uint8_t)fl;
+    if (ep_returns) ep_returns[e] = ep;
+}
+
 // ------------------------------------------------------------------------------------------
 // k_rollout_pair: the fused random-policy rollout with TWO lanes per env (lane parity = player index = pot
 // slot owned).  One wavefront per SIMD issues at most one instruction every four cycles, so with 65 536 envs
@@ -1543,6 +1583,22 @@ void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_st
     const bool small = b->max_pots >= 1 && b->max_pots <= 2;
     const size_t smem = (size_t)n_obj * 8 * BLOCK * sizeof(uint32_t);
     const dim3 grid(grid_for(b->n_envs)), block(BLOCK);
+    if (!EVENTS && !(options & OC_OPT_PREDICATE_INTERACT)) {
+#define GO3(U, MP, LL)                                                                                               \
+    do {                                                                                                             \
+        if (smem > 40 * 1024)                                                                                        \
+            (void)hipFuncSetAttribute((const void*)k_step3<U, MP, LL>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                      (int)smem);                                                                    \
+        hipLaunchKernelGGL((k_step3<U, MP, LL>), grid, block, smem, s, b->d_layouts, b->n_layouts, b->d_layout_id,   \
+                           (const uint4*)d_state_in, (uint4*)d_state_out, d_actions, (float4*)d_rewards, d_flags,    \
+                           (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options);                     \
+    } while (0)
+        if (uniform) { if (small) GO3(true, 2, true); else GO3(true, 8, true); }
+        else if (lds) { if (small) GO3(false, 2, true); else GO3(false, 8, true); }
+        else { if (small) GO3(false, 2, false); else GO3(false, 8, false); }
+#undef GO3
+        return;
+    }
 #define GO(U, MP, LL)                                                                                                    do {                                                                                                                     if (smem > 48 * 1024)                                                                                                    (void)hipFuncSetAttribute((const void*)k_step<U, MP, LL, EVENTS>,                                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                hipLaunchKernelGGL((k_step<U, MP, LL, EVENTS>), grid, block, smem, s, b->d_layouts, b->n_layouts,                                       b->d_layout_id, (const uint4*)d_state_in, (uint4*)d_state_out, d_actions,                                            (float4*)d_rewards, d_flags, (float4*)d_ep_returns, d_events, b->n_envs, b->width, n_obj,                            horizon, options);                                                                            } while (0)
     if (uniform) { if (small) GO(true, 2, true); else GO(true, 8, true); }
     else if (lds) { if (small) GO(false, 2, true); else GO(false, 8, true); }
@@ -1575,6 +1631,19 @@ int oc_step(const OcBatch* b, const void* d_state_in, void* d_state_out, const u
         launch_step<false>(b, n_obj, d_state_in, d_state_out, d_actions, d_rewards, d_flags, d_ep_returns, nullptr,
                            horizon, options, s);
     return check_launch("oc_step");
+}
+
+int oc_step_many(const OcBatch* b, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
+                 float* d_ep_returns, int n_steps, int horizon, uint32_t options, void* stream) {
+    if (n_steps < 0) return fail(OC_EINVAL, "oc_step_many: n_steps < 0");
+    if (!b) return fail(OC_EINVAL, "batch is NULL");
+    for (int k = 0; k < n_steps; ++k) {
+        const int64_t off = (int64_t)k * b->n_envs;
+        if (int rc = oc_step(b, d_state, d_state, d_actions + 2 * off, d_rewards + 4 * off, d_flags + off, d_ep_returns,
+                             nullptr, horizon, options, stream))
+            return rc;
+    }
+    return OC_OK;
 }
 
 int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t* d_flags, float* d_ep_returns,

@@ -70,6 +70,9 @@ class VecOvercookedEnv:
             max_pots=self.table.max_pots,
             batch_flags=_lib.BATCH_TWO_PLAYERS if all(s.num_players == 2 for s in self.table.specs) else 0)
         self._bref = ctypes.byref(self._batch)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._state_ptr, self._rewards_ptr, self._flags_ptr = self.state.data_ptr(), self.rewards.data_ptr(), self.flags.data_ptr()
+        self._ep_ptr = self.ep_returns.data_ptr() if self.ep_returns is not None else None
         self.reset()
 
     # ------------------------------------------------------------------ helpers
@@ -96,6 +99,13 @@ class VecOvercookedEnv:
                                    self.ep_returns.data_ptr() if self.ep_returns is not None else None, self._stream())
         _lib.check(rc, "oc_reset")
 
+    def _launch(self, fn, *args):
+        """Call a C-ABI entry point with this env's device current (skips the context switch when it already is)."""
+        if torch.cuda.current_device() == self._dev_index:
+            return fn(*args, torch.cuda.current_stream().cuda_stream)
+        with torch.cuda.device(self.device):
+            return fn(*args, torch.cuda.current_stream().cuda_stream)
+
     def step(self, actions, state_out=None, events_out=None):
         """actions: uint8 tensor [n_envs, 2] of action indices (Action.INDEX_TO_ACTION order).
         Returns (rewards [n_envs,4] = sparse0, sparse1, shaped0, shaped1; flags [n_envs] OC_F_* bits).
@@ -106,15 +116,25 @@ class VecOvercookedEnv:
         if actions.dtype != torch.uint8 or actions.shape != (self.n_envs, 2) or not actions.is_contiguous() \
                 or actions.device != self.state.device:
             raise ValueError("actions must be a contiguous uint8 [n_envs, 2] tensor on %s" % self.device)
-        out = self.state if state_out is None else state_out
-        with torch.cuda.device(self.device):
-            rc = self.lib.oc_step(self._bref, self.state.data_ptr(), out.data_ptr(), actions.data_ptr(),
-                                  self.rewards.data_ptr(), self.flags.data_ptr(),
-                                  self.ep_returns.data_ptr() if self.ep_returns is not None else None,
-                                  events_out.data_ptr() if events_out is not None else None,
-                                  self.horizon, self.options, self._stream())
-        _lib.check(rc, "oc_step")
+        out = self._state_ptr if state_out is None else state_out.data_ptr()
+        rc = self._launch(self.lib.oc_step, self._bref, self._state_ptr, out, actions.data_ptr(), self._rewards_ptr,
+                          self._flags_ptr, self._ep_ptr, events_out.data_ptr() if events_out is not None else None,
+                          self.horizon, self.options)
+        if rc:
+            _lib.check(rc, "oc_step")
         return self.rewards, self.flags
+
+    def step_many(self, actions, rewards_out, flags_out):
+        """K consecutive steps enqueued from C: actions uint8 [K, n_envs, 2] -> rewards_out float32 [K, n_envs, 4],
+        flags_out uint8 [K, n_envs]."""
+        K = actions.shape[0]
+        assert actions.dtype == torch.uint8 and actions.shape == (K, self.n_envs, 2) and actions.is_contiguous()
+        assert rewards_out.dtype == torch.float32 and rewards_out.shape == (K, self.n_envs, 4) and rewards_out.is_contiguous()
+        assert flags_out.dtype == torch.uint8 and flags_out.shape == (K, self.n_envs) and flags_out.is_contiguous()
+        rc = self._launch(self.lib.oc_step_many, self._bref, self._state_ptr, actions.data_ptr(), rewards_out.data_ptr(),
+                          flags_out.data_ptr(), self._ep_ptr, int(K), self.horizon, self.options)
+        _lib.check(rc, "oc_step_many")
+        return rewards_out, flags_out
 
     def rollout_random(self, n_steps, rewards_out=None, flags_out=None):
         """n_steps fused random-policy transitions in one launch (Philox actions, see include/oc_amd.h).

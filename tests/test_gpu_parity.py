@@ -248,6 +248,16 @@ def test_full_size_rollout_vs_oracle(kernel, gpu):
     env3 = make_env(spec, n, gpu, horizon=400, auto_reset=True, seed=1234)
     env3.rollout_random(20)
     assert torch.equal(env2.state, env3.state)
+    # ... and so does oc_step_many on the same action tensor
+    env4 = make_env(spec, n, gpu, horizon=400, auto_reset=True)
+    acts = torch.from_numpy(np.stack([O.random_actions(1234, 0, t, n) for t in range(20)])).to(gpu)
+    rew4 = torch.zeros((20, n, 4), dtype=torch.float32, device=gpu)
+    fl4 = torch.zeros((20, n), dtype=torch.uint8, device=gpu)
+    env4.step_many(acts, rew4, fl4)
+    rew3 = torch.zeros((20, n, 4), dtype=torch.float32, device=gpu)
+    env5 = make_env(spec, n, gpu, horizon=400, auto_reset=True, seed=1234)
+    env5.rollout_random(20, rew3, None)
+    assert torch.equal(env4.state, env3.state) and torch.equal(rew4, rew3)
     # sharding property: a shard that owns envs [a, b) reproduces exactly that slice
     a, b = 12345, 12345 + 777
     shard = make_env(spec, b - a, gpu, horizon=400, auto_reset=True, seed=1234, env_offset=a)
