@@ -704,7 +704,8 @@ __device__ __forceinline__ IOut3 interact3(const Lay L, const uint8_t* s_lut, bo
     r.ddelta = (int32_t)((ent.y >> 16) & 3u) - 1;
     r.slot = slot;
     r.cell_obj = (r.flags & LF_SWAP) ? r.new_o : o_cell;
-    r.sparse = (r.flags & LF_SERVE) ? L.value(recipe_idx(h) & 15u) : 0.f;  // deliver_soup (mdp.py:1631-1642)
+    const float value = L.value(recipe_idx(h) & 15u);  // unconditional read: keeps both players' look-ups in one block
+    r.sparse = (r.flags & LF_SERVE) ? value : 0.f;      // deliver_soup (mdp.py:1631-1642)
     return r;
 }
 
@@ -719,19 +720,37 @@ __device__ __forceinline__ void apply_pot3(Env3<MAXP>& s, const IOut3& r) {
     }
 }
 
-// get_state_transition (mdp.py:1375-1430), table-driven.  Same sequencing argument as env_step: both interacts are
-// evaluated on the pre-step pots/cells, player 1 replays only when player 0 touched the very cell or pot it uses.
+// get_state_transition (mdp.py:1375-1430), table-driven, in three pieces so that the rollout loop can issue the
+// LDS reads of step k+1 before the tail (env effects, bookkeeping, output stores) of step k:
+//   probe3      the four cells a step looks at: the faced cells (pre-move pose, mdp.py:1452-1454) and the move targets
+//   step3_main  resolve_interacts + resolve_movement.  Same sequencing argument as env_step: both interacts are
+//               evaluated on the pre-step pots/cells, player 1 replays only when player 0 touched its cell or pot
+//   step3_env   step_environment_effects
+struct Probe3 {
+    uint32_t f0, f1, m0, m1;
+    uint32_t c_f0, c_f1, c_m0, c_m1;
+};
+
 template <int MAXP>
-__device__ __forceinline__ void env_step3(const LayC& C, const Lay L, const uint8_t* s_lut, uint16_t* cells,
-                                          Env3<MAXP>& s, uint32_t delta4, uint32_t a0, uint32_t a1, float4& r) {
+__device__ __forceinline__ Probe3 probe3(const uint16_t* cells, const Env3<MAXP>& s, uint32_t delta4, uint32_t a0,
+                                         uint32_t a1) {
+    Probe3 q;
     const bool two = s.pos1 != 0xFFu;
-    const uint32_t f0 = step_cell(s.pos0, s.or0, delta4);
-    const uint32_t f1 = two ? step_cell(s.pos1, s.or1, delta4) : f0;
+    q.f0 = step_cell(s.pos0, s.or0, delta4);
+    q.f1 = two ? step_cell(s.pos1, s.or1, delta4) : q.f0;
+    q.m0 = a0 < 4u ? step_cell(s.pos0, a0, delta4) : s.pos0;
+    q.m1 = (two & (a1 < 4u)) ? step_cell(s.pos1, a1, delta4) : (two ? s.pos1 : s.pos0);
+    q.c_f0 = rd_cell3(cells, q.f0); q.c_f1 = rd_cell3(cells, q.f1);
+    q.c_m0 = rd_cell3(cells, q.m0); q.c_m1 = rd_cell3(cells, q.m1);
+    return q;
+}
+
+template <int MAXP>
+__device__ __forceinline__ void step3_main(const LayC& C, const Lay L, const uint8_t* s_lut, uint16_t* cells,
+                                           Env3<MAXP>& s, uint32_t a0, uint32_t a1, const Probe3& q, float4& r) {
+    const bool two = s.pos1 != 0xFFu;
     const bool mv0 = a0 < 4u, mv1 = two & (a1 < 4u);
-    const uint32_t m0 = mv0 ? step_cell(s.pos0, a0, delta4) : s.pos0;
-    const uint32_t m1 = mv1 ? step_cell(s.pos1, a1, delta4) : (two ? s.pos1 : s.pos0);
-    const uint32_t c_f0 = rd_cell3(cells, f0), c_f1 = rd_cell3(cells, f1);
-    const uint32_t c_m0 = rd_cell3(cells, m0), c_m1 = rd_cell3(cells, m1);
+    const uint32_t f0 = q.f0, f1 = q.f1, c_f0 = q.c_f0, c_f1 = q.c_f1;
 
     // pot_states before any interact (mdp.py:1439): ready / cooking / 1..2 idle items  <=>  class not in {empty, idle 3}
     uint32_t useful_pots = 0;
@@ -765,15 +784,18 @@ __device__ __forceinline__ void env_step3(const LayC& C, const Lay L, const uint
     r = make_float4(r0.sparse, r1.sparse, sh0, sh1);
 
     // resolve_movement (mdp.py:1644-1727)
-    const uint32_t np0 = (mv0 & (((c_m0 >> 8) & 7u) == OC_T_FLOOR)) ? m0 : s.pos0;
-    const uint32_t np1 = (mv1 & (((c_m1 >> 8) & 7u) == OC_T_FLOOR)) ? m1 : s.pos1;
+    const uint32_t np0 = (mv0 & (((q.c_m0 >> 8) & 7u) == OC_T_FLOOR)) ? q.m0 : s.pos0;
+    const uint32_t np1 = (mv1 & (((q.c_m1 >> 8) & 7u) == OC_T_FLOOR)) ? q.m1 : s.pos1;
     s.or0 = mv0 ? a0 : s.or0;
     s.or1 = mv1 ? a1 : s.or1;
     const bool collide = two & ((np0 == np1) | ((np0 == s.pos1) & (np1 == s.pos0)));
     s.pos0 = collide ? s.pos0 : np0;
     s.pos1 = collide ? s.pos1 : np1;
+}
 
-    // step_environment_effects (mdp.py:1691-1703): advance cooking pots, promote them to ready
+// step_environment_effects (mdp.py:1691-1703): advance cooking pots, promote them to ready
+template <int MAXP>
+__device__ __forceinline__ void step3_env(const LayC& C, Env3<MAXP>& s) {
     s.t += 1u;
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
@@ -787,6 +809,14 @@ __device__ __forceinline__ void env_step3(const LayC& C, const Lay L, const uint
         s.pc[k] = pc;
         s.tk[k] = tk;
     }
+}
+
+template <int MAXP>
+__device__ __forceinline__ void env_step3(const LayC& C, const Lay L, const uint8_t* s_lut, uint16_t* cells,
+                                          Env3<MAXP>& s, uint32_t delta4, uint32_t a0, uint32_t a1, float4& r) {
+    const Probe3 q = probe3<MAXP>(cells, s, delta4, a0, a1);
+    step3_main<MAXP>(C, L, s_lut, cells, s, a0, a1, q, r);
+    step3_env<MAXP>(C, s);
 }
 
 template <int MAXP>
@@ -911,6 +941,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
     const uint64_t g = (uint64_t)(env_offset + e);
     const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
     uint32_t rnd[4] = {0, 0, 0, 0};
+    // (issuing step k+1's cell reads before step k's tail was tried and measured: no gain — the loop is bound by
+    //  instruction issue, not by LDS latency)
     for (int k = 0; k < n_steps; ++k) {
         const uint64_t t = (uint64_t)(t0 + k);
         const uint32_t s8 = (uint32_t)t & 7u;
