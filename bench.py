@@ -45,6 +45,7 @@ def parse():
                     help="BASELINE.json config index (1-based): 2 = headline (default); 3 = asymmetric_advantages + "
                          "lossless encoding every step; 4 = 5-layout mix padded to 9x5; 5 = 4096 generated 9x5 terrains")
     ap.add_argument("--lane-per-env", action="store_true", help="force the one-lane-per-env rollout kernel")
+    ap.add_argument("--lane-pair", action="store_true", help="force the two-lanes-per-env rollout kernel")
     ap.add_argument("--predicate-interact", action="store_true", help="lane-per-env kernel with the predicate-network interact (v2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the step-API and encode side measurements")
@@ -119,6 +120,7 @@ def main():
     env = VecOvercookedEnv(args.layout, n, horizon=HORIZON, device=dev, auto_reset=True, seed=0,
                            env_offset=rank * n)
     env.lane_per_env = args.lane_per_env
+    env.lane_pair = args.lane_pair
     env.predicate_interact = args.predicate_interact
     fuse = max(1, min(args.fuse, args.steps))
     rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
@@ -158,7 +160,8 @@ def main():
         # mean over equal-size launches only; the ragged tail launch is excluded pro rata
         launch_ms = dev_ms * (fuse / float(args.steps))
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-    kernel = "k_rollout" if args.predicate_interact else "k_rollout3" if (args.lane_per_env or n > 49152) else "k_rollout_pair"
+    kernel = ("k_rollout" if args.predicate_interact else "k_rollout_pair" if args.lane_pair
+              else "k_rollout3" if (args.lane_per_env or n > 32768) else "k_rollout_pair")
     traffic = None
     try:  # PMC HBM bytes per launch measured by tools/profile_round.sh on this same command (profiles/traffic.json)
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:

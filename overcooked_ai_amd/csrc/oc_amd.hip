@@ -532,9 +532,15 @@ __global__ __launch_bounds__(BLOCK) void k_step(const OcLayout* __restrict__ g_l
 // expanded into base-6 digits by multiply-high (digit = mulhi(x, 6), x <- x * 6), two digits (player
 // 0, player 1) per step.  oracle_random_actions restates the same mapping.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bitsel(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+
 __device__ __forceinline__ void draw_actions(const uint32_t (&rnd)[4], uint32_t s8, uint32_t& a0, uint32_t& a1) {
-    const uint32_t w = s8 < 2u ? rnd[0] : s8 < 4u ? rnd[1] : s8 < 6u ? rnd[2] : rnd[3];  // s8 is wave-uniform
-    const uint32_t x = (s8 & 1u) ? w * 36u : w;
+    // s8 is wave-uniform; masks + v_bfi keep the step free of (uniform) branches, the multiplier stays scalar
+    uint32_t w = rnd[0];
+    w = bitsel(0u - (uint32_t)(s8 >= 2u), rnd[1], w);
+    w = bitsel(0u - (uint32_t)(s8 >= 4u), rnd[2], w);
+    w = bitsel(0u - (uint32_t)(s8 >= 6u), rnd[3], w);
+    const uint32_t x = w * ((s8 & 1u) ? 36u : 1u);
     a0 = __umulhi(x, 6u);
     a1 = __umulhi(x * 6u, 6u);
 }
@@ -1200,8 +1206,11 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_pair(const OcLayout* __restri
             const uint64_t blk = t >> 3;
             philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, rnd);
         }
-        const uint32_t w = s8 < 2u ? rnd[0] : s8 < 4u ? rnd[1] : s8 < 6u ? rnd[2] : rnd[3];
-        const uint32_t x = ((s8 & 1u) ? w * 36u : w) * mul_p;
+        uint32_t w = rnd[0];
+        w = bitsel(0u - (uint32_t)(s8 >= 2u), rnd[1], w);
+        w = bitsel(0u - (uint32_t)(s8 >= 4u), rnd[2], w);
+        w = bitsel(0u - (uint32_t)(s8 >= 6u), rnd[3], w);
+        const uint32_t x = w * ((s8 & 1u) ? 36u : 1u) * mul_p;
         const uint32_t a = __umulhi(x, 6u);
         float sp, sh;
         pair_step(C, L, lut, cellw, p, s, delta4, a, sp, sh);
@@ -1692,11 +1701,11 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
     const bool lds = b->n_layouts <= LDS_LAYOUT_MAX;
     const bool small = b->max_pots >= 1 && b->max_pots <= 2;
     // Lane pairs pay ~1.5x the total VALU work of one lane per env but halve the per-wavefront instruction stream:
-    // they win while one lane per env leaves SIMDs without a wavefront (measured on MI355X, us per batched step,
-    // pair vs lane: 0.90 vs 1.09 at 32 768 envs, 1.11 vs 1.10 at 65 536, 1.93 vs 1.44 at 131 072).
+    // they win while one lane per env leaves half of the SIMDs without a wavefront (measured on MI355X, us per
+    // batched step, pair vs lane: 0.81 vs 1.02 at 32 768 envs, 1.11 vs 1.03 at 40 960, 1.13 vs 1.01 at 65 536).
     const bool pair_ok = small && (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0;
     const bool want_pair = (options & OC_OPT_LANE_PAIR) ||
-                           (!(options & (OC_OPT_LANE_PER_ENV | OC_OPT_PREDICATE_INTERACT)) && b->n_envs <= 48 * simd_count());
+                           (!(options & (OC_OPT_LANE_PER_ENV | OC_OPT_PREDICATE_INTERACT)) && b->n_envs <= 32 * simd_count());
     if (pair_ok && want_pair) {
         // two lanes per env (k_rollout_pair)
         const size_t smem2 = (size_t)n_obj * 8 * PAIR_ENVS * sizeof(uint32_t);
