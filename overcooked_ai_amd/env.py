@@ -46,20 +46,19 @@ class OvercookedEnv:
         return OvercookedEnv(mdp_generator_fn=self.mdp_generator_fn, start_state_fn=self.start_state_fn,
                              horizon=self.horizon, info_level=self.info_level, num_mdp=self.num_mdp)
 
-    # ---------------------------------------------------------------- env.py:244-325
+    # ---------------------------------------------------------------- stepping (API of env.py:244-325)
     def step(self, joint_action, joint_agent_action_info=None, display_phi=False):
+        """One joint action -> (next_state, summed sparse reward, done, env_info); refuses to step a finished env."""
         assert not self.is_done()
-        if joint_agent_action_info is None:
-            joint_agent_action_info = [{}, {}]
+        agent_infos = joint_agent_action_info if joint_agent_action_info is not None else [{}, {}]
         next_state, mdp_infos = self.mdp.get_state_transition(self.state, joint_action, display_phi)
-        self._update_game_stats(mdp_infos)
+        self._update_game_stats(mdp_infos)  # events are stamped with the pre-step timestep (env.py:385)
         self.state = next_state
         done = self.is_done()
-        env_info = self._prepare_info_dict(joint_agent_action_info, mdp_infos)
+        env_info = self._prepare_info_dict(agent_infos, mdp_infos)
         if done:
             self._add_episode_info(env_info)
-        timestep_sparse_reward = sum(mdp_infos["sparse_reward_by_agent"])
-        return (next_state, timestep_sparse_reward, done, env_info)
+        return next_state, sum(mdp_infos["sparse_reward_by_agent"]), done, env_info
 
     def lossless_state_encoding_mdp(self, state):
         return self.mdp.lossless_state_encoding(state, self.horizon)
@@ -67,52 +66,47 @@ class OvercookedEnv:
     def reset(self, regen_mdp=True, outside_info={}):
         if regen_mdp:
             self.mdp = self.mdp_generator_fn(outside_info)
-        if self.start_state_fn is None:
-            self.state = self.mdp.get_standard_start_state()
-        else:
-            self.state = self.start_state_fn()
-        events_dict = {k: [[] for _ in range(self.mdp.num_players)] for k in EVENT_TYPES}
-        rewards_dict = {
-            "cumulative_sparse_rewards_by_agent": np.array([0] * self.mdp.num_players),
-            "cumulative_shaped_rewards_by_agent": np.array([0] * self.mdp.num_players),
-        }
-        self.game_stats = {**events_dict, **rewards_dict}
+        self.state = self.start_state_fn() if self.start_state_fn is not None else self.mdp.get_standard_start_state()
+        n = self.mdp.num_players
+        self.game_stats = {name: [[] for _ in range(n)] for name in EVENT_TYPES}
+        for key in ("cumulative_sparse_rewards_by_agent", "cumulative_shaped_rewards_by_agent"):
+            self.game_stats[key] = np.zeros(n, dtype=np.int64)
 
     def is_done(self):
         return self.state.timestep >= self.horizon or self.mdp.is_terminal(self.state)
 
     def _prepare_info_dict(self, joint_agent_action_info, mdp_infos):
-        env_info = {"agent_infos": [joint_agent_action_info[i] for i in range(self.mdp.num_players)]}
-        env_info["sparse_r_by_agent"] = mdp_infos["sparse_reward_by_agent"]
-        env_info["shaped_r_by_agent"] = mdp_infos["shaped_reward_by_agent"]
-        env_info["phi_s"] = mdp_infos.get("phi_s")
-        env_info["phi_s_prime"] = mdp_infos.get("phi_s_prime")
-        return env_info
+        """Per-step info: the keys of env.py:339-361."""
+        n = self.mdp.num_players
+        return {
+            "agent_infos": list(joint_agent_action_info[:n]),
+            "sparse_r_by_agent": mdp_infos["sparse_reward_by_agent"],
+            "shaped_r_by_agent": mdp_infos["shaped_reward_by_agent"],
+            "phi_s": mdp_infos.get("phi_s"),
+            "phi_s_prime": mdp_infos.get("phi_s_prime"),
+        }
 
     def _add_episode_info(self, env_info):
-        env_info["episode"] = {
-            "ep_game_stats": self.game_stats,
-            "ep_sparse_r": sum(self.game_stats["cumulative_sparse_rewards_by_agent"]),
-            "ep_shaped_r": sum(self.game_stats["cumulative_shaped_rewards_by_agent"]),
-            "ep_sparse_r_by_agent": self.game_stats["cumulative_sparse_rewards_by_agent"],
-            "ep_shaped_r_by_agent": self.game_stats["cumulative_shaped_rewards_by_agent"],
-            "ep_length": self.state.timestep,
-        }
+        """Episode summary attached to the last step's info: the keys of env.py:363-380."""
+        sparse = self.game_stats["cumulative_sparse_rewards_by_agent"]
+        shaped = self.game_stats["cumulative_shaped_rewards_by_agent"]
+        env_info["episode"] = dict(ep_game_stats=self.game_stats, ep_sparse_r=sum(sparse), ep_shaped_r=sum(shaped),
+                                   ep_sparse_r_by_agent=sparse, ep_shaped_r_by_agent=shaped,
+                                   ep_length=self.state.timestep)
         return env_info
 
     def _update_game_stats(self, infos):
-        """Events are logged at the pre-step timestep (env.py:382-401)."""
-        self.game_stats["cumulative_sparse_rewards_by_agent"] = (
-            self.game_stats["cumulative_sparse_rewards_by_agent"] + np.array(infos["sparse_reward_by_agent"]))
-        self.game_stats["cumulative_shaped_rewards_by_agent"] = (
-            self.game_stats["cumulative_shaped_rewards_by_agent"] + np.array(infos["shaped_reward_by_agent"]))
-        for event_type, bool_list_by_agent in infos["event_infos"].items():
-            for idx, occurred in enumerate(bool_list_by_agent):
-                if occurred:
-                    self.game_stats[event_type][idx].append(self.state.timestep)
+        t = self.state.timestep
+        for key, src in (("cumulative_sparse_rewards_by_agent", "sparse_reward_by_agent"),
+                         ("cumulative_shaped_rewards_by_agent", "shaped_reward_by_agent")):
+            self.game_stats[key] = self.game_stats[key] + np.asarray(infos[src])
+        for name, flags in infos["event_infos"].items():
+            for agent, happened in enumerate(flags):
+                if happened:
+                    self.game_stats[name][agent].append(t)
 
     def execute_plan(self, start_state, joint_action_plan, display=False):
-        """env.py:407-424: run a list of joint actions from start_state; returns (end_state, done)."""
+        """Run a list of joint actions from start_state; returns (end_state, done) like env.py:407-424."""
         self.state = start_state
         done = False
         for joint_action in joint_action_plan:
