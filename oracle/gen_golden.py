@@ -521,7 +521,88 @@ def gen_random_starts():
     print("random_starts", list(out))
 
 
+def _quiet(fn, *a, **k):
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def _planner_modules():
+    from overcooked_ai_py.planning import planners as P
+    # never pickle planners into /root/reference (planners.py:70-73, 126-137, 1127-1130)
+    P.MotionPlanner.save_to_file = lambda self, fn: None
+    P.MediumLevelActionManager.save_to_file = lambda self, fn: None
+    return P
+
+
+def gen_featurize():
+    """featurize_state (mdp.py:2579-2898) fixtures.
+    (1) The reference's own golden: GreedyHumanModel rollouts of overcooked_test.py:1069-1093 reproduced here with
+        np.random.seed(0); the features are asserted equal to data/testing/test_state_featurization/expected_2.pickle
+        before being stored, together with the states, actions and rewards of those 5 x 400 steps (a second,
+        delivery-rich pin for the transition itself).
+    (2) Randomized states (objects in row-major dict order) on several layouts, for counter_goals = [] (the
+        reference's default NO_COUNTERS_PARAMS) and counter_goals = all counters."""
+    import pickle
+    import types
+    P = _planner_modules()
+    from overcooked_ai_py.agents.agent import AgentPair, GreedyHumanModel
+
+    spec, mdp = make_ref_mdp("cramped_room", {})
+    activate(mdp)
+    mlam = _quiet(P.MediumLevelActionManager.from_pickle_or_compute, mdp, P.NO_COUNTERS_PARAMS, force_compute=True)
+    env = R.OvercookedEnv.from_mdp(mdp, horizon=400, info_level=0)
+    pair = AgentPair(GreedyHumanModel(mlam), GreedyHumanModel(mlam))
+    np.random.seed(0)
+    trajs = _quiet(env.get_rollouts, pair, num_games=5, info=False)
+    feats = np.array([[mdp.featurize_state(s, mlam, num_pots=2) for s in ep] for ep in trajs["ep_states"]])
+    exp = np.array(pickle.load(open(os.path.join(REF_TESTING, "test_state_featurization", "expected_2.pickle"), "rb")))
+    assert feats.shape == exp.shape == (5, 400, 2, 96) and np.array_equal(feats, exp), "reference golden pickle not reproduced"
+    n_planes = 1 + (spec.width * spec.height + 15) // 16
+    n_ep, T = 5, 400
+    packed = np.zeros((n_planes, n_ep * T, 16), np.uint8)
+    acts = np.zeros((n_ep * T, 2), np.uint8)
+    rews = np.zeros((n_ep * T,), np.float64)
+    for e in range(n_ep):
+        for t in range(T):
+            S.pack_state_dict(spec, trajs["ep_states"][e][t].to_dict(), packed, e * T + t)
+            ja = trajs["ep_actions"][e][t]
+            acts[e * T + t] = [Action.ACTION_TO_INDEX[a if isinstance(a, str) else tuple(a)] for a in ja]
+            rews[e * T + t] = trajs["ep_rewards"][e][t]
+    np.savez_compressed(os.path.join(GOLDEN, "ref_greedy_rollouts.npz"), states=packed, actions=acts, rewards=rews,
+                        features=feats.reshape(n_ep * T, 2, 96).astype(np.float32), n_episodes=np.array(n_ep), horizon=np.array(T))
+    print("greedy rollouts: reference pickle reproduced; sparse return per episode", rews.reshape(n_ep, T).sum(1))
+
+    out = {}
+    for name in ("cramped_room", "asymmetric_advantages", "forced_coordination", "counter_circuit", "mdp_test"):
+        spec, mdp = make_ref_mdp(name, {})
+        activate(mdp)
+        rng = np.random.default_rng(555)
+        for label, cg in (("none", []), ("all", mdp.get_counter_locations())):
+            mp = _quiet(P.MotionPlanner, mdp, cg)
+            fake = types.SimpleNamespace(motion_planner=mp)
+            n = 300
+            n_planes = 1 + (spec.width * spec.height + 15) // 16
+            packed = np.zeros((n_planes, n, 16), np.uint8)
+            fz = np.zeros((n, 2, 96), np.float32)
+            for e in range(n):
+                st = random_ref_state(mdp, spec, rng)
+                d = st.to_dict()
+                d["objects"] = sorted(d["objects"], key=lambda o: (o["position"][1], o["position"][0]))  # row-major dict order
+                st = R.OvercookedState.from_dict(d)
+                S.pack_state_dict(spec, d, packed, e)
+                fz[e] = np.array(mdp.featurize_state(st, fake, num_pots=2))
+            np.savez_compressed(os.path.join(GOLDEN, "featurize_%s_%s.npz" % (name, label)), states=packed, features=fz)
+            out["%s_%s" % (name, label)] = {"layout": spec.to_layout_dict(), "counter_goals": label, "n": n}
+    with open(os.path.join(GOLDEN, "featurize_manifest.json"), "w") as f:
+        json.dump(out, f)
+    print("featurize fixtures", list(out))
+
+
 def main():
+    if "--featurize-only" in sys.argv:
+        gen_featurize()
+        return
     if "--random-starts-only" in sys.argv:
         gen_random_starts()
         return
@@ -553,6 +634,7 @@ def main():
     gen_layout_luts()
     gen_env_episodes()
     gen_random_starts()
+    gen_featurize()
     with open(os.path.join(GOLDEN, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
     print("done")

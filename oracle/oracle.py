@@ -240,6 +240,26 @@ class Oracle:
         return obs
 
 
+def featurize(orc, state, counter_goals="none", num_pots=2, layout_id=None):
+    """featurize_state of every env: float32 [n_envs, 2, 2*(num_pots*10+26)+4]. counter_goals: "none" (the reference's
+    NO_COUNTERS_PARAMS) or "all" (every counter is a motion goal)."""
+    n = state.shape[1]
+    lid = orc._lid(layout_id, n)
+    mask = None
+    if counter_goals == "all":
+        mask = np.zeros((orc.n, MAX_CELLS), dtype=np.int32)
+        for l in range(orc.n):
+            t = orc.arr[l].terrain
+            for c in range(orc.arr[l].width * orc.arr[l].height):
+                mask[l, c] = 1 if t[c:c + 1] == b"X" else 0
+    out = np.zeros((n, 2, 2 * (num_pots * 10 + 26) + 4), dtype=np.float32)
+    rc = lib().oracle_featurize(orc.arr, orc.n, _ptr(lid, ctypes.c_uint16), _ptr(mask, ctypes.c_int32),
+                                _ptr(np.ascontiguousarray(state), ctypes.c_uint8), _ptr(out, ctypes.c_float),
+                                ctypes.c_int64(n), int(num_pots))
+    assert rc == 0
+    return out
+
+
 def random_actions(seed, env_offset, t, n_envs):
     a = np.zeros((n_envs, 2), dtype=np.uint8)
     lib().oracle_random_actions(ctypes.c_uint64(seed), ctypes.c_int64(env_offset), ctypes.c_int64(t),

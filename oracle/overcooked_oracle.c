@@ -750,3 +750,215 @@ int oracle_encode_lossless(const OracleMdp* mdps, int n_mdps, const uint16_t* la
 }
 
 size_t oracle_mdp_size(void) { return sizeof(OracleMdp); }
+
+/* ====================================================================================================
+ * featurize_state (mdp.py:2579-2898) with the MotionPlanner distances it needs
+ * (planning/planners.py:46-450, planning/search.py:167-310).
+ * ==================================================================================================== */
+
+typedef struct Planner {
+    int n_floor;
+    int floor_cell[MAX_CELLS]; /* get_valid_player_positions(): free cells, row-major (mdp.py:1733-1734) */
+    int floor_idx[MAX_CELLS];  /* cell -> index in floor_cell or -1 */
+    int region[MAX_CELLS];     /* connected component of the free cell (Graph.are_in_same_cc, search.py:294-310) */
+    int n_states;              /* (pos, orientation) states, planners.py:315-340 */
+    int* dist;                 /* [n_states][n_states] shortest path lengths, -1 unreachable (search.py:205-213) */
+    int counter_goal[MAX_CELLS]; /* MotionPlanner.counter_goals as a cell mask */
+} Planner;
+
+/* _move_if_direction (mdp.py:1718-1727) on (cell, orientation) states for a motion action 0..3 */
+static int planner_successor(const OracleMdp* m, const Planner* pl, int state, int a) {
+    int c = pl->floor_cell[state / 4];
+    int x = c % m->width + DIR_DX[a], y = c / m->width + DIR_DY[a];
+    int nc = y * m->width + x;
+    if (m->terrain[nc] != ' ') return (state / 4) * 4 + a; /* blocked: turn in place */
+    return pl->floor_idx[nc] * 4 + a;
+}
+
+static void planner_build(const OracleMdp* m, const int* counter_goal_mask, Planner* pl) {
+    int ncells = m->width * m->height;
+    pl->n_floor = 0;
+    for (int c = 0; c < ncells; ++c) {
+        pl->floor_idx[c] = -1;
+        pl->region[c] = -1;
+        pl->counter_goal[c] = counter_goal_mask ? counter_goal_mask[c] : 0;
+        if (m->terrain[c] == ' ') { pl->floor_idx[c] = pl->n_floor; pl->floor_cell[pl->n_floor++] = c; }
+    }
+    /* connected components of the free region */
+    int n_regions = 0, stack[MAX_CELLS];
+    for (int i = 0; i < pl->n_floor; ++i) {
+        int c0 = pl->floor_cell[i];
+        if (pl->region[c0] >= 0) continue;
+        int sp = 0;
+        stack[sp++] = c0;
+        pl->region[c0] = n_regions;
+        while (sp) {
+            int c = stack[--sp];
+            for (int d = 0; d < 4; ++d) {
+                int nc = (c / m->width + DIR_DY[d]) * m->width + c % m->width + DIR_DX[d];
+                if (m->terrain[nc] == ' ' && pl->region[nc] < 0) { pl->region[nc] = n_regions; stack[sp++] = nc; }
+            }
+        }
+        ++n_regions;
+    }
+    /* all-pairs BFS over (pos, orientation) states with unit action costs (planners.py:342-358) */
+    pl->n_states = pl->n_floor * 4;
+    int ns = pl->n_states;
+    pl->dist = (int*)malloc(sizeof(int) * (size_t)ns * ns);
+    int* queue = (int*)malloc(sizeof(int) * (size_t)ns);
+    for (int s0 = 0; s0 < ns; ++s0) {
+        int* d = pl->dist + (size_t)s0 * ns;
+        for (int i = 0; i < ns; ++i) d[i] = -1;
+        int qh = 0, qt = 0;
+        d[s0] = 0;
+        queue[qt++] = s0;
+        while (qh < qt) {
+            int s = queue[qh++];
+            for (int a = 0; a < 4; ++a) {
+                int t = planner_successor(m, pl, s, a);
+                if (d[t] < 0) { d[t] = d[s] + 1; queue[qt++] = t; }
+            }
+        }
+    }
+    free(queue);
+}
+
+/* is_valid_motion_goal (planners.py:211-230) for the goal "stand on `adj`, face feature cell `f`" */
+static int valid_goal_feature(const OracleMdp* m, const Planner* pl, int f) {
+    char t = m->terrain[f];
+    if (t == ' ') return 0;
+    if (t == 'X' && !pl->counter_goal[f]) return 0;
+    return 1;
+}
+
+/* min_cost_to_feature(..., with_argmin=True) (planners.py:391-423): returns the best feature cell or -1 */
+static int min_cost_to_feature(const OracleMdp* m, const Planner* pl, int start_cell, int start_or, const int* features,
+                               int n_features, int* min_cost_out) {
+    int start = pl->floor_idx[start_cell] * 4 + start_or;
+    int min_dist = -1, best = -1;
+    for (int i = 0; i < n_features; ++i) {
+        int f = features[i];
+        int fx = f % m->width, fy = f / m->width;
+        for (int d = 0; d < 4; ++d) { /* _get_possible_motion_goals_for_feature, planners.py:439-450 */
+            int ax = fx + DIR_DX[d], ay = fy + DIR_DY[d];
+            if (ax < 0 || ay < 0 || ax >= m->width || ay >= m->height) continue;
+            int adj = ay * m->width + ax;
+            if (m->terrain[adj] != ' ') continue;
+            static const int OPP[4] = {1, 0, 3, 2}; /* OPPOSITE_DIRECTIONS, actions.py:17 */
+            int goal = pl->floor_idx[adj] * 4 + OPP[d];
+            if (!valid_goal_feature(m, pl, f)) continue;
+            if (pl->region[adj] != pl->region[start_cell]) continue; /* positions_are_connected */
+            int cur = pl->dist[(size_t)start * pl->n_states + goal];
+            if (cur < 0) continue;
+            if (min_dist < 0 || cur < min_dist) { best = f; min_dist = cur; }
+        }
+    }
+    if (min_cost_out) *min_cost_out = min_dist + 1;
+    return best;
+}
+
+/* one player's block of featurize_state: appends to `out`, returns the number of values written */
+static int featurize_player(const OracleMdp* m, const Planner* pl, const State* st, int i, int num_pots, float* out) {
+    const Player* p = &st->players[i];
+    int ncells = m->width * m->height, k = 0;
+    int pcell = p->y * m->width + p->x;
+    /* orientation one-hot, held object one-hot over IDX_TO_OBJ = [onion, soup, dish, tomato] (mdp.py:2739-2765) */
+    for (int d = 0; d < 4; ++d) out[k++] = (p->o == d) ? 1.f : 0.f;
+    static const int OBJ_SLOT[5] = {-1, 0, 3, 2, 1};
+    for (int j = 0; j < 4; ++j) out[k++] = (p->held.name != NAME_NONE && OBJ_SLOT[p->held.name] == j) ? 1.f : 0.f;
+    /* closest onion / tomato / dish / soup / serving / empty counter (make_closest_feature, mdp.py:2622-2655) */
+    static const char DISP[3] = {'O', 'T', 'D'};
+    static const int NAMES[3] = {NAME_ONION, NAME_TOMATO, NAME_DISH};
+    int feats[MAX_CELLS];
+    for (int q = 0; q < 6; ++q) {
+        int nf = 0, held_match = 0;
+        if (q < 3) {
+            for (int c = 0; c < ncells; ++c) if (m->terrain[c] == DISP[q]) feats[nf++] = c;           /* dispensers first */
+            for (int c = 0; c < ncells; ++c)
+                if (m->terrain[c] == 'X' && st->objects[c].name == NAMES[q]) feats[nf++] = c;          /* then counters */
+            held_match = p->held.name == NAMES[q];
+        } else if (q == 3) {
+            for (int c = 0; c < ncells; ++c) if (m->terrain[c] == 'X' && st->objects[c].name == NAME_SOUP) feats[nf++] = c;
+            held_match = p->held.name == NAME_SOUP;
+        } else if (q == 4) {
+            for (int c = 0; c < ncells; ++c) if (m->terrain[c] == 'S') feats[nf++] = c;
+        } else {
+            for (int c = 0; c < ncells; ++c) if (m->terrain[c] == 'X' && st->objects[c].name == NAME_NONE) feats[nf++] = c;
+        }
+        const Obj* obj = 0;
+        float dx = 0.f, dy = 0.f;
+        if (held_match) obj = &p->held;
+        else {
+            int loc = min_cost_to_feature(m, pl, pcell, p->o, feats, nf, 0);
+            if (loc >= 0) {
+                dx = (float)(loc % m->width - p->x);  /* pos_distance(location, player.position), utils.py:95 */
+                dy = (float)(loc / m->width - p->y);
+                if (st->objects[loc].name != NAME_NONE) obj = &st->objects[loc];
+            }
+        }
+        out[k++] = dx; out[k++] = dy;
+        if (q == 3) {
+            int n_o = 0, n_t = 0;
+            if (obj) count_ing(obj, &n_o, &n_t);
+            out[k++] = (float)n_o; out[k++] = (float)n_t;
+        }
+    }
+    /* the num_pots closest pots (mdp.py:2818-2829, make_pot_feature 2657-2731) */
+    int pots[MAX_CELLS], np_ = 0;
+    for (int c = 0; c < ncells; ++c) if (m->terrain[c] == 'P') pots[np_++] = c;
+    for (int j = 0; j < num_pots; ++j) {
+        int loc = min_cost_to_feature(m, pl, pcell, p->o, pots, np_, 0);
+        if (loc < 0) { for (int z = 0; z < 10; ++z) out[k++] = 0.f; continue; }
+        const Obj* soup = &st->objects[loc];
+        int is_empty = soup->name == NAME_NONE;
+        int is_ready = !is_empty && soup_is_ready(m, soup), is_cooking = !is_empty && soup_is_cooking(m, soup);
+        int is_full = is_cooking || is_ready || (!is_empty && soup->n_ing == m->max_num_ingredients);
+        int n_o = 0, n_t = 0;
+        double remaining = 0;
+        if (!is_empty) {
+            count_ing(soup, &n_o, &n_t);
+            if (!soup_is_idle(soup)) { remaining = soup_cook_time(m, soup) - soup->tick; if (remaining < 0) remaining = 0; }
+        }
+        out[k++] = 1.f; out[k++] = (float)is_empty; out[k++] = (float)is_full; out[k++] = (float)is_cooking;
+        out[k++] = (float)is_ready; out[k++] = (float)n_o; out[k++] = (float)n_t; out[k++] = (float)remaining;
+        out[k++] = (float)(loc % m->width - p->x); out[k++] = (float)(loc / m->width - p->y);
+        int w = 0;
+        for (int z = 0; z < np_; ++z) if (pots[z] != loc) pots[w++] = pots[z]; /* pot_locations.remove(closest) */
+        np_ = w;
+    }
+    /* walls in the four directions (mdp.py:2831-2838) */
+    for (int d = 0; d < 4; ++d) out[k++] = terrain_at(m, p->x + DIR_DX[d], p->y + DIR_DY[d]) == ' ' ? 0.f : 1.f;
+    return k;
+}
+
+/* features: [n_envs][2][2*(num_pots*10 + 26) + 4] floats; counter_goal_mask: [n_mdps][MAX_CELLS] ints or NULL (none) */
+int oracle_featurize(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, const int32_t* counter_goal_mask,
+                     const uint8_t* state, float* features, int64_t n_envs, int num_pots) {
+    Planner* pls = (Planner*)calloc((size_t)n_mdps, sizeof(Planner));
+    for (int l = 0; l < n_mdps; ++l) {
+        int mask[MAX_CELLS];
+        for (int c = 0; c < MAX_CELLS; ++c) mask[c] = counter_goal_mask ? counter_goal_mask[l * MAX_CELLS + c] : 0;
+        planner_build(&mdps[l], mask, &pls[l]);
+    }
+    int per = num_pots * 10 + 26, total = 2 * per + 4;
+    for (int64_t e = 0; e < n_envs; ++e) {
+        int l = layout_id ? layout_id[e] : 0;
+        const OracleMdp* m = &mdps[l];
+        State s;
+        unpack_state(m, state, n_envs, e, &s);
+        float blocks[2][256];
+        for (int i = 0; i < 2; ++i) featurize_player(m, &pls[l], &s, i, num_pots, blocks[i]);
+        for (int i = 0; i < 2; ++i) { /* [own, other, other - own position, own position] (mdp.py:2849-2896) */
+            float* o = features + ((size_t)e * 2 + i) * total;
+            memcpy(o, blocks[i], per * sizeof(float));
+            memcpy(o + per, blocks[1 - i], per * sizeof(float));
+            o[2 * per + 0] = (float)(s.players[1 - i].x - s.players[i].x);
+            o[2 * per + 1] = (float)(s.players[1 - i].y - s.players[i].y);
+            o[2 * per + 2] = (float)s.players[i].x;
+            o[2 * per + 3] = (float)s.players[i].y;
+        }
+    }
+    for (int l = 0; l < n_mdps; ++l) free(pls[l].dist);
+    free(pls);
+    return 0;
+}
