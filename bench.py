@@ -329,6 +329,21 @@ def bench_encode(dev, torch, VecOvercookedEnv, iters=200):
         res[name] = {"launch_ms": ms, "bytes_per_launch": b, "achieved_GBs": b / (ms * 1e-3) / 1e9,
                      "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "env_encodes_per_s": n / (ms * 1e-3)}
     res["note"] = "k_encode on asymmetric_advantages x 65536; SURVEY 8d: 2384 B (u8) / 9404 B (f32) per env"
+    # featurize_state (mdp.py:2579): 2 x 96 float32 per env
+    feat = torch.empty((n, 2, 96), dtype=torch.float32, device=dev)
+    for _ in range(5):
+        env.featurize(out=feat)
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(iters):
+        env.featurize(out=feat)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    ms = ev0.elapsed_time(ev1) / iters
+    fb = n * (S_ASYM + 2 * 96 * 4)
+    res["featurize_state"] = {"launch_ms": ms, "bytes_per_launch": fb, "achieved_GBs": fb / (ms * 1e-3) / 1e9,
+                              "frac": fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "env_featurizations_per_s": n / (ms * 1e-3)}
     return res
 
 

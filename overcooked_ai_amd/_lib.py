@@ -17,7 +17,7 @@ OBS_U8, OBS_F32 = 0, 1
 
 EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_step", "oc_step_many",
            "oc_rollout_random",
-           "oc_encode_lossless", "oc_reset")
+           "oc_encode_lossless", "oc_featurize", "oc_reset")
 
 
 class OcBatch(ctypes.Structure):
@@ -72,6 +72,8 @@ def load():
     L.oc_rollout_random.argtypes = [bp, vp, vp, vp, vp, i32, u32, u64, i64, i64, i32, vp]
     L.oc_encode_lossless.restype = i32
     L.oc_encode_lossless.argtypes = [bp, vp, vp, i32, i32, vp]
+    L.oc_featurize.restype = i32
+    L.oc_featurize.argtypes = [bp, vp, vp, vp, vp, i32, vp]
     L.oc_reset.restype = i32
     L.oc_reset.argtypes = [bp, vp, vp, vp, vp]
     if L.oc_abi_version() != ABI_VERSION:

@@ -769,7 +769,7 @@ __device__ __forceinline__ void step3_main(const LayC& C, const Lay L, const uin
     // shaped rewards; is_dish_pickup_useful (mdp.py:2180-2204) sees the live hands / counters and the stale pots
     const bool du0 = two & (((s.held1 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (s.dcount == 0);
     const float sh0 = ((r0.flags & LF_PLACE) ? C.rew_place : 0.f) + ((r0.flags & LF_PLATE) ? C.rew_soup : 0.f) +
-                      (((r0.flags & LF_TAKE_DISH) != 0u) & du0 ? C.rew_dish : 0.f);
+                      ((((r0.flags & LF_TAKE_DISH) != 0u) & du0) ? C.rew_dish : 0.f);
     s.held0 = r0.new_h;
     s.dcount += r0.ddelta;
     apply_pot3<MAXP>(s, r0);
@@ -781,7 +781,7 @@ __device__ __forceinline__ void step3_main(const LayC& C, const Lay L, const uin
     if (__builtin_expect(conflict, 0)) r1 = interact3<MAXP>(L, s_lut, act1, s.held1, c_f1_live, s.ps, s.tk, s.pc);
     const bool du1 = two & (((s.held0 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (s.dcount == 0);
     const float sh1 = ((r1.flags & LF_PLACE) ? C.rew_place : 0.f) + ((r1.flags & LF_PLATE) ? C.rew_soup : 0.f) +
-                      (((r1.flags & LF_TAKE_DISH) != 0u) & du1 ? C.rew_dish : 0.f);
+                      ((((r1.flags & LF_TAKE_DISH) != 0u) & du1) ? C.rew_dish : 0.f);
     s.held1 = r1.new_h;
     s.dcount += r1.ddelta;
     apply_pot3<MAXP>(s, r1);
@@ -1552,6 +1552,145 @@ __global__ __launch_bounds__(BLOCK) void k_encode_uniform(const OcLayout* __rest
 }
 
 // ------------------------------------------------------------------------------------------
+// k_featurize: featurize_state (mdp.py:2579-2898), the hand-crafted feature vector used by the behaviour-cloning
+// agents.  Two lanes per env (lane parity = player).  Each lane walks the grid once; for every feature cell it
+// reads COST[state][cell] (fewest actions from the player's (cell, orientation) to a goal of that feature,
+// precomputed on the host from the reference's MotionPlanner semantics, overcooked_ai_amd/planner.py) and keeps the
+// arg-min per category.  min_cost_to_feature (planners.py:391-423) breaks ties by list order — dispensers before
+// counter objects, row-major inside each group — which is the lexicographic minimum of (cost, group, cell).
+// The 2 x (2*(num_pots*10+26)+4) floats of an env are assembled in an LDS image and streamed out coalesced.
+// ------------------------------------------------------------------------------------------
+constexpr int FEAT_ENVS = BLOCK / 2;
+
+__device__ __forceinline__ uint32_t feat_key(uint32_t cost, uint32_t group, uint32_t cell) {
+    return (cost << 9) | (group << 8) | cell;  // cost < 255, cell < 128
+}
+
+template <bool LAY_LDS>
+__global__ __launch_bounds__(BLOCK) void k_featurize(const OcLayout* __restrict__ g_layouts, int n_layouts,
+                                                     const uint16_t* __restrict__ layout_id,
+                                                     const uint8_t* __restrict__ plan_blob,
+                                                     const uint32_t* __restrict__ plan_off,
+                                                     const uint4* __restrict__ st, float* __restrict__ out, int64_t n,
+                                                     int W, int H, int n_planes, int num_pots) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint4 s_lay[LAY_LDS ? LDS_LAYOUT_MAX * 16 : 1];
+    const int per = num_pots * 10 + 26, total = 2 * per + 4;  // floats per player block / per (env, player) row
+    uint4* s_state = reinterpret_cast<uint4*>(smem);           // [FEAT_ENVS][n_planes]
+    float* s_img = reinterpret_cast<float*>(smem + (size_t)FEAT_ENVS * n_planes * 16);  // [FEAT_ENVS][2][total]
+    const uint32_t p = threadIdx.x & 1u, el = threadIdx.x >> 1;
+    const int64_t e0 = (int64_t)blockIdx.x * FEAT_ENVS;
+    const int ne = (int)min((int64_t)FEAT_ENVS, n - e0);
+    const int64_t e = e0 + el;
+    const bool active = (int)el < ne;
+    for (int i = threadIdx.x; i < ne * n_planes; i += BLOCK)
+        s_state[(i % ne) * n_planes + (i / ne)] = st[(int64_t)(i / ne) * n + e0 + (i % ne)];
+    const Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains the barrier
+    if (active) {
+        const uint8_t* se = reinterpret_cast<const uint8_t*>(s_state + el * n_planes);
+        const uint32_t lid = layout_id ? layout_id[e] : 0u;
+        const uint8_t* plan = plan_blob + plan_off[lid];
+        const uint32_t pos = se[3 * p], ori = se[3 * p + 1], held = se[3 * p + 2];
+        const uint32_t opos = se[3 * (1 - p)];
+        const uint32_t cells = (uint32_t)(W * H);
+        const uint32_t inv_w = 65536u / (uint32_t)W + 1u;
+        const uint32_t py = (pos * inv_w) >> 16, px = pos - py * (uint32_t)W;
+        const uint8_t* cost_row = plan + 128 + ((uint32_t)plan[pos] * 4u + ori) * cells;
+        // arg-min keys: 0 onion, 1 tomato, 2 dish, 3 counter soup, 4 serving, 5 empty counter; two best pots
+        uint32_t best[6] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
+        uint32_t pot1 = ~0u, pot2 = ~0u, pot3 = ~0u, pot4 = ~0u;
+        for (uint32_t c = 0; c < cells; ++c) {
+            const uint32_t type = L.terrain(c) & 7u;
+            if (type == OC_T_FLOOR) continue;
+            const uint32_t cost = cost_row[c];
+            if (cost == 255u) continue;
+            const uint32_t o = se[16 + c];
+            if (type == OC_T_ONION_DISP) best[0] = min(best[0], feat_key(cost, 0, c));
+            else if (type == OC_T_TOMATO_DISP) best[1] = min(best[1], feat_key(cost, 0, c));
+            else if (type == OC_T_DISH_DISP) best[2] = min(best[2], feat_key(cost, 0, c));
+            else if (type == OC_T_SERVE) best[4] = min(best[4], feat_key(cost, 0, c));
+            else if (type == OC_T_POT) {
+                const uint32_t k = feat_key(cost, 0, c);  // keep the four smallest keys in order
+                if (k < pot1) { pot4 = pot3; pot3 = pot2; pot2 = pot1; pot1 = k; }
+                else if (k < pot2) { pot4 = pot3; pot3 = pot2; pot2 = k; }
+                else if (k < pot3) { pot4 = pot3; pot3 = k; }
+                else if (k < pot4) pot4 = k;
+            } else {  // counter
+                if (o == 0u) best[5] = min(best[5], feat_key(cost, 0, c));
+                else if (o == OC_O_ONION) best[0] = min(best[0], feat_key(cost, 1, c));
+                else if (o == OC_O_TOMATO) best[1] = min(best[1], feat_key(cost, 1, c));
+                else if (o == OC_O_DISH) best[2] = min(best[2], feat_key(cost, 1, c));
+                else best[3] = min(best[3], feat_key(cost, 0, c));
+            }
+        }
+        float* own = s_img + ((size_t)el * 2 + p) * total;              // this player's row: own block first
+        float* oth = s_img + ((size_t)el * 2 + (1 - p)) * total + per;  // the other row carries it second
+        int k = 0;
+        auto put = [&](float v) { own[k] = v; oth[k] = v; ++k; };
+        for (uint32_t d = 0; d < 4; ++d) put(ori == d ? 1.f : 0.f);
+        // IDX_TO_OBJ = [onion, soup, dish, tomato] (mdp.py:2733)
+        put(held == OC_O_ONION ? 1.f : 0.f); put((held & OC_O_SOUP) ? 1.f : 0.f);
+        put(held == OC_O_DISH ? 1.f : 0.f); put(held == OC_O_TOMATO ? 1.f : 0.f);
+        const bool held_is[6] = {held == OC_O_ONION, held == OC_O_TOMATO, held == OC_O_DISH, (held & OC_O_SOUP) != 0u,
+                                 false, false};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            float dx = 0.f, dy = 0.f;
+            uint32_t soup = 0;
+            if (held_is[q]) { soup = held; }  // a held object of this kind: deltas (0, 0) (mdp.py:2629-2632)
+            else if (best[q] != ~0u) {
+                const uint32_t c = best[q] & 0x7Fu;
+                const uint32_t cy = (c * inv_w) >> 16, cx = c - cy * (uint32_t)W;
+                dx = (float)((int)cx - (int)px); dy = (float)((int)cy - (int)py);
+                soup = se[16 + c];
+            }
+            put(dx); put(dy);
+            if (q == 3) {  // ingredient counts of the closest (or held) soup
+                const uint32_t nn = (soup & OC_O_SOUP) ? ((soup >> 3) & 3u) : 0u;
+                const uint32_t nt = (soup & OC_O_SOUP) ? __popc(soup & 7u) : 0u;
+                put((float)(nn - nt)); put((float)nt);
+            }
+        }
+        const uint32_t potk[4] = {pot1, pot2, pot3, pot4};
+        for (int j = 0; j < num_pots; ++j) {
+            const uint32_t key = j < 4 ? potk[j] : ~0u;
+            if (key == ~0u) { for (int z = 0; z < 10; ++z) put(0.f); continue; }
+            const uint32_t c = key & 0x7Fu;
+            const uint32_t cy = (c * inv_w) >> 16, cx = c - cy * (uint32_t)W;
+            const uint32_t o = se[16 + c], tk = se[8 + (L.terrain(c) >> 3)];
+            const uint32_t nn = (o >> 3) & 3u, nt = __popc(o & 7u);
+            const uint32_t ct = L.cook_time((nn - nt) + 4u * nt);
+            const bool empty = o == 0u, idle = tk == 0u;
+            const bool ready = !empty && !idle && (tk - 1u) >= ct, cooking = !empty && !idle && !ready;
+            const bool full = cooking || ready || (!empty && nn == 3u);
+            const uint32_t remaining = (empty || idle || ready) ? 0u : ct - (tk - 1u);
+            put(1.f); put(empty ? 1.f : 0.f); put(full ? 1.f : 0.f); put(cooking ? 1.f : 0.f); put(ready ? 1.f : 0.f);
+            put(empty ? 0.f : (float)(nn - nt)); put(empty ? 0.f : (float)nt); put((float)remaining);
+            put((float)((int)cx - (int)px)); put((float)((int)cy - (int)py));
+        }
+        for (uint32_t d = 0; d < 4; ++d) {  // walls (mdp.py:2831-2838)
+            const uint32_t c = pos + (uint32_t)(d == 0 ? -W : d == 1 ? W : d == 2 ? 1 : -1);
+            put((L.terrain(c) & 7u) == OC_T_FLOOR ? 0.f : 1.f);
+        }
+        const uint32_t oy = (opos * inv_w) >> 16, ox = opos - oy * (uint32_t)W;
+        float* row = s_img + ((size_t)el * 2 + p) * total;
+        row[2 * per + 0] = (float)((int)ox - (int)px);  // other player's position relative to this one
+        row[2 * per + 1] = (float)((int)oy - (int)py);
+        row[2 * per + 2] = (float)px;
+        row[2 * per + 3] = (float)py;
+    }
+    __syncthreads();
+    const size_t n_f = (size_t)ne * 2 * total;  // floats of this block; rows are contiguous in the output
+    float* gdst = out + (size_t)e0 * 2 * total;
+    if ((((size_t)e0 * 2 * total) & 3u) == 0 && (n_f & 3u) == 0) {
+        for (size_t i = threadIdx.x; i < n_f / 4; i += BLOCK)
+            reinterpret_cast<float4*>(gdst)[i] = reinterpret_cast<const float4*>(s_img)[i];
+    } else {
+        for (size_t i = threadIdx.x; i < n_f; i += BLOCK) gdst[i] = s_img[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 int fail(int code, const char* msg) {
@@ -1754,6 +1893,32 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
     else { if (small) GO(false, 2, false); else GO(false, 8, false); }
 #undef GO
     return check_launch("oc_rollout_random");
+}
+
+int oc_featurize(const OcBatch* b, const uint8_t* d_plan_blob, const uint32_t* d_plan_off, const void* d_state,
+                 float* d_features, int num_pots, void* stream) {
+    int n_obj = 0;
+    if (int rc = check_batch(b, &n_obj)) return rc;
+    if (!d_plan_blob || !d_plan_off || !d_state || !d_features) return fail(OC_EINVAL, "oc_featurize: NULL pointer");
+    if (num_pots < 0 || num_pots > 4) return fail(OC_EINVAL, "oc_featurize: num_pots must be in 0..4");
+    if (!(b->batch_flags & OC_BATCH_TWO_PLAYERS)) return fail(OC_EINVAL, "oc_featurize: needs 2-player layouts");
+    if (((uintptr_t)d_features & 15u) != 0) return fail(OC_EINVAL, "oc_featurize: d_features must be 16-byte aligned");
+    if (b->n_envs == 0) return OC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int n_planes = 1 + n_obj;
+    const int total = 2 * (num_pots * 10 + 26) + 4;
+    const size_t smem = (size_t)FEAT_ENVS * n_planes * 16 + (size_t)FEAT_ENVS * 2 * total * sizeof(float);
+    const dim3 grid((unsigned)((b->n_envs + FEAT_ENVS - 1) / FEAT_ENVS)), block(BLOCK);
+    if (b->n_layouts <= LDS_LAYOUT_MAX) {
+        (void)hipFuncSetAttribute((const void*)k_featurize<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((k_featurize<true>), grid, block, smem, s, b->d_layouts, b->n_layouts, b->d_layout_id, d_plan_blob,
+                           d_plan_off, (const uint4*)d_state, d_features, b->n_envs, b->width, b->height, n_planes, num_pots);
+    } else {
+        (void)hipFuncSetAttribute((const void*)k_featurize<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((k_featurize<false>), grid, block, smem, s, b->d_layouts, b->n_layouts, b->d_layout_id, d_plan_blob,
+                           d_plan_off, (const uint4*)d_state, d_features, b->n_envs, b->width, b->height, n_planes, num_pots);
+    }
+    return check_launch("oc_featurize");
 }
 
 int oc_reset(const OcBatch* b, void* d_state, const uint8_t* d_mask, float* d_ep_returns, void* stream) {

@@ -63,6 +63,11 @@ class OvercookedEnv:
     def lossless_state_encoding_mdp(self, state):
         return self.mdp.lossless_state_encoding(state, self.horizon)
 
+    def featurize_state_mdp(self, state, num_pots=2):
+        """env.py:282-286; the reference passes env.mlam built from mlam_params (default: no counter goals)."""
+        cg = (self.mlam_params or {}).get("counter_goals") or "none"
+        return self.mdp.featurize_state(state, None, num_pots=num_pots, counter_goals=cg)
+
     def reset(self, regen_mdp=True, outside_info={}):
         if regen_mdp:
             self.mdp = self.mdp_generator_fn(outside_info)

@@ -260,6 +260,26 @@ class OvercookedGridworld:
         enc = self.lossless_state_encodings([overcooked_state], horizon)
         return tuple(enc[0, i] for i in range(2))
 
+    def get_featurize_state_shape(self, num_pots=2):
+        return (self.num_players * (num_pots * 10 + 28),)
+
+    def featurize_states(self, states, num_pots=2, counter_goals="none"):
+        """Batched featurize_state: float32 [n, 2, 2*(num_pots*10+26)+4]."""
+        assert self.num_players == 2
+        env = self._env(len(states))
+        env.set_packed_state(pack_states(self.spec, states))
+        return env.featurize(num_pots=num_pots, counter_goals=counter_goals).cpu().numpy()
+
+    def featurize_state(self, overcooked_state, mlam=None, num_pots=2, **kwargs):
+        """Hand-crafted features of both players (mdp.py:2579-2898) -> [features_p0, features_p1].  `mlam` is only
+        consulted for its motion planner's counter_goals (the reference's default NO_COUNTERS_PARAMS has none)."""
+        counter_goals = kwargs.get("counter_goals", "none")
+        mp = getattr(mlam, "motion_planner", None)
+        if mp is not None and getattr(mp, "counter_goals", None):
+            counter_goals = list(mp.counter_goals)
+        f = self.featurize_states([overcooked_state], num_pots, counter_goals)[0].astype(np.float64)
+        return [f[0], f[1]]
+
     # ---------------------------------------------------------------- layout info (mdp.py:1733-1807)
     def get_valid_player_positions(self):
         return self.terrain_pos_dict[" "]

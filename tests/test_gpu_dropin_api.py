@@ -112,3 +112,25 @@ def test_batched_transitions_and_gym_wrapper():
         ob_main = base_env.lossless_state_encoding_mdp(obs["overcooked_state"])[env.agent_idx]
         assert np.array_equal(obs["both_agent_obs"][0], ob_main)
     assert n == 20 and info["episode"]["ep_length"] == 20 and info["episode"]["policy_agent_idx"] == env.agent_idx
+
+
+def test_featurize_state_api_matches_reference_golden():
+    """OvercookedEnv.featurize_state_mdp (env.py:282) on states of the reference's own featurization test."""
+    from overcooked_ai_amd import OvercookedEnv, OvercookedGridworld
+    from overcooked_ai_amd import state as S
+
+    with open(os.path.join(GOLDEN, "featurize_manifest.json")) as f:
+        man = json.load(f)
+    from overcooked_ai_amd.layouts import LayoutSpec
+
+    spec = LayoutSpec(man["cramped_room_none"]["layout"])
+    mdp = OvercookedGridworld.from_spec(spec)
+    env = OvercookedEnv.from_mdp(mdp, horizon=400, info_level=0)
+    d = np.load(os.path.join(GOLDEN, "ref_greedy_rollouts.npz"))
+    assert mdp.get_featurize_state_shape() == (96,)
+    for e in (0, 57, 203, 399, 1500, 1999):
+        state = S.unpack_states(spec, d["states"][:, e:e + 1])[0]
+        f0, f1 = env.featurize_state_mdp(state)
+        assert f0.shape == (96,) and np.array_equal(f0, d["features"][e, 0]) and np.array_equal(f1, d["features"][e, 1])
+    batch = mdp.featurize_states(S.unpack_states(spec, d["states"][:, :64]))
+    assert np.array_equal(batch, d["features"][:64])

@@ -457,3 +457,56 @@ def test_many_pots_layout_vs_oracle(gpu):
     env2.rollout_random(70)
     orc2.rollout_random(st2, 70, horizon=400, options=1, seed=4, layout_id=lid, want_outputs=False)
     assert np.array_equal(env2.get_packed_state(), st2)
+
+
+def test_featurize_state_golden_and_oracle(gpu):
+    """featurize_state (mdp.py:2579): reference fixtures (incl. the states behind the reference's own golden
+    expected_2.pickle) and, on every 2-player layout, the oracle — for both counter_goals settings."""
+    import json
+
+    from oracle import oracle as O
+    from overcooked_ai_amd.layouts import LayoutSpec, LayoutTable, layout_names, spec_from_name
+
+    with open(os.path.join(GOLDEN, "featurize_manifest.json")) as f:
+        man = json.load(f)
+    for key, cfg in man.items():
+        spec = LayoutSpec(cfg["layout"])
+        d = np.load(os.path.join(GOLDEN, "featurize_%s.npz" % key))
+        env = make_env(spec, d["states"].shape[1], gpu)
+        env.set_packed_state(d["states"])
+        got = u8(env.featurize(num_pots=2, counter_goals=cfg["counter_goals"]))
+        assert got.shape == d["features"].shape and np.array_equal(got, d["features"]), key
+    d = np.load(os.path.join(GOLDEN, "ref_greedy_rollouts.npz"))
+    env = make_env(LayoutSpec(man["cramped_room_none"]["layout"]), d["states"].shape[1], gpu)
+    env.set_packed_state(d["states"])
+    assert np.array_equal(u8(env.featurize()), d["features"])  # == the reference's expected_2.pickle
+    # symmetry (overcooked_test.py:1094-1110): swapping the players swaps the two feature rows
+    sw = env.state.clone()
+    sw[0, :, 0:3], sw[0, :, 3:6] = env.state[0, :, 3:6], env.state[0, :, 0:3]
+    a, b = env.featurize(), env.featurize(state=sw)
+    assert torch.equal(a[:, 0], b[:, 1]) and torch.equal(a[:, 1], b[:, 0])
+    rng = np.random.default_rng(99)
+    for name in layout_names():
+        spec = spec_from_name(name)
+        if spec.num_players != 2:
+            continue
+        orc = oracle_for(spec)
+        for n, num_pots in ((700, 2), (65, 0), (129, 3)):
+            st = random_packed_states(spec, n, rng)
+            env = make_env(spec, n, gpu)
+            env.set_packed_state(st)
+            for cg in ("none", "all"):
+                got = u8(env.featurize(num_pots=num_pots, counter_goals=cg))
+                assert np.array_equal(got, O.featurize(orc, st, counter_goals=cg, num_pots=num_pots)), (name, cg, num_pots)
+    # mixed-layout table
+    table = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+    n = 5000
+    lid = (np.arange(n) % 5).astype(np.uint16)
+    st = np.zeros((table.n_planes, n, 16), np.uint8)
+    for l in range(5):
+        idx = np.nonzero(lid == l)[0]
+        st[:, idx] = random_packed_states(table.specs[l], len(idx), rng)
+    env = make_env(table, n, gpu, layout_id=lid)
+    env.set_packed_state(st)
+    orc = oracle_for(table.specs)
+    assert np.array_equal(u8(env.featurize(counter_goals="all")), O.featurize(orc, st, counter_goals="all", layout_id=lid))
