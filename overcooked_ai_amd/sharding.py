@@ -31,7 +31,7 @@ def init_process_group(backend=None):
     import torch.distributed as dist
 
     rank, local_rank, world = dist_env()
-    if world == 1:
+    if world == 1 and not os.environ.get("OC_FORCE_DIST"):  # OC_FORCE_DIST: exercise the RCCL path with one rank
         return rank, local_rank, world
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -43,11 +43,17 @@ def init_process_group(backend=None):
     return rank, local_rank, world
 
 
+def _live():
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or bool(os.environ.get("OC_FORCE_DIST")))
+
+
 def allreduce_metrics(t):
     """In-place SUM of a small metrics tensor over all ranks (no-op for a single process)."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _live():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
@@ -55,7 +61,7 @@ def allreduce_metrics(t):
 def allreduce_max(t):
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _live():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
 
@@ -63,5 +69,5 @@ def allreduce_max(t):
 def barrier():
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _live():
         dist.barrier()
