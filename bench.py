@@ -344,6 +344,22 @@ def bench_encode(dev, torch, VecOvercookedEnv, iters=200):
     fb = n * (S_ASYM + 2 * 96 * 4)
     res["featurize_state"] = {"launch_ms": ms, "bytes_per_launch": fb, "achieved_GBs": fb / (ms * 1e-3) / 1e9,
                               "frac": fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "env_featurizations_per_s": n / (ms * 1e-3)}
+    # potential_function (mdp.py:2920): one float64 per env, on mid-episode states
+    env.rollout_random(120)
+    phi = torch.empty((n,), dtype=torch.float64, device=dev)
+    for _ in range(5):
+        env.potential(out=phi)
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(iters):
+        env.potential(out=phi)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    ms = ev0.elapsed_time(ev1) / iters
+    pb = n * (S_ASYM + 8)
+    res["potential_function"] = {"launch_ms": ms, "bytes_per_launch": pb, "achieved_GBs": pb / (ms * 1e-3) / 1e9,
+                                 "frac": pb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "env_potentials_per_s": n / (ms * 1e-3)}
     return res
 
 

@@ -223,6 +223,26 @@ int oc_featurize(const OcBatch* batch, const uint8_t* d_plan_blob, const uint32_
                  float* d_features, int num_pots, void* stream);
 
 /*
+ * oc_potential — phi(s), the potential used for potential-based reward shaping.
+ * Replaces OvercookedGridworld.potential_function(state, mp, gamma) (mdp.py:2920-3238) as called by
+ * get_state_transition(display_phi=True) (mdp.py:1421-1429) for `phi_s` / `phi_s_prime`, which the RLlib
+ * environment turns into the dense reward gamma * phi_s_prime - phi_s (human_aware_rl/rllib/rllib.py:314-319).
+ *   d_plan_blob / d_plan_off  the motion-cost tables of oc_featurize (any counter_goals: only pots and serving
+ *       cells are looked up)
+ *   d_phi_tables [n_layouts][oc_phi_table_size()] per-layout records for ONE discount factor, built on the host by
+ *       overcooked_ai_amd.potential.pack_phi_tables (layout documented there): steady-state value, the best
+ *       completion of every ingredient multiset (_get_optimal_possible_recipe, mdp.py:1976-2016), gamma ** k;
+ *       8-byte aligned
+ *   d_phi  [n_envs] float64
+ * Arithmetic is float64 in the reference's operand order without contraction: results are bit-identical to the
+ * reference under CPython 3.8-3.12 (whose set iteration order decides ties between partially full pots,
+ * mdp.py:1882-1890).
+ */
+int oc_potential(const OcBatch* batch, const uint8_t* d_plan_blob, const uint32_t* d_plan_off,
+                 const uint8_t* d_phi_tables, const void* d_state, double* d_phi, void* stream);
+int oc_phi_table_size(void);
+
+/*
  * oc_reset — write the standard start state (OvercookedGridworld.get_standard_start_state,
  * mdp.py:1297-1305: players at start positions facing NORTH, no objects, timestep 0) into every
  * env whose d_mask byte is non-zero (all envs when d_mask is NULL).  Replaces OvercookedEnv.reset

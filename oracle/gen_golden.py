@@ -599,7 +599,67 @@ def gen_featurize():
     print("featurize fixtures", list(out))
 
 
+POTENTIAL_LAYOUTS = [  # (fixture name, layout name or None, custom layout dict)
+    ("cramped_room", "cramped_room", None),
+    ("asymmetric_advantages", "asymmetric_advantages", None),
+    ("forced_coordination", "forced_coordination", None),
+    ("counter_circuit", "counter_circuit", None),
+    ("mdp_test", "mdp_test", None),
+    ("cramped_room_tomato", "cramped_room_tomato", None),
+    ("marshmallow_experiment", "marshmallow_experiment", None),
+    ("seven_pots", None, {
+        "grid": "XPPPPPX\nO 1 2 O\nX     X\nXDPSPTX",
+        "start_all_orders": [{"ingredients": ["onion", "onion", "onion"]}, {"ingredients": ["onion", "onion", "tomato"]},
+                             {"ingredients": ["onion", "tomato", "tomato"]}, {"ingredients": ["tomato", "tomato", "tomato"]},
+                             {"ingredients": ["onion", "tomato"]}],
+        "start_bonus_orders": [{"ingredients": ["onion", "tomato", "tomato"]}],
+        "onion_value": 21, "tomato_value": 13, "onion_time": 7, "tomato_time": 4}),
+]
+
+
+def gen_potential():
+    """potential_function (mdp.py:2920-3238) on randomized states, gamma 0.99 (the default) and 0.9, with a
+    MotionPlanner without counter goals (what OvercookedEnv.mp builds, env.py:102-115)."""
+    P = _planner_modules()
+    out = {}
+    for name, lname, custom in POTENTIAL_LAYOUTS:
+        if custom is None:
+            spec, mdp = make_ref_mdp(lname, {})
+        else:
+            spec = L.LayoutSpec(dict(custom))
+            base = {k: v for k, v in custom.items() if k != "grid"}
+            mdp = R.OvercookedGridworld.from_grid(custom["grid"].split("\n"), base_layout_params=base)
+        activate(mdp)
+        mp = _quiet(P.MotionPlanner, mdp, [])
+        rng = np.random.default_rng(4242)
+        n = 400
+        n_planes = 1 + (spec.width * spec.height + 15) // 16
+        packed = np.zeros((n_planes, n, 16), np.uint8)
+        phi = np.zeros((2, n), np.float64)
+        states = []
+        for e in range(n):
+            st = random_ref_state(mdp, spec, rng)
+            if e % 5 == 0:  # make several pots partially full so that the set-ordered tie-breaking is exercised
+                for pos in mdp.get_pot_locations():
+                    k = int(rng.integers(0, 3))
+                    if k and pos in st.objects:
+                        st.objects[pos] = R.SoupState(pos, [R.ObjectState("onion", pos) for _ in range(k)])
+            states.append(st)
+            S.pack_state_dict(spec, st.to_dict(), packed, e)
+        for gi, g in enumerate((0.99, 0.9)):
+            for e, st in enumerate(states):
+                phi[gi, e] = mdp.potential_function(st, mp, gamma=g)
+        np.savez_compressed(os.path.join(GOLDEN, "potential_%s.npz" % name), states=packed, phi=phi, gammas=np.array([0.99, 0.9]))
+        out[name] = {"layout": spec.to_layout_dict(), "n": n, "gammas": [0.99, 0.9]}
+        print("potential", name, phi[0, :4], float(phi.min()), float(phi.max()))
+    with open(os.path.join(GOLDEN, "potential_manifest.json"), "w") as f:
+        json.dump(out, f)
+
+
 def main():
+    if "--potential-only" in sys.argv:
+        gen_potential()
+        return
     if "--featurize-only" in sys.argv:
         gen_featurize()
         return
@@ -635,6 +695,7 @@ def main():
     gen_env_episodes()
     gen_random_starts()
     gen_featurize()
+    gen_potential()
     with open(os.path.join(GOLDEN, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
     print("done")

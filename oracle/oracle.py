@@ -66,7 +66,7 @@ def build(force=False):
         return _LIB
     os.makedirs(_BUILD, exist_ok=True)
     tmp = _LIB + ".%d.tmp" % os.getpid()
-    subprocess.check_call(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-Wall", "-o", tmp, _SRC])
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-o", tmp, _SRC, "-lm"])
     os.replace(tmp, _LIB)
     return _LIB
 
@@ -258,6 +258,37 @@ def featurize(orc, state, counter_goals="none", num_pots=2, layout_id=None):
                                 ctypes.c_int64(n), int(num_pots))
     assert rc == 0
     return out
+
+
+class PotentialParams(ctypes.Structure):
+    _fields_ = [("gamma", ctypes.c_double), ("tomato_value", ctypes.c_double), ("onion_value", ctypes.c_double),
+                ("max_delivery_steps", ctypes.c_int32), ("max_pickup_steps", ctypes.c_int32),
+                ("pot_onion_steps", ctypes.c_int32), ("pot_tomato_steps", ctypes.c_int32)]
+
+
+def potential(orc, state, params, layout_id=None):
+    """potential_function of every env: float64 [n_envs].  params: one dict per mdp with the keys of the reference's
+    `potential_params` (mdp.py:2972-2982): gamma, tomato_value, onion_value, max_delivery_steps, max_pickup_steps,
+    pot_onion_steps, pot_tomato_steps."""
+    n = state.shape[1]
+    lid = orc._lid(layout_id, n)
+    arr = (PotentialParams * orc.n)()
+    for l, p in enumerate(params):
+        for k, _ in PotentialParams._fields_:
+            setattr(arr[l], k, p[k])
+    out = np.zeros((n,), dtype=np.float64)
+    rc = lib().oracle_potential(orc.arr, orc.n, _ptr(lid, ctypes.c_uint16), arr,
+                                _ptr(np.ascontiguousarray(state), ctypes.c_uint8), _ptr(out, ctypes.c_double), ctypes.c_int64(n))
+    assert rc == 0
+    return out
+
+
+def py_set_order(width, cells):
+    """Iteration order of `set().union(cells)` for (x, y) = (c % width, c // width), per the oracle's restatement."""
+    a = np.asarray(cells, dtype=np.int32)
+    out = np.zeros_like(a)
+    lib().oracle_py_set_order(int(width), _ptr(a, ctypes.c_int32), len(a), _ptr(out, ctypes.c_int32))
+    return [int(c) for c in out]
 
 
 def random_actions(seed, env_offset, t, n_envs):

@@ -962,3 +962,311 @@ int oracle_featurize(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_i
     free(pls);
     return 0;
 }
+
+/* ====================================================================================================
+ * potential_function (mdp.py:2920-3238): phi(s) for potential-based reward shaping.
+ *
+ * Two pieces of the host language's runtime take part in the reference's result and are restated here:
+ *  - `gamma ** k` is C `pow` (CPython float_pow / numpy npy_pow both call libm);
+ *  - `get_partially_full_pots` (mdp.py:1882-1890) returns `list(set().union(...))` of position tuples, so the
+ *    order of partially full pots — which breaks ties of the stable sort at mdp.py:3013-3024 and therefore decides
+ *    which pot the greedy matching serves first — is CPython's set iteration order.  py_set_order restates
+ *    CPython 3.10's tuple hash (Objects/tupleobject.c, xxHash-style) and open-addressing set (Objects/setobject.c:
+ *    set_add_entry, set_table_resize, set_insert_clean); tests/test_oracle_golden.py checks it against the running
+ *    interpreter's own `list(set().union(a, b))`.
+ * ==================================================================================================== */
+#include <math.h>
+
+typedef struct PotentialParams { /* potential_params, mdp.py:2972-2982 */
+    double gamma, tomato_value, onion_value;
+    int32_t max_delivery_steps, max_pickup_steps, pot_onion_steps, pot_tomato_steps;
+} PotentialParams;
+
+static uint64_t py_tuple2_hash(uint64_t x, uint64_t y) { /* tuplehash of a 2-tuple of small non-negative ints */
+    const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P5 = 2870177450012600261ULL;
+    uint64_t acc = P5, lane[2] = {x, y};
+    for (int i = 0; i < 2; ++i) {
+        acc += lane[i] * P2;
+        acc = (acc << 31) | (acc >> 33);
+        acc *= P1;
+    }
+    acc += 2 ^ (P5 ^ 3527539ULL);
+    if (acc == (uint64_t)-1) return 1546275796ULL;
+    return acc;
+}
+
+typedef struct PySetEntry { int used; uint64_t hash; int value; } PySetEntry;
+
+static void py_set_insert_clean(PySetEntry* table, size_t mask, uint64_t hash, int value) {
+    size_t perturb = hash, i = (size_t)hash & mask;
+    for (;;) {
+        PySetEntry* e = &table[i];
+        if (!e->used) { e->used = 1; e->hash = hash; e->value = value; return; }
+        if (i + 9 <= mask) {
+            for (int j = 0; j < 9; ++j) {
+                ++e;
+                if (!e->used) { e->used = 1; e->hash = hash; e->value = value; return; }
+            }
+        }
+        perturb >>= 5;
+        i = (i * 5 + 1 + perturb) & mask;
+    }
+}
+
+/* order in which `list(set().union(*lists))` yields n distinct position tuples inserted in the given order */
+static void py_set_order(const OracleMdp* m, const int* cells, int n, int* out) {
+    PySetEntry tab_a[64], tab_b[64];
+    PySetEntry* table = tab_a;
+    size_t mask = 7, fill = 0;
+    memset(tab_a, 0, sizeof(tab_a));
+    for (int k = 0; k < n; ++k) {
+        uint64_t hash = py_tuple2_hash((uint64_t)(cells[k] % m->width), (uint64_t)(cells[k] / m->width));
+        size_t perturb = hash, i = (size_t)hash & mask;
+        PySetEntry* slot = NULL;
+        while (!slot) { /* set_add_entry; keys are distinct, so only the free-slot search remains */
+            PySetEntry* e = &table[i];
+            int probes = (i + 9 <= mask) ? 9 : 0;
+            do {
+                if (!e->used) { slot = e; break; }
+                ++e;
+            } while (probes--);
+            if (slot) break;
+            perturb >>= 5;
+            i = (i * 5 + 1 + perturb) & mask;
+        }
+        slot->used = 1; slot->hash = hash; slot->value = cells[k];
+        ++fill;
+        if (fill * 5 >= mask * 3) { /* set_table_resize(so, used * 4) */
+            size_t newsize = 8;
+            while (newsize <= fill * 4) newsize <<= 1;
+            PySetEntry* nt = (table == tab_a) ? tab_b : tab_a;
+            memset(nt, 0, sizeof(tab_a));
+            for (size_t s = 0; s <= mask; ++s)
+                if (table[s].used) py_set_insert_clean(nt, newsize - 1, table[s].hash, table[s].value);
+            table = nt;
+            mask = newsize - 1;
+        }
+    }
+    int k = 0;
+    for (size_t s = 0; s <= mask; ++s)
+        if (table[s].used) out[k++] = table[s].value;
+}
+
+/* get_recipe_value(..., discounted=True, base_recipe), mdp.py:1603-1628 */
+static double discounted_recipe_value(const OracleMdp* m, int n_o, int n_t, int base_o, int base_t, const PotentialParams* pp) {
+    int n_onions = n_o - base_o, n_tomatoes = n_t - base_t;
+    return pow(pp->gamma, recipe_time(m, n_o, n_t)) * pow(pp->gamma, (double)(pp->pot_onion_steps * n_onions)) *
+           pow(pp->gamma, (double)(pp->pot_tomato_steps * n_tomatoes)) * get_recipe_value(m, n_o, n_t);
+}
+
+/* _get_optimal_possible_recipe, mdp.py:1976-2016.  has_start == 0 is the reference's recipe=None. */
+static void optimal_possible_recipe(const OracleMdp* m, int has_start, int s_o, int s_t, const PotentialParams* pp,
+                                    int* best_o, int* best_t, double* best_value) {
+    int visited[5][5] = {{0}}, stack[64][2], sp = 0;
+    *best_o = has_start ? s_o : -1;
+    *best_t = has_start ? s_t : -1;
+    *best_value = 0.0;
+    if (!has_start) { /* for ingredient in Recipe.ALL_INGREDIENTS = [onion, tomato] */
+        stack[sp][0] = 1; stack[sp++][1] = 0;
+        stack[sp][0] = 0; stack[sp++][1] = 1;
+    } else { stack[sp][0] = s_o; stack[sp++][1] = s_t; }
+    while (sp) {
+        --sp;
+        int o = stack[sp][0], t = stack[sp][1];
+        if (visited[o][t]) continue;
+        visited[o][t] = 1;
+        double v = discounted_recipe_value(m, o, t, has_start ? s_o : 0, has_start ? s_t : 0, pp);
+        if (v > *best_value) { *best_value = v; *best_o = o; *best_t = t; }
+        if (o + t < m->max_num_ingredients) { /* Recipe.neighbors, mdp.py:193-205 */
+            if (!visited[o + 1][t]) { stack[sp][0] = o + 1; stack[sp++][1] = t; }
+            if (!visited[o][t + 1]) { stack[sp][0] = o; stack[sp++][1] = t + 1; }
+        }
+    }
+}
+
+/* mp.min_cost_to_feature(player.pos_and_or, cells) as a double (np.inf when no goal is reachable) */
+static double cost_to(const OracleMdp* m, const Planner* pl, const Player* p, const int* cells, int n) {
+    int cost = 0;
+    int best = min_cost_to_feature(m, pl, cell_of(m, p->x, p->y), p->o, cells, n, &cost);
+    return best < 0 ? INFINITY : (double)cost;
+}
+
+static double dmax(double a, double b) { return a >= b ? a : b; } /* Python max(a, b): b only if b > a */
+static double dmin(double a, double b) { return b < a ? b : a; }
+
+static double potential_one(const OracleMdp* m, const Planner* pl, const State* st, const PotentialParams* pp) {
+    const double gamma = pp->gamma;
+    int ncells = m->width * m->height;
+    int pot_cells[MAX_CELLS], n_pots = 0, serve_cells[MAX_CELLS], n_serve = 0;
+    for (int c = 0; c < ncells; ++c) {
+        if (m->terrain[c] == 'P') pot_cells[n_pots++] = c;
+        if (m->terrain[c] == 'S') serve_cells[n_serve++] = c;
+    }
+    PotStates ps;
+    get_pot_states(m, st, &ps);
+
+    /* steady state: geometric sum of optimal soups, mdp.py:2985-3001 */
+    int opt_o, opt_t;
+    double disc_value;
+    optimal_possible_recipe(m, 0, 0, 0, pp, &opt_o, &opt_t, &disc_value);
+    double opt_value = get_recipe_value(m, opt_o, opt_t);
+    double discount = disc_value / opt_value;
+    double potential = (discount / (1 - discount)) * opt_value;
+
+    /* idle soups: full-but-not-cooking, then partially full (set order), stable-sorted by best completion value */
+    int idle[MAX_POTS], n_idle = 0;
+    for (int k = 0; k < n_pots; ++k) if (ps.cls[k] == m->max_num_ingredients) idle[n_idle++] = pot_cells[k];
+    {
+        int part[MAX_POTS], n_part = 0, ordered[MAX_POTS];
+        for (int items = 1; items < m->max_num_ingredients; ++items)
+            for (int k = 0; k < n_pots; ++k) if (ps.cls[k] == items) part[n_part++] = pot_cells[k];
+        py_set_order(m, part, n_part, ordered);
+        for (int k = 0; k < n_part; ++k) idle[n_idle++] = ordered[k];
+    }
+    double idle_key[MAX_POTS];
+    for (int k = 0; k < n_idle; ++k) {
+        int n_o, n_t, bo, bt;
+        count_ing(&st->objects[idle[k]], &n_o, &n_t);
+        optimal_possible_recipe(m, 1, n_o, n_t, pp, &bo, &bt, &idle_key[k]);
+    }
+    for (int a = 1; a < n_idle; ++a) { /* sorted(..., reverse=True) is stable: insertion sort, strict compare */
+        int c = idle[a];
+        double key = idle_key[a];
+        int b = a - 1;
+        while (b >= 0 && idle_key[b] < key) { idle[b + 1] = idle[b]; idle_key[b + 1] = idle_key[b]; --b; }
+        idle[b + 1] = c;
+        idle_key[b + 1] = key;
+    }
+
+    /* non-idle soups (cooking then ready, pot order) and their default values, mdp.py:3026-3046 */
+    int non_idle[MAX_POTS], n_non_idle = 0;
+    double non_idle_val[MAX_POTS];
+    for (int k = 0; k < n_pots; ++k) if (ps.cls[k] == POT_COOKING) non_idle[n_non_idle++] = pot_cells[k];
+    for (int k = 0; k < n_pots; ++k) if (ps.cls[k] == POT_READY) non_idle[n_non_idle++] = pot_cells[k];
+    for (int k = 0; k < n_non_idle; ++k) {
+        const Obj* soup = &st->objects[non_idle[k]];
+        int n_o, n_t;
+        count_ing(soup, &n_o, &n_t);
+        double remaining = soup_cook_time(m, soup) - soup->tick;
+        non_idle_val[k] = pow(gamma, pp->max_delivery_steps + dmax(pp->max_pickup_steps, remaining)) *
+                          dmax(get_recipe_value(m, n_o, n_t), 1);
+    }
+
+    int holding_onion[2] = {0, 0}, holding_tomato[2] = {0, 0};
+    for (int i = 0; i < m->n_players; ++i) {
+        holding_onion[i] = st->players[i].held.name == NAME_ONION;
+        holding_tomato[i] = st->players[i].held.name == NAME_TOMATO;
+    }
+
+    /* step 4: players holding soups, mdp.py:3078-3090 */
+    for (int i = 0; i < m->n_players; ++i) {
+        const Player* p = &st->players[i];
+        if (p->held.name != NAME_SOUP) continue;
+        int n_o, n_t;
+        count_ing(&p->held, &n_o, &n_t);
+        double delivery_dist = cost_to(m, pl, p, serve_cells, n_serve);
+        potential += pow(gamma, dmin(delivery_dist, pp->max_delivery_steps)) * dmax(get_recipe_value(m, n_o, n_t), 1);
+    }
+
+    /* step 3: players holding dishes, mdp.py:3092-3133 */
+    for (int i = 0; i < m->n_players; ++i) {
+        const Player* p = &st->players[i];
+        if (p->held.name != NAME_DISH) continue;
+        int best = -1;
+        double best_value = 0;
+        for (int k = 0; k < n_non_idle; ++k) {
+            const Obj* soup = &st->objects[non_idle[k]];
+            int n_o, n_t;
+            count_ing(soup, &n_o, &n_t);
+            double pickup_dist = cost_to(m, pl, p, &non_idle[k], 1);
+            double is_useful = pickup_dist < INFINITY ? 1.0 : 0.0;
+            double pickup_soup_value = pow(gamma, pp->max_delivery_steps) * dmax(get_recipe_value(m, n_o, n_t), 1);
+            double remaining = soup_cook_time(m, soup) - soup->tick;
+            double disc = pow(gamma, dmax(remaining, dmin(pickup_dist, pp->max_pickup_steps)));
+            double pickup_value = disc * pickup_soup_value * is_useful;
+            if (pickup_dist < INFINITY && pickup_value > best_value) { best = k; best_value = pickup_value; }
+        }
+        if (best >= 0) non_idle_val[best] = dmax(non_idle_val[best], best_value);
+    }
+    for (int k = 0; k < n_non_idle; ++k) potential += non_idle_val[k];
+
+    /* step 2: idle soups in decreasing value, mdp.py:3135-3211 */
+    for (int k = 0; k < n_idle; ++k) {
+        const Obj* soup = &st->objects[idle[k]];
+        int n_o, n_t, bo, bt;
+        double unused;
+        count_ing(soup, &n_o, &n_t);
+        optimal_possible_recipe(m, 1, n_o, n_t, pp, &bo, &bt, &unused);
+        int missing[3], n_missing = 0; /* sorted ingredient tuple of the optimal recipe minus the soup's: onions first */
+        for (int j = 0; j < bo - n_o; ++j) missing[n_missing++] = NAME_ONION;
+        for (int j = 0; j < bt - n_t; ++j) missing[n_missing++] = NAME_TOMATO;
+        double disc = pow(gamma, dmax(pp->max_pickup_steps, recipe_time(m, bo, bt)) + pp->max_delivery_steps);
+        for (int j = 0; j < n_missing; ++j) {
+            int* pertinent = missing[j] == NAME_TOMATO ? holding_tomato : holding_onion;
+            double dist = INFINITY;
+            int closest = -1;
+            for (int i = 0; i < m->n_players; ++i) {
+                if (!pertinent[i]) continue;
+                double cur = cost_to(m, pl, &st->players[i], &idle[k], 1);
+                if (cur < dist) { dist = cur; closest = i; }
+            }
+            disc *= pow(gamma, dmin(dist, missing[j] == NAME_TOMATO ? pp->pot_tomato_steps : pp->pot_onion_steps));
+            if (closest >= 0) pertinent[closest] = 0;
+        }
+        if (n_missing) disc *= gamma;
+        else {
+            double cook_dist = INFINITY;
+            for (int i = 0; i < m->n_players; ++i) {
+                if (st->players[i].held.name != NAME_NONE) continue;
+                double cur = cost_to(m, pl, &st->players[i], &idle[k], 1);
+                if (cur < cook_dist) cook_dist = cur;
+            }
+            disc *= pow(gamma, dmin(cook_dist, pp->max_pickup_steps));
+        }
+        potential += disc * dmax(get_recipe_value(m, bo, bt), 1);
+    }
+
+    /* step 1: left-over ingredients go to empty pots, mdp.py:3213-3245 */
+    int empty[MAX_POTS], n_empty = 0;
+    for (int k = 0; k < n_pots; ++k) if (ps.cls[k] == POT_EMPTY) empty[n_empty++] = pot_cells[k];
+    for (int pass = 0; pass < 2; ++pass) { /* tomatoes first, then onions */
+        const int* holding = pass == 0 ? holding_tomato : holding_onion;
+        for (int i = 0; i < m->n_players; ++i) {
+            if (!holding[i]) continue;
+            double dist = cost_to(m, pl, &st->players[i], empty, n_empty);
+            double is_useful = dist < INFINITY ? 1.0 : 0.0;
+            double steps = dmin(pass == 0 ? pp->pot_tomato_steps : pp->pot_onion_steps, dist) + pp->max_pickup_steps +
+                           pp->max_delivery_steps;
+            double disc = pow(gamma, steps) * is_useful;
+            potential += disc * (pass == 0 ? pp->tomato_value : pp->onion_value);
+        }
+    }
+    return potential;
+}
+
+/* phi: [n_envs] doubles; params: [n_mdps] */
+int oracle_potential(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, const PotentialParams* params,
+                     const uint8_t* state, double* phi, int64_t n_envs) {
+    Planner* pls = (Planner*)calloc((size_t)n_mdps, sizeof(Planner));
+    for (int l = 0; l < n_mdps; ++l) planner_build(&mdps[l], NULL, &pls[l]);
+    for (int64_t e = 0; e < n_envs; ++e) {
+        int l = layout_id ? layout_id[e] : 0;
+        State s;
+        unpack_state(&mdps[l], state, n_envs, e, &s);
+        phi[e] = potential_one(&mdps[l], &pls[l], &s, &params[l]);
+    }
+    for (int l = 0; l < n_mdps; ++l) free(pls[l].dist);
+    free(pls);
+    return 0;
+}
+
+/* test hook: CPython set iteration order of n distinct (x, y) cells inserted in order */
+void oracle_py_set_order(int width, const int32_t* cells, int n, int32_t* out) {
+    OracleMdp m;
+    memset(&m, 0, sizeof(m));
+    m.width = width;
+    int in[MAX_POTS * 4] = {0}, o[MAX_POTS * 4] = {0}; /* n <= 18: the tables above hold 64 slots */
+    for (int i = 0; i < n; ++i) in[i] = cells[i];
+    py_set_order(&m, in, n, o);
+    for (int i = 0; i < n; ++i) out[i] = o[i];
+}

@@ -17,7 +17,7 @@ OBS_U8, OBS_F32 = 0, 1
 
 EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_step", "oc_step_many",
            "oc_rollout_random",
-           "oc_encode_lossless", "oc_featurize", "oc_reset")
+           "oc_encode_lossless", "oc_featurize", "oc_potential", "oc_phi_table_size", "oc_reset")
 
 
 class OcBatch(ctypes.Structure):
@@ -74,6 +74,9 @@ def load():
     L.oc_encode_lossless.argtypes = [bp, vp, vp, i32, i32, vp]
     L.oc_featurize.restype = i32
     L.oc_featurize.argtypes = [bp, vp, vp, vp, vp, i32, vp]
+    L.oc_potential.restype = i32
+    L.oc_potential.argtypes = [bp, vp, vp, vp, vp, vp, vp]
+    L.oc_phi_table_size.restype = i32
     L.oc_reset.restype = i32
     L.oc_reset.argtypes = [bp, vp, vp, vp, vp]
     if L.oc_abi_version() != ABI_VERSION:

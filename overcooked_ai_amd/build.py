@@ -33,7 +33,7 @@ def build_extension(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     tmp = LIB + ".%d.tmp" % os.getpid()
-    cmd = [hipcc_path(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC", "-o", tmp, SRC]
+    cmd = [hipcc_path(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", tmp, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1691,6 +1691,251 @@ __global__ __launch_bounds__(BLOCK) void k_featurize(const OcLayout* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// k_potential: potential_function (mdp.py:2920-3238), phi(s) of potential-based reward shaping.  One lane per env.
+// Everything that depends only on the layout and gamma — the steady-state value, the best completion of every
+// ingredient multiset (_get_optimal_possible_recipe, mdp.py:1976-2016), gamma ** k — comes from the per-layout
+// record built on the host (overcooked_ai_amd/potential.py); motion costs come from the planner tables of
+// k_featurize (+1 for the interact action, planners.py:418-419).  The kernel multiplies and adds those float64
+// values in the reference's order with contraction off (__dmul_rn / __dadd_rn), so phi is bit-identical to the
+// reference's Python float.  The one order the reference leaves to its runtime — `list(set().union(...))` of the
+// partially full pots (mdp.py:1882-1890), which breaks ties of the greedy pot/ingredient matching — is CPython's
+// set iteration order, restated in py_set_order below (tuple hash + open addressing, CPython 3.8-3.12).
+// ------------------------------------------------------------------------------------------
+constexpr int PHI_BYTES = 456 + 8 * 512;
+constexpr uint32_t COST_INF = 0xFFFFu;
+
+struct Phi {
+    const uint8_t* b;
+    __device__ __forceinline__ double f64(int off) const { return *reinterpret_cast<const double*>(b + off); }
+    __device__ __forceinline__ int i32(int off) const { return *reinterpret_cast<const int*>(b + off); }
+    __device__ __forceinline__ double steady() const { return f64(0); }
+    __device__ __forceinline__ double onion_value() const { return f64(8); }
+    __device__ __forceinline__ double tomato_value() const { return f64(16); }
+    __device__ __forceinline__ uint32_t max_delivery() const { return (uint32_t)i32(24); }
+    __device__ __forceinline__ uint32_t max_pickup() const { return (uint32_t)i32(28); }
+    __device__ __forceinline__ uint32_t pot_onion() const { return (uint32_t)i32(32); }
+    __device__ __forceinline__ uint32_t pot_tomato() const { return (uint32_t)i32(36); }
+    __device__ __forceinline__ double sort_value(uint32_t k) const { return f64(40 + 8 * (int)k); }
+    __device__ __forceinline__ double opt_value_max1(uint32_t k) const { return f64(168 + 8 * (int)k); }
+    __device__ __forceinline__ double value_max1(uint32_t k) const { return f64(296 + 8 * (int)k); }
+    __device__ __forceinline__ uint32_t opt_key(uint32_t k) const { return b[424 + k]; }
+    __device__ __forceinline__ uint32_t opt_time(uint32_t k) const { return b[440 + k]; }
+    __device__ __forceinline__ double pw(uint32_t k) const { return f64(456 + 8 * (int)k); }  // gamma ** k
+};
+
+// hash((x, y)) of CPython's tuplehash for two small non-negative ints
+__device__ __forceinline__ uint64_t py_tuple2_hash(uint64_t x, uint64_t y) {
+    const uint64_t P1 = 11400714785074694791ull, P2 = 14029467366897019727ull, P5 = 2870177450012600261ull;
+    uint64_t acc = P5;
+    acc += x * P2; acc = (acc << 31) | (acc >> 33); acc *= P1;
+    acc += y * P2; acc = (acc << 31) | (acc >> 33); acc *= P1;
+    acc += 2ull ^ (P5 ^ 3527539ull);
+    return acc == ~0ull ? 1546275796ull : acc;
+}
+
+// Iteration order of `set().union(...)` after inserting the n (<= 8) distinct cells in the given order.
+__device__ void py_set_order(const uint32_t* cells, int n, uint32_t W, uint32_t* out) {
+    uint64_t th[32];
+    int tv[32], tv2[32];
+    uint64_t th2[32];
+    for (int i = 0; i < 32; ++i) { tv[i] = -1; tv2[i] = -1; }
+    uint32_t mask = 7u, fill = 0;
+    bool grown = false;
+    const uint32_t inv_w = 65536u / W + 1u;
+    for (int k = 0; k < n; ++k) {
+        const uint32_t cy = (cells[k] * inv_w) >> 16, cx = cells[k] - cy * W;
+        const uint64_t hash = py_tuple2_hash(cx, cy);
+        uint64_t perturb = hash;
+        uint32_t i = (uint32_t)hash & mask;
+        int* V = grown ? tv2 : tv;
+        uint64_t* Hh = grown ? th2 : th;
+        for (;;) {  // set_add_entry: keys are distinct, only the free-slot search remains
+            uint32_t probes = (i + 9u <= mask) ? 9u : 0u, j = i;
+            bool found = false;
+            for (uint32_t q = 0; q <= probes; ++q, ++j)
+                if (V[j] < 0) { found = true; break; }
+            if (found) { V[j] = (int)cells[k]; Hh[j] = hash; break; }
+            perturb >>= 5;
+            i = (uint32_t)((uint64_t)i * 5u + 1u + perturb) & mask;
+        }
+        ++fill;
+        if (!grown && fill * 5u >= mask * 3u) {  // set_table_resize(so, used * 4): 5 entries -> 32 slots
+            for (uint32_t s = 0; s <= mask; ++s) {
+                if (tv[s] < 0) continue;
+                const uint64_t h = th[s];
+                uint64_t pb = h;
+                uint32_t ii = (uint32_t)h & 31u;
+                for (;;) {  // set_insert_clean
+                    uint32_t j = ii;
+                    bool found = tv2[j] < 0;
+                    if (!found && ii + 9u <= 31u)
+                        for (uint32_t q = 0; q < 9u; ++q) { ++j; if (tv2[j] < 0) { found = true; break; } }
+                    if (found) { tv2[j] = tv[s]; th2[j] = h; break; }
+                    pb >>= 5;
+                    ii = (uint32_t)((uint64_t)ii * 5u + 1u + pb) & 31u;
+                }
+            }
+            grown = true;
+            mask = 31u;
+        }
+    }
+    const int* V = grown ? tv2 : tv;
+    int k = 0;
+    for (uint32_t s = 0; s <= mask; ++s)
+        if (V[s] >= 0) out[k++] = (uint32_t)V[s];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_potential(const OcLayout* __restrict__ g_layouts,
+                                                     const uint16_t* __restrict__ layout_id,
+                                                     const uint8_t* __restrict__ plan_blob,
+                                                     const uint32_t* __restrict__ plan_off,
+                                                     const uint8_t* __restrict__ phi_tables,
+                                                     const uint4* __restrict__ st, double* __restrict__ out, int64_t n,
+                                                     int W, int H) {
+#pragma clang fp contract(off)  // __dmul_rn / __dadd_rn are plain * and + in ROCm's headers: keep them unfused
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= n) return;
+    const uint32_t lid = layout_id ? layout_id[e] : 0u;
+    const Lay L{reinterpret_cast<const uint8_t*>(g_layouts + lid)};
+    const Phi T{phi_tables + (size_t)lid * PHI_BYTES};
+    const uint8_t* plan = plan_blob + plan_off[lid];
+    const uint32_t cells = (uint32_t)(W * H);
+    const uint4 hw = st[e];
+    const uint32_t hdr[4] = {hw.x, hw.y, hw.z, hw.w};
+    auto hbyte = [&](uint32_t i) { return (hdr[i >> 2] >> (8u * (i & 3u))) & 0xFFu; };
+    auto obj_at = [&](uint32_t c) {
+        return (uint32_t) reinterpret_cast<const uint8_t*>(st + (int64_t)(1 + (c >> 4)) * n + e)[c & 15u];
+    };
+    const uint32_t np = hbyte(3) == 0xFFu ? 1u : 2u;
+    uint32_t held[2] = {hbyte(2), np > 1u ? hbyte(5) : 0xFFu};
+    const uint8_t* cost_row[2];
+    cost_row[0] = plan + 128 + ((uint32_t)plan[hbyte(0)] * 4u + hbyte(1)) * cells;
+    cost_row[1] = np > 1u ? plan + 128 + ((uint32_t)plan[hbyte(3)] * 4u + hbyte(4)) * cells : cost_row[0];
+    auto cost = [&](uint32_t p, uint32_t c) {  // min_cost_to_feature(player, [c]); COST_INF = np.inf
+        const uint32_t v = cost_row[p][c];
+        return v == 255u ? COST_INF : v + 1u;
+    };
+    const uint32_t max_del = T.max_delivery(), max_pick = T.max_pickup();
+
+    // get_pot_states (mdp.py:1809-1838), pots in get_pot_locations order = slot order
+    const uint32_t n_pots = L.n_pots();
+    enum { EMPTY = 0, COOKING = 4, READY = 5 };  // 1..3 = idle with that many ingredients
+    uint32_t pcell[OC_MAX_POTS], pkey[OC_MAX_POTS], pcls[OC_MAX_POTS], prem[OC_MAX_POTS];
+    for (uint32_t k = 0; k < n_pots; ++k) {
+        const uint32_t c = L.pot_cell((int)k), o = obj_at(c), tk = hbyte(8u + k);
+        const uint32_t key = o ? recipe_idx(o) : 0u, ct = L.cook_time(key), cnt = (o >> 3) & 3u;
+        pcell[k] = c; pkey[k] = key;
+        pcls[k] = o == 0u ? (uint32_t)EMPTY : tk == 0u ? cnt : (tk - 1u >= ct ? (uint32_t)READY : (uint32_t)COOKING);
+        prem[k] = pcls[k] == COOKING ? ct - (tk - 1u) : 0u;  // cook_time - _cooking_tick
+    }
+
+    double phi = T.steady();  // mdp.py:2985-3001
+
+    // non-idle soups: cooking then ready, each in pot order, with their default value (mdp.py:3026-3046)
+    uint32_t ni[OC_MAX_POTS], n_ni = 0;
+    double ni_val[OC_MAX_POTS];
+    for (uint32_t cls = COOKING; cls <= READY; ++cls)
+        for (uint32_t k = 0; k < n_pots; ++k)
+            if (pcls[k] == cls) {
+                ni_val[n_ni] = __dmul_rn(T.pw(max_del + max(max_pick, prem[k])), T.value_max1(pkey[k]));
+                ni[n_ni++] = k;
+            }
+
+    bool has_onion[2] = {held[0] == OC_O_ONION, held[1] == OC_O_ONION};
+    bool has_tomato[2] = {held[0] == OC_O_TOMATO, held[1] == OC_O_TOMATO};
+
+    // step 4: players holding a soup walk to the closest serving cell (mdp.py:3078-3090)
+    for (uint32_t p = 0; p < np; ++p) {
+        if (held[p] == 0xFFu || !(held[p] & OC_O_SOUP)) continue;
+        uint32_t d = COST_INF;
+        for (uint32_t c = 0; c < cells; ++c)
+            if ((L.terrain(c) & 7u) == OC_T_SERVE) d = min(d, cost(p, c));
+        phi = __dadd_rn(phi, __dmul_rn(T.pw(min(d, max_del)), T.value_max1(recipe_idx(held[p]))));
+    }
+
+    // step 3: players holding a dish pursue the non-idle soup that is worth most to them (mdp.py:3092-3133)
+    for (uint32_t p = 0; p < np; ++p) {
+        if (held[p] != OC_O_DISH) continue;
+        int best = -1;
+        double best_value = 0.0;
+        for (uint32_t i = 0; i < n_ni; ++i) {
+            const uint32_t k = ni[i], d = cost(p, pcell[k]);
+            const double soup_value = __dmul_rn(T.pw(max_del), T.value_max1(pkey[k]));
+            const double value = __dmul_rn(T.pw(max(prem[k], min(d, max_pick))), soup_value);
+            if (d != COST_INF && value > best_value) { best = (int)i; best_value = value; }
+        }
+        if (best >= 0 && best_value > ni_val[best]) ni_val[best] = best_value;
+    }
+    for (uint32_t i = 0; i < n_ni; ++i) phi = __dadd_rn(phi, ni_val[i]);
+
+    // idle soups: full-but-not-cooking (pot order), then partially full (CPython set order), stable-sorted by the
+    // value of their best completion, highest first (mdp.py:3003-3024)
+    uint32_t idle[OC_MAX_POTS], n_idle = 0;
+    for (uint32_t k = 0; k < n_pots; ++k)
+        if (pcls[k] == 3u) idle[n_idle++] = k;
+    {
+        uint32_t part_cells[OC_MAX_POTS], ordered[OC_MAX_POTS], n_part = 0;
+        for (uint32_t items = 1; items < 3u; ++items)
+            for (uint32_t k = 0; k < n_pots; ++k)
+                if (pcls[k] == items) part_cells[n_part++] = pcell[k];
+        if (n_part > 1u) py_set_order(part_cells, (int)n_part, (uint32_t)W, ordered);
+        else if (n_part == 1u) ordered[0] = part_cells[0];
+        for (uint32_t j = 0; j < n_part; ++j)
+            for (uint32_t k = 0; k < n_pots; ++k)
+                if (pcell[k] == ordered[j]) idle[n_idle++] = k;
+    }
+    for (uint32_t a = 1; a < n_idle; ++a) {  // insertion sort, strict compare = Python's stable sorted(reverse=True)
+        const uint32_t k = idle[a];
+        const double key = T.sort_value(pkey[k]);
+        int b = (int)a - 1;
+        while (b >= 0 && T.sort_value(pkey[idle[b]]) < key) { idle[b + 1] = idle[b]; --b; }
+        idle[b + 1] = k;
+    }
+
+    // step 2 (mdp.py:3135-3211)
+    for (uint32_t a = 0; a < n_idle; ++a) {
+        const uint32_t k = idle[a], key = pkey[k], ok = T.opt_key(key);
+        const uint32_t missing_onions = (ok & 3u) - (key & 3u), missing_tomatoes = (ok >> 2) - (key >> 2);
+        double disc = T.pw(max(max_pick, T.opt_time(key)) + max_del);
+        for (uint32_t j = 0; j < missing_onions + missing_tomatoes; ++j) {
+            bool* pertinent = j < missing_onions ? has_onion : has_tomato;
+            uint32_t dist = COST_INF;
+            int closest = -1;
+            for (uint32_t p = 0; p < np; ++p) {
+                if (!pertinent[p]) continue;
+                const uint32_t cur = cost(p, pcell[k]);
+                if (cur < dist) { dist = cur; closest = (int)p; }
+            }
+            disc = __dmul_rn(disc, T.pw(min(dist, j < missing_onions ? T.pot_onion() : T.pot_tomato())));
+            if (closest >= 0) pertinent[closest] = false;
+        }
+        if (missing_onions + missing_tomatoes) disc = __dmul_rn(disc, T.pw(1));
+        else {
+            uint32_t cook_dist = COST_INF;
+            for (uint32_t p = 0; p < np; ++p)
+                if (held[p] == 0u) cook_dist = min(cook_dist, cost(p, pcell[k]));
+            disc = __dmul_rn(disc, T.pw(min(cook_dist, max_pick)));
+        }
+        phi = __dadd_rn(phi, __dmul_rn(disc, T.opt_value_max1(key)));
+    }
+
+    // step 1: ingredients left over go to the closest empty pot, tomatoes first (mdp.py:3213-3245)
+    for (uint32_t pass = 0; pass < 2u; ++pass) {
+        const bool* holding = pass == 0u ? has_tomato : has_onion;
+        for (uint32_t p = 0; p < np; ++p) {
+            if (!holding[p]) continue;
+            uint32_t dist = COST_INF;
+            for (uint32_t k = 0; k < n_pots; ++k)
+                if (pcls[k] == EMPTY) dist = min(dist, cost(p, pcell[k]));
+            if (dist == COST_INF) continue;  // is_useful == 0: adds 0.0
+            const double disc = T.pw(min(pass == 0u ? T.pot_tomato() : T.pot_onion(), dist) + max_pick + max_del);
+            phi = __dadd_rn(phi, __dmul_rn(disc, pass == 0u ? T.tomato_value() : T.onion_value()));
+        }
+    }
+    out[e] = phi;
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 int fail(int code, const char* msg) {
@@ -1919,6 +2164,22 @@ int oc_featurize(const OcBatch* b, const uint8_t* d_plan_blob, const uint32_t* d
                            d_plan_off, (const uint4*)d_state, d_features, b->n_envs, b->width, b->height, n_planes, num_pots);
     }
     return check_launch("oc_featurize");
+}
+
+int oc_phi_table_size(void) { return PHI_BYTES; }
+
+int oc_potential(const OcBatch* b, const uint8_t* d_plan_blob, const uint32_t* d_plan_off, const uint8_t* d_phi_tables,
+                 const void* d_state, double* d_phi, void* stream) {
+    int n_obj = 0;
+    if (int rc = check_batch(b, &n_obj)) return rc;
+    if (!d_plan_blob || !d_plan_off || !d_phi_tables || !d_state || !d_phi) return fail(OC_EINVAL, "oc_potential: NULL pointer");
+    if (((uintptr_t)d_phi_tables & 7u) != 0 || ((uintptr_t)d_phi & 7u) != 0)
+        return fail(OC_EINVAL, "oc_potential: d_phi_tables / d_phi must be 8-byte aligned");
+    if (b->n_envs == 0) return OC_OK;
+    hipLaunchKernelGGL(k_potential, dim3(grid_for(b->n_envs)), dim3(BLOCK), 0, (hipStream_t)stream, b->d_layouts,
+                       b->d_layout_id, d_plan_blob, d_plan_off, d_phi_tables, (const uint4*)d_state, d_phi, b->n_envs,
+                       b->width, b->height);
+    return check_launch("oc_potential");
 }
 
 int oc_reset(const OcBatch* b, void* d_state, const uint8_t* d_mask, float* d_ep_returns, void* stream) {

@@ -233,10 +233,23 @@ class OvercookedGridworld:
 
     def get_state_transition(self, state, joint_action, display_phi=False, motion_planner=None):
         """(new_state, infos) exactly like mdp.py:1375-1430; the input state is not modified."""
-        if display_phi:
-            raise NotImplementedError("potential_function (display_phi) is outside the accelerated hot path")
         nxt, infos = self.get_state_transitions([state], [joint_action])
+        if display_phi:  # mdp.py:1421-1429; the motion planner's distances are built in (planner.py)
+            phi = self.potential_functions([state, nxt[0]])
+            infos[0]["phi_s"], infos[0]["phi_s_prime"] = float(phi[0]), float(phi[1])
         return nxt[0], infos[0]
+
+    # ---------------------------------------------------------------- potential (mdp.py:2920-3238)
+    def potential_functions(self, states, gamma=0.99):
+        """Batched potential_function: float64 [n]."""
+        env = self._env(len(states))
+        env.set_packed_state(pack_states(self.spec, states))
+        return env.potential(gamma).cpu().numpy()
+
+    def potential_function(self, state, mp=None, gamma=0.99):
+        """phi(state) for potential-based reward shaping.  `mp` (the reference's MotionPlanner argument) is accepted
+        for signature compatibility; the distances it would supply are precomputed per layout."""
+        return float(self.potential_functions([state], gamma)[0])
 
     # ---------------------------------------------------------------- encodings (mdp.py:2382-2561)
     def get_lossless_state_encoding_shape(self):

@@ -71,6 +71,7 @@ class VecOvercookedEnv:
             batch_flags=_lib.BATCH_TWO_PLAYERS if all(s.num_players == 2 for s in self.table.specs) else 0)
         self._bref = ctypes.byref(self._batch)
         self._plans = {}
+        self._phi_tables = {}
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._state_ptr, self._rewards_ptr, self._flags_ptr = self.state.data_ptr(), self.rewards.data_ptr(), self.flags.data_ptr()
         self._ep_ptr = self.ep_returns.data_ptr() if self.ep_returns is not None else None
@@ -175,12 +176,7 @@ class VecOvercookedEnv:
     def featurize(self, num_pots=2, counter_goals="none", out=None, state=None):
         """[n_envs, 2, 2*(num_pots*10+26)+4] float32 hand-crafted features (mdp.py:2579); out[:, i] is for player i.
         counter_goals: "none" (the reference's NO_COUNTERS_PARAMS default), "all", or a list of (x, y) counters."""
-        key = counter_goals if isinstance(counter_goals, str) else tuple(sorted(map(tuple, counter_goals)))
-        if key not in self._plans:
-            from .planner import pack_plan_tables
-            blob, offs = pack_plan_tables(self.table.specs, counter_goals)
-            self._plans[key] = (torch.from_numpy(blob).to(self.device), torch.from_numpy(offs.view(np.int32).copy()).to(self.device))
-        blob, offs = self._plans[key]
+        blob, offs = self._plan(counter_goals)
         total = 2 * (num_pots * 10 + 26) + 4
         if out is None:
             out = torch.empty((self.n_envs, 2, total), dtype=torch.float32, device=self.device)
@@ -190,6 +186,32 @@ class VecOvercookedEnv:
         rc = self._launch(self.lib.oc_featurize, self._bref, blob.data_ptr(), offs.data_ptr(), st.data_ptr(), out.data_ptr(),
                           int(num_pots))
         _lib.check(rc, "oc_featurize")
+        return out
+
+    def _plan(self, counter_goals):
+        key = counter_goals if isinstance(counter_goals, str) else tuple(sorted(map(tuple, counter_goals)))
+        if key not in self._plans:
+            from .planner import pack_plan_tables
+            blob, offs = pack_plan_tables(self.table.specs, counter_goals)
+            self._plans[key] = (torch.from_numpy(blob).to(self.device), torch.from_numpy(offs.view(np.int32).copy()).to(self.device))
+        return self._plans[key]
+
+    def potential(self, gamma=0.99, out=None, state=None):
+        """[n_envs] float64 phi(s) of potential-based reward shaping (potential_function, mdp.py:2920) for the
+        discount factor `gamma`; the per-layout tables are built once per gamma on the host (potential.py)."""
+        gamma = float(gamma)
+        if gamma not in self._phi_tables:
+            from .potential import pack_phi_tables
+            self._phi_tables[gamma] = torch.from_numpy(pack_phi_tables(self.table.specs, gamma)).to(self.device)
+        blob, offs = self._plan("none")
+        if out is None:
+            out = torch.empty((self.n_envs,), dtype=torch.float64, device=self.device)
+        else:
+            assert out.dtype == torch.float64 and out.is_contiguous() and out.numel() == self.n_envs
+        st = self.state if state is None else state
+        rc = self._launch(self.lib.oc_potential, self._bref, blob.data_ptr(), offs.data_ptr(),
+                          self._phi_tables[gamma].data_ptr(), st.data_ptr(), out.data_ptr())
+        _lib.check(rc, "oc_potential")
         return out
 
     # ------------------------------------------------------------------ host <-> device state

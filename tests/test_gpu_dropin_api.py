@@ -134,3 +134,26 @@ def test_featurize_state_api_matches_reference_golden():
         assert f0.shape == (96,) and np.array_equal(f0, d["features"][e, 0]) and np.array_equal(f1, d["features"][e, 1])
     batch = mdp.featurize_states(S.unpack_states(spec, d["states"][:, :64]))
     assert np.array_equal(batch, d["features"][:64])
+
+
+def test_potential_function_api_matches_reference_golden():
+    """OvercookedGridworld.potential_function / get_state_transition(display_phi=True) (mdp.py:1421-1429, 2920)."""
+    from overcooked_ai_amd import Action, OvercookedEnv, OvercookedGridworld
+    from overcooked_ai_amd import state as S
+    from overcooked_ai_amd.layouts import LayoutSpec
+
+    with open(os.path.join(GOLDEN, "potential_manifest.json")) as f:
+        man = json.load(f)
+    spec = LayoutSpec(dict(man["counter_circuit"]["layout"]))
+    mdp = OvercookedGridworld.from_spec(spec)
+    d = np.load(os.path.join(GOLDEN, "potential_counter_circuit.npz"))
+    states = S.unpack_states(spec, d["states"][:, :32])
+    for e in (0, 7, 31):
+        assert mdp.potential_function(states[e], None) == d["phi"][0, e]
+        assert mdp.potential_function(states[e], None, gamma=0.9) == d["phi"][1, e]
+    assert np.array_equal(mdp.potential_functions(states), d["phi"][0, :32])
+    nxt, infos = mdp.get_state_transition(states[3], (Action.STAY, Action.INTERACT), display_phi=True)
+    assert infos["phi_s"] == d["phi"][0, 3] and infos["phi_s_prime"] == mdp.potential_function(nxt, None)
+    env = OvercookedEnv.from_mdp(mdp, horizon=400, info_level=0)
+    _, _, _, info = env.step((Action.STAY, Action.STAY), display_phi=True)
+    assert info["phi_s"] == info["phi_s_prime"] == mdp.potential_function(mdp.get_standard_start_state(), None)

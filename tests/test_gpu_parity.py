@@ -510,3 +510,61 @@ def test_featurize_state_golden_and_oracle(gpu):
     env.set_packed_state(st)
     orc = oracle_for(table.specs)
     assert np.array_equal(u8(env.featurize(counter_goals="all")), O.featurize(orc, st, counter_goals="all", layout_id=lid))
+
+
+def test_potential_function_golden_and_oracle(gpu):
+    """potential_function (mdp.py:2920-3238): float64 phi bit-identical to the reference fixtures (8 layouts incl. a
+    7-pot layout with tomatoes and a bonus order, gamma 0.99 and 0.9) and to the oracle on every layout."""
+    import json
+
+    from oracle import oracle as O
+    from overcooked_ai_amd.layouts import LayoutSpec, LayoutTable, layout_names, spec_from_name
+    from overcooked_ai_amd.potential import potential_params
+
+    with open(os.path.join(GOLDEN, "potential_manifest.json")) as f:
+        man = json.load(f)
+    for key, cfg in man.items():
+        spec = LayoutSpec(dict(cfg["layout"]))
+        d = np.load(os.path.join(GOLDEN, "potential_%s.npz" % key))
+        env = make_env(spec, d["states"].shape[1], gpu)
+        env.set_packed_state(d["states"])
+        for gi, gamma in enumerate(cfg["gammas"]):
+            got = env.potential(gamma).cpu().numpy()
+            assert got.dtype == np.float64 and np.array_equal(got, d["phi"][gi]), (key, gamma, np.abs(got - d["phi"][gi]).max())
+    rng = np.random.default_rng(2024)
+    for name in layout_names():
+        spec = spec_from_name(name)
+        if spec.num_players not in (1, 2):
+            continue
+        try:
+            pp = potential_params(spec, 0.97)
+            from overcooked_ai_amd.potential import phi_record
+            phi_record(spec, 0.97)
+        except ValueError:
+            continue  # no order with a positive value: the reference divides by zero there
+        orc = oracle_for(spec)
+        st = random_packed_states(spec, 1500, rng)
+        env = make_env(spec, 1500, gpu)
+        env.set_packed_state(st)
+        got = env.potential(0.97).cpu().numpy()
+        assert np.array_equal(got, O.potential(orc, st, [pp]), equal_nan=True), name  # tutorial_3's infinite recipe value gives nan in the reference too
+    # mixed-layout table, a few million values at BASELINE size: phi(s) >= steady-state > 0 and finite
+    table = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+    n = 5000
+    lid = (np.arange(n) % 5).astype(np.uint16)
+    st = np.zeros((table.n_planes, n, 16), np.uint8)
+    for l in range(5):
+        idx = np.nonzero(lid == l)[0]
+        st[:, idx] = random_packed_states(table.specs[l], len(idx), rng)
+    env = make_env(table, n, gpu, layout_id=lid)
+    env.set_packed_state(st)
+    orc = oracle_for(table.specs)
+    got = env.potential(0.99).cpu().numpy()
+    assert np.array_equal(got, O.potential(orc, st, [potential_params(s_, 0.99) for s_ in table.specs], layout_id=lid))
+    big = make_env("cramped_room", 65536, gpu, horizon=400, auto_reset=True, seed=1)
+    big.rollout_random(150)
+    phi = big.potential().cpu().numpy()
+    sub = big.get_packed_state()[:, :4096]
+    assert np.isfinite(phi).all() and phi.min() > 0
+    assert np.array_equal(phi[:4096], O.potential(oracle_for(spec_from_name("cramped_room")), sub,
+                                                  [potential_params(spec_from_name("cramped_room"), 0.99)]))

@@ -196,3 +196,33 @@ def test_generated_layouts_are_valid_and_diverse():
     assert len(grids) > 190
     small = generate_layouts(5, seed=1, inner_shape=(5, 4), outer_shape=(9, 5))
     assert all(s.shape == (9, 5) for s in small)
+
+
+def test_potential_tables_host_side():
+    """Host-built records for k_potential (potential.py): sizes, the DFS of _get_optimal_possible_recipe
+    (mdp.py:1976-2016) and the steady-state value (mdp.py:2985-3001) on known configurations."""
+    import struct
+
+    from overcooked_ai_amd.layouts import spec_from_name
+    from overcooked_ai_amd.potential import (PHI_BYTES, optimal_possible_recipe, pack_phi_tables, phi_record,
+                                               potential_params)
+
+    spec = spec_from_name("cramped_room")  # only order: 3 onions worth 20, cook time 20
+    pp = potential_params(spec, 0.99)
+    assert (pp["onion_value"], pp["tomato_value"], pp["max_delivery_steps"]) == (21, 13, 10)
+    key, value = optimal_possible_recipe(spec, None, pp)
+    assert key == (3, 0) and value == 0.99 ** 20 * 0.99 ** 30 * 0.99 ** 0 * 20
+    assert optimal_possible_recipe(spec, (1, 0), pp) == ((3, 0), 0.99 ** 20 * 0.99 ** 20 * 0.99 ** 0 * 20)
+    assert optimal_possible_recipe(spec, (0, 2), pp) == ((0, 2), 0)  # nothing valuable reachable: stays put
+    rec = phi_record(spec, 0.99)
+    assert len(rec) == PHI_BYTES
+    steady, onion_value, tomato_value = struct.unpack_from("<3d", rec, 0)
+    d = value / 20
+    assert steady == (d / (1 - d)) * 20 and (onion_value, tomato_value) == (21.0, 13.0)
+    assert struct.unpack_from("<4i", rec, 24) == (10, 10, 10, 10)
+    pw = struct.unpack_from("<512d", rec, 456)
+    assert pw[0] == 1.0 and pw[1] == 0.99 and pw[37] == 0.99 ** 37
+    assert rec[424 + 1] == 3 and rec[440 + 1] == 20  # one onion -> completes to ooo, cook time 20
+    cc = spec_from_name("counter_circuit")  # bonus order onion+tomato worth 2 * 34
+    assert optimal_possible_recipe(cc, None, potential_params(cc, 0.99))[0] == (1, 1)
+    assert pack_phi_tables([spec, cc]).shape == (2, PHI_BYTES)
