@@ -1997,7 +1997,8 @@ inline int64_t simd_count() {
     }
 
 // kernel variant selection: UNIFORM (one layout for the whole batch -> layout constants in SGPRs),
-// MAXP (pot slots kept in registers: 2 covers every canonical layout, 8 is the format's maximum),
+// MAXP (pot slots kept in registers: 1 for single-pot batches of one layout such as cramped_room, 2 covers every
+// canonical layout, 8 is the format's maximum),
 // LAY_LDS (layout table staged in LDS vs read from HBM/L2 for tables of more than 32 layouts)
 template <bool EVENTS>
 void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_state_out, const uint8_t* d_actions,
@@ -2018,7 +2019,7 @@ void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_st
                            (const uint4*)d_state_in, (uint4*)d_state_out, d_actions, (float4*)d_rewards, d_flags,    \
                            (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options);                     \
     } while (0)
-        if (uniform) { if (small) GO3(true, 2, true); else GO3(true, 8, true); }
+        if (uniform) { if (b->max_pots == 1) GO3(true, 1, true); else if (small) GO3(true, 2, true); else GO3(true, 8, true); }
         else if (lds) { if (small) GO3(false, 2, true); else GO3(false, 8, true); }
         else { if (small) GO3(false, 2, false); else GO3(false, 8, false); }
 #undef GO3
@@ -2124,7 +2125,7 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
                            b->n_envs, b->width, n_obj, horizon, options, (uint32_t)seed, (uint32_t)(seed >> 32),    \
                            env_offset, t0, n_steps);                                                                 \
     } while (0)
-        if (uniform) { if (small) GO3(true, 2, true); else GO3(true, 8, true); }
+        if (uniform) { if (b->max_pots == 1) GO3(true, 1, true); else if (small) GO3(true, 2, true); else GO3(true, 8, true); }
         else if (lds) { if (small) GO3(false, 2, true); else GO3(false, 8, true); }
         else { if (small) GO3(false, 2, false); else GO3(false, 8, false); }
 #undef GO3
