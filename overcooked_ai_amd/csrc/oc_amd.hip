@@ -26,7 +26,7 @@ constexpr int BLOCK = 256;
 constexpr int LDS_LAYOUT_MAX = 32;  // layout tables up to this many entries are staged in LDS (8 KiB)
 
 // byte offsets inside OcLayout (include/oc_amd.h)
-constexpr int L_NPOTS = 3, L_NPLAYERS = 4, L_OLDDYN = 5, L_START_POS = 8, L_START_OR = 10, L_POT_CELL = 16,
+constexpr int L_NCELLS = 2, L_NPOTS = 3, L_NPLAYERS = 4, L_OLDDYN = 5, L_START_POS = 8, L_START_OR = 10, L_POT_CELL = 16,
               L_PCLASS = 24, L_REW = 32, L_COOK = 48, L_VALUE = 64, L_TERRAIN = 128;
 static_assert(sizeof(OcLayout) == 256, "OcLayout must be 256 bytes");
 
@@ -737,24 +737,28 @@ struct Probe3 {
     uint32_t c_f0, c_f1, c_m0, c_m1;
 };
 
-template <int MAXP>
+// FAST = one layout for the whole batch, two players, at most 64 cells: "is there a second player" folds away and the
+// floor test of resolve_movement becomes a bit test against a wave-uniform 64-bit mask instead of two LDS reads.
+template <int MAXP, bool FAST>
 __device__ __forceinline__ Probe3 probe3(const uint16_t* cells, const Env3<MAXP>& s, uint32_t delta4, uint32_t a0,
                                          uint32_t a1) {
     Probe3 q;
-    const bool two = s.pos1 != 0xFFu;
+    const bool two = FAST || s.pos1 != 0xFFu;
     q.f0 = step_cell(s.pos0, s.or0, delta4);
     q.f1 = two ? step_cell(s.pos1, s.or1, delta4) : q.f0;
     q.m0 = a0 < 4u ? step_cell(s.pos0, a0, delta4) : s.pos0;
     q.m1 = (two & (a1 < 4u)) ? step_cell(s.pos1, a1, delta4) : (two ? s.pos1 : s.pos0);
     q.c_f0 = rd_cell3(cells, q.f0); q.c_f1 = rd_cell3(cells, q.f1);
-    q.c_m0 = rd_cell3(cells, q.m0); q.c_m1 = rd_cell3(cells, q.m1);
+    if (!FAST) { q.c_m0 = rd_cell3(cells, q.m0); q.c_m1 = rd_cell3(cells, q.m1); }
+    else { q.c_m0 = 0; q.c_m1 = 0; }
     return q;
 }
 
-template <int MAXP>
+template <int MAXP, bool FAST>
 __device__ __forceinline__ void step3_main(const LayC& C, const Lay L, const uint8_t* s_lut, uint16_t* cells,
-                                           Env3<MAXP>& s, uint32_t a0, uint32_t a1, const Probe3& q, float4& r) {
-    const bool two = s.pos1 != 0xFFu;
+                                           Env3<MAXP>& s, uint32_t a0, uint32_t a1, const Probe3& q, float4& r,
+                                           uint64_t floor_mask) {
+    const bool two = FAST || s.pos1 != 0xFFu;
     const bool mv0 = a0 < 4u, mv1 = two & (a1 < 4u);
     const uint32_t f0 = q.f0, f1 = q.f1, c_f0 = q.c_f0, c_f1 = q.c_f1;
 
@@ -790,8 +794,10 @@ __device__ __forceinline__ void step3_main(const LayC& C, const Lay L, const uin
     r = make_float4(r0.sparse, r1.sparse, sh0, sh1);
 
     // resolve_movement (mdp.py:1644-1727)
-    const uint32_t np0 = (mv0 & (((q.c_m0 >> 8) & 7u) == OC_T_FLOOR)) ? q.m0 : s.pos0;
-    const uint32_t np1 = (mv1 & (((q.c_m1 >> 8) & 7u) == OC_T_FLOOR)) ? q.m1 : s.pos1;
+    const bool fl0 = FAST ? ((floor_mask >> q.m0) & 1ull) != 0ull : ((q.c_m0 >> 8) & 7u) == OC_T_FLOOR;
+    const bool fl1 = FAST ? ((floor_mask >> q.m1) & 1ull) != 0ull : ((q.c_m1 >> 8) & 7u) == OC_T_FLOOR;
+    const uint32_t np0 = (mv0 & fl0) ? q.m0 : s.pos0;
+    const uint32_t np1 = (mv1 & fl1) ? q.m1 : s.pos1;
     s.or0 = mv0 ? a0 : s.or0;
     s.or1 = mv1 ? a1 : s.or1;
     const bool collide = two & ((np0 == np1) | ((np0 == s.pos1) & (np1 == s.pos0)));
@@ -817,12 +823,23 @@ __device__ __forceinline__ void step3_env(const LayC& C, Env3<MAXP>& s) {
     }
 }
 
-template <int MAXP>
+template <int MAXP, bool FAST = false>
 __device__ __forceinline__ void env_step3(const LayC& C, const Lay L, const uint8_t* s_lut, uint16_t* cells,
-                                          Env3<MAXP>& s, uint32_t delta4, uint32_t a0, uint32_t a1, float4& r) {
-    const Probe3 q = probe3<MAXP>(cells, s, delta4, a0, a1);
-    step3_main<MAXP>(C, L, s_lut, cells, s, a0, a1, q, r);
+                                          Env3<MAXP>& s, uint32_t delta4, uint32_t a0, uint32_t a1, float4& r,
+                                          uint64_t floor_mask = 0) {
+    const Probe3 q = probe3<MAXP, FAST>(cells, s, delta4, a0, a1);
+    step3_main<MAXP, FAST>(C, L, s_lut, cells, s, a0, a1, q, r, floor_mask);
     step3_env<MAXP>(C, s);
+}
+
+// bit c set <=> cell c is floor; wave-uniform (layouts of at most 64 cells, one layout per batch)
+__device__ __forceinline__ uint64_t make_floor_mask(const Lay L, int n_cells) {
+    uint32_t lo = 0, hi = 0;
+    for (int c = 0; c < n_cells && c < 32; ++c) lo |= ((L.terrain(c) & 7u) == OC_T_FLOOR ? 1u : 0u) << c;
+    for (int c = 32; c < n_cells && c < 64; ++c) hi |= ((L.terrain(c) & 7u) == OC_T_FLOOR ? 1u : 0u) << (c - 32);
+    lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+    hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 template <int MAXP>
@@ -922,7 +939,7 @@ __device__ __forceinline__ const uint8_t* stage_lut(uint2* s_lut, uint32_t old_d
     return reinterpret_cast<const uint8_t*>(s_lut) + (old_dyn ? LUT_ENTRIES * 8 : 0);
 }
 
-template <bool UNIFORM, int MAXP, bool LAY_LDS>
+template <bool UNIFORM, int MAXP, bool LAY_LDS, bool FAST = false>
 __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                     const uint16_t* __restrict__ layout_id, uint4* st,
                                                     float4* __restrict__ rewards, uint8_t* __restrict__ flags,
@@ -943,26 +960,72 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
     const uint32_t delta4 = make_delta4(W);
     Env3<MAXP> s;
     load_env3<MAXP>(C, L, st, n, e, n_obj, s, cells);
+    const uint64_t floor_mask = FAST ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull;
     float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     const uint64_t g = (uint64_t)(env_offset + e);
     const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
     uint32_t rnd[4] = {0, 0, 0, 0};
+    // outputs of step k live at [k][e]: a wave-uniform base per step (SALU) + this lane's 32-bit offset
+    float4* const rew_blk = rewards ? rewards + (int64_t)blockIdx.x * BLOCK : nullptr;
+    uint8_t* const flg_blk = flags ? flags + (int64_t)blockIdx.x * BLOCK : nullptr;
     // (issuing step k+1's cell reads before step k's tail was tried and measured: no gain — the loop is bound by
     //  instruction issue, not by LDS latency)
-    for (int k = 0; k < n_steps; ++k) {
-        const uint64_t t = (uint64_t)(t0 + k);
-        const uint32_t s8 = (uint32_t)t & 7u;
-        if (k == 0 || s8 == 0u) {
-            const uint64_t blk = t >> 3;
+    if (FAST) {
+        // One Philox block = 8 steps: the loop is unrolled over the block so that the word / digit position of every
+        // step is a compile-time constant (x runs through w, 6w, 36w, 216w: no word select, no x36 multiply) and the
+        // refresh test and the back edge are paid once per 8 steps.  A launch may start and end inside a block.
+        int k = 0;
+        uint32_t s8 = (uint32_t)t0 & 7u;
+        uint64_t blk = (uint64_t)t0 >> 3;
+        philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, rnd);
+        uint32_t x = (s8 & 1u) ? rnd[s8 >> 1] * 36u : 0u;
+#define OC_STEP(S8)                                                                                      \
+    {                                                                                                    \
+        if (((S8) & 1u) == 0u) x = rnd[(S8) >> 1];                                                       \
+        const uint32_t a0 = __umulhi(x, 6u);                                                             \
+        x *= 6u;                                                                                         \
+        const uint32_t a1 = __umulhi(x, 6u);                                                             \
+        x *= 6u;                                                                                         \
+        float4 r;                                                                                        \
+        env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask);                       \
+        const uint32_t fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);             \
+        if (rew_blk) (rew_blk + (int64_t)k * n)[threadIdx.x] = r;                                        \
+        if (flg_blk) (flg_blk + (int64_t)k * n)[threadIdx.x] = (uint8_t)fl;                              \
+        if (++k == n_steps) break;                                                                       \
+    }
+        for (;;) {
+            switch (s8) {
+                case 0: OC_STEP(0u)  // fall through: the rest of the block
+                case 1: OC_STEP(1u)
+                case 2: OC_STEP(2u)
+                case 3: OC_STEP(3u)
+                case 4: OC_STEP(4u)
+                case 5: OC_STEP(5u)
+                case 6: OC_STEP(6u)
+                default: OC_STEP(7u)
+            }
+            if (k == n_steps) break;
+            s8 = 0u;
+            ++blk;
             philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, rnd);
         }
-        uint32_t a0, a1;
-        draw_actions(rnd, s8, a0, a1);
-        float4 r;
-        env_step3<MAXP>(C, L, lut, cells, s, delta4, a0, a1, r);
-        const uint32_t fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);
-        if (rewards) rewards[(int64_t)k * n + e] = r;
-        if (flags) flags[(int64_t)k * n + e] = (uint8_t)fl;
+#undef OC_STEP
+    } else {
+        for (int k = 0; k < n_steps; ++k) {
+            const uint64_t t = (uint64_t)(t0 + k);
+            const uint32_t s8 = (uint32_t)t & 7u;
+            if (k == 0 || s8 == 0u) {
+                const uint64_t blk = t >> 3;
+                philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, rnd);
+            }
+            uint32_t a0, a1;
+            draw_actions(rnd, s8, a0, a1);
+            float4 r;
+            env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask);
+            const uint32_t fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);
+            if (rew_blk) (rew_blk + (int64_t)k * n)[threadIdx.x] = r;
+            if (flg_blk) (flg_blk + (int64_t)k * n)[threadIdx.x] = (uint8_t)fl;
+        }
     }
     store_env3<MAXP>(C, L, st, n, e, n_obj, s, cells);
     if (ep_returns) ep_returns[e] = ep;
@@ -970,7 +1033,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
 
 // k_step3: one transition per launch with caller-supplied actions, table-driven interact (no event logging;
 // oc_step with d_events != NULL uses k_step, whose predicate-network interact produces the event bits)
-template <bool UNIFORM, int MAXP, bool LAY_LDS>
+template <bool UNIFORM, int MAXP, bool LAY_LDS, bool FAST = false>
 __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                  const uint16_t* __restrict__ layout_id, const uint4* st_in,
                                                  uint4* st_out, const uint8_t* __restrict__ actions,
@@ -999,7 +1062,8 @@ __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_
     if (a0 > 5u || a1 > 5u) {
         fl = OC_F_BAD_ACTION;  // get_state_transition raises ValueError (mdp.py:1394-1398): leave the env untouched
     } else {
-        env_step3<MAXP>(C, L, lut, cells, s, delta4, a0, a1, r);
+        env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r,
+                              FAST ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull);
         fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);
     }
     store_env3<MAXP>(C, L, st_out, n, e, n_obj, s, cells);
@@ -2007,19 +2071,22 @@ void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_st
     const bool uniform = b->n_layouts == 1;
     const bool lds = b->n_layouts <= LDS_LAYOUT_MAX;
     const bool small = b->max_pots >= 1 && b->max_pots <= 2;
+    const bool fast = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0 && b->width * b->height <= 64;
     const size_t smem = (size_t)n_obj * 8 * BLOCK * sizeof(uint32_t);
     const dim3 grid(grid_for(b->n_envs)), block(BLOCK);
     if (!EVENTS && !(options & OC_OPT_PREDICATE_INTERACT)) {
-#define GO3(U, MP, LL)                                                                                               \
+#define GO3(U, MP, LL, ...)                                                                                          \
     do {                                                                                                             \
         if (smem > 40 * 1024)                                                                                        \
-            (void)hipFuncSetAttribute((const void*)k_step3<U, MP, LL>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                      (int)smem);                                                                    \
-        hipLaunchKernelGGL((k_step3<U, MP, LL>), grid, block, smem, s, b->d_layouts, b->n_layouts, b->d_layout_id,   \
+            (void)hipFuncSetAttribute((const void*)k_step3<U, MP, LL, ##__VA_ARGS__>,                                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                        \
+        hipLaunchKernelGGL((k_step3<U, MP, LL, ##__VA_ARGS__>), grid, block, smem, s, b->d_layouts, b->n_layouts, b->d_layout_id,   \
                            (const uint4*)d_state_in, (uint4*)d_state_out, d_actions, (float4*)d_rewards, d_flags,    \
                            (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options);                     \
     } while (0)
-        if (uniform) { if (b->max_pots == 1) GO3(true, 1, true); else if (small) GO3(true, 2, true); else GO3(true, 8, true); }
+        if (uniform && fast && b->max_pots == 1) GO3(true, 1, true, true);
+        else if (uniform && fast && small) GO3(true, 2, true, true);
+        else if (uniform) { if (b->max_pots == 1) GO3(true, 1, true); else if (small) GO3(true, 2, true); else GO3(true, 8, true); }
         else if (lds) { if (small) GO3(false, 2, true); else GO3(false, 8, true); }
         else { if (small) GO3(false, 2, false); else GO3(false, 8, false); }
 #undef GO3
@@ -2113,19 +2180,22 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         return check_launch("oc_rollout_random");
     }
     if ((options & OC_OPT_PREDICATE_INTERACT) == 0) {
+        const bool fast = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0 && b->width * b->height <= 64;
         const size_t smem3 = (size_t)n_obj * 16 * BLOCK * sizeof(uint16_t);
         const dim3 grid3(grid_for(b->n_envs)), block3(BLOCK);
-#define GO3(U, MP, LL)                                                                                               \
+#define GO3(U, MP, LL, ...)                                                                                          \
     do {                                                                                                             \
         if (smem3 > 40 * 1024)                                                                                       \
-            (void)hipFuncSetAttribute((const void*)k_rollout3<U, MP, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)smem3);                                                                   \
-        hipLaunchKernelGGL((k_rollout3<U, MP, LL>), grid3, block3, smem3, s, b->d_layouts, b->n_layouts,             \
+            (void)hipFuncSetAttribute((const void*)k_rollout3<U, MP, LL, ##__VA_ARGS__>,                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);                       \
+        hipLaunchKernelGGL((k_rollout3<U, MP, LL, ##__VA_ARGS__>), grid3, block3, smem3, s, b->d_layouts, b->n_layouts,             \
                            b->d_layout_id, (uint4*)d_state, (float4*)d_rewards, d_flags, (float4*)d_ep_returns,     \
                            b->n_envs, b->width, n_obj, horizon, options, (uint32_t)seed, (uint32_t)(seed >> 32),    \
                            env_offset, t0, n_steps);                                                                 \
     } while (0)
-        if (uniform) { if (b->max_pots == 1) GO3(true, 1, true); else if (small) GO3(true, 2, true); else GO3(true, 8, true); }
+        if (uniform && fast && b->max_pots == 1) GO3(true, 1, true, true);
+        else if (uniform && fast && small) GO3(true, 2, true, true);
+        else if (uniform) { if (b->max_pots == 1) GO3(true, 1, true); else if (small) GO3(true, 2, true); else GO3(true, 8, true); }
         else if (lds) { if (small) GO3(false, 2, true); else GO3(false, 8, true); }
         else { if (small) GO3(false, 2, false); else GO3(false, 8, false); }
 #undef GO3

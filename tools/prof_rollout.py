@@ -1,0 +1,21 @@
+"""Tiny driver for rocprofv3 counter passes over the fused rollout kernel (keeps the rocpd database small):
+    MODE=<lane_per_env|lane_pair|predicate_interact> LAYOUT=<name> ENVS=<n> python tools/prof_rollout.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from overcooked_ai_amd.vec_env import VecOvercookedEnv  # noqa: E402
+
+dev = torch.device("cuda:0")
+n = int(os.environ.get("ENVS", "65536"))
+env = VecOvercookedEnv(os.environ.get("LAYOUT", "cramped_room"), n, horizon=400, device=dev, auto_reset=True, seed=0)
+mode = os.environ.get("MODE", "")
+if mode:
+    setattr(env, mode, True)
+rew = torch.zeros((100, n, 4), dtype=torch.float32, device=dev)
+fl = torch.zeros((100, n), dtype=torch.uint8, device=dev)
+for _ in range(12):
+    env.rollout_random(100, rew, fl)
+torch.cuda.synchronize()
