@@ -212,8 +212,9 @@ int oc_encode_lossless(const OcBatch* batch, const void* d_state, void* d_obs, i
  *   d_plan_blob / d_plan_off  per-layout motion-cost tables built on the host by overcooked_ai_amd.planner
  *       (the MotionPlanner distances of planning/planners.py:391-423): at byte d_plan_off[layout] of the blob,
  *       floor_index[128] (cell -> index among the free cells, row-major) followed by
- *       cost[(floor_index[cell] * 4 + orientation) * n_cells + feature_cell] = fewest actions to stand next to the
- *       feature facing it, 255 = unreachable or not a motion goal (counters outside MotionPlanner.counter_goals)
+ *       cost[(floor_index[cell] * 4 + orientation) * row_stride + feature_cell] = fewest actions to stand next to the
+ *       feature facing it, 255 = unreachable or not a motion goal (counters outside MotionPlanner.counter_goals);
+ *       row_stride = n_cells rounded up to a multiple of 16 (rows are fetched as 16-byte words), padding = 255
  *   d_features  [n_envs][2][2 * (num_pots * 10 + 26) + 4] float32, 16-byte aligned; row i = features for player i
  *   num_pots    0..4 (the reference's default is 2 -> 96 features)
  * Ties between equally cheap counter objects are broken by cell order (row-major); the reference breaks them by the

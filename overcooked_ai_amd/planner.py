@@ -96,11 +96,15 @@ def feature_costs(spec, counter_goals="none"):
 
 
 def pack_plan_tables(specs, counter_goals="none"):
-    """Blob + offsets for a layout table: per layout [floor_index: 128 B][cost: n_states * n_cells B], 16-byte aligned."""
+    """Blob + offsets for a layout table: per layout [floor_index: 128 B][cost: n_states rows of n_cells bytes, each
+    row padded to a multiple of 16 bytes], 16-byte aligned."""
     offs, parts, pos = [], [], 0
     for s in specs:
         fi, cost = feature_costs(s, counter_goals)
-        raw = fi.tobytes() + cost.tobytes()
+        stride = (cost.shape[1] + 15) & ~15
+        rows = np.full((cost.shape[0], stride), UNREACHABLE, dtype=np.uint8)
+        rows[:, :cost.shape[1]] = cost
+        raw = fi.tobytes() + rows.tobytes()
         raw += b"\0" * ((-len(raw)) % 16)
         offs.append(pos)
         parts.append(raw)
