@@ -11,6 +11,7 @@ BENCH="python $ROOT/bench.py --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- $BENCH > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- $BENCH > $OUT/bench_write.log 2>&1
-find $OUT -name "*.csv" | head -50
-# keep only small summaries: drop huge per-dispatch traces beyond 20 MB
-find $OUT -size +20M -delete
+# summarise on the box and keep only the text / json (the rocpd databases exceed what gpurun_out carries back)
+python $ROOT/tools/summarize_prof.py $OUT $OUT/${TAG}_bench_rocprof.txt > /dev/null
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write
+ls -la $OUT

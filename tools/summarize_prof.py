@@ -20,6 +20,13 @@ def q(dbpath, sql):
         db.close()
 
 
+def short(name):
+    """`void (anonymous namespace)::k_x<...>(args)` / `(anonymous namespace)::k_y(args)` -> `k_x<...>` / `k_y`."""
+    name = name.replace("void ", "", 1) if name.startswith("void ") else name
+    name = name.replace("(anonymous namespace)::", "")
+    return name.split("(")[0]
+
+
 def main(src, dst):
     lines = []
     trace = glob.glob(os.path.join(src, "trace", "*.db"))
@@ -32,8 +39,7 @@ def main(src, dst):
         lines.append("%-70s %7s %12s %10s %10s %14s %5s %5s %7s %9s %5s" % (
             "kernel", "calls", "mean_ns", "min_ns", "max_ns", "total_ns", "vgpr", "sgpr", "lds", "grid", "wg"))
         for r in rows:
-            name = r[0].replace("void (anonymous namespace)::", "")
-            name = name.split("(")[0]
+            name = short(r[0])
             kern[r[0]] = r
             lines.append("%-70s %7d %12.1f %10d %10d %14d %5s %5s %7s %9s %5s" % (name[:70], r[1], r[2], r[3], r[4], r[5],
                                                                            r[6], r[7], r[8], r[9], r[10]))
@@ -48,7 +54,7 @@ def main(src, dst):
         lines.append("%-70s %7s %14s %12s %12s %s" % ("kernel", "calls", "mean_KiB", "min_KiB", "max_KiB",
                                                       "mean_bytes_corrected" if counter == "FETCH_SIZE" else "mean_bytes"))
         for r in rows:
-            name = r[0].replace("void (anonymous namespace)::", "").split("(")[0]
+            name = short(r[0])
             b = r[2] * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
             lines.append("%-70s %7d %14.2f %12.2f %12.2f %.0f" % (name[:70], r[1], r[2], r[3], r[4], b))
     # PMC HBM traffic per launch of our kernels -> JSON that bench.py reports as roofline.traffic
@@ -59,7 +65,7 @@ def main(src, dst):
             continue
         for name, cnt, mean in q(dbs[0], "select name, count(*), avg(counter_value) from pmc_events where counter_name='%s' "
                                          "and name like '%%anonymous namespace%%' group by name" % counter):
-            k = name.replace("void (anonymous namespace)::", "").split("(")[0]
+            k = short(name)
             if not k.startswith("k_"):
                 continue
             traffic.setdefault(k, {})[counter + "_bytes_per_launch"] = mean * 1024.0 * scale
