@@ -224,6 +224,28 @@ int oc_featurize(const OcBatch* batch, const uint8_t* d_plan_blob, const uint32_
                  float* d_features, int num_pots, void* stream);
 
 /*
+ * oc_reset_random — randomized start states drawn on the GPU.
+ * Replaces the start_state_fn of OvercookedGridworld.get_random_start_state_fn(random_start_pos,
+ * rnd_obj_prob_thresh) (mdp.py:1307-1369) as used by OvercookedEnv.reset (env.py:288-319) for training-time
+ * diversity.  Same distribution as the reference: joint positions uniform over ordered tuples of distinct free cells
+ * (orientation NORTH), each pot filled with probability thresh (n = 1..3 onions, then 0..3-n tomatoes; cooking from
+ * tick 0 with probability thresh, else idle), each player holding an object with probability thresh (dish 0.2,
+ * onion 0.6, finished soup 0.2 with the same ingredient draw).  The draws come from this library's counter-based
+ * stream, not from numpy's global generator (the numpy-exact version stays on the host:
+ * overcooked_ai_amd.mdp.OvercookedGridworld.get_random_start_state_fn):
+ *      block(b) = philox4x32_10(counter = {epoch, g_lo, g_hi, b}, key = {seed_lo, seed_hi ^ 0x52535421})
+ *      b = 0: word 0 -> joint position index mulhi(word, n_joint) into the row-major product of free cells
+ *      b = 1 + i (player i): {u, kind, n, m}: holds iff u < T; kind < 858993459 dish, < 3435973836 onion, else soup;
+ *                            n_onion = 1 + mulhi(n, 3), n_tomato = mulhi(m, 4 - n_onion)
+ *      b = 3 + k (pot k):    {u, n, m, q}: filled iff u < T; cooking (tick 0) iff q < T
+ *      T = floor(rnd_obj_prob_thresh * 2^32)
+ * for global env g = env_offset + e.  d_mask as in oc_reset.
+ */
+int oc_reset_random(const OcBatch* batch, void* d_state, const uint8_t* d_mask, float* d_ep_returns, uint64_t seed,
+                    int64_t env_offset, uint32_t epoch, int random_start_pos, double rnd_obj_prob_thresh,
+                    void* stream);
+
+/*
  * oc_potential — phi(s), the potential used for potential-based reward shaping.
  * Replaces OvercookedGridworld.potential_function(state, mp, gamma) (mdp.py:2920-3238) as called by
  * get_state_transition(display_phi=True) (mdp.py:1421-1429) for `phi_s` / `phi_s_prime`, which the RLlib

@@ -194,6 +194,18 @@ class Oracle:
                            _ptr(m, ctypes.c_uint8), _ptr(ep_returns, ctypes.c_float), ctypes.c_int64(n))
         return state
 
+    def reset_random(self, state, seed=0, env_offset=0, epoch=0, random_start_pos=False, rnd_obj_prob_thresh=0.0,
+                     layout_id=None, mask=None):
+        """Randomized start states (get_random_start_state_fn, mdp.py:1307-1369) from the stream of oc_reset_random."""
+        n = state.shape[1]
+        lid = self._lid(layout_id, n)
+        rc = lib().oracle_reset_random(self.arr, self.n, _ptr(lid, ctypes.c_uint16), _ptr(state, ctypes.c_uint8),
+                                       _ptr(mask, ctypes.c_uint8), ctypes.c_int64(n), ctypes.c_uint64(seed),
+                                       ctypes.c_int64(env_offset), ctypes.c_uint32(epoch), int(bool(random_start_pos)),
+                                       ctypes.c_double(rnd_obj_prob_thresh))
+        assert rc == 0
+        return state
+
     def step(self, state, actions, horizon=400, options=0, layout_id=None, ep_returns=None):
         """Returns (next_state, rewards[n,4] f32, flags[n] u8). `state` is not modified."""
         n = state.shape[1]

@@ -1270,3 +1270,81 @@ void oracle_py_set_order(int width, const int32_t* cells, int n, int32_t* out) {
     py_set_order(&m, in, n, o);
     for (int i = 0; i < n; ++i) out[i] = o[i];
 }
+
+/* ====================================================================================================
+ * Randomized start states: the start_state_fn of get_random_start_state_fn (mdp.py:1307-1369), with the draws
+ * taken from the counter-based stream documented at oc_reset_random (include/oc_amd.h) instead of numpy's global
+ * generator.  Structured like the reference: choose the joint position, build the standard start state, then
+ * randomize pots and held objects.
+ * ==================================================================================================== */
+static uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+static void random_soup(Obj* o, uint32_t word_n, uint32_t word_m, int tick) {
+    int n = 1 + (int)mulhi32(word_n, 3u);          /* np.random.randint(low=1, high=4) */
+    int m = (int)mulhi32(word_m, (uint32_t)(4 - n)); /* np.random.randint(low=0, high=4 - n) */
+    o->name = NAME_SOUP;
+    o->n_ing = n + m;
+    for (int i = 0; i < n; ++i) o->ing[i] = NAME_ONION; /* SoupState.get_soup: onions + tomatoes, mdp.py:683-689 */
+    for (int i = 0; i < m; ++i) o->ing[n + i] = NAME_TOMATO;
+    o->tick = tick;
+}
+
+static void random_start_state(const OracleMdp* m, State* s, uint64_t seed, uint64_t g, uint32_t epoch,
+                               int random_start_pos, uint64_t thresh) {
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x52535421u}, ctr[4], r[4];
+    int ncells = m->width * m->height;
+    standard_start_state(m, s);
+    if (random_start_pos) {
+        /* valid_positions[np.random.choice(len(valid_positions))], get_valid_joint_player_positions (mdp.py:1736-1747) */
+        int floor[MAX_CELLS], n_floor = 0;
+        for (int c = 0; c < ncells; ++c) if (m->terrain[c] == ' ') floor[n_floor++] = c;
+        int joint[MAX_CELLS * MAX_CELLS][2], n_joint = 0;
+        for (int a = 0; a < n_floor; ++a) {
+            if (m->n_players == 1) { joint[n_joint][0] = floor[a]; joint[n_joint++][1] = -1; continue; }
+            for (int b = 0; b < n_floor; ++b)
+                if (a != b) { joint[n_joint][0] = floor[a]; joint[n_joint++][1] = floor[b]; }
+        }
+        ctr[0] = epoch; ctr[1] = (uint32_t)g; ctr[2] = (uint32_t)(g >> 32); ctr[3] = 0;
+        oracle_philox4x32_10(ctr, key, r);
+        int idx = (int)mulhi32(r[0], (uint32_t)n_joint);
+        for (int i = 0; i < m->n_players; ++i) {
+            s->players[i].x = joint[idx][i] % m->width;
+            s->players[i].y = joint[idx][i] / m->width;
+        }
+    }
+    if (thresh == 0) return; /* rnd_obj_prob_thresh == 0 */
+    int k = 0;
+    for (int c = 0; c < ncells; ++c) { /* pots in get_pot_locations order */
+        if (m->terrain[c] != 'P') continue;
+        ctr[0] = epoch; ctr[1] = (uint32_t)g; ctr[2] = (uint32_t)(g >> 32); ctr[3] = 3u + (uint32_t)k++;
+        oracle_philox4x32_10(ctr, key, r);
+        if ((uint64_t)r[0] < thresh) random_soup(&s->objects[c], r[1], r[2], (uint64_t)r[3] < thresh ? 0 : -1);
+    }
+    for (int i = 0; i < m->n_players; ++i) {
+        ctr[0] = epoch; ctr[1] = (uint32_t)g; ctr[2] = (uint32_t)(g >> 32); ctr[3] = 1u + (uint32_t)i;
+        oracle_philox4x32_10(ctr, key, r);
+        if ((uint64_t)r[0] >= thresh) continue;
+        Obj* h = &s->players[i].held;
+        if (r[1] < 858993459u) { h->name = NAME_DISH; h->n_ing = 0; h->tick = -1; }        /* p = [0.2, 0.6, 0.2] */
+        else if (r[1] < 3435973836u) { h->name = NAME_ONION; h->n_ing = 0; h->tick = -1; }
+        else { /* finished=True -> auto_finish: tick = cook time (mdp.py:576-580) */
+            random_soup(h, r[2], r[3], 0);
+            h->tick = (int)soup_cook_time(m, h);
+        }
+    }
+}
+
+int oracle_reset_random(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, uint8_t* state, const uint8_t* mask,
+                        int64_t n_envs, uint64_t seed, int64_t env_offset, uint32_t epoch, int random_start_pos,
+                        double rnd_obj_prob_thresh) {
+    uint64_t thresh = (uint64_t)(rnd_obj_prob_thresh * 4294967296.0);
+    for (int64_t e = 0; e < n_envs; ++e) {
+        if (mask && !mask[e]) continue;
+        const OracleMdp* m = &mdps[layout_id ? layout_id[e] : 0];
+        State s;
+        random_start_state(m, &s, seed, (uint64_t)(env_offset + e), epoch, random_start_pos, thresh);
+        pack_state(m, &s, state, n_envs, e);
+    }
+    (void)n_mdps;
+    return 0;
+}

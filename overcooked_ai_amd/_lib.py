@@ -17,7 +17,7 @@ OBS_U8, OBS_F32 = 0, 1
 
 EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_step", "oc_step_many",
            "oc_rollout_random",
-           "oc_encode_lossless", "oc_featurize", "oc_potential", "oc_phi_table_size", "oc_reset")
+           "oc_encode_lossless", "oc_featurize", "oc_potential", "oc_phi_table_size", "oc_reset", "oc_reset_random")
 
 
 class OcBatch(ctypes.Structure):
@@ -77,6 +77,8 @@ def load():
     L.oc_potential.restype = i32
     L.oc_potential.argtypes = [bp, vp, vp, vp, vp, vp, vp]
     L.oc_phi_table_size.restype = i32
+    L.oc_reset_random.restype = i32
+    L.oc_reset_random.argtypes = [bp, vp, vp, vp, u64, i64, u32, i32, ctypes.c_double, vp]
     L.oc_reset.restype = i32
     L.oc_reset.argtypes = [bp, vp, vp, vp, vp]
     if L.oc_abi_version() != ABI_VERSION:

@@ -43,6 +43,7 @@ class VecOvercookedEnv:
         self.seed = int(seed)
         self.env_offset = int(env_offset)
         self.t_global = 0  # global step counter feeding the Philox counter of rollout_random
+        self.reset_epoch = 0  # counter of randomized resets (oc_reset_random's epoch)
         self.width, self.height = self.table.width, self.table.height
         self.n_planes = self.table.n_planes
         assert self.lib.oc_state_planes(self.width, self.height) == self.n_planes
@@ -90,15 +91,23 @@ class VecOvercookedEnv:
         return self.table.specs[0 if self.layout_id is None else int(self.layout_id_host[e])]
 
     # ------------------------------------------------------------------ env API
-    def reset(self, mask=None):
-        """Standard start state (mdp.py:1297) for all envs, or those with mask != 0 (u8/bool tensor [n_envs])."""
+    def reset(self, mask=None, random_start_pos=False, rnd_obj_prob_thresh=0.0):
+        """Start states for all envs, or those with mask != 0 (u8/bool tensor [n_envs]): the standard start state
+        (mdp.py:1297) by default; with random_start_pos / rnd_obj_prob_thresh the randomized start states of
+        get_random_start_state_fn (mdp.py:1307-1369), drawn on the GPU from (seed, global env index, reset epoch)."""
         d_mask = None
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
             d_mask = mask.data_ptr()
+        d_ep = self.ep_returns.data_ptr() if self.ep_returns is not None else None
         with torch.cuda.device(self.device):
-            rc = self.lib.oc_reset(self._bref, self.state.data_ptr(), d_mask,
-                                   self.ep_returns.data_ptr() if self.ep_returns is not None else None, self._stream())
+            if random_start_pos or rnd_obj_prob_thresh:
+                rc = self.lib.oc_reset_random(self._bref, self.state.data_ptr(), d_mask, d_ep, self.seed, self.env_offset,
+                                              self.reset_epoch & 0xFFFFFFFF, int(bool(random_start_pos)),
+                                              float(rnd_obj_prob_thresh), self._stream())
+                self.reset_epoch += 1
+            else:
+                rc = self.lib.oc_reset(self._bref, self.state.data_ptr(), d_mask, d_ep, self._stream())
         _lib.check(rc, "oc_reset")
 
     def _launch(self, fn, *args):

@@ -568,3 +568,44 @@ def test_potential_function_golden_and_oracle(gpu):
     assert np.isfinite(phi).all() and phi.min() > 0
     assert np.array_equal(phi[:4096], O.potential(oracle_for(spec_from_name("cramped_room")), sub,
                                                   [potential_params(spec_from_name("cramped_room"), 0.99)]))
+
+
+def test_reset_random_matches_oracle(gpu):
+    """oc_reset_random: bit-exact against the oracle's restatement of the same Philox stream — single layouts
+    (1 and 2 players, 7 pots), a mixed table, masks, shards and epochs; ep_returns cleared for the reset envs."""
+    from overcooked_ai_amd.layouts import LayoutSpec, LayoutTable, spec_from_name
+
+    seven = LayoutSpec({"grid": "XPPPPPX\nO 1 2 O\nX     X\nXDPSPTX", "onion_time": 3, "tomato_time": 5,
+                        "onion_value": 7, "tomato_value": 4})
+    specs = [spec_from_name(nm) for nm in ("cramped_room", "asymmetric_advantages", "cramped_room_single", "corridor",
+                                           "counter_circuit")] + [seven]
+    for spec in specs:
+        n = 3000
+        orc = oracle_for(spec)
+        env = make_env(spec, n, gpu, seed=21, env_offset=700)
+        for pos, t in ((True, 0.0), (False, 0.4), (True, 1.0), (True, 0.27)):
+            epoch = env.reset_epoch
+            env.reset(random_start_pos=pos, rnd_obj_prob_thresh=t)
+            want = orc.reset_random(orc.new_state(n), seed=21, env_offset=700, epoch=epoch, random_start_pos=pos,
+                                    rnd_obj_prob_thresh=t)
+            assert np.array_equal(env.get_packed_state(), want), (spec.layout_name, pos, t)
+        assert env.reset_epoch == 4
+    table = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+    n = 4097
+    lid = (np.arange(n) % 5).astype(np.uint16)
+    env = make_env(table, n, gpu, layout_id=lid, seed=5)
+    env.rollout_random(37)
+    before = env.get_packed_state()
+    mask = (np.arange(n) % 3 == 0)
+    env.ep_returns.fill_(1.0)
+    env.reset(mask=torch.from_numpy(mask), random_start_pos=True, rnd_obj_prob_thresh=0.5)
+    want = oracle_for(table.specs).reset_random(before.copy(), seed=5, epoch=0, random_start_pos=True, rnd_obj_prob_thresh=0.5,
+                                                layout_id=lid, mask=mask.astype(np.uint8))
+    assert np.array_equal(env.get_packed_state(), want)
+    ep = env.ep_returns.cpu().numpy()
+    assert (ep[mask] == 0).all() and (ep[~mask] == 1).all()
+    # a randomized batch steps like any other: fused rollout == oracle from those states
+    st = env.get_packed_state()
+    env.rollout_random(25)
+    oracle_for(table.specs).rollout_random(st, 25, horizon=400, options=0, seed=5, t0=37, layout_id=lid, want_outputs=False)
+    assert np.array_equal(env.get_packed_state(), st)
