@@ -609,3 +609,32 @@ def test_reset_random_matches_oracle(gpu):
     env.rollout_random(25)
     oracle_for(table.specs).rollout_random(st, 25, horizon=400, options=0, seed=5, t0=37, layout_id=lid, want_outputs=False)
     assert np.array_equal(env.get_packed_state(), st)
+
+
+def test_hip_graph_capture_of_step_and_encode(gpu):
+    """The C-ABI launches on the caller's stream without synchronising, so a step + encode pair can be captured in
+    a HIP graph (torch.cuda.graph) and replayed with new actions: same states, rewards and observations as eager."""
+    n = 4096
+    env = make_env("asymmetric_advantages", n, gpu, horizon=50, auto_reset=True, seed=0)
+    ref = make_env("asymmetric_advantages", n, gpu, horizon=50, auto_reset=True, seed=0)
+    acts = torch.zeros((n, 2), dtype=torch.uint8, device=gpu)
+    obs, obs_ref = (torch.empty((n, 2, 9, 5, 26), dtype=torch.uint8, device=gpu) for _ in range(2))
+    side = torch.cuda.Stream(device=gpu)
+    side.wait_stream(torch.cuda.current_stream(gpu))
+    with torch.cuda.stream(side):
+        env.step(acts)
+        env.encode_lossless(out=obs)
+    torch.cuda.current_stream(gpu).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        env.step(acts)
+        env.encode_lossless(out=obs)
+    env.reset()
+    gen = torch.Generator(device=gpu).manual_seed(3)
+    for _ in range(60):  # crosses the horizon: auto-reset inside the captured step
+        acts.copy_(torch.randint(0, 6, (n, 2), dtype=torch.uint8, device=gpu, generator=gen))
+        graph.replay()
+        ref.step(acts)
+        ref.encode_lossless(out=obs_ref)
+        assert torch.equal(env.rewards, ref.rewards) and torch.equal(env.flags, ref.flags)
+    assert torch.equal(env.state, ref.state) and torch.equal(obs, obs_ref) and torch.equal(env.ep_returns, ref.ep_returns)
