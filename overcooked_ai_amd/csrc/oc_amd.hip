@@ -2112,6 +2112,164 @@ __global__ __launch_bounds__(BLOCK) void k_potential(const OcLayout* __restrict_
     out[e] = phi;
 }
 
+// k_potential2: the same function for layout tables with at most two pots (every layout the reference ships).
+// The pot lists of the reference (non-idle soups: cooking then ready; idle soups: full, then partially full in set
+// order, stable-sorted by the value of their best completion) have at most two entries, so they are kept as
+// (first, second) pairs in registers and the matching loops are straight-line code; the set order of two partially
+// full pots is precomputed per layout on the host (two bits in the record: which pot comes out first for either
+// insertion order).  All motion costs are fetched up front so that their latencies overlap.
+__global__ __launch_bounds__(BLOCK) void k_potential2(const OcLayout* __restrict__ g_layouts,
+                                                      const uint16_t* __restrict__ layout_id,
+                                                      const uint8_t* __restrict__ plan_blob,
+                                                      const uint32_t* __restrict__ plan_off,
+                                                      const uint8_t* __restrict__ phi_tables,
+                                                      const uint4* __restrict__ st, double* __restrict__ out, int64_t n,
+                                                      int W, int H) {
+#pragma clang fp contract(off)
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= n) return;
+    const uint32_t lid = layout_id ? layout_id[e] : 0u;
+    const Lay L{reinterpret_cast<const uint8_t*>(g_layouts + lid)};
+    const Phi T{phi_tables + (size_t)lid * PHI_BYTES};
+    const uint8_t* plan = plan_blob + plan_off[lid];
+    const uint32_t cells = (uint32_t)(W * H), row_stride = (cells + 15u) & ~15u;
+    const uint4 hw = st[e];
+    const uint32_t np = (hw.x >> 24) == 0xFFu ? 1u : 2u;
+    const uint32_t held0 = (hw.x >> 16) & 0xFFu, held1 = np > 1u ? (hw.y >> 8) & 0xFFu : 0xFFu;
+    const uint8_t* row0 = plan + 128 + ((uint32_t)plan[hw.x & 0xFFu] * 4u + ((hw.x >> 8) & 0xFFu)) * row_stride;
+    const uint8_t* row1 = np > 1u ? plan + 128 + ((uint32_t)plan[hw.x >> 24] * 4u + (hw.y & 0xFFu)) * row_stride : row0;
+    const uint32_t n_pots = L.n_pots();
+    const uint32_t cellA = L.pot_cell(0), cellB = n_pots > 1u ? L.pot_cell(1) : cellA;
+    // everything that comes from memory, issued together
+    const uint32_t rA0 = row0[cellA], rA1 = row1[cellA], rB0 = row0[cellB], rB1 = row1[cellB];
+    const uint32_t oA = reinterpret_cast<const uint8_t*>(st + (int64_t)(1 + (cellA >> 4)) * n + e)[cellA & 15u];
+    const uint32_t oB = reinterpret_cast<const uint8_t*>(st + (int64_t)(1 + (cellB >> 4)) * n + e)[cellB & 15u];
+    uint32_t serve0 = 255u, serve1 = 255u;  // min over the serving cells (255 = unreachable stays the maximum)
+    for (uint32_t c = 0; c < cells; ++c)
+        if ((L.terrain(c) & 7u) == OC_T_SERVE) { serve0 = min(serve0, (uint32_t)row0[c]); serve1 = min(serve1, (uint32_t)row1[c]); }
+    auto fin = [](uint32_t v) { return v == 255u ? COST_INF : v + 1u; };  // + the interact; COST_INF = np.inf
+    // cost[player][pot]
+    const uint32_t cA[2] = {fin(rA0), fin(rA1)}, cB[2] = {fin(rB0), fin(rB1)};
+    const uint32_t dserve[2] = {fin(serve0), fin(serve1)};
+    const uint32_t held[2] = {held0, held1};
+    const uint32_t max_del = T.max_delivery(), max_pick = T.max_pickup();
+
+    enum { EMPTY = 0, COOKING = 4, READY = 5, ABSENT = 7 };
+    auto classify = [&](uint32_t o, uint32_t tk, uint32_t& key, uint32_t& rem) {
+        key = o ? recipe_idx(o) : 0u;
+        const uint32_t ct = L.cook_time(key), cnt = (o >> 3) & 3u;
+        const uint32_t cls = o == 0u ? (uint32_t)EMPTY : tk == 0u ? cnt : (tk - 1u >= ct ? (uint32_t)READY : (uint32_t)COOKING);
+        rem = cls == COOKING ? ct - (tk - 1u) : 0u;
+        return cls;
+    };
+    uint32_t key[2], rem[2], cls[2];
+    cls[0] = classify(oA, hw.z & 0xFFu, key[0], rem[0]);
+    cls[1] = classify(oB, (hw.z >> 8) & 0xFFu, key[1], rem[1]);
+    if (n_pots < 2u) cls[1] = ABSENT;
+    auto pcost = [&](uint32_t p, uint32_t k) { return k == 0u ? cA[p] : cB[p]; };
+
+    double phi = T.steady();
+
+    // non-idle soups: cooking before ready, pot order inside a class (mdp.py:3026-3046)
+    const bool ni0 = cls[0] == COOKING || cls[0] == READY, ni1 = cls[1] == COOKING || cls[1] == READY;
+    const bool swap_ni = ni0 && ni1 && cls[0] == READY && cls[1] == COOKING;
+    const uint32_t n_ni = (ni0 ? 1u : 0u) + (ni1 ? 1u : 0u);
+    uint32_t nk[2];  // pots in list order
+    nk[0] = ni0 ? (swap_ni ? 1u : 0u) : 1u;
+    nk[1] = swap_ni ? 0u : 1u;
+    double nv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) nv[i] = __dmul_rn(T.pw(max_del + max(max_pick, rem[nk[i]])), T.value_max1(key[nk[i]]));
+
+    bool has_onion[2] = {held[0] == OC_O_ONION, held[1] == OC_O_ONION};
+    bool has_tomato[2] = {held[0] == OC_O_TOMATO, held[1] == OC_O_TOMATO};
+
+    // step 4 (mdp.py:3078-3090)
+#pragma unroll
+    for (uint32_t p = 0; p < 2u; ++p) {
+        if (p >= np || held[p] == 0xFFu || !(held[p] & OC_O_SOUP)) continue;
+        phi = __dadd_rn(phi, __dmul_rn(T.pw(min(dserve[p], max_del)), T.value_max1(recipe_idx(held[p]))));
+    }
+    // step 3 (mdp.py:3092-3133)
+#pragma unroll
+    for (uint32_t p = 0; p < 2u; ++p) {
+        if (p >= np || held[p] != OC_O_DISH) continue;
+        int best = -1;
+        double best_value = 0.0;
+#pragma unroll
+        for (uint32_t i = 0; i < 2u; ++i) {
+            if (i >= n_ni) continue;
+            const uint32_t k = nk[i], d = pcost(p, k);
+            const double soup_value = __dmul_rn(T.pw(max_del), T.value_max1(key[k]));
+            const double value = __dmul_rn(T.pw(max(rem[k], min(d, max_pick))), soup_value);
+            if (d != COST_INF && value > best_value) { best = (int)i; best_value = value; }
+        }
+        if (best == 0 && best_value > nv[0]) nv[0] = best_value;
+        if (best == 1 && best_value > nv[1]) nv[1] = best_value;
+    }
+    if (n_ni > 0u) phi = __dadd_rn(phi, nv[0]);
+    if (n_ni > 1u) phi = __dadd_rn(phi, nv[1]);
+
+    // idle soups in processing order (mdp.py:3003-3024)
+    const bool id0 = cls[0] >= 1u && cls[0] <= 3u, id1 = cls[1] >= 1u && cls[1] <= 3u;
+    const uint32_t n_idle = (id0 ? 1u : 0u) + (id1 ? 1u : 0u);
+    bool b_first = false;  // with both idle: does pot B precede pot A before the sort?
+    if (id0 && id1) {
+        if (cls[0] == 3u || cls[1] == 3u) b_first = cls[0] != 3u;  // full pots first, pot order among them
+        else {
+            const uint32_t bits = T.opt_key(0);  // host-computed CPython set order of the two pot positions
+            b_first = (cls[0] == 2u && cls[1] == 1u) ? (bits & 2u) != 0u : (bits & 1u) != 0u;
+        }
+        const double sa = T.sort_value(key[0]), sb = T.sort_value(key[1]);
+        if (b_first ? sa > sb : sb > sa) b_first = !b_first;  // stable descending sort of two
+    }
+    uint32_t ik[2];
+    ik[0] = id0 ? (b_first ? 1u : 0u) : 1u;
+    ik[1] = b_first ? 0u : 1u;
+    // step 2 (mdp.py:3135-3211)
+#pragma unroll
+    for (uint32_t a = 0; a < 2u; ++a) {
+        if (a >= n_idle) continue;
+        const uint32_t k = ik[a], kk = key[k], ok = T.opt_key(kk);
+        const uint32_t missing_onions = (ok & 3u) - (kk & 3u), missing_tomatoes = (ok >> 2) - (kk >> 2);
+        double disc = T.pw(max(max_pick, T.opt_time(kk)) + max_del);
+        for (uint32_t j = 0; j < missing_onions + missing_tomatoes; ++j) {
+            const bool onion = j < missing_onions;
+            const bool av0 = onion ? has_onion[0] : has_tomato[0], av1 = (np > 1u) && (onion ? has_onion[1] : has_tomato[1]);
+            uint32_t dist = COST_INF;
+            int closest = -1;
+            if (av0 && pcost(0, k) < dist) { dist = pcost(0, k); closest = 0; }
+            if (av1 && pcost(1, k) < dist) { dist = pcost(1, k); closest = 1; }
+            disc = __dmul_rn(disc, T.pw(min(dist, onion ? T.pot_onion() : T.pot_tomato())));
+            if (closest == 0) { if (onion) has_onion[0] = false; else has_tomato[0] = false; }
+            if (closest == 1) { if (onion) has_onion[1] = false; else has_tomato[1] = false; }
+        }
+        if (missing_onions + missing_tomatoes) disc = __dmul_rn(disc, T.pw(1));
+        else {
+            uint32_t cook_dist = COST_INF;
+            if (held[0] == 0u) cook_dist = min(cook_dist, pcost(0, k));
+            if (np > 1u && held[1] == 0u) cook_dist = min(cook_dist, pcost(1, k));
+            disc = __dmul_rn(disc, T.pw(min(cook_dist, max_pick)));
+        }
+        phi = __dadd_rn(phi, __dmul_rn(disc, T.opt_value_max1(kk)));
+    }
+    // step 1 (mdp.py:3213-3245)
+#pragma unroll
+    for (uint32_t pass = 0; pass < 2u; ++pass) {
+#pragma unroll
+        for (uint32_t p = 0; p < 2u; ++p) {
+            if (p >= np || !(pass == 0u ? has_tomato[p] : has_onion[p])) continue;
+            uint32_t dist = COST_INF;
+            if (cls[0] == EMPTY) dist = min(dist, cA[p]);
+            if (cls[1] == EMPTY) dist = min(dist, cB[p]);
+            if (dist == COST_INF) continue;
+            const double disc = T.pw(min(pass == 0u ? T.pot_tomato() : T.pot_onion(), dist) + max_pick + max_del);
+            phi = __dadd_rn(phi, __dmul_rn(disc, pass == 0u ? T.tomato_value() : T.onion_value()));
+        }
+    }
+    out[e] = phi;
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -2360,9 +2518,14 @@ int oc_potential(const OcBatch* b, const uint8_t* d_plan_blob, const uint32_t* d
     if (((uintptr_t)d_phi_tables & 7u) != 0 || ((uintptr_t)d_phi & 7u) != 0)
         return fail(OC_EINVAL, "oc_potential: d_phi_tables / d_phi must be 8-byte aligned");
     if (b->n_envs == 0) return OC_OK;
-    hipLaunchKernelGGL(k_potential, dim3(grid_for(b->n_envs)), dim3(BLOCK), 0, (hipStream_t)stream, b->d_layouts,
-                       b->d_layout_id, d_plan_blob, d_plan_off, d_phi_tables, (const uint4*)d_state, d_phi, b->n_envs,
-                       b->width, b->height);
+    if (b->max_pots >= 1 && b->max_pots <= 2)
+        hipLaunchKernelGGL(k_potential2, dim3(grid_for(b->n_envs)), dim3(BLOCK), 0, (hipStream_t)stream, b->d_layouts,
+                           b->d_layout_id, d_plan_blob, d_plan_off, d_phi_tables, (const uint4*)d_state, d_phi, b->n_envs,
+                           b->width, b->height);
+    else
+        hipLaunchKernelGGL(k_potential, dim3(grid_for(b->n_envs)), dim3(BLOCK), 0, (hipStream_t)stream, b->d_layouts,
+                           b->d_layout_id, d_plan_blob, d_plan_off, d_phi_tables, (const uint4*)d_state, d_phi, b->n_envs,
+                           b->width, b->height);
     return check_launch("oc_potential");
 }
 

@@ -23,7 +23,9 @@ Record layout (little endian, 8-byte aligned):
     40   f64  sort_value[16]     discounted value of the best completion of multiset k = n_onion + 4 * n_tomato
     168  f64  opt_value_max1[16] max(get_recipe_value(best completion), 1)
     296  f64  value_max1[16]     max(get_recipe_value(multiset itself), 1)
-    424  u8   opt_key[16]        best completion as n_onion | n_tomato << 2
+    424  u8   opt_key[16]        best completion as n_onion | n_tomato << 2; entry 0 (no such multiset) carries the set
+                             order of the layout's first two pots A, B: bit 0 = B comes first out of
+                             list(set().union([A], [B])), bit 1 = B comes first out of list(set().union([B], [A]))
     440  u8   opt_time[16]       Recipe.time of the best completion
     456  f64  pow[POW_N]         gamma ** k
 """
@@ -87,6 +89,64 @@ def optimal_possible_recipe(spec, start_key, params):
     return best_key, best_value
 
 
+def _tuple2_hash(x, y):
+    """CPython's tuplehash for a 2-tuple of small non-negative ints (Objects/tupleobject.c, 3.8+)."""
+    m = (1 << 64) - 1
+    p1, p2, p5 = 11400714785074694791, 14029467366897019727, 2870177450012600261
+    acc = p5
+    for lane in (x, y):
+        acc = (acc + lane * p2) & m
+        acc = ((acc << 31) | (acc >> 33)) & m
+        acc = (acc * p1) & m
+    acc = (acc + (2 ^ (p5 ^ 3527539))) & m
+    return 1546275796 if acc == m else acc
+
+
+def py_set_order(positions):
+    """Iteration order of `set().union(positions)` for distinct (x, y) tuples, restating CPython 3.8-3.12's
+    open-addressing set (Objects/setobject.c: set_add_entry, set_table_resize, set_insert_clean) — the order
+    `get_partially_full_pots` (mdp.py:1882-1890) hands to potential_function.  Independent of the interpreter
+    running this module, and identical to what k_potential computes on the GPU."""
+    table, mask, fill = [None] * 8, 7, 0
+
+    def insert_clean(tab, msk, h, v):
+        perturb, i = h, h & msk
+        while True:
+            if tab[i] is None:
+                tab[i] = (h, v)
+                return
+            if i + 9 <= msk:
+                for j in range(1, 10):
+                    if tab[i + j] is None:
+                        tab[i + j] = (h, v)
+                        return
+            perturb >>= 5
+            i = (i * 5 + 1 + perturb) & msk
+
+    for pos in positions:
+        h = _tuple2_hash(int(pos[0]), int(pos[1]))
+        perturb, i = h, h & mask
+        while True:
+            probes = 9 if i + 9 <= mask else 0
+            slot = next((i + j for j in range(probes + 1) if table[i + j] is None), None)
+            if slot is not None:
+                table[slot] = (h, pos)
+                break
+            perturb >>= 5
+            i = (i * 5 + 1 + perturb) & mask
+        fill += 1
+        if fill * 5 >= mask * 3:
+            newsize = 8
+            while newsize <= fill * 4:
+                newsize <<= 1
+            new = [None] * newsize
+            for ent in table:
+                if ent is not None:
+                    insert_clean(new, newsize - 1, ent[0], ent[1])
+            table, mask = new, newsize - 1
+    return [ent[1] for ent in table if ent is not None]
+
+
 def phi_record(spec, gamma=0.99):
     """The PHI_BYTES record of one layout for one discount factor."""
     gamma = float(gamma)
@@ -113,6 +173,10 @@ def phi_record(spec, gamma=0.99):
             value_max1[k] = float(max(spec.delivery_value(key), 1))
             opt_keys[k] = best[0] | (best[1] << 2)
             opt_times[k] = t
+    pots = spec.cells_of("P")
+    if len(pots) >= 2:  # set order of the first two pots, for k_potential2
+        a, b = pots[0], pots[1]
+        opt_keys[0] = (1 if py_set_order([a, b])[0] == b else 0) | (2 if py_set_order([b, a])[0] == b else 0)
     steps = (params["max_delivery_steps"], params["max_pickup_steps"], params["pot_onion_steps"], params["pot_tomato_steps"])
     if 3 * max(steps) + 256 > POW_N:
         raise ValueError("potential constants too large for the power table")

@@ -226,3 +226,20 @@ def test_potential_tables_host_side():
     cc = spec_from_name("counter_circuit")  # bonus order onion+tomato worth 2 * 34
     assert optimal_possible_recipe(cc, None, potential_params(cc, 0.99))[0] == (1, 1)
     assert pack_phi_tables([spec, cc]).shape == (2, PHI_BYTES)
+
+
+def test_py_set_order_port_matches_interpreter():
+    """potential.py's port of CPython's set ordering (it fills the two-pot order bits of the phi record)."""
+    import random
+    import sys
+
+    from overcooked_ai_amd.potential import py_set_order
+
+    if not (3, 8) <= sys.version_info[:2] <= (3, 12):
+        pytest.skip("set/tuple-hash internals restated for CPython 3.8-3.12")
+    rnd = random.Random(5)
+    for _ in range(3000):
+        W, H = rnd.randint(3, 14), rnd.randint(3, 9)
+        cells = rnd.sample(range(W * H), rnd.randint(0, 9))
+        pos = [(c % W, c // W) for c in cells]
+        assert py_set_order(pos) == list(set().union(pos))
