@@ -192,6 +192,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         out["step_api"] = bench_step_api(env, dev, torch)
         out["encode"] = bench_encode(dev, torch, VecOvercookedEnv)
+        out["training_env"] = bench_training_env(dev, torch)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.layout, args.cpu_seconds)
     if rank == 0:
@@ -305,6 +306,30 @@ def bench_step_api(env, dev, torch, iters=2000):
     return {"value": n * iters / wall, "step_many": many, "unit": "env steps/s", "launch_ms": ms, "bytes_per_launch": b,
             "achieved_GBs": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "note": "oc_step, one launch per batched step incl. Python/ctypes launch overhead; SURVEY 8d: 67 B/env-step"}
+
+
+def bench_training_env(dev, torch, iters=300):
+    """The RLlib-shaped training environment (VecOvercookedMultiAgent.step: oc_step + oc_potential + oc_shape_rewards +
+    masked oc_reset + oc_encode_lossless, use_phi, caller-supplied actions) on 65 536 cramped_room envs."""
+    from overcooked_ai_amd.multi_agent import VecOvercookedMultiAgent
+
+    n = N_ENVS_PER_GPU
+    out = {}
+    for name, dt in (("obs_u8", torch.uint8), ("obs_f32", torch.float32)):
+        env = VecOvercookedMultiAgent("cramped_room", n, horizon=HORIZON, reward_shaping_factor=1.0, use_phi=True,
+                                      obs_dtype=dt, device=dev)
+        acts = torch.randint(0, 6, (16, n, 2), dtype=torch.uint8, device=dev)
+        for i in range(20):
+            env.step(acts[i % 16])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(iters):
+            env.step(acts[i % 16])
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        out[name] = {"value": n * iters / wall, "unit": "env steps/s", "us_per_batched_step": wall / iters * 1e6}
+    out["note"] = "per batched step: 6 kernels (step, potential, shape_rewards, reset[mask], encode) + 1 copy, driven from Python"
+    return out
 
 
 def bench_encode(dev, torch, VecOvercookedEnv, iters=200):

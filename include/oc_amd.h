@@ -224,6 +224,36 @@ int oc_featurize(const OcBatch* batch, const uint8_t* d_plan_blob, const uint32_
                  float* d_features, int num_pots, void* stream);
 
 /*
+ * oc_shape_rewards — the per-agent training reward of the RLlib environment.
+ * Replaces the reward arithmetic of OvercookedMultiAgent.step (human_aware_rl/rllib/rllib.py:306-329):
+ *      out[e][i] = (sparse0 + sparse1) + reward_shaping_factor * dense_i
+ * with dense_i = phi_next[e] - phi_cur[e] for both agents when d_phi_next != NULL (use_phi), else the shaped
+ * reward of agent i from d_rewards.  float64, like the reference's Python floats.
+ *   d_rewards [n_envs][4], d_flags [n_envs]   as written by oc_step
+ *   d_phi_next [n_envs] phi(s') (oc_potential after the step, before any reset), or NULL
+ *   d_phi_cur  [n_envs] in: phi(s); out: the potential of the state the next step starts from — phi(s'), or
+ *              d_phi_start[layout] where the episode is done (the caller resets those envs with d_done as the mask)
+ *   d_phi_start [n_layouts] potential of each layout's standard start state
+ *   d_out  [n_envs][2] float64, 16-byte aligned;  d_done [n_envs] 1 where OC_F_DONE is set, or NULL
+ */
+int oc_shape_rewards(const OcBatch* batch, const float* d_rewards, const uint8_t* d_flags, const double* d_phi_next,
+                     double* d_phi_cur, const double* d_phi_start, double reward_shaping_factor, double* d_out,
+                     uint8_t* d_done, void* stream);
+
+/*
+ * oc_multi_agent_step — one step of the RLlib training environment, enqueued by a single call.
+ * Replaces OvercookedMultiAgent.step (human_aware_rl/rllib/rllib.py:293-342) for a batch: oc_step (no auto-reset) ->
+ * oc_potential on s' (when d_phi_tables != NULL: use_phi) -> oc_shape_rewards -> copy of the episode returns ->
+ * oc_reset of the finished envs (mask = d_done) -> oc_encode_lossless of the states the next step starts from
+ * (when d_obs != NULL).  Arguments as in those entry points; d_done is required.
+ */
+int oc_multi_agent_step(const OcBatch* batch, void* d_state, const uint8_t* d_actions, float* d_rewards,
+                        uint8_t* d_flags, float* d_ep_returns, float* d_ep_returns_out, const uint8_t* d_plan_blob,
+                        const uint32_t* d_plan_off, const uint8_t* d_phi_tables, double* d_phi_next,
+                        double* d_phi_cur, const double* d_phi_start, double reward_shaping_factor, double* d_shaped,
+                        uint8_t* d_done, void* d_obs, int obs_dtype, int horizon, void* stream);
+
+/*
  * oc_reset_random — randomized start states drawn on the GPU.
  * Replaces the start_state_fn of OvercookedGridworld.get_random_start_state_fn(random_start_pos,
  * rnd_obj_prob_thresh) (mdp.py:1307-1369) as used by OvercookedEnv.reset (env.py:288-319) for training-time

@@ -656,7 +656,91 @@ def gen_potential():
         json.dump(out, f)
 
 
+MULTI_AGENT_CASES = [  # (fixture name, layout, horizon, OvercookedMultiAgent kwargs)
+    ("counter_circuit_phi", "counter_circuit", 60, dict(reward_shaping_factor=1.0, reward_shaping_horizon=0, use_phi=True)),
+    ("cramped_room_shaped_bc", "cramped_room", 120,
+     dict(reward_shaping_factor=0.7, reward_shaping_horizon=400, use_phi=False, bc_schedule=[(0, 0.6), (300, 0.2)])),
+    ("asymmetric_advantages_phi_anneal", "asymmetric_advantages", 50,
+     dict(reward_shaping_factor=0.5, reward_shaping_horizon=120, use_phi=True, bc_schedule=[(0, 0.3), (1000, 0.3)])),
+]
+
+
+def gen_multi_agent():
+    """OvercookedMultiAgent (human_aware_rl/rllib/rllib.py:112-438), the RLlib training environment: agent-role
+    assignment, observations per agent type, rewards sparse + factor * (phi' - phi | shaped), annealing.  Five
+    seeded episodes per case, actions from an independent generator."""
+    import types
+    P = _planner_modules()
+    rl = ref_harness.load_rllib()
+    planners = {}
+
+    def planner(env):
+        key = env.mdp.layout_name
+        if key not in planners:
+            planners[key] = _quiet(P.MotionPlanner, env.mdp, [])
+        return planners[key]
+
+    # the env's lazily built planners (env.py:92-115) would be pickled into the reference tree and, for the MLAM, take
+    # minutes; featurize_state / potential_function only ever use the motion planner
+    R.env_module.OvercookedEnv.mp = property(lambda self: planner(self))
+    R.env_module.OvercookedEnv.mlam = property(lambda self: types.SimpleNamespace(motion_planner=planner(self)))
+    out = {}
+    for name, lname, horizon, kw in MULTI_AGENT_CASES:
+        spec, mdp = make_ref_mdp(lname, {})
+        activate(mdp)
+        base_env = R.OvercookedEnv.from_mdp(mdp, horizon=horizon, info_level=0)
+        np.random.seed(2024)
+        kw = {k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()}
+        env = rl.OvercookedMultiAgent(base_env, **kw)
+        arng = np.random.default_rng(99)
+        eps, total = [], 0
+        for ep in range(5):
+            obs = env.reset()
+            agents = list(env.curr_agents)
+            rec = {"agents": agents, "obs0": [obs[a].tolist() for a in agents], "steps": []}
+            done = False
+            while not done:
+                a = [int(x) for x in arng.choice(6, size=2, p=[0.15, 0.15, 0.15, 0.15, 0.05, 0.35])]
+                obs, rew, dones, infos = env.step({agents[0]: a[0], agents[1]: a[1]})
+                done = dones["__all__"]
+                info = infos[agents[0]]
+                total += 1
+                rec["steps"].append({"actions": a, "rewards": [float(rew[x]) for x in agents], "done": bool(done),
+                                     "obs": [obs[x].tolist() for x in agents],
+                                     "phi_s": info.get("phi_s"), "phi_s_prime": info.get("phi_s_prime"),
+                                     "factor": float(env.reward_shaping_factor), "bc_factor": float(env.bc_factor)})
+                if total % 7 == 0:
+                    env.anneal_reward_shaping_factor(total)
+                    env.anneal_bc_factor(total)
+            rec["ep_sparse_r"] = float(info["episode"]["ep_sparse_r"])
+            rec["ep_shaped_r"] = float(info["episode"]["ep_shaped_r"])
+            eps.append(rec)
+        # observations go to a compressed npz (small integers, mostly zero); everything else to the JSON manifest
+        rows = []
+        for rec in eps:
+            rows.append(rec.pop("obs0"))
+            for st_ in rec["steps"]:
+                rows.append(st_.pop("obs"))
+        width = max(np.asarray(o).size for r in rows for o in r)
+        arr = np.zeros((len(rows), 2, width), np.float32)
+        lens = np.zeros((len(rows), 2), np.int32)
+        for i, r in enumerate(rows):
+            for j, o in enumerate(r):
+                flat = np.asarray(o, np.float32).ravel()
+                arr[i, j, :flat.size] = flat
+                lens[i, j] = flat.size
+        assert np.array_equal(arr, arr.astype(np.int16))
+        np.savez_compressed(os.path.join(GOLDEN, "multi_agent_%s.npz" % name), obs=arr.astype(np.int16), obs_len=lens)
+        out[name] = {"layout": spec.to_layout_dict(), "horizon": horizon, "kwargs": kw, "episodes": eps}
+        print("multi agent", name, [e["agents"] for e in eps], [e["ep_shaped_r"] for e in eps])
+    with open(os.path.join(GOLDEN, "multi_agent.json"), "w") as f:
+        json.dump(out, f)
+
+
 def main():
+    if "--multi-agent-only" in sys.argv:
+        gen_multi_agent()
+        return
     if "--potential-only" in sys.argv:
         gen_potential()
         return
@@ -696,6 +780,7 @@ def main():
     gen_random_starts()
     gen_featurize()
     gen_potential()
+    gen_multi_agent()
     with open(os.path.join(GOLDEN, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
     print("done")

@@ -82,3 +82,48 @@ def load():
         EVENT_TYPES=m.EVENT_TYPES,
     )
     return ns
+
+
+def load_rllib():
+    """The reference's RLlib environment class (human_aware_rl/rllib/rllib.py) with `ray` and `gym` stubbed out —
+    only OvercookedMultiAgent (a plain class once MultiAgentEnv is `object`) is used, for fixture generation."""
+    import numpy as np
+
+    load()
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    if "human_aware_rl.rllib.rllib" not in sys.modules:
+        class Discrete:
+            def __init__(self, n):
+                self.n = n
+
+            def contains(self, a):
+                return isinstance(a, (int, np.integer)) and 0 <= int(a) < self.n
+
+        class Box:
+            def __init__(self, low, high, dtype=None):
+                self.low, self.high, self.dtype, self.shape = low, high, dtype, low.shape
+
+        class Dict(dict):
+            def __init__(self, d):
+                super().__init__(d)
+
+        gym = stub("gym")
+        gym.spaces = stub("gym.spaces", Discrete=Discrete, Box=Box, Dict=Dict)
+        stub("ray")
+        for name, attrs in (("ray.rllib", {}), ("ray.rllib.agents", {}), ("ray.rllib.agents.ppo", {"PPOTrainer": object}),
+                            ("ray.rllib.algorithms", {}), ("ray.rllib.algorithms.callbacks", {"DefaultCallbacks": object}),
+                            ("ray.rllib.env", {}), ("ray.rllib.env.multi_agent_env", {"MultiAgentEnv": object}),
+                            ("ray.rllib.models", {"ModelCatalog": object}), ("ray.tune", {}),
+                            ("ray.tune.logger", {"UnifiedLogger": object}),
+                            ("ray.tune.registry", {"register_env": lambda *a, **k: None}),
+                            ("ray.tune.result", {"DEFAULT_RESULTS_DIR": "/tmp"})):
+            stub(name, **attrs)
+    from human_aware_rl.rllib import rllib
+
+    return rllib

@@ -17,7 +17,7 @@ OBS_U8, OBS_F32 = 0, 1
 
 EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_step", "oc_step_many",
            "oc_rollout_random",
-           "oc_encode_lossless", "oc_featurize", "oc_potential", "oc_phi_table_size", "oc_reset", "oc_reset_random")
+           "oc_encode_lossless", "oc_featurize", "oc_potential", "oc_phi_table_size", "oc_reset", "oc_reset_random", "oc_shape_rewards", "oc_multi_agent_step")
 
 
 class OcBatch(ctypes.Structure):
@@ -77,6 +77,10 @@ def load():
     L.oc_potential.restype = i32
     L.oc_potential.argtypes = [bp, vp, vp, vp, vp, vp, vp]
     L.oc_phi_table_size.restype = i32
+    L.oc_multi_agent_step.restype = i32
+    L.oc_multi_agent_step.argtypes = [bp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_double, vp, vp, vp, i32, i32, vp]
+    L.oc_shape_rewards.restype = i32
+    L.oc_shape_rewards.argtypes = [bp, vp, vp, vp, vp, vp, ctypes.c_double, vp, vp, vp]
     L.oc_reset_random.restype = i32
     L.oc_reset_random.argtypes = [bp, vp, vp, vp, u64, i64, u32, i32, ctypes.c_double, vp]
     L.oc_reset.restype = i32

@@ -2271,6 +2271,36 @@ __global__ __launch_bounds__(BLOCK) void k_potential2(const OcLayout* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// k_shape_rewards: the per-agent training reward of the RLlib environment (OvercookedMultiAgent.step,
+// human_aware_rl/rllib/rllib.py:293-342): sparse_reward + reward_shaping_factor * dense_reward[i], with
+// sparse_reward = sum of both agents' sparse rewards (env.py:273) and dense = phi(s') - phi(s) for both agents
+// (use_phi) or shaped_r_by_agent.  float64 like the reference's Python floats.  It also carries phi forward
+// (phi(s) of the next step = phi(s'), or the start state's potential where the episode ended) and emits the done
+// byte mask that oc_reset takes.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_shape_rewards(const float4* __restrict__ rewards,
+                                                         const uint8_t* __restrict__ flags,
+                                                         const uint16_t* __restrict__ layout_id,
+                                                         const double* __restrict__ phi_next, double* __restrict__ phi_cur,
+                                                         const double* __restrict__ phi_start, double factor,
+                                                         double* __restrict__ out, uint8_t* __restrict__ done, int64_t n) {
+#pragma clang fp contract(off)
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= n) return;
+    const float4 r = rewards[e];
+    const double sparse = (double)r.x + (double)r.y;
+    const bool is_done = (flags[e] & OC_F_DONE) != 0;
+    double d0 = (double)r.z, d1 = (double)r.w;
+    if (phi_next) {
+        const double pn = phi_next[e], pc = phi_cur[e];
+        d0 = d1 = pn - pc;
+        phi_cur[e] = is_done ? phi_start[layout_id ? layout_id[e] : 0] : pn;
+    }
+    reinterpret_cast<double2*>(out)[e] = make_double2(sparse + factor * d0, sparse + factor * d1);
+    if (done) done[e] = is_done ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 int fail(int code, const char* msg) {
@@ -2510,6 +2540,20 @@ int oc_featurize(const OcBatch* b, const uint8_t* d_plan_blob, const uint32_t* d
 
 int oc_phi_table_size(void) { return PHI_BYTES; }
 
+int oc_shape_rewards(const OcBatch* b, const float* d_rewards, const uint8_t* d_flags, const double* d_phi_next,
+                     double* d_phi_cur, const double* d_phi_start, double reward_shaping_factor, double* d_out,
+                     uint8_t* d_done, void* stream) {
+    if (!b) return fail(OC_EINVAL, "batch is NULL");
+    if (!d_rewards || !d_flags || !d_out) return fail(OC_EINVAL, "oc_shape_rewards: NULL rewards/flags/out pointer");
+    if (d_phi_next && (!d_phi_cur || !d_phi_start)) return fail(OC_EINVAL, "oc_shape_rewards: phi_next needs phi_cur and phi_start");
+    if (((uintptr_t)d_out & 15u) != 0) return fail(OC_EINVAL, "oc_shape_rewards: d_out must be 16-byte aligned");
+    if (b->n_envs == 0) return OC_OK;
+    hipLaunchKernelGGL(k_shape_rewards, dim3(grid_for(b->n_envs)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       (const float4*)d_rewards, d_flags, b->n_layouts > 1 ? b->d_layout_id : nullptr, d_phi_next, d_phi_cur,
+                       d_phi_start, reward_shaping_factor, d_out, d_done, b->n_envs);
+    return check_launch("oc_shape_rewards");
+}
+
 int oc_potential(const OcBatch* b, const uint8_t* d_plan_blob, const uint32_t* d_plan_off, const uint8_t* d_phi_tables,
                  const void* d_state, double* d_phi, void* stream) {
     int n_obj = 0;
@@ -2540,6 +2584,31 @@ int oc_reset(const OcBatch* b, void* d_state, const uint8_t* d_mask, float* d_ep
                            (uint4*)d_state, d_mask, (float4*)d_ep_returns, b->n_envs);
     });
     return check_launch("oc_reset");
+}
+
+int oc_reset(const OcBatch* b, void* d_state, const uint8_t* d_mask, float* d_ep_returns, void* stream);
+
+int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
+                        float* d_ep_returns, float* d_ep_returns_out, const uint8_t* d_plan_blob,
+                        const uint32_t* d_plan_off, const uint8_t* d_phi_tables, double* d_phi_next, double* d_phi_cur,
+                        const double* d_phi_start, double reward_shaping_factor, double* d_shaped, uint8_t* d_done,
+                        void* d_obs, int obs_dtype, int horizon, void* stream) {
+    if (!d_done) return fail(OC_EINVAL, "oc_multi_agent_step: d_done is required (it is the reset mask)");
+    if (int rc = oc_step(b, d_state, d_state, d_actions, d_rewards, d_flags, d_ep_returns, nullptr, horizon, 0u, stream)) return rc;
+    if (d_phi_tables) {
+        if (int rc = oc_potential(b, d_plan_blob, d_plan_off, d_phi_tables, d_state, d_phi_next, stream)) return rc;
+    }
+    if (int rc = oc_shape_rewards(b, d_rewards, d_flags, d_phi_tables ? d_phi_next : nullptr, d_phi_cur, d_phi_start,
+                                  reward_shaping_factor, d_shaped, d_done, stream))
+        return rc;
+    if (d_ep_returns && d_ep_returns_out && b->n_envs > 0) {
+        if (hipMemcpyAsync(d_ep_returns_out, d_ep_returns, (size_t)b->n_envs * 4 * sizeof(float), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream) != hipSuccess)
+            return fail(OC_ELAUNCH, "oc_multi_agent_step: copy of the episode returns failed");
+    }
+    if (int rc = oc_reset(b, d_state, d_done, d_ep_returns, stream)) return rc;
+    if (d_obs) return oc_encode_lossless(b, d_state, d_obs, obs_dtype, horizon, stream);
+    return OC_OK;
 }
 
 int oc_reset_random(const OcBatch* b, void* d_state, const uint8_t* d_mask, float* d_ep_returns, uint64_t seed,
