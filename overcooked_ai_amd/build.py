@@ -26,7 +26,9 @@ def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in (SRC, HDR))
+    csrc = os.path.dirname(SRC)
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [HDR]
+    return any(os.path.getmtime(p) > t for p in deps if os.path.exists(p))
 
 
 def build_extension(force=False, verbose=False):

@@ -1,0 +1,115 @@
+// reset.hpp — start states: k_reset, k_reset_random
+// Part of liboc_amd.so: included by oc_amd.hip inside its anonymous namespace, in this order:
+//   common, step_predicate, step_table, rollout_pair, reset, encode, featurize, potential, shaping.
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// k_reset
+// ------------------------------------------------------------------------------------------
+template <int NOBJ>
+__global__ __launch_bounds__(BLOCK) void k_reset(const OcLayout* __restrict__ g_layouts,
+                                                 const uint16_t* __restrict__ layout_id, uint4* st,
+                                                 const uint8_t* __restrict__ mask, float4* __restrict__ ep_returns,
+                                                 int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= n) return;
+    if (mask && !mask[e]) return;
+    const uint32_t lid = layout_id ? layout_id[e] : 0u;
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(g_layouts) + (size_t)lid * 256u;
+    const uint32_t pos0 = base[L_START_POS], pos1 = base[L_START_POS + 1];
+    const uint32_t or0 = base[L_START_OR], or1 = pos1 == 0xFFu ? 0u : base[L_START_OR + 1];
+    st[e] = make_uint4(pos0 | (or0 << 8) | (pos1 << 24), or1, 0u, 0u);
+    const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int p = 0; p < NOBJ; ++p) st[(int64_t)(1 + p) * n + e] = z;
+    if (ep_returns) ep_returns[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_reset_random: get_random_start_state_fn (mdp.py:1307-1369) drawn in-kernel.  Same distribution as the reference
+// — joint player positions uniform over ordered tuples of distinct free cells (when random_start_pos), every pot
+// non-empty with probability thresh (1..3 onions, then 0..3-n tomatoes, cooking from tick 0 with probability thresh,
+// else idle), every player holding something with probability thresh (dish 0.2 / onion 0.6 / finished soup 0.2 with
+// the same ingredient draw) — but from this library's own counter-based stream instead of numpy's global
+// generator: block b of env g at reset epoch ep is philox4x32_10({ep, g_lo, g_hi, b}, {seed_lo, seed_hi ^ "RST!"});
+// block 0 word 0 picks the joint position, block 1 + i = player i {p, kind, n, m}, block 3 + k = pot k {p, n, m, q}.
+// Integer maps: "u < thresh" is word < floor(thresh * 2^32); randint(lo, hi) is lo + mulhi(word, hi - lo).
+// oracle_reset_random restates it; overcooked_ai_amd.mdp.get_random_start_state_fn keeps the numpy-exact host path.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t RESET_KEY_TWEAK = 0x52535421u;  // "RST!"
+
+__global__ __launch_bounds__(BLOCK) void k_reset_random(const OcLayout* __restrict__ g_layouts,
+                                                        const uint16_t* __restrict__ layout_id, uint4* st,
+                                                        const uint8_t* __restrict__ mask,
+                                                        float4* __restrict__ ep_returns, int64_t n, int n_obj,
+                                                        uint32_t seed_lo, uint32_t seed_hi, int64_t env_offset,
+                                                        uint32_t epoch, int random_start_pos, uint64_t thresh) {
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= n) return;
+    if (mask && !mask[e]) return;
+    const uint32_t lid = layout_id ? layout_id[e] : 0u;
+    const Lay L{reinterpret_cast<const uint8_t*>(g_layouts) + (size_t)lid * 256u};
+    const uint64_t g = (uint64_t)(env_offset + e);
+    const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
+    const uint32_t k1 = seed_hi ^ RESET_KEY_TWEAK;
+    const uint32_t cells = L.u8(L_NCELLS), np = L.n_players();
+    uint32_t r[4];
+    uint32_t pos0 = L.u8(L_START_POS), pos1 = L.u8(L_START_POS + 1);
+    if (random_start_pos) {
+        uint32_t n_floor = 0;
+        for (uint32_t c = 0; c < cells; ++c) n_floor += (L.terrain(c) & 7u) == OC_T_FLOOR ? 1u : 0u;
+        philox4x32_10(epoch, g_lo, g_hi, 0u, seed_lo, k1, r);
+        // index into itertools.product(valid, repeat=n_players) without overlaps (mdp.py:1736-1747), row-major
+        const uint32_t n_joint = np == 2u ? n_floor * (n_floor - 1u) : n_floor;
+        const uint32_t idx = __umulhi(r[0], n_joint);
+        uint32_t a = idx, b = 0xFFFFFFFFu;
+        if (np == 2u) {
+            a = idx / (n_floor - 1u);
+            b = idx - a * (n_floor - 1u);
+            b += b >= a ? 1u : 0u;
+        }
+        uint32_t seen = 0;
+        for (uint32_t c = 0; c < cells; ++c) {
+            if ((L.terrain(c) & 7u) != OC_T_FLOOR) continue;
+            if (seen == a) pos0 = c;
+            if (seen == b) pos1 = c;
+            ++seen;
+        }
+    }
+    uint32_t held[2] = {0u, 0u};
+    uint32_t ticks[2] = {0u, 0u};  // header bytes 8..15
+    uint8_t pot_obj[OC_MAX_POTS];
+    const uint32_t n_pots = L.n_pots();
+    for (uint32_t k = 0; k < (uint32_t)OC_MAX_POTS; ++k) pot_obj[k] = 0;
+    auto soup_code = [](uint32_t n_on, uint32_t n_to) {  // onions first, then tomatoes (SoupState.get_soup, mdp.py:664-693)
+        return OC_O_SOUP | ((n_on + n_to) << 3) | (((1u << n_to) - 1u) << n_on);
+    };
+    if (thresh != 0ull) {
+        for (uint32_t i = 0; i < np; ++i) {
+            philox4x32_10(epoch, g_lo, g_hi, 1u + i, seed_lo, k1, r);
+            if ((uint64_t)r[0] < thresh) {
+                const uint32_t n_on = 1u + __umulhi(r[2], 3u), n_to = __umulhi(r[3], 4u - n_on);
+                held[i] = r[1] < 858993459u ? (uint32_t)OC_O_DISH : r[1] < 3435973836u ? (uint32_t)OC_O_ONION : soup_code(n_on, n_to);
+            }
+        }
+        for (uint32_t k = 0; k < n_pots; ++k) {
+            philox4x32_10(epoch, g_lo, g_hi, 3u + k, seed_lo, k1, r);
+            if ((uint64_t)r[0] < thresh) {
+                const uint32_t n_on = 1u + __umulhi(r[1], 3u), n_to = __umulhi(r[2], 4u - n_on);
+                pot_obj[k] = (uint8_t)soup_code(n_on, n_to);
+                if ((uint64_t)r[3] < thresh) ticks[k >> 2] |= 1u << (8u * (k & 3u));  // cooking_tick 0 -> stored 1
+            }
+        }
+    }
+    if (np < 2u) pos1 = 0xFFu;
+    st[e] = make_uint4(pos0 | (held[0] << 16) | (pos1 << 24), np == 2u ? (held[1] << 8) : 0u, ticks[0], ticks[1]);
+    for (int p = 0; p < n_obj; ++p) {
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        for (uint32_t k = 0; k < n_pots; ++k) {
+            const uint32_t c = L.pot_cell((int)k);
+            if ((int)(c >> 4) == p) w[(c >> 2) & 3u] |= (uint32_t)pot_obj[k] << (8u * (c & 3u));
+        }
+        st[(int64_t)(1 + p) * n + e] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    if (ep_returns) ep_returns[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
