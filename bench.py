@@ -309,8 +309,8 @@ def bench_step_api(env, dev, torch, iters=2000):
 
 
 def bench_training_env(dev, torch, iters=300):
-    """The RLlib-shaped training environment (VecOvercookedMultiAgent.step: oc_step + oc_potential + oc_shape_rewards +
-    masked oc_reset + oc_encode_lossless, use_phi, caller-supplied actions) on 65 536 cramped_room envs."""
+    """The RLlib-shaped training environment (VecOvercookedMultiAgent.step = oc_multi_agent_step: step, phi(s'),
+    shaped rewards, restart of finished envs, observation; use_phi, caller-supplied actions) on 65 536 cramped_room envs."""
     from overcooked_ai_amd.multi_agent import VecOvercookedMultiAgent
 
     n = N_ENVS_PER_GPU
@@ -328,7 +328,7 @@ def bench_training_env(dev, torch, iters=300):
         torch.cuda.synchronize(dev)
         wall = time.perf_counter() - t0
         out[name] = {"value": n * iters / wall, "unit": "env steps/s", "us_per_batched_step": wall / iters * 1e6}
-    out["note"] = "per batched step: 6 kernels (step, potential, shape_rewards, reset[mask], encode) + 1 copy, driven from Python"
+    out["note"] = "per batched step: one oc_multi_agent_step call = k_train_step (step + phi + shaped rewards + restart, fused) + k_encode"
     return out
 
 

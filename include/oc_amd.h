@@ -245,7 +245,8 @@ int oc_shape_rewards(const OcBatch* batch, const float* d_rewards, const uint8_t
  * Replaces OvercookedMultiAgent.step (human_aware_rl/rllib/rllib.py:293-342) for a batch: oc_step (no auto-reset) ->
  * oc_potential on s' (when d_phi_tables != NULL: use_phi) -> oc_shape_rewards -> copy of the episode returns ->
  * oc_reset of the finished envs (mask = d_done) -> oc_encode_lossless of the states the next step starts from
- * (when d_obs != NULL).  Arguments as in those entry points; d_done is required.
+ * (when d_obs != NULL).  Arguments as in those entry points; d_done is required.  Two-player tables with at most two
+ * pots run everything before the encoding as one kernel (k_train_step) with identical results.
  */
 int oc_multi_agent_step(const OcBatch* batch, void* d_state, const uint8_t* d_actions, float* d_rewards,
                         uint8_t* d_flags, float* d_ep_returns, float* d_ep_returns_out, const uint8_t* d_plan_blob,

@@ -334,6 +334,45 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
                         const double* d_phi_start, double reward_shaping_factor, double* d_shaped, uint8_t* d_done,
                         void* d_obs, int obs_dtype, int horizon, void* stream) {
     if (!d_done) return fail(OC_EINVAL, "oc_multi_agent_step: d_done is required (it is the reset mask)");
+    {
+        int n_obj = 0;
+        if (int rc = check_batch(b, &n_obj)) return rc;
+        const bool fused = b->max_pots >= 1 && b->max_pots <= 2 && (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0;
+        if (fused) {  // the whole step in one kernel (k_train_step), then the observation
+            if (!d_state || !d_actions || !d_rewards || !d_flags || !d_shaped)
+                return fail(OC_EINVAL, "oc_multi_agent_step: NULL state/actions/rewards/flags/shaped pointer");
+            if (d_phi_tables && (!d_plan_blob || !d_plan_off || !d_phi_next || !d_phi_cur || !d_phi_start))
+                return fail(OC_EINVAL, "oc_multi_agent_step: use_phi needs the plan tables and the three phi buffers");
+            if (horizon < 1 || horizon > 65535) return fail(OC_EINVAL, "oc_multi_agent_step: horizon must be in 1..65535");
+            if (((uintptr_t)d_shaped & 15u) != 0) return fail(OC_EINVAL, "oc_multi_agent_step: d_shaped must be 16-byte aligned");
+            if (b->n_envs > 0) {
+                const bool uniform = b->n_layouts == 1, lds = b->n_layouts <= LDS_LAYOUT_MAX;
+                const bool fast = b->width * b->height <= 64;
+                const size_t smem = (size_t)n_obj * 16 * BLOCK * sizeof(uint16_t);
+                const dim3 grid(grid_for(b->n_envs)), block(BLOCK);
+#define GOT(U, MP, LL, F)                                                                                             \
+    do {                                                                                                              \
+        if (smem > 40 * 1024)                                                                                         \
+            (void)hipFuncSetAttribute((const void*)k_train_step<U, MP, LL, F>,                                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                         \
+        hipLaunchKernelGGL((k_train_step<U, MP, LL, F>), grid, block, smem, (hipStream_t)stream, b->d_layouts,        \
+                           b->n_layouts, b->d_layout_id, (uint4*)d_state, d_actions, (float4*)d_rewards, d_flags,     \
+                           (float4*)d_ep_returns, (float4*)d_ep_returns_out, d_plan_blob, d_plan_off, d_phi_tables,   \
+                           d_phi_next, d_phi_cur, d_phi_start, reward_shaping_factor, d_shaped, d_done, b->n_envs,    \
+                           b->width, b->height, n_obj, horizon);                                                      \
+    } while (0)
+                if (uniform && fast && b->max_pots == 1) GOT(true, 1, true, true);
+                else if (uniform && fast) GOT(true, 2, true, true);
+                else if (uniform) GOT(true, 2, true, false);
+                else if (lds) GOT(false, 2, true, false);
+                else GOT(false, 2, false, false);
+#undef GOT
+                if (int rc = check_launch("oc_multi_agent_step")) return rc;
+            }
+            if (d_obs) return oc_encode_lossless(b, d_state, d_obs, obs_dtype, horizon, stream);
+            return OC_OK;
+        }
+    }
     if (int rc = oc_step(b, d_state, d_state, d_actions, d_rewards, d_flags, d_ep_returns, nullptr, horizon, 0u, stream)) return rc;
     if (d_phi_tables) {
         if (int rc = oc_potential(b, d_plan_blob, d_plan_off, d_phi_tables, d_state, d_phi_next, stream)) return rc;

@@ -254,33 +254,23 @@ __global__ __launch_bounds__(BLOCK) void k_potential(const OcLayout* __restrict_
 // order, stable-sorted by the value of their best completion) have at most two entries, so they are kept as
 // (first, second) pairs in registers and the matching loops are straight-line code; the set order of two partially
 // full pots is precomputed per layout on the host (two bits in the record: which pot comes out first for either
-// insertion order).  All motion costs are fetched up front so that their latencies overlap.
-__global__ __launch_bounds__(BLOCK) void k_potential2(const OcLayout* __restrict__ g_layouts,
-                                                      const uint16_t* __restrict__ layout_id,
-                                                      const uint8_t* __restrict__ plan_blob,
-                                                      const uint32_t* __restrict__ plan_off,
-                                                      const uint8_t* __restrict__ phi_tables,
-                                                      const uint4* __restrict__ st, double* __restrict__ out, int64_t n,
-                                                      int W, int H) {
+// insertion order).  All motion costs are fetched up front so that their latencies overlap.  potential2_core works
+// from registers so that the fused training step (shaping.hpp) can call it on the state it has just computed.
+// phi of one env whose dynamic state is already in registers: the players (cell, orientation, held; n_players = 1 or
+// 2), the object byte and tick byte (cooking_tick + 1) of the first two pot slots.
+__device__ __forceinline__ double potential2_core(const Lay L, const Phi T, const uint8_t* __restrict__ plan,
+                                                  uint32_t cells, uint32_t np, uint32_t pos0, uint32_t or0, uint32_t held0,
+                                                  uint32_t pos1, uint32_t or1, uint32_t held1_in, uint32_t oA, uint32_t oB,
+                                                  uint32_t tkA, uint32_t tkB) {
 #pragma clang fp contract(off)
-    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= n) return;
-    const uint32_t lid = layout_id ? layout_id[e] : 0u;
-    const Lay L{reinterpret_cast<const uint8_t*>(g_layouts + lid)};
-    const Phi T{phi_tables + (size_t)lid * PHI_BYTES};
-    const uint8_t* plan = plan_blob + plan_off[lid];
-    const uint32_t cells = (uint32_t)(W * H), row_stride = (cells + 15u) & ~15u;
-    const uint4 hw = st[e];
-    const uint32_t np = (hw.x >> 24) == 0xFFu ? 1u : 2u;
-    const uint32_t held0 = (hw.x >> 16) & 0xFFu, held1 = np > 1u ? (hw.y >> 8) & 0xFFu : 0xFFu;
-    const uint8_t* row0 = plan + 128 + ((uint32_t)plan[hw.x & 0xFFu] * 4u + ((hw.x >> 8) & 0xFFu)) * row_stride;
-    const uint8_t* row1 = np > 1u ? plan + 128 + ((uint32_t)plan[hw.x >> 24] * 4u + (hw.y & 0xFFu)) * row_stride : row0;
+    const uint32_t row_stride = (cells + 15u) & ~15u;
+    const uint32_t held1 = np > 1u ? held1_in : 0xFFu;
+    const uint8_t* row0 = plan + 128 + ((uint32_t)plan[pos0] * 4u + or0) * row_stride;
+    const uint8_t* row1 = np > 1u ? plan + 128 + ((uint32_t)plan[pos1] * 4u + or1) * row_stride : row0;
     const uint32_t n_pots = L.n_pots();
     const uint32_t cellA = L.pot_cell(0), cellB = n_pots > 1u ? L.pot_cell(1) : cellA;
     // everything that comes from memory, issued together
     const uint32_t rA0 = row0[cellA], rA1 = row1[cellA], rB0 = row0[cellB], rB1 = row1[cellB];
-    const uint32_t oA = reinterpret_cast<const uint8_t*>(st + (int64_t)(1 + (cellA >> 4)) * n + e)[cellA & 15u];
-    const uint32_t oB = reinterpret_cast<const uint8_t*>(st + (int64_t)(1 + (cellB >> 4)) * n + e)[cellB & 15u];
     uint32_t serve0 = 255u, serve1 = 255u;  // min over the serving cells (255 = unreachable stays the maximum)
     for (uint32_t c = 0; c < cells; ++c)
         if ((L.terrain(c) & 7u) == OC_T_SERVE) { serve0 = min(serve0, (uint32_t)row0[c]); serve1 = min(serve1, (uint32_t)row1[c]); }
@@ -300,8 +290,8 @@ __global__ __launch_bounds__(BLOCK) void k_potential2(const OcLayout* __restrict
         return cls;
     };
     uint32_t key[2], rem[2], cls[2];
-    cls[0] = classify(oA, hw.z & 0xFFu, key[0], rem[0]);
-    cls[1] = classify(oB, (hw.z >> 8) & 0xFFu, key[1], rem[1]);
+    cls[0] = classify(oA, tkA, key[0], rem[0]);
+    cls[1] = classify(oB, tkB, key[1], rem[1]);
     if (n_pots < 2u) cls[1] = ABSENT;
     auto pcost = [&](uint32_t p, uint32_t k) { return k == 0u ? cA[p] : cB[p]; };
 
@@ -404,5 +394,27 @@ __global__ __launch_bounds__(BLOCK) void k_potential2(const OcLayout* __restrict
             phi = __dadd_rn(phi, __dmul_rn(disc, pass == 0u ? T.tomato_value() : T.onion_value()));
         }
     }
-    out[e] = phi;
+    return phi;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_potential2(const OcLayout* __restrict__ g_layouts,
+                                                      const uint16_t* __restrict__ layout_id,
+                                                      const uint8_t* __restrict__ plan_blob,
+                                                      const uint32_t* __restrict__ plan_off,
+                                                      const uint8_t* __restrict__ phi_tables,
+                                                      const uint4* __restrict__ st, double* __restrict__ out, int64_t n,
+                                                      int W, int H) {
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= n) return;
+    const uint32_t lid = layout_id ? layout_id[e] : 0u;
+    const Lay L{reinterpret_cast<const uint8_t*>(g_layouts + lid)};
+    const Phi T{phi_tables + (size_t)lid * PHI_BYTES};
+    const uint4 hw = st[e];
+    const uint32_t np = (hw.x >> 24) == 0xFFu ? 1u : 2u;
+    const uint32_t cellA = L.pot_cell(0), cellB = L.n_pots() > 1u ? L.pot_cell(1) : cellA;
+    const uint32_t oA = reinterpret_cast<const uint8_t*>(st + (int64_t)(1 + (cellA >> 4)) * n + e)[cellA & 15u];
+    const uint32_t oB = reinterpret_cast<const uint8_t*>(st + (int64_t)(1 + (cellB >> 4)) * n + e)[cellB & 15u];
+    out[e] = potential2_core(L, T, plan_blob + plan_off[lid], (uint32_t)(W * H), np, hw.x & 0xFFu, (hw.x >> 8) & 0xFFu,
+                             (hw.x >> 16) & 0xFFu, np > 1u ? hw.x >> 24 : 0u, hw.y & 0xFFu, (hw.y >> 8) & 0xFFu, oA, oB,
+                             hw.z & 0xFFu, (hw.z >> 8) & 0xFFu);
 }

@@ -32,3 +32,73 @@ __global__ __launch_bounds__(BLOCK) void k_shape_rewards(const float4* __restric
     reinterpret_cast<double2*>(out)[e] = make_double2(sparse + factor * d0, sparse + factor * d1);
     if (done) done[e] = is_done ? 1 : 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// k_train_step: the whole batched step of the RLlib environment for two-player tables with at most two pots, in
+// one kernel: oc_step (table-driven, no auto-reset) -> phi(s') from the registers the step just produced
+// (potential2_core) -> the shaped rewards of k_shape_rewards -> restart of finished envs -> state written once.
+// Same outputs, bit for bit, as the sequence oc_step / oc_potential / oc_shape_rewards / copy / oc_reset that
+// oc_multi_agent_step enqueues for every other table (tests/test_gpu_parity.py compares the two).
+// ------------------------------------------------------------------------------------------
+template <bool UNIFORM, int MAXP, bool LAY_LDS, bool FAST>
+__global__ __launch_bounds__(BLOCK) void k_train_step(const OcLayout* __restrict__ g_layouts, int n_layouts,
+                                                      const uint16_t* __restrict__ layout_id, uint4* st,
+                                                      const uint8_t* __restrict__ actions, float4* __restrict__ rewards,
+                                                      uint8_t* __restrict__ flags, float4* __restrict__ ep_returns,
+                                                      float4* __restrict__ ep_out, const uint8_t* __restrict__ plan_blob,
+                                                      const uint32_t* __restrict__ plan_off,
+                                                      const uint8_t* __restrict__ phi_tables, double* __restrict__ phi_next,
+                                                      double* __restrict__ phi_cur, const double* __restrict__ phi_start,
+                                                      double factor, double* __restrict__ shaped, uint8_t* __restrict__ done,
+                                                      int64_t n, int W, int H, int n_obj, int horizon) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_cells3[];  // [n_obj * 16][BLOCK]
+    __shared__ uint4 s_lay[LAY_LDS ? LDS_LAYOUT_MAX * 16 : 1];
+    __shared__ uint2 s_lut[2 * LUT_ENTRIES];
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = e < n;
+    for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
+    const Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains the barrier
+    if (!active) return;
+    uint16_t* cells = s_cells3 + threadIdx.x;
+    const LayC C = load_consts<UNIFORM>(L);
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut) + (C.old_dyn ? LUT_ENTRIES * 8 : 0);
+    const uint32_t delta4 = make_delta4(W);
+    const uint32_t lid = layout_id ? layout_id[e] : 0u;
+    Env3<MAXP> s;
+    load_env3<MAXP>(C, L, st, n, e, n_obj, s, cells);
+    const uint32_t a01 = reinterpret_cast<const uint16_t*>(actions)[e];
+    const uint32_t a0 = a01 & 0xFFu, a1 = a01 >> 8;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t fl;
+    if (a0 > 5u || a1 > 5u) {
+        fl = OC_F_BAD_ACTION;  // the env stays untouched (mdp.py:1394-1398 raises)
+    } else {
+        env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, FAST ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull);
+        fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, 0u, r, ep);
+    }
+    const bool is_done = (fl & OC_F_DONE) != 0u;
+    const double sparse = (double)r.x + (double)r.y;
+    double d0 = (double)r.z, d1 = (double)r.w;
+    if (phi_tables) {
+        const Phi T{phi_tables + (size_t)lid * PHI_BYTES};
+        const double pn = potential2_core(L, T, plan_blob + plan_off[lid], (uint32_t)(W * H), 2u, s.pos0, s.or0, s.held0,
+                                          s.pos1, s.or1, s.held1, s.ps[0], MAXP > 1 ? s.ps[MAXP - 1] : 0u, s.tk[0],
+                                          MAXP > 1 ? s.tk[MAXP - 1] : 0u);
+        d0 = d1 = pn - phi_cur[e];
+        phi_next[e] = pn;
+        phi_cur[e] = is_done ? phi_start[lid] : pn;
+    }
+    reinterpret_cast<double2*>(shaped)[e] = make_double2(sparse + factor * d0, sparse + factor * d1);
+    done[e] = is_done ? 1 : 0;
+    if (ep_out) ep_out[e] = ep;
+    if (is_done) {
+        env_reset3<MAXP>(L, n_obj, s, cells);
+        ep = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    store_env3<MAXP>(C, L, st, n, e, n_obj, s, cells);
+    rewards[e] = r;
+    flags[e] = (uint8_t)fl;
+    if (ep_returns) ep_returns[e] = ep;
+}

@@ -638,3 +638,54 @@ def test_hip_graph_capture_of_step_and_encode(gpu):
         ref.encode_lossless(out=obs_ref)
         assert torch.equal(env.rewards, ref.rewards) and torch.equal(env.flags, ref.flags)
     assert torch.equal(env.state, ref.state) and torch.equal(obs, obs_ref) and torch.equal(env.ep_returns, ref.ep_returns)
+
+
+def test_fused_training_step_equals_the_kernel_sequence(gpu):
+    """oc_multi_agent_step runs k_train_step (one kernel) for two-player tables with <= 2 pots and the sequence
+    oc_step -> oc_potential -> oc_shape_rewards -> copy -> oc_reset otherwise; both must produce identical states,
+    rewards, flags, episode returns, potentials, shaped rewards and done masks, with and without use_phi, across
+    episode ends and illegal actions."""
+    from overcooked_ai_amd.layouts import LayoutSpec, LayoutTable, spec_from_name
+    from overcooked_ai_amd.multi_agent import VecOvercookedMultiAgent
+
+    seven = LayoutSpec({"grid": "XPPPPPX\nO 1 2 O\nX     X\nXDPSPTX", "onion_time": 3, "tomato_time": 5,
+                        "onion_value": 7, "tomato_value": 4})
+    cases = [("cramped_room", None), ("coordination_ring", None), ("corridor", None), ("counter_circuit", None),
+             (LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5)), 5), (seven, None)]
+    rng = np.random.default_rng(8)
+    for layouts, n_lay in cases:
+        for use_phi in (True, False):
+            n = 3000
+            lid = (np.arange(n) % n_lay).astype(np.uint16) if n_lay else None
+            env = VecOvercookedMultiAgent(layouts, n, horizon=23, reward_shaping_factor=0.37, use_phi=use_phi, device=gpu,
+                                          layout_id=lid, seed=1)
+            ref = VecOvercookedMultiAgent(layouts, n, horizon=23, reward_shaping_factor=0.37, use_phi=use_phi, device=gpu,
+                                          layout_id=lid, seed=1)
+            v = ref.venv
+            env.venv.reset(random_start_pos=True, rnd_obj_prob_thresh=0.5)
+            v.set_packed_state(env.venv.get_packed_state())
+            if use_phi:
+                env.phi_cur.copy_(env.venv.potential(0.99))
+                ref.phi_cur.copy_(env.phi_cur)
+            for t in range(60):
+                a = rng.integers(0, 6, size=(n, 2)).astype(np.uint8)
+                a[rng.integers(0, n, size=5), rng.integers(0, 2, size=5)] = 9  # illegal actions: env untouched, flagged
+                acts = torch.from_numpy(a).to(gpu)
+                env.step(acts)
+                # the same step through the separate entry points
+                rew, fl = v.step(acts)
+                if use_phi:
+                    v.potential(0.99, out=ref.phi_next)
+                rc = v.lib.oc_shape_rewards(v._bref, rew.data_ptr(), fl.data_ptr(), ref.phi_next.data_ptr() if use_phi else None,
+                                            ref.phi_cur.data_ptr(), ref.phi_start.data_ptr(), 0.37, ref.shaped.data_ptr(),
+                                            ref.done.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                assert rc == 0
+                ref.ep_returns.copy_(v.ep_returns)
+                v.reset(mask=ref.done)
+                for name, x, y in (("state", env.venv.state, v.state), ("rewards", env.venv.rewards, v.rewards),
+                                   ("flags", env.venv.flags, v.flags), ("ep", env.venv.ep_returns, v.ep_returns),
+                                   ("ep_out", env.ep_returns, ref.ep_returns), ("shaped", env.shaped, ref.shaped),
+                                   ("done", env.done, ref.done), ("phi_next", env.phi_next, ref.phi_next),
+                                   ("phi_cur", env.phi_cur, ref.phi_cur)):
+                    assert torch.equal(x, y), (getattr(layouts, "layout_name", layouts), use_phi, t, name)
+            assert int(env.done.sum()) >= 0 and (env.venv.flags & 2).any()
