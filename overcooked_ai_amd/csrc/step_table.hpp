@@ -90,7 +90,7 @@ struct IOut3 {
 };
 
 // one player's INTERACT through the table; `s_lut` = this lane's table variant in LDS, `c16` the faced cell word
-template <int MAXP>
+template <int MAXP, bool EAGER_VALUE = true>
 __device__ __forceinline__ IOut3 interact3(const Lay L, const uint8_t* s_lut, bool act, uint32_t h, uint32_t c16,
                                            const uint32_t (&ps)[MAXP], const uint32_t (&tkr)[MAXP],
                                            const uint32_t (&pcr)[MAXP]) {
@@ -126,8 +126,12 @@ __device__ __forceinline__ IOut3 interact3(const Lay L, const uint8_t* s_lut, bo
     r.ddelta = (int32_t)((ent.y >> 16) & 3u) - 1;
     r.slot = slot;
     r.cell_obj = (r.flags & LF_SWAP) ? r.new_o : o_cell;
-    const float value = L.value(recipe_idx(h) & 15u);  // unconditional read: keeps both players' look-ups in one block
-    r.sparse = (r.flags & LF_SERVE) ? value : 0.f;      // deliver_soup (mdp.py:1631-1642)
+    if (EAGER_VALUE) {
+        const float value = L.value(recipe_idx(h) & 15u);  // unconditional read: keeps both players' look-ups in one block
+        r.sparse = (r.flags & LF_SERVE) ? value : 0.f;      // deliver_soup (mdp.py:1631-1642)
+    } else {
+        r.sparse = 0.f;  // the caller looks the value up, and only when some lane of the wavefront delivers
+    }
     return r;
 }
 
@@ -184,8 +188,9 @@ __device__ __forceinline__ void step3_main(const LayC& C, const Lay L, const uin
     for (int k = 0; k < MAXP; ++k) useful_pots += ((s.pc[k] != PC_EMPTY) & (s.pc[k] != PC_IDLE3)) ? 1u : 0u;
 
     const bool act0 = a0 == OC_A_INTERACT, act1 = two & (a1 == OC_A_INTERACT);
-    const IOut3 r0 = interact3<MAXP>(L, s_lut, act0, s.held0, c_f0, s.ps, s.tk, s.pc);
-    IOut3 r1 = interact3<MAXP>(L, s_lut, act1, s.held1, c_f1, s.ps, s.tk, s.pc);
+    const uint32_t h0_before = s.held0, h1_before = s.held1;
+    const IOut3 r0 = interact3<MAXP, false>(L, s_lut, act0, s.held0, c_f0, s.ps, s.tk, s.pc);
+    IOut3 r1 = interact3<MAXP, false>(L, s_lut, act1, s.held1, c_f1, s.ps, s.tk, s.pc);
     // shaped rewards; is_dish_pickup_useful (mdp.py:2180-2204) sees the live hands / counters and the stale pots
     const bool du0 = two & (((s.held1 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (s.dcount == 0);
     const float sh0 = ((r0.flags & LF_PLACE) ? C.rew_place : 0.f) + ((r0.flags & LF_PLATE) ? C.rew_soup : 0.f) +
@@ -198,7 +203,7 @@ __device__ __forceinline__ void step3_main(const LayC& C, const Lay L, const uin
     const uint32_t c_f1_live = (same_cell & swap0) ? ((c_f1 & 0xFF00u) | r0.cell_obj) : c_f1;
     const bool conflict = act1 & ((same_cell & swap0) | (((r0.flags & LF_POT_UPD) != 0u) &
                                                           (((c_f1 >> 8) & 7u) == OC_T_POT) & ((c_f1 >> 11) == r0.slot)));
-    if (__builtin_expect(conflict, 0)) r1 = interact3<MAXP>(L, s_lut, act1, s.held1, c_f1_live, s.ps, s.tk, s.pc);
+    if (__builtin_expect(conflict, 0)) r1 = interact3<MAXP, false>(L, s_lut, act1, s.held1, c_f1_live, s.ps, s.tk, s.pc);
     const bool du1 = two & (((s.held0 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (s.dcount == 0);
     const float sh1 = ((r1.flags & LF_PLACE) ? C.rew_place : 0.f) + ((r1.flags & LF_PLATE) ? C.rew_soup : 0.f) +
                       ((((r1.flags & LF_TAKE_DISH) != 0u) & du1) ? C.rew_dish : 0.f);
@@ -207,7 +212,14 @@ __device__ __forceinline__ void step3_main(const LayC& C, const Lay L, const uin
     apply_pot3<MAXP>(s, r1);
     wr_obj3(cells, f0, r0.cell_obj);
     wr_obj3(cells, f1, (r1.flags & LF_SWAP) ? r1.cell_obj : (c_f1_live & 0xFFu));
-    r = make_float4(r0.sparse, r1.sparse, sh0, sh1);
+    // deliver_soup (mdp.py:1631-1642): deliveries are rare, so the recipe-value look-ups sit behind a wave-uniform branch
+    float sp0 = 0.f, sp1 = 0.f;
+    const bool serve0 = (r0.flags & LF_SERVE) != 0u, serve1 = (r1.flags & LF_SERVE) != 0u;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(serve0 | serve1) != 0ull, 0)) {
+        sp0 = serve0 ? L.value(recipe_idx(h0_before) & 15u) : 0.f;
+        sp1 = serve1 ? L.value(recipe_idx(h1_before) & 15u) : 0.f;
+    }
+    r = make_float4(sp0, sp1, sh0, sh1);
 
     // resolve_movement (mdp.py:1644-1727)
     const bool fl0 = FAST ? ((floor_mask >> q.m0) & 1ull) != 0ull : ((q.c_m0 >> 8) & 7u) == OC_T_FLOOR;
