@@ -349,7 +349,7 @@ __device__ __forceinline__ uint32_t finish_step3(const Lay L, int n_obj, uint16_
                                                  uint32_t options, const float4& r, float4& ep) {
     ep.x += r.x; ep.y += r.y; ep.z += r.z; ep.w += r.w;
     uint32_t fl = 0;
-    if ((int)s.t >= horizon) {
+    if (__builtin_expect((int)s.t >= horizon, 0)) {  // once per episode: keep the restart out of the straight-line path
         fl |= OC_F_DONE;
         if (options & OC_OPT_AUTO_RESET) {
             env_reset3<MAXP>(L, n_obj, s, cells);
@@ -407,6 +407,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
         uint64_t blk = (uint64_t)t0 >> 3;
         philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, rnd);
         uint32_t x = (s8 & 1u) ? rnd[s8 >> 1] * 36u : 0u;
+        float4* rew_k = rew_blk;  // wave-uniform row pointers, advanced by n per step
+        uint8_t* flg_k = flg_blk;
 #define OC_STEP(S8)                                                                                      \
     {                                                                                                    \
         if (((S8) & 1u) == 0u) x = rnd[(S8) >> 1];                                                       \
@@ -417,8 +419,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
         float4 r;                                                                                        \
         env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask);                       \
         const uint32_t fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);             \
-        if (rew_blk) (rew_blk + (int64_t)k * n)[threadIdx.x] = r;                                        \
-        if (flg_blk) (flg_blk + (int64_t)k * n)[threadIdx.x] = (uint8_t)fl;                              \
+        if (rew_k) { rew_k[threadIdx.x] = r; rew_k += n; }                                               \
+        if (flg_k) { flg_k[threadIdx.x] = (uint8_t)fl; flg_k += n; }                                     \
         if (++k == n_steps) break;                                                                       \
     }
         for (;;) {
