@@ -222,14 +222,14 @@ def run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
                                layout_id=lid)
         workload, sbytes = "5 canonical layouts padded to 9x5 (env e -> layout e %% 5) x %d envs/GPU, random policy" % n, 34
     else:
-        from overcooked_ai_amd.layout_gen import generate_layouts
+        from overcooked_ai_amd.layout_gen import reference_generated_layouts
 
-        K = 4096
-        table = LayoutTable(generate_layouts(K, seed=0, inner_shape=(9, 5), prop_empty=0.9, prop_feats=0.1))
+        K = 4096  # the reference LayoutGenerator's own terrains (np.random.seed(0)), recorded as package data
+        table = LayoutTable(reference_generated_layouts(K))
         lid = ((np.arange(n) + rank * n) % K).astype(np.uint16)
         env = VecOvercookedEnv(table, n, horizon=HORIZON, device=dev, auto_reset=True, seed=0, env_offset=rank * n,
                                layout_id=lid)
-        workload, sbytes = "%d generated 9x5 terrains (env e -> terrain e %% %d) x %d envs/GPU, random policy" % (K, K, n), 36
+        workload, sbytes = "%d LayoutGenerator 9x5 terrains (reference generator, seed 0; env e -> terrain e %% %d) x %d envs/GPU, random policy" % (K, K, n), 36
     fuse = 1 if encode else max(1, min(args.fuse, args.steps))
     rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)

@@ -737,7 +737,41 @@ def gen_multi_agent():
         json.dump(out, f)
 
 
+def gen_generated_layouts(k=4096):
+    """BASELINE configs[4]: the terrains the reference's own LayoutGenerator produces for
+    mdp_gen_fn_from_dict({inner_shape (9, 5), prop_empty 0.9, prop_feats 0.1, one 3-onion order worth 20 cooking for
+    20}, outer_shape=(9, 5)) after np.random.seed(0) / random.seed(0) (layout_generator.py:110-142) — shipped as
+    package data so that the benchmark runs on the reference's layouts, not on look-alikes."""
+    import gzip
+    import random
+
+    from overcooked_ai_py.mdp.layout_generator import LayoutGenerator
+
+    params = {"inner_shape": (9, 5), "prop_empty": 0.9, "prop_feats": 0.1,
+              "start_all_orders": [{"ingredients": ["onion", "onion", "onion"]}], "recipe_values": [20],
+              "recipe_times": [20], "display": False}
+    np.random.seed(0)
+    random.seed(0)
+    fn = LayoutGenerator.mdp_gen_fn_from_dict(params, outer_shape=(9, 5))
+    grids = []
+    for _ in range(k):
+        mdp = fn()
+        rows = [list(r) for r in mdp.terrain_mtx]
+        for i, (x, y) in enumerate(mdp.start_player_positions):
+            rows[y][x] = str(i + 1)
+        grids.append(["".join(r) for r in rows])
+    out = {"generator": "LayoutGenerator.mdp_gen_fn_from_dict, np.random.seed(0), random.seed(0)",
+           "mdp_params": {k_: v for k_, v in params.items() if k_ not in ("display",)}, "outer_shape": [9, 5], "grids": grids}
+    path = os.path.join(ROOT, "overcooked_ai_amd", "data", "ref_generated_9x5_seed0.json.gz")
+    with gzip.open(path, "wt", compresslevel=9) as f:
+        json.dump(out, f)
+    print("generated layouts", k, "distinct", len({"|".join(g) for g in grids}), os.path.getsize(path), "bytes")
+
+
 def main():
+    if "--generated-layouts-only" in sys.argv:
+        gen_generated_layouts()
+        return
     if "--multi-agent-only" in sys.argv:
         gen_multi_agent()
         return
@@ -781,6 +815,7 @@ def main():
     gen_featurize()
     gen_potential()
     gen_multi_agent()
+    gen_generated_layouts()
     with open(os.path.join(GOLDEN, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
     print("done")

@@ -87,3 +87,26 @@ def generate_layouts(n, seed=0, inner_shape=(9, 5), outer_shape=None, prop_empty
         d["grid"] = "\n".join(rows)
         specs.append(LayoutSpec(d))
     return specs
+
+
+def reference_generated_layouts(n=None):
+    """The terrains BASELINE configs[4] names: what the reference's own `LayoutGenerator.mdp_gen_fn_from_dict(
+    {inner_shape (9, 5), prop_empty 0.9, prop_feats 0.1, one 3-onion order worth 20 cooking for 20}, outer_shape=(9, 5))`
+    yields after `np.random.seed(0); random.seed(0)` — 4096 grids recorded from the reference (oracle/gen_golden.py
+    --generated-layouts-only) and shipped as package data, since the generator itself is host-side tooling of the
+    reference and draws from numpy's global stream."""
+    import gzip
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "ref_generated_9x5_seed0.json.gz")
+    with gzip.open(path, "rt") as f:
+        d = json.load(f)
+    params = {k: v for k, v in d["mdp_params"].items() if k in ("start_all_orders", "recipe_values", "recipe_times")}
+    grids = d["grids"] if n is None else d["grids"][:n]
+    specs = []
+    for rows in grids:
+        cfg = dict(params)
+        cfg["grid"] = "\n".join(rows)
+        specs.append(LayoutSpec(cfg))
+    return specs

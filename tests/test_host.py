@@ -243,3 +243,18 @@ def test_py_set_order_port_matches_interpreter():
         cells = rnd.sample(range(W * H), rnd.randint(0, 9))
         pos = [(c % W, c // W) for c in cells]
         assert py_set_order(pos) == list(set().union(pos))
+
+
+def test_reference_generated_layouts_package_data():
+    """BASELINE configs[4] terrains recorded from the reference's LayoutGenerator: all valid, distinct, one pot, 9x5."""
+    from overcooked_ai_amd.layout_gen import reference_generated_layouts
+    from overcooked_ai_amd.layouts import LayoutTable
+
+    specs = reference_generated_layouts()
+    assert len(specs) == 4096 and len({(s.layout_name, tuple(s.start_player_positions)) for s in specs}) == 4096
+    assert all(s.shape == (9, 5) and s.num_players == 2 and len(s.cells_of("P")) >= 1 for s in specs)
+    assert specs[0].layout_name == "XXXDPXXOX|X    X  X|S       X|X  X    X|XXXXXXXXX"
+    assert specs[0].start_player_positions == [(4, 1), (6, 3)]
+    table = LayoutTable(specs[:100])
+    assert table.records.shape == (100, 256) and table.max_pots >= 1
+    assert all(s.delivery_value((3, 0)) == 20 and s.recipe_time((3, 0)) == 20 for s in specs[:50])
