@@ -75,7 +75,8 @@ __global__ __launch_bounds__(BLOCK) void k_train_step(const OcLayout* __restrict
     if (a0 > 5u || a1 > 5u) {
         fl = OC_F_BAD_ACTION;  // the env stays untouched (mdp.py:1394-1398 raises)
     } else {
-        env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, FAST ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull);
+        env_step3<MAXP, FAST ? 2 : 0>(C, L, lut, cells, s, delta4, a0, a1, r,
+                                      FAST ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull);
         fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, 0u, r, ep);
     }
     const bool is_done = (fl & OC_F_DONE) != 0u;

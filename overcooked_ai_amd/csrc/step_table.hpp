@@ -157,28 +157,29 @@ struct Probe3 {
     uint32_t c_f0, c_f1, c_m0, c_m1;
 };
 
-// FAST = one layout for the whole batch, two players, at most 64 cells: "is there a second player" folds away and the
+// FAST levels: 0 generic; 1 = every layout of the table has two players ("is there a second player" folds away; the
+// rollout loop is unrolled over the Philox block); 2 = 1 + one layout for the whole batch with at most 64 cells: the
 // floor test of resolve_movement becomes a bit test against a wave-uniform 64-bit mask instead of two LDS reads.
-template <int MAXP, bool FAST>
+template <int MAXP, int FAST>
 __device__ __forceinline__ Probe3 probe3(const uint16_t* cells, const Env3<MAXP>& s, uint32_t delta4, uint32_t a0,
                                          uint32_t a1) {
     Probe3 q;
-    const bool two = FAST || s.pos1 != 0xFFu;
+    const bool two = FAST >= 1 || s.pos1 != 0xFFu;
     q.f0 = step_cell(s.pos0, s.or0, delta4);
     q.f1 = two ? step_cell(s.pos1, s.or1, delta4) : q.f0;
     q.m0 = a0 < 4u ? step_cell(s.pos0, a0, delta4) : s.pos0;
     q.m1 = (two & (a1 < 4u)) ? step_cell(s.pos1, a1, delta4) : (two ? s.pos1 : s.pos0);
     q.c_f0 = rd_cell3(cells, q.f0); q.c_f1 = rd_cell3(cells, q.f1);
-    if (!FAST) { q.c_m0 = rd_cell3(cells, q.m0); q.c_m1 = rd_cell3(cells, q.m1); }
+    if (FAST < 2) { q.c_m0 = rd_cell3(cells, q.m0); q.c_m1 = rd_cell3(cells, q.m1); }
     else { q.c_m0 = 0; q.c_m1 = 0; }
     return q;
 }
 
-template <int MAXP, bool FAST>
+template <int MAXP, int FAST>
 __device__ __forceinline__ void step3_main(const LayC& C, const Lay L, const uint8_t* s_lut, uint16_t* cells,
                                            Env3<MAXP>& s, uint32_t a0, uint32_t a1, const Probe3& q, float4& r,
                                            uint64_t floor_mask) {
-    const bool two = FAST || s.pos1 != 0xFFu;
+    const bool two = FAST >= 1 || s.pos1 != 0xFFu;
     const bool mv0 = a0 < 4u, mv1 = two & (a1 < 4u);
     const uint32_t f0 = q.f0, f1 = q.f1, c_f0 = q.c_f0, c_f1 = q.c_f1;
 
@@ -222,8 +223,8 @@ __device__ __forceinline__ void step3_main(const LayC& C, const Lay L, const uin
     r = make_float4(sp0, sp1, sh0, sh1);
 
     // resolve_movement (mdp.py:1644-1727)
-    const bool fl0 = FAST ? ((floor_mask >> q.m0) & 1ull) != 0ull : ((q.c_m0 >> 8) & 7u) == OC_T_FLOOR;
-    const bool fl1 = FAST ? ((floor_mask >> q.m1) & 1ull) != 0ull : ((q.c_m1 >> 8) & 7u) == OC_T_FLOOR;
+    const bool fl0 = FAST == 2 ? ((floor_mask >> q.m0) & 1ull) != 0ull : ((q.c_m0 >> 8) & 7u) == OC_T_FLOOR;
+    const bool fl1 = FAST == 2 ? ((floor_mask >> q.m1) & 1ull) != 0ull : ((q.c_m1 >> 8) & 7u) == OC_T_FLOOR;
     const uint32_t np0 = (mv0 & fl0) ? q.m0 : s.pos0;
     const uint32_t np1 = (mv1 & fl1) ? q.m1 : s.pos1;
     s.or0 = mv0 ? a0 : s.or0;
@@ -251,7 +252,7 @@ __device__ __forceinline__ void step3_env(const LayC& C, Env3<MAXP>& s) {
     }
 }
 
-template <int MAXP, bool FAST = false>
+template <int MAXP, int FAST = 0>
 __device__ __forceinline__ void env_step3(const LayC& C, const Lay L, const uint8_t* s_lut, uint16_t* cells,
                                           Env3<MAXP>& s, uint32_t delta4, uint32_t a0, uint32_t a1, float4& r,
                                           uint64_t floor_mask = 0) {
@@ -367,7 +368,7 @@ __device__ __forceinline__ const uint8_t* stage_lut(uint2* s_lut, uint32_t old_d
     return reinterpret_cast<const uint8_t*>(s_lut) + (old_dyn ? LUT_ENTRIES * 8 : 0);
 }
 
-template <bool UNIFORM, int MAXP, bool LAY_LDS, bool FAST = false>
+template <bool UNIFORM, int MAXP, bool LAY_LDS, int FAST = 0>
 __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                     const uint16_t* __restrict__ layout_id, uint4* st,
                                                     float4* __restrict__ rewards, uint8_t* __restrict__ flags,
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
     const uint32_t delta4 = make_delta4(W);
     Env3<MAXP> s;
     load_env3<MAXP>(C, L, st, n, e, n_obj, s, cells);
-    const uint64_t floor_mask = FAST ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull;
+    const uint64_t floor_mask = FAST == 2 ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull;
     float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     const uint64_t g = (uint64_t)(env_offset + e);
     const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
@@ -492,8 +493,8 @@ __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_
     if (a0 > 5u || a1 > 5u) {
         fl = OC_F_BAD_ACTION;  // get_state_transition raises ValueError (mdp.py:1394-1398): leave the env untouched
     } else {
-        env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r,
-                              FAST ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull);
+        env_step3<MAXP, FAST ? 2 : 0>(C, L, lut, cells, s, delta4, a0, a1, r,
+                                      FAST ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull);
         fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);
     }
     store_env3<MAXP>(C, L, st_out, n, e, n_obj, s, cells);
