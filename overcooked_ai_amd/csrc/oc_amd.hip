@@ -69,6 +69,8 @@ int check_batch(const OcBatch* b, int* n_obj) {
     return OC_OK;
 }
 
+// LDS bytes one encode workgroup may fill with output (default 40 KiB = 3 workgroups per CU); OC_ENC_LDS overrides it
+// for tuning runs (read once per process).
 inline int enc_lds_budget() {
     static int v = []() { const char* e = getenv("OC_ENC_LDS"); return e ? atoi(e) : 40 * 1024; }();
     return v;
@@ -430,7 +432,7 @@ int oc_encode_lossless(const OcBatch* b, const void* d_state, void* d_obs, int o
     if (smem > 160 * 1024) return fail(OC_EINVAL, "oc_encode_lossless: grid too large for LDS staging");
     // single layout + u8: persistent template kernel (measured 30.2 vs 32.4 us on 65 536 asymmetric_advantages envs;
     // f32 is HBM-write bound either way and the generic kernel is marginally faster there: 112 vs 116 us)
-    if (b->n_layouts == 1 && obs_dtype == OC_OBS_U8 && !getenv("OC_ENC_GENERIC")) {
+    if (b->n_layouts == 1 && obs_dtype == OC_OBS_U8) {
         int unit = 1;
         while (((env_bytes * unit) & 15u) != 0) unit *= 2;              // 1, 2 or 4 envs per template
         const size_t unit_bytes = env_bytes * unit;
