@@ -79,6 +79,12 @@ class VecOvercookedEnv:
         self.reset()
 
     # ------------------------------------------------------------------ helpers
+    def _check(self, t, dtype, numel, what):
+        """Caller-owned output / input buffers must be contiguous tensors of the right type ON THIS GPU: the kernels
+        write through the raw pointer."""
+        if t.dtype != dtype or t.device != self.state.device or not t.is_contiguous() or t.numel() != numel:
+            raise ValueError("%s must be a contiguous %s tensor with %d elements on %s" % (what, dtype, numel, self.state.device))
+
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
@@ -123,7 +129,9 @@ class VecOvercookedEnv:
         The returned tensors are reused by the next call.  events_out: optional int64 tensor [n_envs] that
         receives the event_infos bit mask of the step (bit 2*k + p = EVENT_TYPES[k] for player p)."""
         if events_out is not None:
-            assert events_out.dtype == torch.int64 and events_out.shape == (self.n_envs,) and events_out.is_contiguous()
+            self._check(events_out, torch.int64, self.n_envs, "events_out")
+        if state_out is not None:
+            self._check(state_out, torch.uint8, self.state.numel(), "state_out")
         if actions.dtype != torch.uint8 or actions.shape != (self.n_envs, 2) or not actions.is_contiguous() \
                 or actions.device != self.state.device:
             raise ValueError("actions must be a contiguous uint8 [n_envs, 2] tensor on %s" % self.device)
@@ -139,9 +147,9 @@ class VecOvercookedEnv:
         """K consecutive steps enqueued from C: actions uint8 [K, n_envs, 2] -> rewards_out float32 [K, n_envs, 4],
         flags_out uint8 [K, n_envs]."""
         K = actions.shape[0]
-        assert actions.dtype == torch.uint8 and actions.shape == (K, self.n_envs, 2) and actions.is_contiguous()
-        assert rewards_out.dtype == torch.float32 and rewards_out.shape == (K, self.n_envs, 4) and rewards_out.is_contiguous()
-        assert flags_out.dtype == torch.uint8 and flags_out.shape == (K, self.n_envs) and flags_out.is_contiguous()
+        self._check(actions, torch.uint8, K * self.n_envs * 2, "actions")
+        self._check(rewards_out, torch.float32, K * self.n_envs * 4, "rewards_out")
+        self._check(flags_out, torch.uint8, K * self.n_envs, "flags_out")
         rc = self._launch(self.lib.oc_step_many, self._bref, self._state_ptr, actions.data_ptr(), rewards_out.data_ptr(),
                           flags_out.data_ptr(), self._ep_ptr, int(K), self.horizon, self.options)
         _lib.check(rc, "oc_step_many")
@@ -151,11 +159,9 @@ class VecOvercookedEnv:
         """n_steps fused random-policy transitions in one launch (Philox actions, see include/oc_amd.h).
         rewards_out: float32 [n_steps, n_envs, 4] or None; flags_out: uint8 [n_steps, n_envs] or None."""
         if rewards_out is not None:
-            assert rewards_out.dtype == torch.float32 and rewards_out.shape == (n_steps, self.n_envs, 4) \
-                and rewards_out.is_contiguous()
+            self._check(rewards_out, torch.float32, int(n_steps) * self.n_envs * 4, "rewards_out")
         if flags_out is not None:
-            assert flags_out.dtype == torch.uint8 and flags_out.shape == (n_steps, self.n_envs) \
-                and flags_out.is_contiguous()
+            self._check(flags_out, torch.uint8, int(n_steps) * self.n_envs, "flags_out")
         with torch.cuda.device(self.device):
             rc = self.lib.oc_rollout_random(
                 self._bref, self.state.data_ptr(),
@@ -173,8 +179,7 @@ class VecOvercookedEnv:
         if out is None:
             out = torch.empty((self.n_envs, 2, self.width, self.height, 26), dtype=dtype, device=self.device)
         else:
-            assert out.dtype == dtype and out.is_contiguous() \
-                and out.numel() == self.n_envs * 2 * self.width * self.height * 26
+            self._check(out, dtype, self.n_envs * 2 * self.width * self.height * 26, "out")
         st = self.state if state is None else state
         with torch.cuda.device(self.device):
             rc = self.lib.oc_encode_lossless(self._bref, st.data_ptr(), out.data_ptr(), code, self.horizon,
@@ -190,7 +195,7 @@ class VecOvercookedEnv:
         if out is None:
             out = torch.empty((self.n_envs, 2, total), dtype=torch.float32, device=self.device)
         else:
-            assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == self.n_envs * 2 * total
+            self._check(out, torch.float32, self.n_envs * 2 * total, "out")
         st = self.state if state is None else state
         rc = self._launch(self.lib.oc_featurize, self._bref, blob.data_ptr(), offs.data_ptr(), st.data_ptr(), out.data_ptr(),
                           int(num_pots))
@@ -216,7 +221,7 @@ class VecOvercookedEnv:
         if out is None:
             out = torch.empty((self.n_envs,), dtype=torch.float64, device=self.device)
         else:
-            assert out.dtype == torch.float64 and out.is_contiguous() and out.numel() == self.n_envs
+            self._check(out, torch.float64, self.n_envs, "out")
         st = self.state if state is None else state
         rc = self._launch(self.lib.oc_potential, self._bref, blob.data_ptr(), offs.data_ptr(),
                           self._phi_tables[gamma].data_ptr(), st.data_ptr(), out.data_ptr())

@@ -404,6 +404,10 @@ def test_abi_argument_errors(gpu):
     assert rc == -1 and b"layout_id" in L.oc_last_error()
     with pytest.raises(ValueError):
         env.step(torch.zeros((8, 2), dtype=torch.int64, device=gpu))
+    with pytest.raises(ValueError):  # host tensors are refused: the kernels write through raw device pointers
+        env.rollout_random(3, torch.zeros((3, env.n_envs, 4)), None)
+    with pytest.raises(ValueError):
+        env.encode_lossless(torch.uint8, out=torch.zeros((5,), dtype=torch.uint8, device=gpu))
 
 
 def test_many_pots_layout_vs_oracle(gpu):
