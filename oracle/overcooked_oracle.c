@@ -8,8 +8,13 @@
  * tests/golden/ that were produced by running the real reference (imported from /root/reference
  * by oracle/gen_golden.py): the reference's own 1500-step golden trajectory
  * (data/testing/test_mdp_dynamics/expected.json), its one-transition fixture, start-state fixture,
- * ~10^5 randomized transitions over 8 layouts (incl. old_dynamics, tomato/bonus layouts), the
- * K1..K11 micro cases of SURVEY.md §8c and lossless encodings of visited states.
+ * ~10^5 randomized transitions over 11 layout configurations (incl. old_dynamics, tomato/bonus
+ * layouts), the K1..K11 micro cases of SURVEY.md §8c, lossless encodings of visited states, whole
+ * OvercookedEnv episodes with game_stats, featurize_state (incl. the reference's own golden pickle
+ * test_state_featurization/expected_2.pickle) and potential_function (6 400 values, bit-identical float64).
+ * oracle_reset_random has no reference counterpart to be pinned against draw for draw (the reference draws
+ * from numpy's global generator): it restates the stream documented at oc_reset_random and its statistics are
+ * checked against the distribution of get_random_start_state_fn.
  *
  * It deliberately mirrors the *structure* of the reference (objects keyed by position, players
  * processed in index order, the helper predicates of the reference) rather than the structure of
