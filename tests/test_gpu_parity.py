@@ -693,3 +693,56 @@ def test_fused_training_step_equals_the_kernel_sequence(gpu):
                                    ("phi_cur", env.phi_cur, ref.phi_cur)):
                     assert torch.equal(x, y), (getattr(layouts, "layout_name", layouts), use_phi, t, name)
             assert int(env.done.sum()) >= 0 and (env.venv.flags & 2).any()
+
+
+def test_no_out_of_bounds_writes_with_ragged_batches(gpu):
+    """Every caller-owned buffer sits between two guard regions; after all kernels ran on ragged batch sizes (not a
+    multiple of the 256-lane workgroup, of the encode group or of the 128-env featurize block) the guards are intact."""
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+    from overcooked_ai_amd.multi_agent import VecOvercookedMultiAgent
+
+    GUARD = 4096
+
+    def guarded(shape, dtype):
+        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        pad = (-n) % 16
+        raw = torch.full((GUARD + n + pad + GUARD,), 0xAB, dtype=torch.uint8, device=gpu)
+        return raw, raw[GUARD:GUARD + n].view(dtype).view(*shape)
+
+    def intact(raw, body_bytes):
+        return bool((raw[:GUARD] == 0xAB).all()) and bool((raw[GUARD + body_bytes:] == 0xAB).all())
+
+    table5 = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+    for layouts, n, n_lay in (("cramped_room", 1, 0), ("cramped_room", 1001, 0), ("asymmetric_advantages", 777, 0),
+                              ("corridor", 333, 0), (table5, 1283, 5)):
+        lid = (np.arange(n) % n_lay).astype(np.uint16) if n_lay else None
+        env = make_env(layouts, n, gpu, horizon=9, auto_reset=True, seed=3, layout_id=lid)
+        bufs = []
+        K = 7
+        r_raw, rew = guarded((K, n, 4), torch.float32); bufs.append((r_raw, rew))
+        f_raw, fl = guarded((K, n), torch.uint8); bufs.append((f_raw, fl))
+        for mode in (None, "lane_per_env", "lane_pair", "predicate_interact"):
+            for m in ("lane_per_env", "lane_pair", "predicate_interact"):
+                setattr(env, m, m == mode)
+            env.rollout_random(K, rew, fl)
+        s_raw, st_out = guarded(tuple(env.state.shape), torch.uint8); bufs.append((s_raw, st_out))
+        e_raw, ev = guarded((n,), torch.int64); bufs.append((e_raw, ev))
+        acts = torch.randint(0, 6, (n, 2), dtype=torch.uint8, device=gpu)
+        env.step(acts, state_out=st_out, events_out=ev)
+        env.step(acts, state_out=st_out)
+        a_raw, acts_k = guarded((K, n, 2), torch.uint8); acts_k.copy_(torch.randint(0, 6, (K, n, 2), dtype=torch.uint8, device=gpu))
+        env.step_many(acts_k, rew, fl)
+        for dt in (torch.uint8, torch.float32):
+            o_raw, obs = guarded((n, 2, env.width, env.height, 26), dt); bufs.append((o_raw, obs))
+            env.encode_lossless(dt, out=obs)
+        ft_raw, feat = guarded((n, 2, 96), torch.float32); bufs.append((ft_raw, feat))
+        env.featurize(out=feat)
+        p_raw, phi = guarded((n,), torch.float64); bufs.append((p_raw, phi))
+        env.potential(out=phi)
+        env.reset(mask=torch.ones(n, dtype=torch.uint8, device=gpu), random_start_pos=True, rnd_obj_prob_thresh=0.5)
+        ma = VecOvercookedMultiAgent(layouts, n, horizon=5, reward_shaping_factor=1.0, use_phi=True, device=gpu, layout_id=lid)
+        for _ in range(7):
+            ma.step(acts)
+        torch.cuda.synchronize()
+        for raw, body in bufs:
+            assert intact(raw, body.numel() * body.element_size()), (getattr(layouts, "layout_name", layouts), n, tuple(body.shape), body.dtype)
