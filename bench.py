@@ -173,6 +173,18 @@ def main():
                 best, traffic = v["launches"], v["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
+    issue = None
+    try:  # SQ counters of the same kernel (tools/pmc_rollout.sh): what bounds it is instruction issue, not HBM
+        with open(os.path.join(ROOT, "profiles", "sq_counters.json")) as f:
+            sq = json.load(f)
+        if kernel == "k_rollout3" and n == N_ENVS_PER_GPU and args.layout == "cramped_room":
+            issue = {"valu_per_env_step": sq["valu_per_env_step"], "salu_per_env_step": sq["salu_per_env_step"],
+                     "lds_per_env_step": sq["lds_per_env_step"], "valu_busy_frac": sq["valu_busy_frac"],
+                     "wait_frac": sq["wait_any_frac"],
+                     "note": "one wavefront per SIMD at 65 536 envs: a VALU instruction occupies the SIMD for 4 clk, so "
+                             "valu_per_env_step * 4 clk is the floor of a batched step whatever the bytes moved"}
+    except (OSError, ValueError, KeyError):
+        pass
     out = {
         "metric": "env steps/sec (whole node), 65k parallel cramped_room envs",
         "value": value, "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -185,7 +197,8 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "bytes_per_launch": bytes_per_launch, "launch_ms": launch_ms,
                      "bytes_model": "n_envs*(2*S + 17*T): S=%d B state in+out once per launch, 17 B outputs per env-step, actions in-kernel" % state_bytes,
-                     "survey_8d_per_step_model_GBs": n * (2 * state_bytes + OUT_BYTES) * fuse / (launch_ms * 1e-3) / 1e9},
+                     "survey_8d_per_step_model_GBs": n * (2 * state_bytes + OUT_BYTES) * fuse / (launch_ms * 1e-3) / 1e9,
+                     "issue_bound": issue},
         "device_ms_timed_region": dev_ms,
         "aggregate": {"sparse_return_last_launch": float(metrics[0]), "shaped_return_last_launch": float(metrics[1]),
                       "episodes_done_last_step": float(metrics[2])},
