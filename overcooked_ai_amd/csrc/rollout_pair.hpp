@@ -143,7 +143,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_pair(const OcLayout* __restri
                                                         int horizon, uint32_t options, uint32_t seed_lo,
                                                         uint32_t seed_hi, int64_t env_offset, int64_t t0, int n_steps) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_cells[];  // [n_obj * 8][PAIR_ENVS]
-    __shared__ uint4 s_lay[LAY_LDS ? LDS_LAYOUT_MAX * 16 : 1];
+    __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];  // one 256-byte record when the batch has one layout
     __shared__ uint2 s_lut[2 * LUT_ENTRIES];
     for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
     const uint32_t p = threadIdx.x & 1u, el = threadIdx.x >> 1;

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(BLOCK) void k_train_step(const OcLayout* __restrict
                                                       int64_t n, int W, int H, int n_obj, int horizon) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) uint16_t s_cells3[];  // [n_obj * 16][BLOCK]
-    __shared__ uint4 s_lay[LAY_LDS ? LDS_LAYOUT_MAX * 16 : 1];
+    __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];  // one 256-byte record when the batch has one layout
     __shared__ uint2 s_lut[2 * LUT_ENTRIES];
     const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool active = e < n;

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(const OcLayout* __restrict__ g_l
                                                 float4* __restrict__ ep_returns, uint64_t* __restrict__ events,
                                                 int64_t n, int W, int n_obj, int horizon, uint32_t options) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_cells[];  // [n_obj * 8][BLOCK]
-    __shared__ uint4 s_lay[LAY_LDS ? LDS_LAYOUT_MAX * 16 : 1];
+    __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];  // one 256-byte record when the batch has one layout
     const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool active = e < n;
     const Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(const OcLayout* __restrict__ 
                                                    int horizon, uint32_t options, uint32_t seed_lo, uint32_t seed_hi,
                                                    int64_t env_offset, int64_t t0, int n_steps) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_cells[];
-    __shared__ uint4 s_lay[LAY_LDS ? LDS_LAYOUT_MAX * 16 : 1];
+    __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];  // one 256-byte record when the batch has one layout
     const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool active = e < n;
     const Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);

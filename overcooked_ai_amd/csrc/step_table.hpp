@@ -376,7 +376,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
                                                     int horizon, uint32_t options, uint32_t seed_lo, uint32_t seed_hi,
                                                     int64_t env_offset, int64_t t0, int n_steps) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_cells3[];  // [n_obj * 16][BLOCK]
-    __shared__ uint4 s_lay[LAY_LDS ? LDS_LAYOUT_MAX * 16 : 1];
+    __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];  // one 256-byte record when the batch has one layout
     __shared__ uint2 s_lut[2 * LUT_ENTRIES];
     const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool active = e < n;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_
                                                  float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,
                                                  int horizon, uint32_t options) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_cells3[];  // [n_obj * 16][BLOCK]
-    __shared__ uint4 s_lay[LAY_LDS ? LDS_LAYOUT_MAX * 16 : 1];
+    __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];  // one 256-byte record when the batch has one layout
     __shared__ uint2 s_lut[2 * LUT_ENTRIES];
     const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool active = e < n;
