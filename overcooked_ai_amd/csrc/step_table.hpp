@@ -99,12 +99,16 @@ __device__ __forceinline__ IOut3 interact3(const Lay L, const uint8_t* s_lut, bo
     const uint32_t type = act ? (tc & 7u) : 7u;  // 7 = no interact: every entry of that row is a no-op
     const uint32_t slot = tc >> 3;
     uint32_t pso = 0, tkv = 0, pcv = 0;
+    if (MAXP == 1) {  // a single pot: slot is 0 for every cell, the values are only used when the cell is that pot
+        pso = ps[0]; tkv = tkr[0]; pcv = pcr[0];
+    } else {
 #pragma unroll
-    for (int k = 0; k < MAXP; ++k) {
-        const bool sel = slot == (uint32_t)k;
-        pso = sel ? ps[k] : pso;
-        tkv = sel ? tkr[k] : tkv;
-        pcv = sel ? pcr[k] : pcv;
+        for (int k = 0; k < MAXP; ++k) {
+            const bool sel = slot == (uint32_t)k;
+            pso = sel ? ps[k] : pso;
+            tkv = sel ? tkr[k] : tkv;
+            pcv = sel ? pcr[k] : pcv;
+        }
     }
     const bool isP = type == OC_T_POT;
     const uint32_t o_cell = c16 & 0xFFu;
@@ -139,7 +143,7 @@ template <int MAXP>
 __device__ __forceinline__ void apply_pot3(Env3<MAXP>& s, const IOut3& r) {
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
-        const bool upd = ((r.flags & LF_POT_UPD) != 0u) & (r.slot == (uint32_t)k);
+        const bool upd = ((r.flags & LF_POT_UPD) != 0u) & (MAXP == 1 || r.slot == (uint32_t)k);
         s.ps[k] = upd ? r.new_o : s.ps[k];
         s.tk[k] = upd ? r.new_tk : s.tk[k];
         s.pc[k] = upd ? r.new_pc : s.pc[k];
