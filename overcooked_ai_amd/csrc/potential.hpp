@@ -14,7 +14,7 @@
 // partially full pots (mdp.py:1882-1890), which breaks ties of the greedy pot/ingredient matching — is CPython's
 // set iteration order, restated in py_set_order below (tuple hash + open addressing, CPython 3.8-3.12).
 // ------------------------------------------------------------------------------------------
-constexpr int PHI_BYTES = 456 + 8 * 512;
+constexpr int PHI_BYTES = 472 + 8 * 512;
 constexpr uint32_t COST_INF = 0xFFFFu;
 
 struct Phi {
@@ -33,7 +33,9 @@ struct Phi {
     __device__ __forceinline__ double value_max1(uint32_t k) const { return f64(296 + 8 * (int)k); }
     __device__ __forceinline__ uint32_t opt_key(uint32_t k) const { return b[424 + k]; }
     __device__ __forceinline__ uint32_t opt_time(uint32_t k) const { return b[440 + k]; }
-    __device__ __forceinline__ double pw(uint32_t k) const { return f64(456 + 8 * (int)k); }  // gamma ** k
+    __device__ __forceinline__ uint32_t n_serve() const { return b[456]; }  // 255: not listed, scan the terrain
+    __device__ __forceinline__ uint32_t serve_cell(uint32_t i) const { return b[457 + i]; }
+    __device__ __forceinline__ double pw(uint32_t k) const { return f64(472 + 8 * (int)k); }  // gamma ** k
 };
 
 // hash((x, y)) of CPython's tuplehash for two small non-negative ints
@@ -162,8 +164,13 @@ __global__ __launch_bounds__(BLOCK) void k_potential(const OcLayout* __restrict_
     for (uint32_t p = 0; p < np; ++p) {
         if (held[p] == 0xFFu || !(held[p] & OC_O_SOUP)) continue;
         uint32_t d = COST_INF;
-        for (uint32_t c = 0; c < cells; ++c)
-            if ((L.terrain(c) & 7u) == OC_T_SERVE) d = min(d, cost(p, c));
+        const uint32_t n_serve = T.n_serve();
+        if (n_serve != 255u) {
+            for (uint32_t i = 0; i < n_serve; ++i) d = min(d, cost(p, T.serve_cell(i)));
+        } else {
+            for (uint32_t c = 0; c < cells; ++c)
+                if ((L.terrain(c) & 7u) == OC_T_SERVE) d = min(d, cost(p, c));
+        }
         phi = __dadd_rn(phi, __dmul_rn(T.pw(min(d, max_del)), T.value_max1(recipe_idx(held[p]))));
     }
 
@@ -272,8 +279,16 @@ __device__ __forceinline__ double potential2_core(const Lay L, const Phi T, cons
     // everything that comes from memory, issued together
     const uint32_t rA0 = row0[cellA], rA1 = row1[cellA], rB0 = row0[cellB], rB1 = row1[cellB];
     uint32_t serve0 = 255u, serve1 = 255u;  // min over the serving cells (255 = unreachable stays the maximum)
-    for (uint32_t c = 0; c < cells; ++c)
-        if ((L.terrain(c) & 7u) == OC_T_SERVE) { serve0 = min(serve0, (uint32_t)row0[c]); serve1 = min(serve1, (uint32_t)row1[c]); }
+    const uint32_t n_serve = T.n_serve();
+    if (n_serve != 255u) {  // the host listed them: no terrain scan
+        for (uint32_t i = 0; i < n_serve; ++i) {
+            const uint32_t c = T.serve_cell(i);
+            serve0 = min(serve0, (uint32_t)row0[c]); serve1 = min(serve1, (uint32_t)row1[c]);
+        }
+    } else {
+        for (uint32_t c = 0; c < cells; ++c)
+            if ((L.terrain(c) & 7u) == OC_T_SERVE) { serve0 = min(serve0, (uint32_t)row0[c]); serve1 = min(serve1, (uint32_t)row1[c]); }
+    }
     auto fin = [](uint32_t v) { return v == 255u ? COST_INF : v + 1u; };  // + the interact; COST_INF = np.inf
     // cost[player][pot]
     const uint32_t cA[2] = {fin(rA0), fin(rA1)}, cB[2] = {fin(rB0), fin(rB1)};

@@ -27,7 +27,8 @@ Record layout (little endian, 8-byte aligned):
                              order of the layout's first two pots A, B: bit 0 = B comes first out of
                              list(set().union([A], [B])), bit 1 = B comes first out of list(set().union([B], [A]))
     440  u8   opt_time[16]       Recipe.time of the best completion
-    456  f64  pow[POW_N]         gamma ** k
+    456  u8   serve[16]          serve[0] = number of serving cells (255: more than 15, scan the terrain), then the cells
+    472  f64  pow[POW_N]         gamma ** k
 """
 import struct
 
@@ -36,7 +37,7 @@ import numpy as np
 from .layouts import MAX_NUM_INGREDIENTS
 
 POW_N = 512
-PHI_BYTES = 456 + 8 * POW_N
+PHI_BYTES = 472 + 8 * POW_N
 
 POTENTIAL_CONSTANTS = {  # mdp.py:1060-1073
     "default": {"max_delivery_steps": 10, "max_pickup_steps": 10, "pot_onion_steps": 10, "pot_tomato_steps": 10},
@@ -183,6 +184,8 @@ def phi_record(spec, gamma=0.99):
     rec = struct.pack("<3d4i", steady, float(params["onion_value"]), float(params["tomato_value"]), *steps)
     rec += struct.pack("<16d", *sort_value) + struct.pack("<16d", *opt_value_max1) + struct.pack("<16d", *value_max1)
     rec += bytes(opt_keys) + bytes(opt_times)
+    serve = [y * spec.width + x for (x, y) in spec.cells_of("S")]
+    rec += bytes([len(serve)] + serve + [0] * (15 - len(serve))) if len(serve) <= 15 else bytes([255] + [0] * 15)
     rec += struct.pack("<%dd" % POW_N, *[gamma ** k for k in range(POW_N)])
     assert len(rec) == PHI_BYTES
     return rec

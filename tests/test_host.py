@@ -220,7 +220,8 @@ def test_potential_tables_host_side():
     d = value / 20
     assert steady == (d / (1 - d)) * 20 and (onion_value, tomato_value) == (21.0, 13.0)
     assert struct.unpack_from("<4i", rec, 24) == (10, 10, 10, 10)
-    pw = struct.unpack_from("<512d", rec, 456)
+    assert rec[456] == 1 and rec[457] == 3 * 5 + 3  # cramped_room: one serving cell at (3, 3)
+    pw = struct.unpack_from("<512d", rec, 472)
     assert pw[0] == 1.0 and pw[1] == 0.99 and pw[37] == 0.99 ** 37
     assert rec[424 + 1] == 3 and rec[440 + 1] == 20  # one onion -> completes to ooo, cook time 20
     cc = spec_from_name("counter_circuit")  # bonus order onion+tomato worth 2 * 34
