@@ -163,16 +163,23 @@ struct Probe3 {
 
 // FAST levels: 0 generic; 1 = every layout of the table has two players ("is there a second player" folds away; the
 // rollout loop is unrolled over the Philox block); 2 = 1 + one layout for the whole batch with at most 64 cells: the
-// floor test of resolve_movement becomes a bit test against a wave-uniform 64-bit mask instead of two LDS reads.
+// floor test of resolve_movement becomes a bit test against a wave-uniform 64-bit mask instead of two LDS reads;
+// 3 = 2 with the whole single-player move in one LDS look-up: MOVE[cell * 8 + action] = the cell the player ends on
+// (the target if it is free, else the cell itself; STAY / INTERACT: the cell itself), built once per workgroup.
 template <int MAXP, int FAST>
 __device__ __forceinline__ Probe3 probe3(const uint16_t* cells, const Env3<MAXP>& s, uint32_t delta4, uint32_t a0,
-                                         uint32_t a1) {
+                                         uint32_t a1, const uint8_t* s_move) {
     Probe3 q;
     const bool two = FAST >= 1 || s.pos1 != 0xFFu;
     q.f0 = step_cell(s.pos0, s.or0, delta4);
     q.f1 = two ? step_cell(s.pos1, s.or1, delta4) : q.f0;
-    q.m0 = a0 < 4u ? step_cell(s.pos0, a0, delta4) : s.pos0;
-    q.m1 = (two & (a1 < 4u)) ? step_cell(s.pos1, a1, delta4) : (two ? s.pos1 : s.pos0);
+    if (FAST == 3) {
+        q.m0 = s_move[s.pos0 * 8u + a0];
+        q.m1 = s_move[s.pos1 * 8u + a1];
+    } else {
+        q.m0 = a0 < 4u ? step_cell(s.pos0, a0, delta4) : s.pos0;
+        q.m1 = (two & (a1 < 4u)) ? step_cell(s.pos1, a1, delta4) : (two ? s.pos1 : s.pos0);
+    }
     q.c_f0 = rd_cell3(cells, q.f0); q.c_f1 = rd_cell3(cells, q.f1);
     if (FAST < 2) { q.c_m0 = rd_cell3(cells, q.m0); q.c_m1 = rd_cell3(cells, q.m1); }
     else { q.c_m0 = 0; q.c_m1 = 0; }
@@ -227,10 +234,16 @@ __device__ __forceinline__ void step3_main(const LayC& C, const Lay L, const uin
     r = make_float4(sp0, sp1, sh0, sh1);
 
     // resolve_movement (mdp.py:1644-1727)
-    const bool fl0 = FAST == 2 ? ((floor_mask >> q.m0) & 1ull) != 0ull : ((q.c_m0 >> 8) & 7u) == OC_T_FLOOR;
-    const bool fl1 = FAST == 2 ? ((floor_mask >> q.m1) & 1ull) != 0ull : ((q.c_m1 >> 8) & 7u) == OC_T_FLOOR;
-    const uint32_t np0 = (mv0 & fl0) ? q.m0 : s.pos0;
-    const uint32_t np1 = (mv1 & fl1) ? q.m1 : s.pos1;
+    uint32_t np0, np1;
+    if (FAST == 3) {  // the move table already holds "target if free, else stay"
+        np0 = q.m0;
+        np1 = q.m1;
+    } else {
+        const bool fl0 = FAST == 2 ? ((floor_mask >> q.m0) & 1ull) != 0ull : ((q.c_m0 >> 8) & 7u) == OC_T_FLOOR;
+        const bool fl1 = FAST == 2 ? ((floor_mask >> q.m1) & 1ull) != 0ull : ((q.c_m1 >> 8) & 7u) == OC_T_FLOOR;
+        np0 = (mv0 & fl0) ? q.m0 : s.pos0;
+        np1 = (mv1 & fl1) ? q.m1 : s.pos1;
+    }
     s.or0 = mv0 ? a0 : s.or0;
     s.or1 = mv1 ? a1 : s.or1;
     const bool collide = two & ((np0 == np1) | ((np0 == s.pos1) & (np1 == s.pos0)));
@@ -259,8 +272,8 @@ __device__ __forceinline__ void step3_env(const LayC& C, Env3<MAXP>& s) {
 template <int MAXP, int FAST = 0>
 __device__ __forceinline__ void env_step3(const LayC& C, const Lay L, const uint8_t* s_lut, uint16_t* cells,
                                           Env3<MAXP>& s, uint32_t delta4, uint32_t a0, uint32_t a1, float4& r,
-                                          uint64_t floor_mask = 0) {
-    const Probe3 q = probe3<MAXP, FAST>(cells, s, delta4, a0, a1);
+                                          uint64_t floor_mask = 0, const uint8_t* s_move = nullptr) {
+    const Probe3 q = probe3<MAXP, FAST>(cells, s, delta4, a0, a1, s_move);
     step3_main<MAXP, FAST>(C, L, s_lut, cells, s, a0, a1, q, r, floor_mask);
     step3_env<MAXP>(C, s);
 }
@@ -386,6 +399,20 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
     const bool active = e < n;
     for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
     const Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains the barrier
+    __shared__ uint8_t s_move[FAST == 3 ? 64 * 8 : 8];
+    if (FAST == 3) {  // MOVE[cell * 8 + action] for the batch's single layout (at most 64 cells)
+        const int nc = (int)L.u8(L_NCELLS);
+        for (int i = threadIdx.x; i < nc * 8; i += BLOCK) {
+            const int c = i >> 3, a = i & 7;
+            int t = c;
+            if (a < 4) {
+                const int t2 = c + (a == 0 ? -W : a == 1 ? W : a == 2 ? 1 : -1);
+                if (t2 >= 0 && t2 < nc && (L.terrain((uint32_t)t2) & 7u) == OC_T_FLOOR) t = t2;
+            }
+            s_move[i] = (uint8_t)t;
+        }
+        __syncthreads();
+    }
     if (!active) return;
     uint16_t* cells = s_cells3 + threadIdx.x;
     const LayC C = load_consts<UNIFORM>(L);
@@ -422,7 +449,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
         const uint32_t a1 = __umulhi(x, 6u);                                                             \
         x *= 6u;                                                                                         \
         float4 r;                                                                                        \
-        env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask);                       \
+        env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask, s_move);               \
         const uint32_t fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);             \
         if (rew_k) { rew_k[threadIdx.x] = r; rew_k += n; }                                               \
         if (flg_k) { flg_k[threadIdx.x] = (uint8_t)fl; flg_k += n; }                                     \
@@ -456,7 +483,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
             uint32_t a0, a1;
             draw_actions(rnd, s8, a0, a1);
             float4 r;
-            env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask);
+            env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask, s_move);
             const uint32_t fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);
             if (rew_blk) (rew_blk + (int64_t)k * n)[threadIdx.x] = r;
             if (flg_blk) (flg_blk + (int64_t)k * n)[threadIdx.x] = (uint8_t)fl;
