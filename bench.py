@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 N_ENVS_PER_GPU = 65536
 HORIZON = 400
+DEFAULT_FUSE = HORIZON  # env steps per oc_rollout_random launch: one whole episode
 
 # SURVEY.md §8d algorithmic bytes.  S = minimal state of cramped_room (2 players x 3 B + 14 non-floor cells
 # + 1 pot tick + 2 B timestep -> 24 B), outputs 17 B per env-step, actions generated in-kernel (0 B).
@@ -38,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--fuse", type=int, default=100, help="env steps fused per oc_rollout_random launch")
+    ap.add_argument("--fuse", type=int, default=DEFAULT_FUSE, help="env steps fused per oc_rollout_random launch (default: one 400-step episode)")
     ap.add_argument("--envs", type=int, default=N_ENVS_PER_GPU, help="envs per GPU")
     ap.add_argument("--layout", default="cramped_room")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
@@ -168,7 +169,7 @@ def main():
             tj = json.load(f)
         best = 0
         for k, v in tj.items():  # the template instance that ran the headline launches (most dispatches)
-            if k.startswith(kernel + "<") and n == N_ENVS_PER_GPU and fuse == 100 and args.layout == "cramped_room" \
+            if k.startswith(kernel + "<") and n == N_ENVS_PER_GPU and fuse == DEFAULT_FUSE and args.layout == "cramped_room" \
                     and v.get("launches", 0) > best:
                 best, traffic = v["launches"], v["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
