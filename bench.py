@@ -302,7 +302,7 @@ def bench_step_api(env, dev, torch, iters=2000):
     wall = time.perf_counter() - t0
     ms = ev0.elapsed_time(ev1) / iters
     b = n * (2 * S_CRAMPED + 2 + OUT_BYTES)
-    # the same launches enqueued from C (oc_step_many): no Python between steps
+    # oc_step_many: the same K transitions with caller-supplied actions in ONE launch
     K = 500
     acts_k = torch.randint(0, 6, (K, n, 2), dtype=torch.uint8, device=dev)
     rew_k = torch.zeros((K, n, 4), dtype=torch.float32, device=dev)
@@ -318,7 +318,7 @@ def bench_step_api(env, dev, torch, iters=2000):
     wall_many = time.perf_counter() - tm0
     ms_many = evm0.elapsed_time(evm1) / K
     many = {"value": n * K / wall_many, "launch_ms": ms_many, "achieved_GBs": b / (ms_many * 1e-3) / 1e9,
-            "frac": b / (ms_many * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "oc_step_many: the same kernel, launches enqueued from C"}
+            "frac": b / (ms_many * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "oc_step_many: K transitions with caller-supplied actions in one launch (envs stay on chip)"}
     return {"value": n * iters / wall, "step_many": many, "unit": "env steps/s", "launch_ms": ms, "bytes_per_launch": b,
             "achieved_GBs": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "note": "oc_step, one launch per batched step incl. Python/ctypes launch overhead; SURVEY 8d: 67 B/env-step"}

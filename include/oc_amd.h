@@ -172,9 +172,10 @@ int oc_step(const OcBatch* batch, const void* d_state_in, void* d_state_out, con
             uint32_t options, void* stream);
 
 /*
- * oc_step_many — n_steps consecutive oc_step calls (in place) enqueued from C: step k consumes
- * d_actions[k][n_envs][2] and writes d_rewards[k][n_envs][4], d_flags[k][n_envs].  Same kernel as oc_step; it only
- * removes the caller's per-step launch overhead (e.g. replaying a pre-sampled action tensor).
+ * oc_step_many — n_steps consecutive oc_step transitions (in place) in ONE launch: step k consumes
+ * d_actions[k][n_envs][2] and writes d_rewards[k][n_envs][4], d_flags[k][n_envs]; the envs stay on chip between the
+ * steps (replaying a fixed joint plan or a pre-sampled action tensor: OvercookedEnv.execute_plan, env.py:334-345;
+ * AgentEvaluator._check_trajectories_dynamics, benchmarking.py:366).  Results are those of n_steps oc_step calls.
  */
 int oc_step_many(const OcBatch* batch, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
                  float* d_ep_returns, int n_steps, int horizon, uint32_t options, void* stream);

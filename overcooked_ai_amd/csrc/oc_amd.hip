@@ -110,7 +110,7 @@ inline int64_t simd_count() {
 template <bool EVENTS>
 void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_state_out, const uint8_t* d_actions,
                  float* d_rewards, uint8_t* d_flags, float* d_ep_returns, uint64_t* d_events, int horizon,
-                 uint32_t options, hipStream_t s) {
+                 uint32_t options, hipStream_t s, int n_steps = 1) {
     const bool uniform = b->n_layouts == 1;
     const bool lds = b->n_layouts <= LDS_LAYOUT_MAX;
     const bool small = b->max_pots >= 1 && b->max_pots <= 2;
@@ -125,7 +125,7 @@ void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_st
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                        \
         hipLaunchKernelGGL((k_step3<U, MP, LL, ##__VA_ARGS__>), grid, block, smem, s, b->d_layouts, b->n_layouts, b->d_layout_id,   \
                            (const uint4*)d_state_in, (uint4*)d_state_out, d_actions, (float4*)d_rewards, d_flags,    \
-                           (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options);                     \
+                           (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options, n_steps);            \
     } while (0)
         if (uniform && fast && b->max_pots == 1) GO3(true, 1, true, true);
         else if (uniform && fast && small) GO3(true, 2, true, true);
@@ -172,7 +172,17 @@ int oc_step(const OcBatch* b, const void* d_state_in, void* d_state_out, const u
 int oc_step_many(const OcBatch* b, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
                  float* d_ep_returns, int n_steps, int horizon, uint32_t options, void* stream) {
     if (n_steps < 0) return fail(OC_EINVAL, "oc_step_many: n_steps < 0");
-    if (!b) return fail(OC_EINVAL, "batch is NULL");
+    int n_obj = 0;
+    if (int rc = check_batch(b, &n_obj)) return rc;
+    if (!d_state || !d_actions || !d_rewards || !d_flags)
+        return fail(OC_EINVAL, "oc_step_many: NULL state/actions/rewards/flags pointer");
+    if (horizon < 1 || horizon > 65535) return fail(OC_EINVAL, "oc_step_many: horizon must be in 1..65535");
+    if (b->n_envs == 0 || n_steps == 0) return OC_OK;
+    if (!(options & OC_OPT_PREDICATE_INTERACT)) {  // all K transitions in one launch, the envs stay on chip in between
+        launch_step<false>(b, n_obj, d_state, d_state, d_actions, d_rewards, d_flags, d_ep_returns, nullptr, horizon,
+                           options, (hipStream_t)stream, n_steps);
+        return check_launch("oc_step_many");
+    }
     for (int k = 0; k < n_steps; ++k) {
         const int64_t off = (int64_t)k * b->n_envs;
         if (int rc = oc_step(b, d_state, d_state, d_actions + 2 * off, d_rewards + 4 * off, d_flags + off, d_ep_returns,

@@ -493,7 +493,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
     if (ep_returns) ep_returns[e] = ep;
 }
 
-// k_step3: one transition per launch with caller-supplied actions, table-driven interact (no event logging;
+// k_step3: transitions with caller-supplied actions (one per launch for oc_step, K for oc_step_many), table-driven
+// interact (no event logging;
 // oc_step with d_events != NULL uses k_step, whose predicate-network interact produces the event bits)
 template <bool UNIFORM, int MAXP, bool LAY_LDS, bool FAST = false>
 __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_layouts, int n_layouts,
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_
                                                  uint4* st_out, const uint8_t* __restrict__ actions,
                                                  float4* __restrict__ rewards, uint8_t* __restrict__ flags,
                                                  float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,
-                                                 int horizon, uint32_t options) {
+                                                 int horizon, uint32_t options, int n_steps) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_cells3[];  // [n_obj * 16][BLOCK]
     __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];  // one 256-byte record when the batch has one layout
     __shared__ uint2 s_lut[2 * LUT_ENTRIES];
@@ -516,20 +517,27 @@ __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_
     const uint32_t delta4 = make_delta4(W);
     Env3<MAXP> s;
     load_env3<MAXP>(C, L, st_in, n, e, n_obj, s, cells);
-    const uint32_t a01 = reinterpret_cast<const uint16_t*>(actions)[e];
-    const uint32_t a0 = a01 & 0xFFu, a1 = a01 >> 8;
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t fl;
+    const uint64_t floor_mask = FAST ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull;
     float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a0 > 5u || a1 > 5u) {
-        fl = OC_F_BAD_ACTION;  // get_state_transition raises ValueError (mdp.py:1394-1398): leave the env untouched
-    } else {
-        env_step3<MAXP, FAST ? 2 : 0>(C, L, lut, cells, s, delta4, a0, a1, r,
-                                      FAST ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull);
-        fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);
+    // n_steps transitions with the caller's actions [n_steps][n][2] (oc_step: one; oc_step_many: K in one launch, the
+    // env staying on chip in between).  The next step's actions are fetched while the current step runs.
+    const uint16_t* act16 = reinterpret_cast<const uint16_t*>(actions) + e;
+    uint32_t a01 = act16[0];
+    for (int k = 0; k < n_steps; ++k) {
+        const uint32_t a01_next = (k + 1 < n_steps) ? act16[(int64_t)(k + 1) * n] : 0u;
+        const uint32_t a0 = a01 & 0xFFu, a1 = a01 >> 8;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t fl;
+        if (a0 > 5u || a1 > 5u) {
+            fl = OC_F_BAD_ACTION;  // get_state_transition raises ValueError (mdp.py:1394-1398): leave the env untouched
+        } else {
+            env_step3<MAXP, FAST ? 2 : 0>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask);
+            fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);
+        }
+        rewards[(int64_t)k * n + e] = r;
+        flags[(int64_t)k * n + e] = (uint8_t)fl;
+        a01 = a01_next;
     }
     store_env3<MAXP>(C, L, st_out, n, e, n_obj, s, cells);
-    rewards[e] = r;
-    flags[e] = (uint8_t)fl;
     if (ep_returns) ep_returns[e] = ep;
 }
