@@ -746,3 +746,40 @@ def test_no_out_of_bounds_writes_with_ragged_batches(gpu):
         torch.cuda.synchronize()
         for raw, body in bufs:
             assert intact(raw, body.numel() * body.element_size()), (getattr(layouts, "layout_name", layouts), n, tuple(body.shape), body.dtype)
+
+
+def test_step_many_equals_single_steps_with_illegal_actions_and_resets(gpu):
+    """oc_step_many (K transitions in one launch) == K oc_step launches == the oracle, across episode ends
+    (auto-reset) and with illegal actions sprinkled in (those envs stay untouched and are flagged), on a single
+    layout, a mixed table and a 7-pot layout."""
+    from overcooked_ai_amd.layouts import LayoutSpec, LayoutTable, spec_from_name
+
+    seven = LayoutSpec({"grid": "XPPPPPX\nO 1 2 O\nX     X\nXDPSPTX", "onion_time": 3, "tomato_time": 5,
+                        "onion_value": 7, "tomato_value": 4})
+    table5 = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+    rng = np.random.default_rng(12)
+    for layouts, n_lay in (("cramped_room", 0), (table5, 5), (seven, 0), ("cramped_room_single", 0)):
+        n, K, horizon = 2500, 61, 17
+        lid = (np.arange(n) % n_lay).astype(np.uint16) if n_lay else None
+        a = rng.integers(0, 6, size=(K, n, 2)).astype(np.uint8)
+        a[rng.integers(0, K, 40), rng.integers(0, n, 40), rng.integers(0, 2, 40)] = 7
+        if layouts == "cramped_room_single":
+            a[:, :, 1] = 4
+        acts = torch.from_numpy(a).to(gpu)
+        many = make_env(layouts, n, gpu, horizon=horizon, auto_reset=True, layout_id=lid)
+        one = make_env(layouts, n, gpu, horizon=horizon, auto_reset=True, layout_id=lid)
+        rew = torch.zeros((K, n, 4), dtype=torch.float32, device=gpu)
+        fl = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
+        many.step_many(acts, rew, fl)
+        specs = layouts.specs if n_lay else [layouts if not isinstance(layouts, str) else spec_from_name(layouts)]
+        orc = oracle_for(specs)
+        st = orc.reset(orc.new_state(n), layout_id=lid)
+        ep = np.zeros((n, 4), np.float32)
+        for k in range(K):
+            r1, f1 = one.step(acts[k])
+            assert torch.equal(r1, rew[k]) and torch.equal(f1, fl[k]), k
+            st, r_o, f_o = orc.step(st, a[k], horizon=horizon, options=1, layout_id=lid, ep_returns=ep)
+            assert np.array_equal(r_o, rew[k].cpu().numpy()) and np.array_equal(f_o, fl[k].cpu().numpy()), k
+        assert torch.equal(many.state, one.state) and torch.equal(many.ep_returns, one.ep_returns)
+        assert np.array_equal(many.get_packed_state(), st) and np.array_equal(many.ep_returns.cpu().numpy(), ep)
+        assert (fl & 2).any() and (fl & 4).any()
