@@ -521,21 +521,26 @@ __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_
     float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     // n_steps transitions with the caller's actions [n_steps][n][2] (oc_step: one; oc_step_many: K in one launch, the
     // env staying on chip in between).  The next step's actions are fetched while the current step runs.
-    const uint16_t* act16 = reinterpret_cast<const uint16_t*>(actions) + e;
-    uint32_t a01 = act16[0];
+    const uint16_t* act_k = reinterpret_cast<const uint16_t*>(actions) + (int64_t)blockIdx.x * BLOCK;  // wave-uniform rows
+    float4* rew_k = rewards + (int64_t)blockIdx.x * BLOCK;
+    uint8_t* flg_k = flags + (int64_t)blockIdx.x * BLOCK;
+    uint32_t a01 = act_k[threadIdx.x];
     for (int k = 0; k < n_steps; ++k) {
-        const uint32_t a01_next = (k + 1 < n_steps) ? act16[(int64_t)(k + 1) * n] : 0u;
+        act_k += n;
+        const uint32_t a01_next = (k + 1 < n_steps) ? act_k[threadIdx.x] : 0u;
         const uint32_t a0 = a01 & 0xFFu, a1 = a01 >> 8;
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
         uint32_t fl;
-        if (a0 > 5u || a1 > 5u) {
+        if (__builtin_expect(a0 > 5u || a1 > 5u, 0)) {
             fl = OC_F_BAD_ACTION;  // get_state_transition raises ValueError (mdp.py:1394-1398): leave the env untouched
         } else {
             env_step3<MAXP, FAST ? 2 : 0>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask);
             fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);
         }
-        rewards[(int64_t)k * n + e] = r;
-        flags[(int64_t)k * n + e] = (uint8_t)fl;
+        rew_k[threadIdx.x] = r;
+        flg_k[threadIdx.x] = (uint8_t)fl;
+        rew_k += n;
+        flg_k += n;
         a01 = a01_next;
     }
     store_env3<MAXP>(C, L, st_out, n, e, n_obj, s, cells);
