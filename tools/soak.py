@@ -84,10 +84,24 @@ def main():
             t0 += 0
             done += 1
             total += n * (k + 1)
+        # K caller-supplied-action transitions in one launch (oc_step_many), illegal actions included
+        K = int(rng.integers(2, 40))
+        a = rng.integers(0, 6, size=(K, n, 2)).astype(np.uint8)
+        a[rng.integers(0, K, 8), rng.integers(0, n, 8), rng.integers(0, 2, 8)] = 6
+        rew = torch.zeros((K, n, 4), dtype=torch.float32, device=dev)
+        fl = torch.zeros((K, n), dtype=torch.uint8, device=dev)
+        env.step_many(torch.from_numpy(a).to(dev), rew, fl)
+        for k in range(K):
+            st, r2, f2 = orc.step(st, a[k], horizon=horizon, options=1, layout_id=lid)
+            assert np.array_equal(rew[k].cpu().numpy(), r2) and np.array_equal(fl[k].cpu().numpy(), f2), ("step_many", seed, k)
+        assert np.array_equal(env.get_packed_state(), st), ("step_many state", seed)
+        total += n * K
         enc = env.encode_lossless(torch.uint8).cpu().numpy().astype(np.int32)
         assert np.array_equal(enc, orc.encode_lossless(st, horizon=horizon, layout_id=lid)), ("encode", seed)
         if all(s.num_players == 2 for s in specs):
-            assert np.array_equal(env.featurize().cpu().numpy(), O.featurize(orc, st, layout_id=lid)), ("featurize", seed)
+            cg = "all" if seed % 2 else "none"
+            assert np.array_equal(env.featurize(counter_goals=cg, num_pots=seed % 4).cpu().numpy(),
+                                  O.featurize(orc, st, counter_goals=cg, num_pots=seed % 4, layout_id=lid)), ("featurize", seed)
         try:
             pp = [potential_params(s, 0.99) for s in specs]
             phi = env.potential(0.99).cpu().numpy()
