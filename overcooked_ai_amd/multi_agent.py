@@ -166,7 +166,8 @@ class VecOvercookedMultiAgent:
     those envs is the first observation of the new episode (the usual vector-env convention)."""
 
     def __init__(self, layouts, n_envs, horizon=400, reward_shaping_factor=0.0, reward_shaping_horizon=0, use_phi=True,
-                 gamma=0.99, obs="ppo", obs_dtype=None, device="cuda", **venv_kwargs):
+                 gamma=0.99, obs="ppo", obs_dtype=None, device="cuda", random_start_pos=False, rnd_obj_prob_thresh=0.0,
+                 **venv_kwargs):
         import torch
 
         from . import _lib
@@ -180,6 +181,10 @@ class VecOvercookedMultiAgent:
         self._initial_reward_shaping_factor = self.reward_shaping_factor = reward_shaping_factor
         self.reward_shaping_horizon = reward_shaping_horizon
         self.obs_kind = obs
+        # start_state_fn = mdp.get_random_start_state_fn(random_start_pos, rnd_obj_prob_thresh) of the reference's
+        # env_params (mdp.py:1307-1369): every episode, including the restarts inside step(), begins from a random state
+        self.random_start_pos, self.rnd_obj_prob_thresh = bool(random_start_pos), float(rnd_obj_prob_thresh)
+        self._random_starts = self.random_start_pos or self.rnd_obj_prob_thresh > 0.0
         self.obs_dtype = obs_dtype or torch.float32  # the reference casts observations to float32 (rllib.py:257)
         dev = v.device
         self.shaped = torch.zeros((self.n_envs, 2), dtype=torch.float64, device=dev)
@@ -195,6 +200,8 @@ class VecOvercookedMultiAgent:
             lid = v.layout_id_host if v.layout_id is not None else np.zeros(self.n_envs, np.int64)
             first = [int(np.nonzero(lid == l)[0][0]) if (lid == l).any() else 0 for l in range(len(v.table))]
             self.phi_start.copy_(self.phi_cur[torch.as_tensor(first, device=dev)])
+        if self._random_starts:
+            self.reset()
 
     def _obs_buffer(self):
         if self._obs is None or self._obs.dtype != self.obs_dtype:
@@ -213,6 +220,11 @@ class VecOvercookedMultiAgent:
         raise ValueError("Unsupported agent type {0}".format(kind))
 
     def reset(self):
+        if self._random_starts:
+            self.venv.reset(random_start_pos=self.random_start_pos, rnd_obj_prob_thresh=self.rnd_obj_prob_thresh)
+            if self.use_phi:
+                self.venv.potential(self.gamma, out=self.phi_cur)
+            return self.observations()
         self.venv.reset()
         if self.use_phi:
             lid = self.venv.layout_id
@@ -225,7 +237,7 @@ class VecOvercookedMultiAgent:
         if actions.dtype != torch.uint8 or actions.shape != (self.n_envs, 2) or not actions.is_contiguous() \
                 or actions.device != v.state.device:
             raise ValueError("actions must be a contiguous uint8 [n_envs, 2] tensor on %s" % v.device)
-        obs = self._obs_buffer() if self.obs_kind == "ppo" else None
+        obs = self._obs_buffer() if (self.obs_kind == "ppo" and not self._random_starts) else None
         code = {torch.uint8: self._lib.OBS_U8, torch.float32: self._lib.OBS_F32}[self.obs_dtype]
         if self.use_phi:
             if self._phi_args is None:
@@ -241,6 +253,10 @@ class VecOvercookedMultiAgent:
                        self.shaped.data_ptr(), self.done.data_ptr(), obs.data_ptr() if obs is not None else None, code,
                        self.horizon)
         self._lib.check(rc, "oc_multi_agent_step")
+        if self._random_starts:  # finished envs were restarted from the standard state: redraw them, then observe
+            v.reset(mask=self.done, random_start_pos=self.random_start_pos, rnd_obj_prob_thresh=self.rnd_obj_prob_thresh)
+            if self.use_phi:
+                v.potential(self.gamma, out=self.phi_cur)  # == phi(s') where the episode goes on, phi(new start) elsewhere
         infos = {"sparse_r_by_agent": v.rewards[:, 0:2], "shaped_r_by_agent": v.rewards[:, 2:4], "flags": v.flags,
                  "ep_returns": self.ep_returns}  # episode totals so far; final where done (the reset cleared the live ones)
         if self.use_phi:

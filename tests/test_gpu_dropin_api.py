@@ -262,3 +262,42 @@ def test_vec_multi_agent_matches_reference_episodes():
         ts = env.venv.state[0][:, 6].long() + 256 * env.venv.state[0][:, 7].long()
         assert int(ts.max()) < 30
     assert n_done == int(((stagger + 45) // 30).sum())
+
+
+def test_vec_multi_agent_random_start_states():
+    """start_state_fn = get_random_start_state_fn(...) for the batched training env: the first states and every
+    restart are drawn by oc_reset_random (checked against the oracle's restatement), phi is carried correctly."""
+    import torch
+
+    from oracle import oracle as O
+    from overcooked_ai_amd import VecOvercookedMultiAgent
+    from overcooked_ai_amd.layouts import spec_from_name
+    from overcooked_ai_amd.potential import potential_params
+
+    dev = torch.device("cuda:0")
+    n, horizon = 2048, 9
+    spec = spec_from_name("coordination_ring")
+    env = VecOvercookedMultiAgent(spec, n, horizon=horizon, reward_shaping_factor=1.0, use_phi=True, device=dev, seed=4,
+                                  random_start_pos=True, rnd_obj_prob_thresh=0.4)
+    orc = O.Oracle([O.mdp_from_layout_dict(spec.to_layout_dict())])
+    pp = [potential_params(spec, 0.99)]
+    st = orc.reset_random(orc.new_state(n), seed=4, epoch=0, random_start_pos=True, rnd_obj_prob_thresh=0.4)
+    assert np.array_equal(env.venv.get_packed_state(), st)
+    assert np.array_equal(env.phi_cur.cpu().numpy(), O.potential(orc, st, pp))
+    gen = torch.Generator(device=dev).manual_seed(1)
+    epoch = 1
+    for t in range(2 * horizon + 3):
+        acts = torch.randint(0, 6, (n, 2), dtype=torch.uint8, device=dev, generator=gen)
+        phi_before = env.phi_cur.clone()
+        ob, rew, done, infos = env.step(acts)
+        st, r, f = orc.step(st, acts.cpu().numpy(), horizon=horizon, options=0)
+        phi_next = O.potential(orc, st, pp)
+        want = (r[:, 0] + r[:, 1]).astype(np.float64)[:, None] + 1.0 * (phi_next - phi_before.cpu().numpy())[:, None]
+        assert np.array_equal(rew.cpu().numpy(), np.repeat(want, 2, axis=1)), t
+        d = (f & 1).astype(np.uint8)
+        assert np.array_equal(done.cpu().numpy(), d)
+        st = orc.reset_random(st, seed=4, epoch=epoch, random_start_pos=True, rnd_obj_prob_thresh=0.4, mask=d)
+        epoch += 1
+        assert np.array_equal(env.venv.get_packed_state(), st), t
+        assert np.array_equal(env.phi_cur.cpu().numpy(), O.potential(orc, st, pp)), t
+        assert np.array_equal(ob.cpu().numpy().astype(np.int32), orc.encode_lossless(st, horizon=horizon)), t
