@@ -247,7 +247,10 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
                            env_offset, t0, n_steps);                                                                 \
     } while (0)
         const bool two = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0;
-        if (uniform && fast && b->max_pots == 1) GO3(true, 1, true, 3);
+        const bool out = d_rewards != nullptr && d_flags != nullptr;
+        if (uniform && fast && b->max_pots == 1 && out) GO3(true, 1, true, 3, true);
+        else if (uniform && fast && small && out) GO3(true, 2, true, 3, true);
+        else if (uniform && fast && b->max_pots == 1) GO3(true, 1, true, 3);
         else if (uniform && fast && small) GO3(true, 2, true, 3);
         else if (uniform) { if (b->max_pots == 1) GO3(true, 1, true); else if (small) GO3(true, 2, true); else GO3(true, 8, true); }
         else if (lds) { if (small && two) GO3(false, 2, true, 1); else if (small) GO3(false, 2, true); else GO3(false, 8, true); }

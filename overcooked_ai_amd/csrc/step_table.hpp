@@ -385,7 +385,8 @@ __device__ __forceinline__ const uint8_t* stage_lut(uint2* s_lut, uint32_t old_d
     return reinterpret_cast<const uint8_t*>(s_lut) + (old_dyn ? LUT_ENTRIES * 8 : 0);
 }
 
-template <bool UNIFORM, int MAXP, bool LAY_LDS, int FAST = 0>
+// OUT = both output arrays are present (the usual case): their null checks leave the step loop
+template <bool UNIFORM, int MAXP, bool LAY_LDS, int FAST = 0, bool OUT = false>
 __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                     const uint16_t* __restrict__ layout_id, uint4* st,
                                                     float4* __restrict__ rewards, uint8_t* __restrict__ flags,
@@ -451,8 +452,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
         float4 r;                                                                                        \
         env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask, s_move);               \
         const uint32_t fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);             \
-        if (rew_k) { rew_k[threadIdx.x] = r; rew_k += n; }                                               \
-        if (flg_k) { flg_k[threadIdx.x] = (uint8_t)fl; flg_k += n; }                                     \
+        if (OUT || rew_k) { rew_k[threadIdx.x] = r; rew_k += n; }                                        \
+        if (OUT || flg_k) { flg_k[threadIdx.x] = (uint8_t)fl; flg_k += n; }                              \
         if (++k == n_steps) break;                                                                       \
     }
         for (;;) {
