@@ -435,13 +435,12 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
         // One Philox block = 8 steps: the loop is unrolled over the block so that the word / digit position of every
         // step is a compile-time constant (x runs through w, 6w, 36w, 216w: no word select, no x36 multiply) and the
         // refresh test and the back edge are paid once per 8 steps.  A launch may start and end inside a block.
+        // Head (up to the next block boundary) and tail (the last n_steps % 8 steps) run through one rolled copy of the
+        // step; the full blocks in between are 8 unrolled steps without any exit test between them.
         int k = 0;
-        uint32_t s8 = (uint32_t)t0 & 7u;
-        uint64_t blk = (uint64_t)t0 >> 3;
-        philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, rnd);
-        uint32_t x = (s8 & 1u) ? rnd[s8 >> 1] * 36u : 0u;
         float4* rew_k = rew_blk;  // wave-uniform row pointers, advanced by n per step
         uint8_t* flg_k = flg_blk;
+        const int head_end = min(n_steps, (int)((8u - ((uint32_t)t0 & 7u)) & 7u));
 #define OC_STEP(S8)                                                                                      \
     {                                                                                                    \
         if (((S8) & 1u) == 0u) x = rnd[(S8) >> 1];                                                       \
@@ -454,23 +453,32 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
         const uint32_t fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);             \
         if (OUT || rew_k) { rew_k[threadIdx.x] = r; rew_k += n; }                                        \
         if (OUT || flg_k) { flg_k[threadIdx.x] = (uint8_t)fl; flg_k += n; }                              \
-        if (++k == n_steps) break;                                                                       \
     }
-        for (;;) {
-            switch (s8) {
-                case 0: OC_STEP(0u)  // fall through: the rest of the block
-                case 1: OC_STEP(1u)
-                case 2: OC_STEP(2u)
-                case 3: OC_STEP(3u)
-                case 4: OC_STEP(4u)
-                case 5: OC_STEP(5u)
-                case 6: OC_STEP(6u)
-                default: OC_STEP(7u)
+        for (int phase = 0; phase < 2; ++phase) {
+            const int upto = phase == 0 ? head_end : n_steps;
+            for (; k < upto; ++k) {  // rolled steps
+                const uint64_t t = (uint64_t)(t0 + k);
+                const uint32_t s8 = (uint32_t)t & 7u;
+                if (k == 0 || s8 == 0u) {
+                    const uint64_t blk = t >> 3;
+                    philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, rnd);
+                }
+                uint32_t a0, a1;
+                draw_actions(rnd, s8, a0, a1);
+                float4 r;
+                env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask, s_move);
+                const uint32_t fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);
+                if (OUT || rew_k) { rew_k[threadIdx.x] = r; rew_k += n; }
+                if (OUT || flg_k) { flg_k[threadIdx.x] = (uint8_t)fl; flg_k += n; }
             }
-            if (k == n_steps) break;
-            s8 = 0u;
-            ++blk;
-            philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, rnd);
+            if (phase == 0) {
+                for (; n_steps - k >= 8; k += 8) {  // whole Philox blocks
+                    const uint64_t blk = (uint64_t)(t0 + k) >> 3;
+                    philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, rnd);
+                    uint32_t x = 0;
+                    OC_STEP(0u) OC_STEP(1u) OC_STEP(2u) OC_STEP(3u) OC_STEP(4u) OC_STEP(5u) OC_STEP(6u) OC_STEP(7u)
+                }
+            }
         }
 #undef OC_STEP
     } else {
