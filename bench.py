@@ -161,8 +161,7 @@ def main():
         # mean over equal-size launches only; the ragged tail launch is excluded pro rata
         launch_ms = dev_ms * (fuse / float(args.steps))
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-    kernel = ("k_rollout" if args.predicate_interact else "k_rollout_pair" if args.lane_pair
-              else "k_rollout3" if (args.lane_per_env or n > 32768) else "k_rollout_pair")
+    kernel = "k_rollout" if args.predicate_interact else "k_rollout_pair" if args.lane_pair else "k_rollout3"
     traffic = None
     try:  # PMC HBM bytes per launch measured by tools/profile_round.sh on this same command (profiles/traffic.json)
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:

@@ -83,9 +83,9 @@ extern "C" {
 /* option bits for oc_step / oc_rollout_random */
 #define OC_OPT_AUTO_RESET 0x1u /* reset a done env to its layout's start state inside the kernel */
 
-#define OC_OPT_LANE_PER_ENV 0x2u /* oc_rollout_random: force the one-lane-per-env kernel */
-#define OC_OPT_LANE_PAIR 0x4u    /* oc_rollout_random: force the lane-pair-per-env kernel where the table allows it
-                                   (2-player layouts, <= 2 pots); default: pairs iff n_envs <= 64 * #SIMDs */
+#define OC_OPT_LANE_PER_ENV 0x2u /* oc_rollout_random: the one-lane-per-env kernel (the default; kept for callers that set it) */
+#define OC_OPT_LANE_PAIR 0x4u    /* oc_rollout_random: the lane-pair-per-env kernel where the table allows it
+                                   (2-player layouts, <= 2 pots); never chosen automatically */
 #define OC_OPT_PREDICATE_INTERACT 0x8u /* oc_rollout_random: one-lane-per-env kernel with the predicate-network
                                          interact instead of the table-driven one (kept for cross-checking) */
 

@@ -13,6 +13,10 @@ SRC = os.path.join(PKG, "csrc", "oc_amd.hip")
 HDR = os.path.join(os.path.dirname(PKG), "include", "oc_amd.h")
 LIB = os.path.join(PKG, "liboc_amd.so")
 ARCH = "gfx950"
+# The step kernels run one wavefront per SIMD at the headline batch size, so latency has to be hidden inside the
+# wavefront: LLVM's max-ILP scheduling strategy (instead of the default, which schedules for occupancy) is worth
+# +14 % on k_rollout3 and is neutral for the bandwidth-bound kernels.
+SCHED = ("-mllvm", "-amdgpu-sched-strategy=max-ilp")
 
 
 def hipcc_path():
@@ -35,7 +39,7 @@ def build_extension(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     tmp = LIB + ".%d.tmp" % os.getpid()
-    cmd = [hipcc_path(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", tmp, SRC]
+    cmd = [hipcc_path(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", *SCHED, "-shared", "-fPIC", "-o", tmp, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -205,12 +205,12 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
     const bool uniform = b->n_layouts == 1;
     const bool lds = b->n_layouts <= LDS_LAYOUT_MAX;
     const bool small = b->max_pots >= 1 && b->max_pots <= 2;
-    // Lane pairs pay ~1.5x the total VALU work of one lane per env but halve the per-wavefront instruction stream:
-    // they win while one lane per env leaves half of the SIMDs without a wavefront (measured on MI355X, us per
-    // batched step, pair vs lane: 0.81 vs 1.02 at 32 768 envs, 1.11 vs 1.03 at 40 960, 1.13 vs 1.01 at 65 536).
+    // Lane pairs (two lanes per env) halve the per-wavefront instruction stream at ~1.5x the total VALU work.  They
+    // used to win for batches that leave SIMDs without a wavefront (<= 32 768 envs); with the table-driven step built
+    // for ILP the lane-per-env kernel is faster at every batch size (us per batched step, lane vs pair, cramped_room:
+    // 0.55 vs 0.73 at 4 096 envs, 0.57 vs 0.76 at 32 768), so pairs run only when OC_OPT_LANE_PAIR asks for them.
     const bool pair_ok = small && (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0;
-    const bool want_pair = (options & OC_OPT_LANE_PAIR) ||
-                           (!(options & (OC_OPT_LANE_PER_ENV | OC_OPT_PREDICATE_INTERACT)) && b->n_envs <= 32 * simd_count());
+    const bool want_pair = (options & OC_OPT_LANE_PAIR) != 0;
     if (pair_ok && want_pair) {
         // two lanes per env (k_rollout_pair)
         const size_t smem2 = (size_t)n_obj * 8 * PAIR_ENVS * sizeof(uint32_t);
