@@ -66,9 +66,23 @@ def run_fused(env, n_steps, fuse, rew, fl):
     return launches
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes show
+    256 logical CPUs but run the job under a 16-CPU quota; oversubscribing it makes the threaded oracle slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(layout, seconds):
-    """The C oracle (a scalar port of the reference's algorithm) on ONE host core: a bounded sample of the same
-    workload (same layout, random policy, horizon 400 with auto-reset, outputs written every step)."""
+    """The C oracle (a scalar port of the reference's algorithm) on the host: a bounded sample of the same workload
+    (same layout, random policy, horizon 400 with auto-reset, outputs written every step), first on one core, then
+    with the independent envs spread over all cores (OpenMP).  `value` is the all-cores figure."""
     import numpy as np
 
     from oracle import oracle as O
@@ -76,24 +90,36 @@ def cpu_baseline(layout, seconds):
 
     spec = spec_from_name(layout)
     orc = O.Oracle(O.mdp_from_layout_dict(spec.to_layout_dict()))
-    n, T = 4096, 100
+    n, T = 8192, 100
     st = orc.reset(orc.new_state(n))
     ep = np.zeros((n, 4), np.float32)
-    orc.rollout_random(st, 10, horizon=HORIZON, options=1, seed=0, t0=0, ep_returns=ep)  # warm
-    t0 = time.perf_counter()
-    orc.rollout_random(st, T, horizon=HORIZON, options=1, seed=0, t0=10, ep_returns=ep)
-    probe = time.perf_counter() - t0
-    reps = max(1, int(seconds / max(probe, 1e-6)))
-    t0 = time.perf_counter()
-    tg = 110
-    for _ in range(reps):
+    tg = 0
+
+    def timed(budget):
+        nonlocal tg
+        orc.rollout_random(st, 10, horizon=HORIZON, options=1, seed=0, t0=tg, ep_returns=ep)  # warm
+        tg += 10
+        t0 = time.perf_counter()
         orc.rollout_random(st, T, horizon=HORIZON, options=1, seed=0, t0=tg, ep_returns=ep)
         tg += T
-    dt = time.perf_counter() - t0
-    steps = reps * n * T
+        probe = time.perf_counter() - t0
+        reps = max(1, int(budget / max(probe, 1e-6)))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            orc.rollout_random(st, T, horizon=HORIZON, options=1, seed=0, t0=tg, ep_returns=ep)
+            tg += T
+        dt = time.perf_counter() - t0
+        return reps * n * T / dt, reps * T, dt
+
+    O.set_threads(1)
+    one, steps1, dt1 = timed(seconds * 0.4)
+    cores = O.set_threads(usable_cores())
+    allc, steps_all, dt_all = (one, steps1, dt1) if cores == 1 else timed(seconds * 0.6)
+    O.set_threads(1)
     return {
-        "value": steps / dt, "unit": "env steps/s", "cores": 1, "kind": "port",
-        "sample": "%d envs x %d steps of %s (C oracle, 1 thread, %.1f s)" % (n, reps * T, layout, dt),
+        "value": allc, "unit": "env steps/s", "cores": cores, "kind": "port", "single_core": one,
+        "sample": "%d envs x %d steps of %s (C oracle, %d threads, %.1f s); single core: %d steps in %.1f s"
+                  % (n, steps_all, layout, cores, dt_all, steps1, dt1),
     }
 
 

@@ -66,7 +66,11 @@ def build(force=False):
         return _LIB
     os.makedirs(_BUILD, exist_ok=True)
     tmp = _LIB + ".%d.tmp" % os.getpid()
-    subprocess.check_call(["gcc", "-O2", "-std=c99", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-o", tmp, _SRC, "-lm"])
+    base = ["gcc", "-O2", "-std=c99", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
+    try:  # OpenMP only parallelises the env loop of oracle_rollout_random (bench.py's all-cores CPU baseline)
+        subprocess.check_call(base + ["-fopenmp", "-o", tmp, _SRC, "-lm"], stderr=subprocess.DEVNULL)
+    except (subprocess.CalledProcessError, OSError):
+        subprocess.check_call(base + ["-o", tmp, _SRC, "-lm"])
     os.replace(tmp, _LIB)
     return _LIB
 
@@ -301,6 +305,11 @@ def py_set_order(width, cells):
     out = np.zeros_like(a)
     lib().oracle_py_set_order(int(width), _ptr(a, ctypes.c_int32), len(a), _ptr(out, ctypes.c_int32))
     return [int(c) for c in out]
+
+
+def set_threads(n):
+    """Host threads for oracle_rollout_random's env loop (OpenMP build only); returns the number in effect."""
+    return int(lib().oracle_set_threads(int(n)))
 
 
 def random_actions(seed, env_offset, t, n_envs):

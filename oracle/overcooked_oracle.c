@@ -646,10 +646,26 @@ void oracle_random_actions(uint64_t seed, int64_t env_offset, int64_t t, int64_t
     }
 }
 
+static int g_threads = 1;
+int oracle_set_threads(int n) { /* returns the number of threads that will be used (1 without OpenMP) */
+#ifdef _OPENMP
+    g_threads = n > 0 ? n : 1;
+#else
+    (void)n;
+    g_threads = 1;
+#endif
+    return g_threads;
+}
+
 int oracle_rollout_random(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, uint8_t* state, float* rewards,
                           uint8_t* flags, float* ep_returns, int64_t n_envs, int horizon, uint32_t options,
                           uint64_t seed, int64_t env_offset, int64_t t0, int n_steps) {
     (void)n_mdps;
+    /* envs are independent (no cross-env data flow in mdp.py): with OpenMP the env loop spreads over the host cores set
+     * by oracle_set_threads (default 1) — used only by bench.py's cpu_baseline to report an all-cores figure */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+#endif
     for (int64_t e = 0; e < n_envs; ++e) {
         const OracleMdp* m = &mdps[layout_id ? layout_id[e] : 0];
         State s;
