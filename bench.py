@@ -127,8 +127,11 @@ def main():
     args = parse()
     import torch
 
-    from overcooked_ai_amd import sharding
+    from overcooked_ai_amd import build, sharding
     from overcooked_ai_amd.vec_env import VecOvercookedEnv
+
+    build.build_extension()  # no-op when liboc_amd.so is up to date (a fresh checkout has none: it is git-ignored);
+    # every rank may do it: the build writes a per-process temp file and renames it atomically
 
     rank, local_rank, world = sharding.init_process_group()
     if world != args.gpus:
