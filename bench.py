@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the step-API and encode side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--min-seconds", type=float, default=0.25,
+                    help="minimum length of the timed region: the --steps-step region is repeated back to back until it lasts this long")
+    ap.add_argument("--stub", action="store_true",
+                    help="CPU-only plumbing test (gloo, no kernels): exercises rank spawning and the reductions; never a measurement")
     return ap.parse_args()
 
 
@@ -123,76 +127,197 @@ def cpu_baseline(layout, seconds):
     }
 
 
+# The reference's own rate (north_star: "next to the reference Python OvercookedEnv.step"): the Python reference cannot
+# travel to the GPU box (/root/reference does not exist there), so the figure measured in the build container
+# (SURVEY §8d-1 protocol: cramped_room, horizon 400, random joint actions, info_level 0) is carried in
+# the JSON with its provenance.
+REFERENCE_PYTHON = {
+    "value": 16400.0, "unit": "env steps/s", "cores": 1,
+    "all_cores": {"value": 74000.0, "cores": 8, "note": "one env per process, multiprocessing.Pool(8)"},
+    "where": "build container (8 vCPU Xeon 2.1 GHz, CPython 3.10.12, numpy 2.2.6), not the GPU box",
+    "what": "reference OvercookedEnv.step (src/overcooked_ai_py/mdp/overcooked_env.py:244), cramped_room, horizon 400, "
+            "np.random.RandomState joint actions, >= 50 episodes after 1 warm-up",
+    "source": "BASELINE.md §2 / SURVEY.md §8d-1",
+}
+
+
+def lcm(a, b):
+    import math
+
+    return a * b // math.gcd(a, b)
+
+
+def plan_repeats(steps, fuse, est_ms_per_step, min_seconds):
+    """The timed region is R back-to-back repetitions of the --steps-step region, launched as whole `fuse`-step
+    launches: R is the smallest count that (a) makes steps * R a multiple of `fuse` and (b) lasts >= min_seconds at the
+    rate estimated during warm-up."""
+    unit = lcm(steps, fuse) // steps  # repetitions per whole number of launches
+    need = max(1, int(-(-min_seconds * 1e3 // max(est_ms_per_step * steps, 1e-9))))
+    return -(-need // unit) * unit
+
+
+class _StubEnv:
+    """CPU stand-in for VecOvercookedEnv used ONLY by `--stub` (tests of the rank-spawning / reduction plumbing on a
+    box without GPUs, gloo backend).  It steps nothing; the JSON it yields says data: "stub"."""
+
+    n_planes = 3
+
+    def __init__(self, n):
+        self.n_envs, self.t_global = n, 0
+
+    def rollout_random(self, k, rew=None, fl=None):
+        self.t_global += k
+        if rew is not None:
+            rew[:k].fill_(1.0 / 16)
+
+
+class _Timer:
+    """Device-side timing of each launch: HIP events on the stream the kernels are launched on (torch's current
+    stream — VecOvercookedEnv launches there); wall clock on CPU for the stub."""
+
+    def __init__(self, torch, dev):
+        self.torch, self.gpu, self.dev, self.ev = torch, dev.type == "cuda", dev, []
+
+    def mark(self):
+        if self.gpu:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.ev.append(e)
+        else:
+            self.ev.append(time.perf_counter())
+
+    def sync(self):
+        if self.gpu:
+            self.torch.cuda.synchronize(self.dev)
+
+    def launch_ms(self):
+        if self.gpu:
+            return [a.elapsed_time(b) for a, b in zip(self.ev[:-1], self.ev[1:])]
+        return [(b - a) * 1e3 for a, b in zip(self.ev[:-1], self.ev[1:])]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this same command (one per GPU) with the
+    torch.distributed rendezvous environment on 127.0.0.1; rank 0's JSON line is the output."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OC_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            rc = p.wait() or rc
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     import torch
 
-    from overcooked_ai_amd import build, sharding
-    from overcooked_ai_amd.vec_env import VecOvercookedEnv
+    from overcooked_ai_amd import sharding
 
-    build.build_extension()  # no-op when liboc_amd.so is up to date (a fresh checkout has none: it is git-ignored);
-    # every rank may do it: the build writes a per-process temp file and renames it atomically
+    if not args.stub:
+        from overcooked_ai_amd import build
+        from overcooked_ai_amd.vec_env import VecOvercookedEnv
 
-    rank, local_rank, world = sharding.init_process_group()
+        build.build_extension()  # no-op when liboc_amd.so is up to date (a fresh checkout has none: it is git-ignored);
+        # every rank may do it: the build writes a per-process temp file and renames it atomically
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+        if args.gpus > torch.cuda.device_count():
+            raise SystemExit("--gpus %d but only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
+    else:
+        VecOvercookedEnv = None
+
+    rank, local_rank, world = sharding.init_process_group("gloo" if args.stub else None)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    dev = torch.device("cpu") if args.stub else torch.device("cuda", local_rank)
+    if not args.stub:
+        torch.cuda.set_device(dev)
 
     n = args.envs
     if args.config != 2:
         return run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world)
-    env = VecOvercookedEnv(args.layout, n, horizon=HORIZON, device=dev, auto_reset=True, seed=0,
-                           env_offset=rank * n)
-    env.lane_per_env = args.lane_per_env
-    env.lane_pair = args.lane_pair
-    env.predicate_interact = args.predicate_interact
-    fuse = max(1, min(args.fuse, args.steps))
+    if args.stub:
+        env = _StubEnv(n)
+    else:
+        env = VecOvercookedEnv(args.layout, n, horizon=HORIZON, device=dev, auto_reset=True, seed=0,
+                               env_offset=rank * n)
+        env.lane_per_env = args.lane_per_env
+        env.lane_pair = args.lane_pair
+        env.predicate_interact = args.predicate_interact
+    fuse = max(1, args.fuse)  # launch shape: independent of --steps (a 20-step --steps must not shrink the launches)
     rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
+    tm = _Timer(torch, dev)
 
+    # warm-up: the W steps asked for, then whole launches of the timed shape (also the calibration of R)
     run_fused(env, args.warmup, fuse, rew, fl)
-    torch.cuda.synchronize(dev)
+    pad = (-env.t_global) % 8  # realign to a Philox block so every timed launch has the same shape
+    if pad:
+        env.rollout_random(pad, rew[:pad], fl[:pad])
+    cal = _Timer(torch, dev)
+    for _ in range(3):
+        cal.mark()
+        env.rollout_random(fuse, rew, fl)
+    cal.mark()
+    cal.sync()
+    est = torch.tensor([min(cal.launch_ms()[1:]) / fuse], dtype=torch.float64, device=dev)
+    sharding.allreduce_max(est)  # every rank must pick the same R
+    repeats = plan_repeats(args.steps, fuse, float(est.item()), args.min_seconds)
+    total_steps = args.steps * repeats
+    launches = total_steps // fuse
+
+    tm.sync()
     sharding.barrier()
-    torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tm.sync()
     t0 = time.perf_counter()
-    ev0.record()
-    launches = run_fused(env, args.steps, fuse, rew, fl)
-    ev1.record()
-    torch.cuda.synchronize(dev)
+    for _ in range(launches):
+        tm.mark()
+        env.rollout_random(fuse, rew, fl)
+    tm.mark()
+    tm.sync()
     sharding.barrier()
-    torch.cuda.synchronize(dev)
+    tm.sync()
     wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    per_launch = sorted(tm.launch_ms())
+    dev_ms = sum(per_launch)
+    launch_med, launch_min = per_launch[len(per_launch) // 2], per_launch[0]
     tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
     sharding.allreduce_max(tmax)
     wall_max = float(tmax.item())
-    # aggregate-return metric: the only collective, outside the hot path (RCCL all-reduce of 6 scalars)
-    done_eps = (fl[-1] & 1).sum().to(torch.float64) if args.steps >= fuse else torch.zeros((), dtype=torch.float64, device=dev)
-    metrics = torch.stack([rew[..., 0:2].sum().to(torch.float64), rew[..., 2:4].sum().to(torch.float64), done_eps])
+    per_rank = torch.zeros((world,), dtype=torch.float64, device=dev)
+    per_rank[rank] = wall * 1e3 / total_steps
+    sharding.allreduce_metrics(per_rank)  # disjoint slots: the sum is a gather
+    # aggregate-return metric: the only collective, outside the hot path (RCCL all-reduce of 3 scalars)
+    metrics = torch.stack([rew[..., 0:2].sum().to(torch.float64), rew[..., 2:4].sum().to(torch.float64),
+                           (fl[-1] & 1).sum().to(torch.float64)])
     sharding.allreduce_metrics(metrics)
 
-    total_env_steps = float(world) * n * args.steps
-    value = total_env_steps / wall_max
+    value = float(world) * n * total_steps / wall_max
 
-    # roofline of the dominant kernel (k_rollout): algorithmic HBM bytes per launch / mean launch duration
+    # roofline of the dominant kernel (k_rollout3): algorithmic HBM bytes per launch / median launch duration
     state_bytes = S_CRAMPED if args.layout == "cramped_room" else 4 * ((env.n_planes * 16) // 4)
     bytes_per_launch = n * (2 * state_bytes + OUT_BYTES * fuse)
-    full_launches = args.steps // fuse
-    launch_ms = dev_ms / launches
-    if args.steps % fuse:
-        # mean over equal-size launches only; the ragged tail launch is excluded pro rata
-        launch_ms = dev_ms * (fuse / float(args.steps))
-    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    achieved = bytes_per_launch / (launch_med * 1e-3) / 1e9
     kernel = "k_rollout" if args.predicate_interact else "k_rollout_pair" if args.lane_pair else "k_rollout3"
     traffic = None
-    try:  # PMC HBM bytes per launch measured by tools/profile_round.sh on this same command (profiles/traffic.json)
+    try:  # PMC HBM bytes per launch measured by tools/profile_round.sh on this same launch shape (profiles/traffic.json)
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             tj = json.load(f)
         best = 0
@@ -217,30 +342,41 @@ def main():
     out = {
         "metric": "env steps/sec (whole node), 65k parallel cramped_room envs",
         "value": value, "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": wall_max * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "ms_per_step": wall_max * 1e3 / total_steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "stub" if args.stub else "synthetic",
+        "repeats": repeats, "timed_steps": total_steps, "timed_region_s": wall_max,
+        "ms_per_step_median": launch_med / fuse, "ms_per_step_min": launch_min / fuse,
+        "ms_per_step_by_rank": [float(x) for x in per_rank.tolist()],
         "config": {"workload": "%s x %d envs/GPU, in-kernel Philox random policy, horizon %d auto-reset, outputs every step"
                                % (args.layout, n, HORIZON),
-                   "envs_per_gpu": n, "fused_steps_per_launch": fuse, "launches": launches, "parallelism": "env-shard x%d" % world},
+                   "envs_per_gpu": n, "fused_steps_per_launch": fuse, "launches": launches, "parallelism": "env-shard x%d" % world,
+                   "timing_rule": "timed region = `repeats` back-to-back repetitions of the --steps-step region (steps x repeats "
+                                  "batched steps, issued as whole %d-step launches whatever --steps is), repeats = smallest count "
+                                  "with steps*repeats a multiple of %d and a region >= %.2f s at the warm-up rate; value and "
+                                  "ms_per_step are over the whole region (wall clock, max over ranks)" % (fuse, fuse, args.min_seconds)},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "bytes_per_launch": bytes_per_launch, "launch_ms": launch_ms,
+                     "bytes_per_launch": bytes_per_launch, "launch_ms": launch_med, "launch_ms_min": launch_min,
+                     "launch_ms_mean": dev_ms / max(1, launches), "launch_timing": "per-launch HIP events on the launch stream, median",
                      "bytes_model": "n_envs*(2*S + 17*T): S=%d B state in+out once per launch, 17 B outputs per env-step, actions in-kernel" % state_bytes,
-                     "survey_8d_per_step_model_GBs": n * (2 * state_bytes + OUT_BYTES) * fuse / (launch_ms * 1e-3) / 1e9,
+                     "survey_8d_per_step_model_GBs": n * (2 * state_bytes + OUT_BYTES) * fuse / (launch_med * 1e-3) / 1e9,
                      "issue_bound": issue},
         "device_ms_timed_region": dev_ms,
         "aggregate": {"sparse_return_last_launch": float(metrics[0]), "shaped_return_last_launch": float(metrics[1]),
-                      "episodes_done_last_step": float(metrics[2])},
+                      "episodes_done_last_step": float(metrics[2]),
+                      "reduced_over": ("RCCL all-reduce" if not args.stub else "gloo all-reduce") if sharding._live() else "single rank"},
     }
 
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and not args.stub:
         out["step_api"] = bench_step_api(env, dev, torch)
+        out["single_env_api"] = bench_single_env_api(dev, torch)
         out["encode"] = bench_encode(dev, torch, VecOvercookedEnv)
         out["training_env"] = bench_training_env(dev, torch)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and not args.stub:
         out["cpu_baseline"] = cpu_baseline(args.layout, args.cpu_seconds)
+        out["cpu_baseline"]["reference_python"] = REFERENCE_PYTHON
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     sharding.barrier()
 
 
@@ -272,44 +408,59 @@ def run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
         env = VecOvercookedEnv(table, n, horizon=HORIZON, device=dev, auto_reset=True, seed=0, env_offset=rank * n,
                                layout_id=lid)
         workload, sbytes = "%d LayoutGenerator 9x5 terrains (reference generator, seed 0; env e -> terrain e %% %d) x %d envs/GPU, random policy" % (K, K, n), 36
-    fuse = 1 if encode else max(1, min(args.fuse, args.steps))
+    fuse = 1 if encode else max(1, args.fuse)
     rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
     obs = torch.empty((n, 2, env.width, env.height, 26), dtype=torch.uint8, device=dev) if encode else None
 
-    def run(steps):
-        left = steps
-        while left > 0:
-            k = min(fuse, left)
-            env.rollout_random(k, rew[:k], fl[:k])
-            if encode:
-                env.encode_lossless(torch.uint8, out=obs)
-            left -= k
+    def launch():  # one `fuse`-step unit of the workload
+        env.rollout_random(fuse, rew, fl)
+        if encode:
+            env.encode_lossless(torch.uint8, out=obs)
 
-    run(args.warmup)
-    torch.cuda.synchronize(dev)
+    for _ in range(-(-args.warmup // fuse)):
+        launch()
+    cal = _Timer(torch, dev)
+    for _ in range(4):
+        cal.mark()
+        launch()
+    cal.mark()
+    cal.sync()
+    est = torch.tensor([min(cal.launch_ms()[1:]) / fuse], dtype=torch.float64, device=dev)
+    sharding.allreduce_max(est)
+    repeats = plan_repeats(args.steps, fuse, float(est.item()), args.min_seconds)
+    total_steps = args.steps * repeats
+    tm = _Timer(torch, dev)
+    tm.sync()
     sharding.barrier()
-    torch.cuda.synchronize(dev)
+    tm.sync()
     t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize(dev)
+    for _ in range(total_steps // fuse):
+        tm.mark()
+        launch()
+    tm.mark()
+    tm.sync()
     sharding.barrier()
-    torch.cuda.synchronize(dev)
+    tm.sync()
     wall = time.perf_counter() - t0
+    per_launch = sorted(tm.launch_ms())
+    unit_med = per_launch[len(per_launch) // 2]
     tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
     sharding.allreduce_max(tmax)
     wall = float(tmax.item())
-    per_step_bytes = n * ((2 * sbytes + OUT_BYTES) if fuse == 1 else OUT_BYTES) + (n * 2 * env.width * env.height * 26 if encode else 0)
-    out = {"metric": "env steps/sec (whole node)", "value": float(world) * n * args.steps / wall, "unit": "env steps/s",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+    unit_bytes = n * (2 * sbytes + OUT_BYTES * fuse) + (n * (sbytes + 2 * env.width * env.height * 26) if encode else 0)
+    out = {"metric": "env steps/sec (whole node)", "value": float(world) * n * total_steps / wall, "unit": "env steps/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / total_steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "repeats": repeats, "timed_steps": total_steps, "timed_region_s": wall, "ms_per_step_median": unit_med / fuse,
            "config": {"workload": workload, "baseline_config": args.config, "envs_per_gpu": n,
                       "fused_steps_per_launch": fuse},
-           "roofline": {"bound": "hbm", "achieved": per_step_bytes * args.steps / wall / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": per_step_bytes * args.steps / wall / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "note": "algorithmic bytes per batched step / wall time per step (all kernels of the step)"}}
+           "roofline": {"bound": "hbm", "achieved": unit_bytes / (unit_med * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": unit_bytes / (unit_med * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "bytes_per_launch": unit_bytes, "launch_ms": unit_med,
+                        "note": "algorithmic bytes of one %d-step unit (all its kernels) / its median duration from HIP events" % fuse}}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     sharding.barrier()
 
 
@@ -350,6 +501,39 @@ def bench_step_api(env, dev, torch, iters=2000):
     return {"value": n * iters / wall, "step_many": many, "unit": "env steps/s", "launch_ms": ms, "bytes_per_launch": b,
             "achieved_GBs": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "note": "oc_step, one launch per batched step incl. Python/ctypes launch overhead; SURVEY 8d: 67 B/env-step"}
+
+
+def bench_single_env_api(dev, torch, episodes=3):
+    """The drop-in single-env surface existing agents hit: OvercookedEnv.step -> OvercookedGridworld.get_state_transition
+    (one env per call: pack -> H2D -> k_step -> D2H -> unpack), same protocol as the reference's CPU measurement
+    (cramped_room, horizon 400, random joint actions, info_level 0).  Reported next to the reference's 16.4 k steps/s."""
+    import numpy as np
+
+    from overcooked_ai_amd.actions import Action
+    from overcooked_ai_amd.env import OvercookedEnv
+    from overcooked_ai_amd.mdp import OvercookedGridworld
+
+    mdp = OvercookedGridworld.from_layout_name("cramped_room", device=str(dev))
+    env = OvercookedEnv.from_mdp(mdp, horizon=HORIZON, info_level=0)
+    rng = np.random.RandomState(0)
+
+    def episode():
+        env.reset(regen_mdp=False)
+        acts = rng.randint(0, 6, (HORIZON, 2))
+        done, k = False, 0
+        while not done:
+            _, _, done, _ = env.step((Action.INDEX_TO_ACTION[acts[k, 0]], Action.INDEX_TO_ACTION[acts[k, 1]]))
+            k += 1
+        return k
+
+    episode()  # warm-up
+    t0 = time.perf_counter()
+    steps = sum(episode() for _ in range(episodes))
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "env steps/s", "us_per_step": dt / steps * 1e6, "episodes": episodes,
+            "reference_python": REFERENCE_PYTHON["value"],
+            "note": "OvercookedEnv.step through the single-env drop-in API (one env, one launch + one D2H per call); "
+                    "latency-bound by construction - batch with VecOvercookedEnv for throughput"}
 
 
 def bench_training_env(dev, torch, iters=300):

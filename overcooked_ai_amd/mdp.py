@@ -8,6 +8,7 @@ by the HIP kernels (a batch of one env for the single-state calls; `get_state_tr
 calls pay a host<->device round trip each.
 """
 import copy
+import math
 import os
 
 import numpy as np
@@ -327,4 +328,4 @@ class OvercookedGridworld:
 def _num(v):
     """float32 reward -> int when integral (the reference returns Python ints for integer-valued configs)."""
     v = float(v)
-    return int(v) if v == int(v) and abs(v) < 2 ** 31 else v
+    return int(v) if math.isfinite(v) and abs(v) < 2 ** 31 and v == int(v) else v  # inf: tutorial_3's order_bonus

@@ -14,14 +14,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(scope="session", autouse=True)
+_NEEDS_LIB = ("test_abi", "test_gpu_", "test_host")  # test modules that load liboc_amd.so
+
+
+@pytest.fixture(scope="session")
 def _native_library():
     """The HIP library is built in-tree (hipcc cross-compiles gfx950 without a GPU) when it is missing or older than its
     sources — e.g. in a fresh checkout, where the git-ignored .so does not exist.  The product itself never builds or
     falls back on its own: overcooked_ai_amd._lib.load() raises when the library is absent."""
+    import subprocess
+
     from overcooked_ai_amd import build
 
-    build.build_extension()
+    try:
+        build.build_extension()
+    except (FileNotFoundError, subprocess.CalledProcessError) as e:  # no hipcc on this machine
+        if not os.path.exists(build.LIB):
+            pytest.skip("liboc_amd.so is not built and hipcc is unavailable: %s" % e)
+
+
+@pytest.fixture(autouse=True)
+def _build_when_needed(request):
+    """Only the tests that load the library trigger the build; the oracle / host-logic / gloo tests run without hipcc."""
+    if request.module.__name__.split(".")[-1].startswith(_NEEDS_LIB) or request.node.get_closest_marker("gpu"):
+        request.getfixturevalue("_native_library")
 
 
 @pytest.fixture(scope="session")
