@@ -152,7 +152,7 @@ def plan_repeats(steps, fuse, est_ms_per_step, min_seconds):
     launches: R is the smallest count that (a) makes steps * R a multiple of `fuse` and (b) lasts >= min_seconds at the
     rate estimated during warm-up."""
     unit = lcm(steps, fuse) // steps  # repetitions per whole number of launches
-    need = max(1, int(-(-min_seconds * 1e3 // max(est_ms_per_step * steps, 1e-9))))
+    need = max(1, int(-(-min_seconds * 1.05e3 // max(est_ms_per_step * steps, 1e-9))))  # 5 % margin over the estimate
     return -(-need // unit) * unit
 
 
@@ -196,6 +196,25 @@ class _Timer:
         return [(b - a) * 1e3 for a, b in zip(self.ev[:-1], self.ev[1:])]
 
 
+def emit(out):
+    """The ONE JSON line of rank 0.  Native libraries (RCCL's version banner) write to C stdio's stdout, which is
+    block-buffered when redirected: flush it first so that nothing of theirs lands after — or inside — the line."""
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(json.dumps(out), flush=True)
+
+
+def quiet_stdout_unless_rank0():
+    """Ranks other than 0 never print the result; send whatever their native libraries write to stdout to stderr."""
+    if int(os.environ.get("RANK", "0")) != 0:
+        sys.stdout.flush()
+        os.dup2(2, 1)
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this same command (one per GPU) with the
     torch.distributed rendezvous environment on 127.0.0.1; rank 0's JSON line is the output."""
@@ -226,6 +245,7 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
+    quiet_stdout_unless_rank0()
     import torch
 
     from overcooked_ai_amd import sharding
@@ -266,11 +286,11 @@ def main():
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
     tm = _Timer(torch, dev)
 
-    # warm-up: the W steps asked for, then whole launches of the timed shape (also the calibration of R)
-    run_fused(env, args.warmup, fuse, rew, fl)
-    pad = (-env.t_global) % 8  # realign to a Philox block so every timed launch has the same shape
-    if pad:
-        env.rollout_random(pad, rew[:pad], fl[:pad])
+    # warm-up: at least the W steps asked for, rounded up to whole launches of the timed shape (so every launch of the
+    # kernel in a profile of this command is the same 400-step launch), then 3 more that calibrate R
+    warm_launches = max(1, -(-args.warmup // fuse))
+    for _ in range(warm_launches):
+        env.rollout_random(fuse, rew, fl)
     cal = _Timer(torch, dev)
     for _ in range(3):
         cal.mark()
@@ -345,6 +365,7 @@ def main():
         "ms_per_step": wall_max * 1e3 / total_steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "stub" if args.stub else "synthetic",
         "repeats": repeats, "timed_steps": total_steps, "timed_region_s": wall_max,
+        "warmup_steps_run": (warm_launches + 3) * fuse,
         "ms_per_step_median": launch_med / fuse, "ms_per_step_min": launch_min / fuse,
         "ms_per_step_by_rank": [float(x) for x in per_rank.tolist()],
         "config": {"workload": "%s x %d envs/GPU, in-kernel Philox random policy, horizon %d auto-reset, outputs every step"
@@ -376,7 +397,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.layout, args.cpu_seconds)
         out["cpu_baseline"]["reference_python"] = REFERENCE_PYTHON
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     sharding.barrier()
 
 
@@ -460,7 +481,7 @@ def run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
                         "bytes_per_launch": unit_bytes, "launch_ms": unit_med,
                         "note": "algorithmic bytes of one %d-step unit (all its kernels) / its median duration from HIP events" % fuse}}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     sharding.barrier()
 
 

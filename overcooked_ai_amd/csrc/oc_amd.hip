@@ -48,13 +48,32 @@ int fail(int code, const char* msg) {
     return code;
 }
 
+thread_local bool g_lds_refused = false;
+
 int check_launch(const char* what) {
+    if (g_lds_refused) {  // want_lds already wrote the message; nothing was launched
+        g_lds_refused = false;
+        return OC_ELAUNCH;
+    }
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(err));
         return OC_ELAUNCH;
     }
     return OC_OK;
+}
+
+// Raise a kernel's dynamic-LDS limit when a launch needs more than the default; a request above what the device
+// offers is reported here (not as a later launch failure).
+template <typename K>
+bool want_lds(K kernel, size_t bytes, size_t dflt = 40 * 1024) {
+    if (bytes <= dflt) return true;
+    const hipError_t err = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (err == hipSuccess) return true;
+    snprintf(g_err, sizeof(g_err), "dynamic LDS request of %zu bytes refused: %s", bytes, hipGetErrorString(err));
+    (void)hipGetLastError();
+    g_lds_refused = true;
+    return false;
 }
 
 int check_batch(const OcBatch* b, int* n_obj) {
@@ -120,9 +139,7 @@ void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_st
     if (!EVENTS && !(options & OC_OPT_PREDICATE_INTERACT)) {
 #define GO3(U, MP, LL, ...)                                                                                          \
     do {                                                                                                             \
-        if (smem > 40 * 1024)                                                                                        \
-            (void)hipFuncSetAttribute((const void*)k_step3<U, MP, LL, ##__VA_ARGS__>,                                \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                        \
+        if (!want_lds(k_step3<U, MP, LL, ##__VA_ARGS__>, smem)) break;                                               \
         hipLaunchKernelGGL((k_step3<U, MP, LL, ##__VA_ARGS__>), grid, block, smem, s, b->d_layouts, b->n_layouts, b->d_layout_id,   \
                            (const uint4*)d_state_in, (uint4*)d_state_out, d_actions, (float4*)d_rewards, d_flags,    \
                            (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options, n_steps);            \
@@ -135,7 +152,14 @@ void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_st
 #undef GO3
         return;
     }
-#define GO(U, MP, LL)                                                                                                    do {                                                                                                                     if (smem > 48 * 1024)                                                                                                    (void)hipFuncSetAttribute((const void*)k_step<U, MP, LL, EVENTS>,                                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                hipLaunchKernelGGL((k_step<U, MP, LL, EVENTS>), grid, block, smem, s, b->d_layouts, b->n_layouts,                                       b->d_layout_id, (const uint4*)d_state_in, (uint4*)d_state_out, d_actions,                                            (float4*)d_rewards, d_flags, (float4*)d_ep_returns, d_events, b->n_envs, b->width, n_obj,                            horizon, options);                                                                            } while (0)
+#define GO(U, MP, LL)                                                                                       \
+    do {                                                                                                    \
+        if (!want_lds(k_step<U, MP, LL, EVENTS>, smem)) break;                                              \
+        hipLaunchKernelGGL((k_step<U, MP, LL, EVENTS>), grid, block, smem, s, b->d_layouts, b->n_layouts,   \
+                           b->d_layout_id, (const uint4*)d_state_in, (uint4*)d_state_out, d_actions,        \
+                           (float4*)d_rewards, d_flags, (float4*)d_ep_returns, d_events, b->n_envs,         \
+                           b->width, n_obj, horizon, options);                                              \
+    } while (0)
     if (uniform) { if (small) GO(true, 2, true); else GO(true, 8, true); }
     else if (lds) { if (small) GO(false, 2, true); else GO(false, 8, true); }
     else { if (small) GO(false, 2, false); else GO(false, 8, false); }
@@ -238,9 +262,7 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         const dim3 grid3(grid_for(b->n_envs)), block3(BLOCK);
 #define GO3(U, MP, LL, ...)                                                                                          \
     do {                                                                                                             \
-        if (smem3 > 40 * 1024)                                                                                       \
-            (void)hipFuncSetAttribute((const void*)k_rollout3<U, MP, LL, ##__VA_ARGS__>,                             \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);                       \
+        if (!want_lds(k_rollout3<U, MP, LL, ##__VA_ARGS__>, smem3)) break;                                           \
         hipLaunchKernelGGL((k_rollout3<U, MP, LL, ##__VA_ARGS__>), grid3, block3, smem3, s, b->d_layouts, b->n_layouts,             \
                            b->d_layout_id, (uint4*)d_state, (float4*)d_rewards, d_flags, (float4*)d_ep_returns,     \
                            b->n_envs, b->width, n_obj, horizon, options, (uint32_t)seed, (uint32_t)(seed >> 32),    \
@@ -260,7 +282,14 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
     }
     const size_t smem = (size_t)n_obj * 8 * BLOCK * sizeof(uint32_t);
     const dim3 grid(grid_for(b->n_envs)), block(BLOCK);
-#define GO(U, MP, LL)                                                                                                    do {                                                                                                                     if (smem > 48 * 1024)                                                                                                    (void)hipFuncSetAttribute((const void*)k_rollout<U, MP, LL>, hipFuncAttributeMaxDynamicSharedMemorySize,                                       (int)smem);                                                                            hipLaunchKernelGGL((k_rollout<U, MP, LL>), grid, block, smem, s, b->d_layouts, b->n_layouts, b->d_layout_id,                            (uint4*)d_state, (float4*)d_rewards, d_flags, (float4*)d_ep_returns, b->n_envs, b->width,                            n_obj, horizon, options, (uint32_t)seed, (uint32_t)(seed >> 32), env_offset, t0, n_steps);     } while (0)
+#define GO(U, MP, LL)                                                                                       \
+    do {                                                                                                    \
+        if (!want_lds(k_rollout<U, MP, LL>, smem)) break;                                                   \
+        hipLaunchKernelGGL((k_rollout<U, MP, LL>), grid, block, smem, s, b->d_layouts, b->n_layouts,        \
+                           b->d_layout_id, (uint4*)d_state, (float4*)d_rewards, d_flags,                    \
+                           (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options,             \
+                           (uint32_t)seed, (uint32_t)(seed >> 32), env_offset, t0, n_steps);                \
+    } while (0)
     if (uniform) { if (small) GO(true, 2, true); else GO(true, 8, true); }
     else if (lds) { if (small) GO(false, 2, true); else GO(false, 8, true); }
     else { if (small) GO(false, 2, false); else GO(false, 8, false); }
@@ -283,11 +312,11 @@ int oc_featurize(const OcBatch* b, const uint8_t* d_plan_blob, const uint32_t* d
     const size_t smem = (size_t)FEAT_ENVS * n_planes * 16 + (size_t)FEAT_ENVS * 2 * (total + 2) * sizeof(int16_t);
     const dim3 grid((unsigned)((b->n_envs + FEAT_ENVS - 1) / FEAT_ENVS)), block(BLOCK);
     if (b->n_layouts <= LDS_LAYOUT_MAX) {
-        (void)hipFuncSetAttribute((const void*)k_featurize<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (!want_lds(k_featurize<true>, smem)) return check_launch("oc_featurize");
         hipLaunchKernelGGL((k_featurize<true>), grid, block, smem, s, b->d_layouts, b->n_layouts, b->d_layout_id, d_plan_blob,
                            d_plan_off, (const uint4*)d_state, d_features, b->n_envs, b->width, b->height, n_planes, num_pots);
     } else {
-        (void)hipFuncSetAttribute((const void*)k_featurize<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (!want_lds(k_featurize<false>, smem)) return check_launch("oc_featurize");
         hipLaunchKernelGGL((k_featurize<false>), grid, block, smem, s, b->d_layouts, b->n_layouts, b->d_layout_id, d_plan_blob,
                            d_plan_off, (const uint4*)d_state, d_features, b->n_envs, b->width, b->height, n_planes, num_pots);
     }
@@ -342,8 +371,6 @@ int oc_reset(const OcBatch* b, void* d_state, const uint8_t* d_mask, float* d_ep
     return check_launch("oc_reset");
 }
 
-int oc_reset(const OcBatch* b, void* d_state, const uint8_t* d_mask, float* d_ep_returns, void* stream);
-
 int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
                         float* d_ep_returns, float* d_ep_returns_out, const uint8_t* d_plan_blob,
                         const uint32_t* d_plan_off, const uint8_t* d_phi_tables, double* d_phi_next, double* d_phi_cur,
@@ -368,9 +395,7 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
                 const dim3 grid(grid_for(b->n_envs)), block(BLOCK);
 #define GOT(U, MP, LL, F)                                                                                             \
     do {                                                                                                              \
-        if (smem > 40 * 1024)                                                                                         \
-            (void)hipFuncSetAttribute((const void*)k_train_step<U, MP, LL, F>,                                        \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                         \
+        if (!want_lds(k_train_step<U, MP, LL, F>, smem)) break;                                                       \
         hipLaunchKernelGGL((k_train_step<U, MP, LL, F>), grid, block, smem, (hipStream_t)stream, b->d_layouts,        \
                            b->n_layouts, b->d_layout_id, (uint4*)d_state, d_actions, (float4*)d_rewards, d_flags,     \
                            (float4*)d_ep_returns, (float4*)d_ep_returns_out, d_plan_blob, d_plan_off, d_phi_tables,   \
@@ -460,17 +485,9 @@ int oc_encode_lossless(const OcBatch* b, const void* d_state, void* d_obs, int o
             if (per_cu < 1) per_cu = 1;
             int64_t grid_u = (simd_count() / 4) * per_cu;
             if (grid_u > n_groups) grid_u = n_groups;
-            if (obs_dtype == OC_OBS_U8) {
-                if (smem_u > 48 * 1024)
-                    (void)hipFuncSetAttribute((const void*)k_encode_uniform<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_u);
-                hipLaunchKernelGGL((k_encode_uniform<uint8_t>), dim3((unsigned)grid_u), dim3(BLOCK), smem_u, s, b->d_layouts,
-                                   (const uint4*)d_state, (uint8_t*)d_obs, b->n_envs, b->width, b->height, n_planes, unit, upg, horizon);
-            } else {
-                if (smem_u > 48 * 1024)
-                    (void)hipFuncSetAttribute((const void*)k_encode_uniform<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_u);
-                hipLaunchKernelGGL((k_encode_uniform<float>), dim3((unsigned)grid_u), dim3(BLOCK), smem_u, s, b->d_layouts,
-                                   (const uint4*)d_state, (float*)d_obs, b->n_envs, b->width, b->height, n_planes, unit, upg, horizon);
-            }
+            if (!want_lds(k_encode_uniform<uint8_t>, smem_u)) return check_launch("oc_encode_lossless");
+            hipLaunchKernelGGL((k_encode_uniform<uint8_t>), dim3((unsigned)grid_u), dim3(BLOCK), smem_u, s, b->d_layouts,
+                               (const uint4*)d_state, (uint8_t*)d_obs, b->n_envs, b->width, b->height, n_planes, unit, upg, horizon);
             return check_launch("oc_encode_lossless");
         }
     }
@@ -478,9 +495,7 @@ int oc_encode_lossless(const OcBatch* b, const void* d_state, void* d_obs, int o
     const bool lds = b->n_layouts <= LDS_LAYOUT_MAX;
 #define LAUNCH_ENC(T, LDSFLAG)                                                                                        \
     do {                                                                                                              \
-        if (smem > 48 * 1024)                                                                                         \
-            (void)hipFuncSetAttribute((const void*)k_encode<T, LDSFLAG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)smem);                                                                     \
+        if (!want_lds(k_encode<T, LDSFLAG>, smem)) break;                                                             \
         hipLaunchKernelGGL((k_encode<T, LDSFLAG>), dim3(grid), dim3(BLOCK), smem, s, b->d_layouts, b->n_layouts,      \
                            b->d_layout_id, (const uint4*)d_state, (T*)d_obs, b->n_envs, b->width, b->height,          \
                            n_planes, epb, horizon);                                                                   \

@@ -123,6 +123,8 @@ class OvercookedEnv:
 
 
 class _Discrete:
+    """Minimal stand-in for gymnasium.spaces.Discrete when gymnasium is not installed."""
+
     def __init__(self, n):
         self.n = n
 
@@ -131,51 +133,72 @@ class _Discrete:
 
 
 class _Box:
+    """Minimal stand-in for gymnasium.spaces.Box."""
+
     def __init__(self, low, high, dtype=None):
         self.low, self.high, self.dtype, self.shape = low, high, dtype, low.shape
 
 
-class Overcooked:
-    """Gym-style single-agent view (env.py:782-909): old 4-tuple step API, obs dict with both agents'
-    observations, the main agent's index drawn at every reset."""
+try:  # the reference derives from gymnasium.Env and registers "Overcooked-v0" (overcooked_ai_py/__init__.py:1-6)
+    import gymnasium as _gym
+    from gymnasium import spaces as _spaces
+
+    _EnvBase, _mk_discrete = _gym.Env, _spaces.Discrete
+    _mk_box = lambda low, high, dtype: _spaces.Box(low, high, dtype=dtype)  # noqa: E731
+except ImportError:  # no gymnasium in this image: same surface, duck-typed spaces
+    _gym, _EnvBase, _mk_discrete, _mk_box = None, object, _Discrete, _Box
+
+
+class Overcooked(_EnvBase):
+    """Gym-style view of one OvercookedEnv for a single learning agent (API of env.py:782-909): the old 4-tuple
+    `step`, an observation dict carrying both agents' featurizations, and a seat (`agent_idx`) redrawn every reset.
+
+    Everything here is seat bookkeeping: the learning agent always speaks first in `step((mine, partner))` and reads
+    its own observation first in `both_agent_obs`, whichever player index it currently occupies."""
 
     env_name = "Overcooked-v0"
 
     def __init__(self, base_env, featurize_fn, baselines_reproducible=False):
         if baselines_reproducible:
-            np.random.seed(0)
-        self.base_env = base_env
-        self.featurize_fn = featurize_fn
-        self.observation_space = self._setup_observation_space()
-        self.action_space = _Discrete(len(Action.ALL_ACTIONS))
+            np.random.seed(0)  # fixed seat sequence, as the reference's flag of the same name does
+        self.base_env, self.featurize_fn = base_env, featurize_fn
+        probe = featurize_fn(base_env.mdp.get_standard_start_state())[0]
+        self.observation_space = _mk_box(np.zeros(probe.shape, np.float32), np.full(probe.shape, np.inf, np.float32),
+                                         np.float32)
+        self.action_space = _mk_discrete(Action.NUM_ACTIONS)
         self.reset()
 
-    def _setup_observation_space(self):
-        dummy_state = self.base_env.mdp.get_standard_start_state()
-        obs_shape = self.featurize_fn(dummy_state)[0].shape
-        high = np.ones(obs_shape, dtype=np.float32) * float("inf")
-        low = np.zeros(obs_shape, dtype=np.float32)
-        return _Box(low, high, dtype=np.float32)
+    def _seated(self, pair):
+        """(player 0's item, player 1's item) -> (learning agent's, partner's)."""
+        return tuple(pair) if self.agent_idx == 0 else (pair[1], pair[0])
+
+    def _observe(self, state):
+        return {"both_agent_obs": self._seated(self.featurize_fn(state)), "overcooked_state": state,
+                "other_agent_env_idx": 1 - self.agent_idx}
 
     def step(self, action):
-        assert all(self.action_space.contains(a) for a in action), "%r (%s) invalid" % (action, type(action))
-        agent_action, other_agent_action = [Action.INDEX_TO_ACTION[a] for a in action]
-        joint_action = (agent_action, other_agent_action) if self.agent_idx == 0 else (other_agent_action, agent_action)
-        next_state, reward, done, env_info = self.base_env.step(joint_action)
-        ob_p0, ob_p1 = self.featurize_fn(next_state)
-        both_agents_ob = (ob_p0, ob_p1) if self.agent_idx == 0 else (ob_p1, ob_p0)
-        env_info["policy_agent_idx"] = self.agent_idx
-        if "episode" in env_info.keys():
-            env_info["episode"]["policy_agent_idx"] = self.agent_idx
-        obs = {"both_agent_obs": both_agents_ob, "overcooked_state": next_state,
-               "other_agent_env_idx": 1 - self.agent_idx}
-        return obs, reward, done, env_info
+        mine, partner = action
+        if not (self.action_space.contains(mine) and self.action_space.contains(partner)):
+            raise AssertionError("%r (%s) invalid" % (action, type(action)))
+        by_player = self._seated((Action.INDEX_TO_ACTION[mine], Action.INDEX_TO_ACTION[partner]))  # a swap is its own inverse
+        state, reward, done, info = self.base_env.step(by_player)
+        info["policy_agent_idx"] = self.agent_idx
+        if done and "episode" in info:
+            info["episode"]["policy_agent_idx"] = self.agent_idx
+        return self._observe(state), reward, done, info
 
-    def reset(self):
+    def reset(self, **_gym_kwargs):
         self.base_env.reset()
         self.mdp = self.base_env.mdp
         self.agent_idx = np.random.choice([0, 1])
-        ob_p0, ob_p1 = self.featurize_fn(self.base_env.state)
-        both_agents_ob = (ob_p0, ob_p1) if self.agent_idx == 0 else (ob_p1, ob_p0)
-        return {"both_agent_obs": both_agents_ob, "overcooked_state": self.base_env.state,
-                "other_agent_env_idx": 1 - self.agent_idx}
+        return self._observe(self.base_env.state)
+
+    def render(self, mode="human", close=False):
+        raise NotImplementedError("rendering is outside the accelerated path (SURVEY §2: visualisation is out of scope)")
+
+
+if _gym is not None:
+    try:
+        _gym.envs.registration.register(id="Overcooked-v0", entry_point="overcooked_ai_amd.env:Overcooked")
+    except Exception:  # already registered (e.g. the reference package is importable too)
+        pass

@@ -1,163 +1,24 @@
-"""The RLlib training environment of the reference, `OvercookedMultiAgent`
-(human_aware_rl/rllib/rllib.py:112-438), on top of the accelerated path — without the `ray` dependency.
+"""The batched form of the reference's RLlib training environment (`OvercookedMultiAgent`,
+human_aware_rl/rllib/rllib.py:112-438) on top of the accelerated path.
 
-* `OvercookedMultiAgent` keeps the reference's per-env dict API (`reset() -> {agent: obs}`,
-  `step({agent: action}) -> obs, rewards, dones, infos`, the annealing setters, `from_config`), its agent-role
-  assignment (same `np.random` calls, so seeded runs agree) and its reward: sparse + factor * (phi(s') - phi(s)) when
-  `use_phi`, else sparse + factor * shaped_r_by_agent[i].  RLlib only needs the duck-typed methods of
-  `MultiAgentEnv`, so the class can be registered with `ray.tune.registry.register_env` unchanged where ray exists.
-* `VecOvercookedMultiAgent` is the same environment for N envs resident in HBM: one `oc_step`, one `oc_potential`,
-  one `oc_shape_rewards`, a masked `oc_reset` and one `oc_encode_lossless` / `oc_featurize` per batched step, no
-  host synchronisation.  Every env has two learning ("ppo") agents; `bc` partners need a behaviour-cloning model, which
-  is outside this package — their observation (`featurize_state`) is available through `observations("bc")`.
+`VecOvercookedMultiAgent` is that environment for N envs resident in HBM: per batched step one
+`oc_multi_agent_step` call (step -> phi(s') -> per-agent training reward sparse + factor * (phi(s') - phi(s) | shaped)
+-> restart of finished envs -> observation), no host synchronisation.  Every env has two learning ("ppo") agents;
+`bc` partners need a behaviour-cloning model, which is outside this package — their observation (`featurize_state`)
+is available through `observations("bc")`.  The reference's per-env dict-API class itself (agent-role sampling, RLlib
+spaces) belongs to its RLlib stack and is out of scope; only its reward / restart / observation
+arithmetic is reproduced, pinned by episodes recorded from the reference class (tests/golden/multi_agent_*.npz).
 """
 import numpy as np
 
-from .actions import Action
-from .env import OvercookedEnv, _Box, _Discrete
 
-
-class _DictSpace(dict):
-    def contains(self, d):
-        return all(k in self and self[k].contains(v) for k, v in d.items())
-
-
-class OvercookedMultiAgent:
-    """Drop-in mirror of rllib.py:112-438 for one env."""
-
-    supported_agents = ["ppo", "bc"]
-    bc_schedule = self_play_bc_schedule = [(0, 0), (float("inf"), 0)]
-    DEFAULT_CONFIG = {
-        "mdp_params": {"layout_name": "cramped_room", "rew_shaping_params": {}},
-        "env_params": {"horizon": 400},
-        "multi_agent_params": {"reward_shaping_factor": 0.0, "reward_shaping_horizon": 0,
-                               "bc_schedule": self_play_bc_schedule, "use_phi": True},
-    }
-
-    def __init__(self, base_env, reward_shaping_factor=0.0, reward_shaping_horizon=0, bc_schedule=None, use_phi=True):
-        if bc_schedule:
-            self.bc_schedule = bc_schedule
-        self._validate_schedule(self.bc_schedule)
-        self.base_env = base_env
-        self.featurize_fn_map = {"ppo": lambda state: self.base_env.lossless_state_encoding_mdp(state),
-                                 "bc": lambda state: self.base_env.featurize_state_mdp(state)}
-        self._initial_reward_shaping_factor = reward_shaping_factor
-        self.reward_shaping_factor = reward_shaping_factor
-        self.reward_shaping_horizon = reward_shaping_horizon
-        self.use_phi = use_phi
-        self.anneal_bc_factor(0)
-        self._agent_ids = set(self.reset().keys())
-        self._spaces_in_preferred_format = True
-
-    @staticmethod
-    def _validate_schedule(schedule):
-        timesteps, values = [p[0] for p in schedule], [p[1] for p in schedule]
-        assert len(schedule) >= 2, "Need at least 2 points to linearly interpolate schedule"
-        assert schedule[0][0] == 0, "Schedule must start at timestep 0"
-        assert all(t >= 0 for t in timesteps), "All timesteps in schedule must be non-negative"
-        assert all(0 <= v <= 1 for v in values), "All values in schedule must be between 0 and 1"
-        assert sorted(timesteps) == timesteps, "Timesteps must be in increasing order in schedule"
-        if schedule[-1][0] < float("inf"):  # flatline after the last point (rllib.py:203-205)
-            schedule.append((float("inf"), schedule[-1][1]))
-
-    def _setup_action_space(self, agents):
-        self.action_space = _DictSpace({a: _Discrete(len(Action.ALL_ACTIONS)) for a in agents})
-        self.shared_action_space = _Discrete(len(Action.ALL_ACTIONS))
-
-    def _setup_observation_space(self, agents):
-        dummy_state = self.base_env.mdp.get_standard_start_state()
-        shape = self.base_env.lossless_state_encoding_mdp(dummy_state)[0].shape
-        self.ppo_observation_space = _Box(np.zeros(shape, np.float32), np.full(shape, np.inf, np.float32), dtype=np.float32)
-        shape = self.base_env.featurize_state_mdp(dummy_state)[0].shape
-        self.bc_observation_space = _Box(np.full(shape, -100, np.float32), np.full(shape, 100, np.float32), dtype=np.float32)
-        self.observation_space = _DictSpace({a: self.ppo_observation_space if a.startswith("ppo") else self.bc_observation_space
-                                             for a in agents})
-
-    def _get_featurize_fn(self, agent_id):
-        if agent_id.startswith("ppo"):
-            return self.featurize_fn_map["ppo"]
-        if agent_id.startswith("bc"):
-            return self.featurize_fn_map["bc"]
-        raise ValueError("Unsupported agent type {0}".format(agent_id))
-
-    def _get_obs(self, state):
-        ob_p0 = self._get_featurize_fn(self.curr_agents[0])(state)[0]
-        ob_p1 = self._get_featurize_fn(self.curr_agents[1])(state)[1]
-        return ob_p0.astype(np.float32), ob_p1.astype(np.float32)
-
-    def _populate_agents(self):
-        agents = ["ppo"]  # always at least one learning agent (rllib.py:259-278)
-        agents.append("bc" if np.random.uniform() < self.bc_factor else "ppo")
-        np.random.shuffle(agents)
-        agents[0], agents[1] = agents[0] + "_0", agents[1] + "_1"
-        self._setup_action_space(agents)
-        self._setup_observation_space(agents)
-        return agents
-
-    @staticmethod
-    def _anneal(start_v, curr_t, end_t, end_v=0, start_t=0):
-        if end_t == 0:
-            return start_v
-        fraction = max(1 - float(curr_t - start_t) / (end_t - start_t), 0)
-        return fraction * start_v + (1 - fraction) * end_v
-
-    def step(self, action_dict):
-        action = [action_dict[self.curr_agents[0]], action_dict[self.curr_agents[1]]]
-        assert all(self.action_space[agent].contains(action_dict[agent]) for agent in action_dict), \
-            "%r (%s) invalid" % (action, type(action))
-        joint_action = [Action.INDEX_TO_ACTION[a] for a in action]
-        if self.use_phi:
-            next_state, sparse_reward, done, info = self.base_env.step(joint_action, display_phi=True)
-            potential = info["phi_s_prime"] - info["phi_s"]
-            dense_reward = (potential, potential)
-        else:
-            next_state, sparse_reward, done, info = self.base_env.step(joint_action, display_phi=False)
-            dense_reward = info["shaped_r_by_agent"]
-        ob_p0, ob_p1 = self._get_obs(next_state)
-        a0, a1 = self.curr_agents
-        rewards = {a0: sparse_reward + self.reward_shaping_factor * dense_reward[0],
-                   a1: sparse_reward + self.reward_shaping_factor * dense_reward[1]}
-        return {a0: ob_p0, a1: ob_p1}, rewards, {a0: done, a1: done, "__all__": done}, {a0: info, a1: info}
-
-    def reset(self, regen_mdp=True):
-        self.base_env.reset(regen_mdp)
-        self.curr_agents = self._populate_agents()
-        ob_p0, ob_p1 = self._get_obs(self.base_env.state)
-        return {self.curr_agents[0]: ob_p0, self.curr_agents[1]: ob_p1}
-
-    def anneal_reward_shaping_factor(self, timesteps):
-        self.set_reward_shaping_factor(self._anneal(self._initial_reward_shaping_factor, timesteps,
-                                                    self.reward_shaping_horizon))
-
-    def anneal_bc_factor(self, timesteps):
-        p_0, p_1, i = self.bc_schedule[0], self.bc_schedule[1], 2
-        while timesteps > p_1[0] and i < len(self.bc_schedule):
-            p_0, p_1 = p_1, self.bc_schedule[i]
-            i += 1
-        (start_t, start_v), (end_t, end_v) = p_0, p_1
-        self.set_bc_factor(self._anneal(start_v, timesteps, end_t, end_v, start_t))
-
-    def set_reward_shaping_factor(self, factor):
-        self.reward_shaping_factor = factor
-
-    def set_bc_factor(self, factor):
-        self.bc_factor = factor
-
-    def seed(self, seed):
-        pass  # the environment is deterministic (rllib.py:391-396)
-
-    @classmethod
-    def from_config(cls, env_config):
-        """rllib.py:398-438 for a fixed layout (`mdp_params`); layout schedules are not supported."""
-        from .mdp import OvercookedGridworld
-
-        assert env_config and "env_params" in env_config and "multi_agent_params" in env_config
-        if "mdp_params" not in env_config:
-            raise NotImplementedError("mdp_params_schedule_fn is not supported; pass fixed mdp_params")
-        mdp_params = dict(env_config["mdp_params"])
-        mdp = OvercookedGridworld.from_layout_name(mdp_params.pop("layout_name"), **mdp_params)
-        base_env = OvercookedEnv.from_mdp(mdp, **env_config["env_params"])
-        return cls(base_env, **env_config["multi_agent_params"])
+def linear_anneal(start_value, t, t_end, end_value=0.0, t_start=0):
+    """Value of the reward-shaping schedule at timestep t: a straight line from (t_start, start_value) to
+    (t_end, end_value), constant afterwards; t_end == 0 switches annealing off (rllib.py:280-291)."""
+    if t_end == 0:
+        return start_value
+    w = min(max((t - t_start) / float(t_end - t_start), 0.0), 1.0)
+    return (1.0 - w) * start_value + w * end_value
 
 
 class VecOvercookedMultiAgent:
@@ -264,8 +125,8 @@ class VecOvercookedMultiAgent:
         return (obs if obs is not None else self.observations()), self.shaped, self.done, infos
 
     def anneal_reward_shaping_factor(self, timesteps):
-        self.reward_shaping_factor = OvercookedMultiAgent._anneal(self._initial_reward_shaping_factor, timesteps,
-                                                                  self.reward_shaping_horizon)
+        self.reward_shaping_factor = linear_anneal(self._initial_reward_shaping_factor, timesteps,
+                                                   self.reward_shaping_horizon)
 
     def set_reward_shaping_factor(self, factor):
         self.reward_shaping_factor = factor

@@ -167,45 +167,6 @@ def _multi_agent_fixture():
         yield name, case, z["obs"].astype(np.float32), z["obs_len"]
 
 
-def test_overcooked_multi_agent_matches_reference_episodes():
-    """The RLlib environment class (human_aware_rl/rllib/rllib.py:112-438) replayed against episodes recorded from the
-    reference: agent roles (same np.random stream), per-agent observations (lossless / featurize_state), rewards
-    sparse + factor * (phi' - phi | shaped) as exact Python floats, dones, annealed factors."""
-    from overcooked_ai_amd import OvercookedEnv, OvercookedGridworld, OvercookedMultiAgent
-    from overcooked_ai_amd.layouts import LayoutSpec
-
-    for name, case, obs, obs_len in _multi_agent_fixture():
-        mdp = OvercookedGridworld.from_spec(LayoutSpec(dict(case["layout"])))
-        base_env = OvercookedEnv.from_mdp(mdp, horizon=case["horizon"], info_level=0)
-        np.random.seed(2024)
-        env = OvercookedMultiAgent(base_env, **{k: (list(map(tuple, v)) if isinstance(v, list) else v)
-                                                for k, v in case["kwargs"].items()})
-        row, total = 0, 0
-        for ep in case["episodes"]:
-            ob = env.reset()
-            agents = list(env.curr_agents)
-            assert agents == ep["agents"], name
-            for j, a in enumerate(agents):
-                assert ob[a].dtype == np.float32 and np.array_equal(ob[a].ravel(), obs[row, j, :obs_len[row, j]])
-            row += 1
-            for st in ep["steps"]:
-                ob, rew, dones, infos = env.step({agents[0]: st["actions"][0], agents[1]: st["actions"][1]})
-                total += 1
-                assert [rew[a] for a in agents] == st["rewards"], (name, total)
-                assert dones["__all__"] == st["done"] and env.reward_shaping_factor == st["factor"] and env.bc_factor == st["bc_factor"]
-                assert infos[agents[0]].get("phi_s") == st["phi_s"] and infos[agents[0]].get("phi_s_prime") == st["phi_s_prime"]
-                for j, a in enumerate(agents):
-                    assert np.array_equal(ob[a].ravel(), obs[row, j, :obs_len[row, j]]), (name, total, a)
-                row += 1
-                if total % 7 == 0:
-                    env.anneal_reward_shaping_factor(total)
-                    env.anneal_bc_factor(total)
-            assert infos[agents[0]]["episode"]["ep_shaped_r"] == ep["ep_shaped_r"]
-    cfg = dict(OvercookedMultiAgent.DEFAULT_CONFIG)
-    env = OvercookedMultiAgent.from_config(cfg)
-    assert sorted(env.reset()) == ["ppo_0", "ppo_1"] and env.base_env.horizon == 400
-
-
 def test_vec_multi_agent_matches_reference_episodes():
     """VecOvercookedMultiAgent (oc_step + oc_potential + oc_shape_rewards + masked oc_reset + encode per batched step)
     on the same recorded episodes, and its restart-on-done behaviour on a batch."""
