@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define OC_ABI_VERSION 1
+#define OC_ABI_VERSION 2
 
 #define OC_MAX_CELLS 128
 #define OC_MAX_POTS 8
@@ -89,8 +89,12 @@ extern "C" {
 #define OC_OPT_PREDICATE_INTERACT 0x8u /* oc_rollout_random: one-lane-per-env kernel with the predicate-network
                                          interact instead of the table-driven one (kept for cross-checking) */
 
+#define OC_OPT_ROLLOUT_V3 0x10u /* oc_rollout_random: the previous table-driven kernel (k_rollout3) instead of k_rollout4
+                                  (kept for cross-checking) */
+
 /* OcBatch.batch_flags */
 #define OC_BATCH_TWO_PLAYERS 0x1u /* every layout of the table has exactly 2 players */
+#define OC_BATCH_NEW_DYNAMICS 0x2u /* no layout of the table uses old_dynamics (mdp.py:1696-1701) */
 
 /* obs dtypes of oc_encode_lossless */
 #define OC_OBS_U8 0
@@ -143,8 +147,17 @@ typedef struct OcBatch {
     int32_t max_pots;            /* max n_pots over the table (1..8), or 0 if unknown: selects how many pot slots
                                     the step kernels keep in registers */
     uint32_t batch_flags;        /* OC_BATCH_* hints about the table */
-    uint32_t reserved;
+    uint32_t max_free_cells;     /* max number of free (floor) cells over the table, or 0 if unknown: single two-player
+                                    layouts with at most 7 free cells (cramped_room) step through a joint move table */
 } OcBatch;
+
+/*
+ * max_pots, batch_flags and max_free_cells are HINTS that select kernel variants, and hard preconditions when set:
+ * a max_pots below a layout's n_pots drops that layout's extra pots, OC_BATCH_TWO_PLAYERS on a one-player layout or a
+ * max_free_cells below the real count index past the tables.  0 / unset is always safe.  oc_batch_hints derives them
+ * from a HOST copy of the layout table (call it before uploading the table; it leaves the other fields alone).
+ */
+int oc_batch_hints(const OcLayout* h_layouts, int n_layouts, OcBatch* batch);
 
 int oc_abi_version(void);
 size_t oc_layout_size(void); /* == sizeof(OcLayout) == 256 */

@@ -6,16 +6,18 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OC_AMD_LIB") or os.path.join(PKG, "liboc_amd.so")  # OC_AMD_LIB: developer override
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 F_DONE, F_BAD_ACTION, F_RESET = 0x01, 0x02, 0x04
 OPT_AUTO_RESET = 0x1
 OPT_LANE_PER_ENV = 0x2
 OPT_LANE_PAIR = 0x4
 OPT_PREDICATE_INTERACT = 0x8
+OPT_ROLLOUT_V3 = 0x10
 BATCH_TWO_PLAYERS = 0x1
+BATCH_NEW_DYNAMICS = 0x2
 OBS_U8, OBS_F32 = 0, 1
 
-EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_step", "oc_step_many",
+EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_batch_hints", "oc_step", "oc_step_many",
            "oc_rollout_random",
            "oc_encode_lossless", "oc_featurize", "oc_potential", "oc_phi_table_size", "oc_reset", "oc_reset_random", "oc_shape_rewards", "oc_multi_agent_step")
 
@@ -30,7 +32,7 @@ class OcBatch(ctypes.Structure):
         ("height", ctypes.c_int32),
         ("max_pots", ctypes.c_int32),
         ("batch_flags", ctypes.c_uint32),
-        ("reserved", ctypes.c_uint32),
+        ("max_free_cells", ctypes.c_uint32),
     ]
 
 
@@ -64,6 +66,8 @@ def load():
     L.oc_last_error.argtypes = []
     L.oc_state_planes.restype = i32
     L.oc_state_planes.argtypes = [i32, i32]
+    L.oc_batch_hints.restype = i32
+    L.oc_batch_hints.argtypes = [vp, i32, bp]
     L.oc_step.restype = i32
     L.oc_step.argtypes = [bp, vp, vp, vp, vp, vp, vp, vp, i32, u32, vp]
     L.oc_step_many.restype = i32

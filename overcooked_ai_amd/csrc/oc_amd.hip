@@ -5,7 +5,8 @@
 //   common.hpp          constants, OcLayout accessor, Philox4x32-10, layout staging
 //   step_predicate.hpp  get_state_transition, mdp.py:1375 (interacts 1432 -> movement 1644 -> env effects 1691) with
 //                       the predicate-network interact that also emits event_infos: k_step, k_rollout
-//   step_table.hpp      the same transition with the table-driven interact: k_step3, k_rollout3 (the default path)
+//   step_table.hpp      the same transition with the table-driven interact: k_step3 (oc_step / oc_step_many), k_rollout3
+//   step_lut4.hpp       the rollout path: key-byte cell words, 16-byte interact LUT, joint move table: k_rollout4
 //   rollout_pair.hpp    two lanes per env: k_rollout_pair
 //   reset.hpp           get_standard_start_state mdp.py:1297, get_random_start_state_fn 1307: k_reset, k_reset_random
 //   encode.hpp          lossless_state_encoding mdp.py:2385-2561: k_encode, k_encode_uniform
@@ -33,6 +34,7 @@ namespace {
 #include "common.hpp"
 #include "step_predicate.hpp"
 #include "step_table.hpp"
+#include "step_lut4.hpp"
 #include "rollout_pair.hpp"
 #include "reset.hpp"
 #include "encode.hpp"
@@ -175,6 +177,27 @@ size_t oc_layout_size(void) { return sizeof(OcLayout); }
 const char* oc_last_error(void) { return g_err; }
 int oc_state_planes(int width, int height) { return 1 + (width * height + 15) / 16; }
 
+int oc_batch_hints(const OcLayout* h_layouts, int n_layouts, OcBatch* batch) {
+    if (!h_layouts || !batch || n_layouts < 1) return fail(OC_EINVAL, "oc_batch_hints: NULL table / batch or no layouts");
+    int max_pots = 0;
+    uint32_t max_free = 0;
+    bool two = true, any_old = false;
+    for (int i = 0; i < n_layouts; ++i) {
+        const OcLayout& l = h_layouts[i];
+        any_old = any_old || l.old_dynamics != 0;
+        if (l.n_pots > OC_MAX_POTS || l.n_cells > OC_MAX_CELLS) return fail(OC_EINVAL, "oc_batch_hints: corrupt layout record");
+        max_pots = l.n_pots > max_pots ? l.n_pots : max_pots;
+        two = two && l.n_players == 2;
+        uint32_t free_cells = 0;
+        for (int c = 0; c < l.n_cells; ++c) free_cells += (l.terrain[c] & 7) == OC_T_FLOOR ? 1u : 0u;
+        max_free = free_cells > max_free ? free_cells : max_free;
+    }
+    batch->max_pots = max_pots;
+    batch->batch_flags = (two ? OC_BATCH_TWO_PLAYERS : 0u) | (any_old ? 0u : OC_BATCH_NEW_DYNAMICS);
+    batch->max_free_cells = max_free;
+    return OC_OK;
+}
+
 int oc_step(const OcBatch* b, const void* d_state_in, void* d_state_out, const uint8_t* d_actions, float* d_rewards,
             uint8_t* d_flags, float* d_ep_returns, uint64_t* d_events, int horizon, uint32_t options, void* stream) {
     int n_obj = 0;
@@ -223,7 +246,7 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
     if (int rc = check_batch(b, &n_obj)) return rc;
     if (!d_state) return fail(OC_EINVAL, "oc_rollout_random: NULL state pointer");
     if (horizon < 1 || horizon > 65535) return fail(OC_EINVAL, "oc_rollout_random: horizon must be in 1..65535");
-    if (n_steps < 0) return fail(OC_EINVAL, "oc_rollout_random: n_steps < 0");
+    if (n_steps < 0 || n_steps > (1 << 30)) return fail(OC_EINVAL, "oc_rollout_random: n_steps must be in 0..2^30");
     if (b->n_envs == 0 || n_steps == 0) return OC_OK;
     hipStream_t s = (hipStream_t)stream;
     const bool uniform = b->n_layouts == 1;
@@ -256,7 +279,35 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
                                env_offset, t0, n_steps);
         return check_launch("oc_rollout_random");
     }
-    if ((options & OC_OPT_PREDICATE_INTERACT) == 0) {
+    if ((options & (OC_OPT_PREDICATE_INTERACT | OC_OPT_ROLLOUT_V3)) == 0) {
+        // k_rollout4.  JOINT move table: one two-player layout with at most JOINT_MAX_FLOOR free cells (hint from the caller)
+        const bool two = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0;
+        const bool joint = uniform && two && b->max_free_cells >= 2 && b->max_free_cells <= (uint32_t)JOINT_MAX_FLOOR;
+        const bool old = (b->batch_flags & OC_BATCH_NEW_DYNAMICS) == 0;  // some layout may use old dynamics
+        const size_t cell_bytes = (size_t)n_obj * 16 * BLOCK * sizeof(uint16_t);
+        const dim3 grid4(grid_for(b->n_envs)), block4(BLOCK);
+        const bool out = d_rewards != nullptr && d_flags != nullptr;
+#define GO4(U, MP, LL, MODE, OUT, OLD, ...)                                                                         \
+    do {                                                                                                            \
+        const size_t smem4 = (size_t)Lds4<U, LL, MODE, ##__VA_ARGS__>::CELLS + cell_bytes;                          \
+        if (!want_lds(k_rollout4<U, MP, LL, MODE, OUT, OLD, ##__VA_ARGS__>, smem4)) break;                          \
+        hipLaunchKernelGGL((k_rollout4<U, MP, LL, MODE, OUT, OLD, ##__VA_ARGS__>), grid4, block4, smem4, s, b->d_layouts, \
+                           b->n_layouts, b->d_layout_id, (uint4*)d_state, (float4*)d_rewards, d_flags,              \
+                           (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options, (uint32_t)seed,     \
+                           (uint32_t)(seed >> 32), env_offset, t0, n_steps);                                        \
+    } while (0)
+        if (joint && b->max_pots == 1 && out && !old && b->max_free_cells <= 6) GO4(true, 1, true, 1, true, false, 6);
+        else if (joint && b->max_pots == 1) GO4(true, 1, true, 1, false, true, JOINT_MAX_FLOOR);
+        else if (joint && small) GO4(true, 2, true, 1, false, true, JOINT_MAX_FLOOR);
+        else if (joint) GO4(true, 8, true, 1, false, true, JOINT_MAX_FLOOR);
+        else if (uniform && !old && out && small) { if (b->max_pots == 1) GO4(true, 1, true, 0, true, false, 0); else GO4(true, 2, true, 0, true, false, 0); }
+        else if (uniform) { if (b->max_pots == 1) GO4(true, 1, true, 0, false, true, 0); else if (small) GO4(true, 2, true, 0, false, true, 0); else GO4(true, 8, true, 0, false, true, 0); }
+        else if (lds) { if (small) GO4(false, 2, true, 0, false, true, 0); else GO4(false, 8, true, 0, false, true, 0); }
+        else { if (small) GO4(false, 2, false, 0, false, true, 0); else GO4(false, 8, false, 0, false, true, 0); }
+#undef GO4
+        return check_launch("oc_rollout_random");
+    }
+    if ((options & OC_OPT_PREDICATE_INTERACT) == 0) {  // OC_OPT_ROLLOUT_V3
         const bool fast = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0 && b->width * b->height <= 64;
         const size_t smem3 = (size_t)n_obj * 16 * BLOCK * sizeof(uint16_t);
         const dim3 grid3(grid_for(b->n_envs)), block3(BLOCK);

@@ -1,0 +1,663 @@
+// step_lut4.hpp — get_state_transition, fourth formulation: k_rollout4 (the default rollout path)
+// Part of liboc_amd.so: included by oc_amd.hip inside its anonymous namespace after step_table.hpp.
+#pragma once
+
+// ==========================================================================================
+// v4: everything a step looks at is one look-up away.
+//
+// At 65 536 envs every SIMD holds ONE wavefront, so a batched step costs (instructions per step) x (issue time):
+// k_rollout3 spends ~235 instructions per env-step (199 VALU).  v4 restructures the data so that the common step is
+// ~90 instructions:
+//
+//  * cell word (LDS, u16 [cell][lane]) = object code (low byte, wire format) | KEY BYTE (high byte) with
+//        key byte = 30 * terrain type + class of what is there
+//                   counter: {empty, dish, other}; pot: {empty, idle 1, idle 2, idle 3, cooking, ready}
+//    The key byte is kept current by whoever changes the cell (the interact writes a whole new word; the env
+//    effects rewrite a pot's key byte when it turns ready).  Pots are ordinary cells: no "is it a pot" selects.
+//  * interact = LUT[key byte + 6 * hand class (+ 240 when the player does not interact)], 16 bytes:
+//        .x  byte selectors          res = v_perm(.y, pool, .x)  ->  [flags][new hand][new object][new key byte]
+//                                    (the new cell word is the upper half: stored with ds_write_b16_d16_hi, no shift)
+//        .y  constants               [new key byte][dispensed object][flags][change of the loose-dish count, signed]
+//        .z  "add ingredient" term   pool = [hand][object][object][key byte] + .z  (byte 2 becomes the soup + ingredient:
+//                                    the entry knows how many items the pot holds and what the hand is)
+//        .w  shaped reward of the outcome: the float itself when the batch has one layout (patched into the LDS copy
+//                                    of the table at kernel start), else its class {0 none, 1 potting, 2 soup pickup}
+//    9 VALU per player: hand class, key, address, pool (perm + add), result perm, new hand, new cell word.
+//  * pots: their class lives only in the cell word.  A countdown register per pot (steps until ready; "a long time" when
+//    not cooking) is decremented every step and the lanes where it reaches zero write "ready" into the pot's key
+//    byte; cook times are looked up only when cooking starts.  2 VALU per pot and step.
+//  * rewards: the shaped reward of potting / soup pickup comes out of the LUT entry; everything else — cooking starts
+//    (countdown), deliveries (recipe value), dish pick-ups that may be useful (is_dish_pickup_useful), the horizon —
+//    happens in ~0.3 % of the lane-steps and sits behind one divergent branch.
+//  * layouts with at most 7 free cells (cramped_room): the JOINT move table.  Joint pose J = both players' (cell,
+//    orientation); row J holds, per joint action, the next joint pose with collisions and blocked moves resolved
+//    (resolve_movement, mdp.py:1644-1727, is ONE LDS read) and the LDS offsets of the two faced cells.  The table is
+//    built by the workgroup at kernel start (~1 % of a 400-step launch).  Other layouts move arithmetically.
+// Semantics are those of step_table.hpp / the oracle: same conflict replay for player 1, stale pot states for the
+// usefulness predicates, same restart at the horizon.
+// ==========================================================================================
+constexpr uint32_t KB_COUNTER = OC_T_COUNTER * 30u, KB_POT = OC_T_POT * 30u;
+enum { F4_TAKE_DISH = 1, F4_PLACE = 2, F4_PLATE = 4, F4_START = 8, F4_SERVE = 16, F4_CHG = 128 };
+constexpr uint32_t F4_POTBITS = F4_PLACE | F4_PLATE | F4_START;
+constexpr int LUT4_KEYS = 240, LUT4_BYTES = 2 * LUT4_KEYS * 16;  // keys 240..479: the "does not interact" copy (all no-ops)
+constexpr uint32_t REM_IDLE = 0x40000000u;  // countdown of a pot that is not cooking
+constexpr uint32_t TK_LIVE = 0xFFFFFFFFu;   // tick register: "derive the tick from the countdown when storing"
+
+struct Lut4Entry { uint32_t sel, cst, add, rew; };
+enum { RW4_NONE = 0, RW4_PLACE = 1, RW4_PLATE = 2 };
+
+constexpr Lut4Entry lut4_entry(int old_dyn, int type, int hc, int oc) {
+    // selectors: 0 hand, 1 object, 2 object + .z, 3 key byte | 4 new key byte, 5 dispensed object, 6 flags | 0x0C zero
+    uint32_t sel_h = 0, sel_o = 1, sel_kb = 3, nkb = 0, cobj = 0, flags = 0, add = 0, rew = RW4_NONE;
+    int dd = 0;
+    if (type == OC_T_COUNTER) {
+        if (hc == 0 && (oc == 1 || oc == 2)) {          // pick up from a counter (mdp.py:1473-1485)
+            sel_h = 1; sel_o = 0x0C; sel_kb = 4; nkb = KB_COUNTER; flags = F4_CHG; dd = oc == 1 ? -1 : 0;
+        } else if (hc != 0 && oc == 0) {                // drop on a counter (mdp.py:1459-1471)
+            sel_h = 0x0C; sel_o = 0; sel_kb = 4; nkb = KB_COUNTER + (hc == 3 ? 1 : 2); flags = F4_CHG; dd = hc == 3 ? 1 : 0;
+        }
+    } else if (type == OC_T_ONION_DISP) {
+        if (hc == 0) { sel_h = 5; cobj = OC_O_ONION; }
+    } else if (type == OC_T_TOMATO_DISP) {
+        if (hc == 0) { sel_h = 5; cobj = OC_O_TOMATO; }
+    } else if (type == OC_T_DISH_DISP) {
+        if (hc == 0) { sel_h = 5; cobj = OC_O_DISH; flags = F4_TAKE_DISH; }
+    } else if (type == OC_T_POT) {
+        if (hc == 0 && oc >= PC_IDLE1 && oc <= PC_IDLE3 && !old_dyn) {   // begin_cooking (mdp.py:1515-1522)
+            sel_kb = 4; nkb = KB_POT + PC_COOKING; flags = F4_CHG | F4_START;
+        } else if (hc == 3 && oc == PC_READY) {                          // soup pickup (mdp.py:1525-1539)
+            sel_h = 1; sel_o = 0x0C; sel_kb = 4; nkb = KB_POT + PC_EMPTY; flags = F4_CHG | F4_PLATE; rew = RW4_PLATE;
+        } else if ((hc == 1 || hc == 2) && oc <= PC_IDLE2) {             // add ingredient (mdp.py:1541-1568)
+            // wire code of the soup afterwards = old code + 8 (one more item) + tomato bit at position n (+ 0x80 for
+            // the first item: the pot's object byte is 0 then)
+            sel_h = 0x0C; sel_o = 2; sel_kb = 4; nkb = KB_POT + oc + 1; flags = F4_CHG | F4_PLACE; rew = RW4_PLACE;
+            add = 8u + ((hc == 2 ? 1u : 0u) << oc) + (oc == 0 ? 0x80u : 0u);
+        }
+    } else if (type == OC_T_SERVE) {
+        if (hc == 4) { sel_h = 0x0C; flags = F4_SERVE; }                 // deliver (mdp.py:1570-1577)
+    }
+    return Lut4Entry{6u | (sel_h << 8) | (sel_o << 16) | (sel_kb << 24),
+                     nkb | (cobj << 8) | (flags << 16) | (((uint32_t)dd & 0xFFu) << 24), add << 16, rew};
+}
+
+struct Lut4Table { Lut4Entry e[2][2 * LUT4_KEYS]; };  // [old_dynamics][key]
+constexpr Lut4Table make_lut4() {
+    Lut4Table t{};
+    for (int od = 0; od < 2; ++od)
+        for (int type = 0; type < 8; ++type)
+            for (int hc = 0; hc < 5; ++hc)
+                for (int oc = 0; oc < 6; ++oc) {
+                    t.e[od][type * 30 + hc * 6 + oc] = lut4_entry(od, type, hc, oc);
+                    t.e[od][LUT4_KEYS + type * 30 + hc * 6 + oc] = lut4_entry(od, 7, hc, oc);
+                }
+    return t;
+}
+__device__ const Lut4Table g_lut4 = make_lut4();
+
+template <int MAXP>
+struct Env4 {
+    uint32_t h0, h1;                 // hands: wire object code in BYTE 1 (the other bytes are whatever the last interact left)
+    uint32_t J;                      // JOINT: byte offset of this joint pose's row in the move table
+    uint32_t pos0, or0, pos1, or1;   // arithmetic movement: cell index / orientation
+    uint32_t tleft, over;            // timestep = horizon - 1 - tleft + over (over > 0: running past the horizon)
+    uint32_t dcount;                 // loose dishes on counters
+    uint32_t rem[MAXP];              // steps until the pot is ready (REM_IDLE when it is not cooking)
+    uint32_t tk[MAXP];               // wire tick byte, or TK_LIVE
+    uint32_t poff[MAXP];             // byte offset of the pot's cell word in this lane's LDS column
+    uint32_t exotic;                 // bit k: pot k arrived holding an ingredient-less soup object (kept as "empty")
+    uint32_t pending;                // bit k: old dynamics, pot k arrived idle with 3 items: it starts in the first step's env effects
+};
+
+// LDS accesses by absolute byte address.  k_rollout4 has no static __shared__, so its dynamic region starts at LDS
+// address 0 and table offsets ARE addresses: nothing is added per access, constants fold into the DS offset field.
+#define OC_LDS __attribute__((address_space(3)))
+typedef uint32_t oc_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t lds_rd16(uint32_t a) { return *(const OC_LDS uint16_t*)(uintptr_t)a; }
+__device__ __forceinline__ uint32_t lds_rd32(uint32_t a) { return *(const OC_LDS uint32_t*)(uintptr_t)a; }
+__device__ __forceinline__ uint4 lds_rd128(uint32_t a) {
+    const oc_u32x4 v = *(const OC_LDS oc_u32x4*)(uintptr_t)a;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void lds_wr16(uint32_t a, uint32_t v) { *(OC_LDS uint16_t*)(uintptr_t)a = (uint16_t)v; }
+__device__ __forceinline__ void lds_wr8(uint32_t a, uint32_t v) { *(OC_LDS uint8_t*)(uintptr_t)a = (uint8_t)v; }
+
+__device__ __forceinline__ uint32_t key_byte_of(uint32_t terrain_type, uint32_t o) {
+    const uint32_t cls = terrain_type == OC_T_COUNTER ? (o == 0u ? 0u : o == OC_O_DISH ? 1u : 2u) : 0u;
+    return terrain_type * 30u + cls;
+}
+
+// one player's INTERACT: `ent` = the LUT entry of (faced cell word, hand, does it interact); h carries the hand in byte 1
+__device__ __forceinline__ uint32_t interact4(const uint4 ent, uint32_t h, uint32_t c16) {
+    const uint32_t pool = __builtin_amdgcn_perm(c16, h, 0x05040401u) + ent.z;  // [hand][object][object + add][key byte]
+    return __builtin_amdgcn_perm(ent.y, pool, ent.x);                           // [flags][new hand][new object][new key byte]
+}
+__device__ __forceinline__ uint32_t lut4_addr(uint32_t off, uint32_t h, uint32_t c16) {
+    return (min((h >> 8) & 0xFFu, 4u) * 6u + (c16 >> 8)) * 16u + off;
+}
+
+template <int MAXP>
+__device__ __forceinline__ void load_env4(const LayC& C, const Lay L, const uint4* __restrict__ st, int64_t n, int64_t e,
+                                          int n_obj, int horizon, Env4<MAXP>& s, uint32_t col) {
+    const uint4 h = st[e];
+    s.pos0 = h.x & 0xFF; s.or0 = (h.x >> 8) & 0xFF; s.h0 = (h.x >> 8) & 0xFF00u; s.pos1 = h.x >> 24;
+    s.or1 = h.y & 0xFF; s.h1 = h.y & 0xFF00u;
+    const uint32_t t = h.y >> 16;
+    s.tleft = t < (uint32_t)horizon ? (uint32_t)horizon - 1u - t : 0u;
+    s.over = t < (uint32_t)horizon ? 0u : t - ((uint32_t)horizon - 1u);
+    uint32_t dishes = 0;
+    for (int p = 0; p < n_obj; ++p) {
+        const uint4 v = st[(int64_t)(1 + p) * n + e];
+        const uint32_t ow[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t T = L.u32(L_TERRAIN + 16 * p + 4 * q);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t o = (ow[q] >> (8 * b)) & 0xFFu, type = (T >> (8 * b)) & 7u;
+                dishes += (type == OC_T_COUNTER && o == OC_O_DISH) ? 1u : 0u;
+                lds_wr16(col + (uint32_t)(16 * p + 4 * q + b) * (BLOCK * 2u), o | (key_byte_of(type, o) << 8));
+            }
+        }
+    }
+    s.dcount = dishes;
+    s.exotic = 0; s.pending = 0;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        s.rem[k] = REM_IDLE; s.tk[k] = 0; s.poff[k] = 0;
+        if ((uint32_t)k < C.n_pots) {
+            s.poff[k] = L.pot_cell(k) * (BLOCK * 2u);
+            uint32_t o = lds_rd16(col + s.poff[k]) & 0xFFu;
+            const uint32_t tkb = ((k < 4 ? h.z : h.w) >> (8 * (k & 3))) & 0xFFu;
+            const uint32_t pc = pot_class(C, o, tkb);
+            if (o == OC_O_SOUP) { s.exotic |= 1u << k; o = 0; }  // a soup object without ingredients behaves as an empty pot
+            if (C.old_dyn && pc == PC_IDLE3) s.pending |= 1u << k;
+            s.tk[k] = pc == PC_COOKING ? TK_LIVE : tkb;
+            s.rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) : REM_IDLE;
+            lds_wr16(col + s.poff[k], o | ((KB_POT + pc) << 8));
+        }
+    }
+}
+
+template <int MAXP>
+__device__ __forceinline__ void store_env4(const LayC& C, const Lay L, uint4* __restrict__ st, int64_t n, int64_t e,
+                                           int n_obj, int horizon, const Env4<MAXP>& s, uint32_t col) {
+    uint4 h;
+    const uint32_t t = (uint32_t)horizon - 1u - s.tleft + s.over;
+    h.x = s.pos0 | (s.or0 << 8) | ((s.h0 & 0xFF00u) << 8) | (s.pos1 << 24);
+    h.y = s.or1 | (s.h1 & 0xFF00u) | (t << 16);
+    h.z = 0; h.w = 0;
+    uint32_t pot_fix_cell[MAXP], pot_fix_obj[MAXP];
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        pot_fix_cell[k] = 0xFFFFFFFFu; pot_fix_obj[k] = 0;
+        if ((uint32_t)k < C.n_pots) {
+            const uint32_t cw = lds_rd16(col + s.poff[k]), o = cw & 0xFFu, pc = (cw >> 8) - KB_POT;
+            uint32_t tkb = s.tk[k];
+            if (tkb == TK_LIVE) {
+                const uint32_t cook = cook_of(C, o);
+                tkb = (pc == PC_COOKING ? cook - s.rem[k] : cook) + 1u;
+            }
+            if (pc < PC_COOKING) tkb = 0;  // empty or idle
+            if (k < 4) h.z |= tkb << (8 * (k & 3));
+            else h.w |= tkb << (8 * (k & 3));
+            if (o == 0u && ((s.exotic >> k) & 1u)) { pot_fix_cell[k] = L.pot_cell(k); pot_fix_obj[k] = OC_O_SOUP; }
+        }
+    }
+    st[e] = h;
+    for (int p = 0; p < n_obj; ++p) {
+        uint32_t ow[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ow[q] = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t c = (uint32_t)(16 * p + 4 * q + b);
+                uint32_t o = lds_rd16(col + c * (BLOCK * 2u)) & 0xFFu;
+#pragma unroll
+                for (int k = 0; k < MAXP; ++k) o = c == pot_fix_cell[k] ? pot_fix_obj[k] : o;
+                ow[q] |= o << (8 * b);
+            }
+        }
+        st[(int64_t)(1 + p) * n + e] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+}
+
+// restart at the horizon (OvercookedEnv.reset with the standard start state, env.py:288-319)
+template <int MAXP>
+__device__ __forceinline__ void env_reset4(const LayC& C, const Lay L, int n_obj, int horizon, Env4<MAXP>& s, uint32_t col) {
+    s.pos0 = L.u8(L_START_POS); s.pos1 = L.u8(L_START_POS + 1);
+    s.or0 = L.u8(L_START_OR); s.or1 = s.pos1 == 0xFFu ? 0u : L.u8(L_START_OR + 1);
+    s.h0 = s.h1 = 0; s.dcount = 0; s.exotic = 0; s.pending = 0;
+    s.tleft = (uint32_t)horizon - 1u; s.over = 0;
+    for (int c = 0; c < n_obj * 16; ++c) lds_wr16(col + (uint32_t)c * (BLOCK * 2u), ((L.terrain((uint32_t)c) & 7u) * 30u) << 8);
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        s.rem[k] = REM_IDLE; s.tk[k] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// JOINT move table (built per workgroup).  Row J = (fi0 * 4 + or0) * NP + (fi1 * 4 + or1), fi = index of the player's
+// cell among the layout's free cells (row-major), NP = 4 * #free cells; a row is 38 u16:
+//    [ja] for ja = 6 * a0 + a1: byte offset (J' * 76) of the joint pose after resolve_movement
+//    [36], [37]: LDS byte offsets (cell * 512) of the cells the two players face in pose J
+// ------------------------------------------------------------------------------------------
+constexpr int MVJ_ROW = 38, MVJ_ROW_BYTES = MVJ_ROW * 2, JOINT_MAX_FLOOR = 7;
+
+__device__ __forceinline__ void build_joint_table(const Lay L, int W, uint16_t* mvj, uint8_t* s_fl, uint8_t* s_fi) {
+    const int nc = (int)L.u8(L_NCELLS);
+    if (threadIdx.x == 0) {
+        int nf = 0;
+        for (int c = 0; c < nc; ++c) {
+            s_fi[c] = 0xFF;
+            if ((L.terrain((uint32_t)c) & 7u) == OC_T_FLOOR && nf < JOINT_MAX_FLOOR) { s_fi[c] = (uint8_t)nf; s_fl[nf++] = (uint8_t)c; }
+        }
+        s_fl[JOINT_MAX_FLOOR] = (uint8_t)nf;
+    }
+    __syncthreads();
+    const int nf = s_fl[JOINT_MAX_FLOOR], NP = 4 * nf, NJ = NP * NP;
+    for (int J = threadIdx.x; J < NJ; J += BLOCK) {
+        const int P0 = J / NP, P1 = J - P0 * NP;
+        const int c0 = s_fl[P0 >> 2], c1 = s_fl[P1 >> 2], o0 = P0 & 3, o1 = P1 & 3;
+        uint16_t* row = mvj + J * MVJ_ROW;
+        auto ahead = [&](int c, int d) {  // cell in direction d, or c itself when that leaves the grid
+            const int t = c + (d == 0 ? -W : d == 1 ? W : d == 2 ? 1 : -1);
+            return (t >= 0 && t < nc) ? t : c;
+        };
+        row[36] = (uint16_t)(ahead(c0, o0) * (BLOCK * 2));
+        row[37] = (uint16_t)(ahead(c1, o1) * (BLOCK * 2));
+        int np0[6], no0[6], np1[6], no1[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {  // _move_if_direction (mdp.py:1718-1727)
+            const int t0 = a < 4 ? ahead(c0, a) : c0, t1 = a < 4 ? ahead(c1, a) : c1;
+            np0[a] = (a < 4 && s_fi[t0] != 0xFF) ? t0 : c0;
+            np1[a] = (a < 4 && s_fi[t1] != 0xFF) ? t1 : c1;
+            no0[a] = a < 4 ? a : o0;
+            no1[a] = a < 4 ? a : o1;
+        }
+#pragma unroll
+        for (int a0 = 0; a0 < 6; ++a0)
+#pragma unroll
+            for (int a1 = 0; a1 < 6; ++a1) {
+                const bool collide = np0[a0] == np1[a1] || (np0[a0] == c1 && np1[a1] == c0);  // mdp.py:1673-1683
+                const int q0 = collide ? c0 : np0[a0], q1 = collide ? c1 : np1[a1];
+                const int Jn = (s_fi[q0] * 4 + no0[a0]) * NP + (s_fi[q1] * 4 + no1[a1]);
+                row[a0 * 6 + a1] = (uint16_t)(Jn * MVJ_ROW_BYTES);
+            }
+    }
+}
+
+// One Philox block = 8 steps (include/oc_amd.h): word s >> 1, top base-36 digit (= 6 * a0 + a1) for even s, second for odd s
+struct Phx4 { uint32_t w0, w1, w2, w3; };
+__device__ __forceinline__ Phx4 philox_words(uint64_t blk, uint32_t g_lo, uint32_t g_hi, uint32_t seed_lo, uint32_t seed_hi) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, r);
+    return Phx4{r[0], r[1], r[2], r[3]};
+}
+__device__ __forceinline__ uint32_t joint_action_of(const Phx4& p, uint32_t s8) {
+    uint32_t w = p.w0;
+    w = s8 >= 2u ? p.w1 : w;
+    w = s8 >= 4u ? p.w2 : w;
+    w = s8 >= 6u ? p.w3 : w;
+    return __umulhi(w * ((s8 & 1u) ? 36u : 1u), 36u);
+}
+
+// LDS map of k_rollout4 — ONE dynamic region at compile-time offsets, starting at LDS address 0 (the kernel has no
+// static __shared__; checked at kernel start), so that table offsets are LDS addresses:
+//    [0, MVJ_CAP)      JOINT move table (MODE 1 only; capacity for NF free cells)
+//    ACT               [2][40] u16: LUT address of "this player does / does not interact" per joint action (MODE 1)
+//    LUT               interact table: one dynamics variant (one layout) or both
+//    LAY               staged layout records
+//    FL / FI           free-cell list / cell -> free-cell index (MODE 1)
+//    CT                [32] cook time by the low five bits of the soup code (one layout)
+//    CELLS             cell words u16 [n_obj * 16][BLOCK]
+template <bool UNIFORM, bool LAY_LDS, int MODE, int NF>
+struct Lds4 {
+    static constexpr int MVJ_CAP = MODE == 1 ? ((16 * NF * NF * MVJ_ROW_BYTES + 15) & ~15) : 0;
+    static constexpr int ACT = MVJ_CAP, ACT_BYTES = MODE == 1 ? 160 : 0;
+    static constexpr int LUT = ACT + ACT_BYTES, LUT_BYTES = UNIFORM ? LUT4_BYTES : 2 * LUT4_BYTES;
+    static constexpr int LAY = LUT + LUT_BYTES, LAY_BYTES = LAY_LDS ? (UNIFORM ? 256 : LDS_LAYOUT_MAX * 256) : 16;
+    static constexpr int FL = LAY + LAY_BYTES, FI = FL + 16, CT = FI + (MODE == 1 ? OC_MAX_CELLS : 0), CELLS = CT + 32;
+    static_assert(MVJ_CAP + ACT_BYTES + LUT4_KEYS * 16 < 65536, "row / LUT addresses are u16 in the tables");
+};
+
+// flags[k][e] for the 64 envs of this wavefront: SGPR row pointer + lane offset, no 64-bit address arithmetic
+__device__ __forceinline__ void store_flag_byte(uint8_t* row, uint32_t lane_off, uint32_t v) {
+    asm volatile("global_store_byte %0, %1, %2" : : "v"(lane_off), "v"(v), "s"(row) : "memory");
+}
+
+// MODE 0: arithmetic movement, any table; MODE 1: JOINT move table (one two-player layout with <= NF free cells)
+// OLD: some layout of the table may use old dynamics (auto-start of full pots in the env effects)
+template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_rollout4(const OcLayout* __restrict__ g_layouts, int n_layouts,
+                                                    const uint16_t* __restrict__ layout_id, uint4* st,
+                                                    float4* __restrict__ rewards, uint8_t* __restrict__ flags,
+                                                    float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,
+                                                    int horizon, uint32_t options, uint32_t seed_lo, uint32_t seed_hi,
+                                                    int64_t env_offset, int64_t t0, int n_steps) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn4[];
+    using M = Lds4<UNIFORM, LAY_LDS, MODE, NF>;
+    if ((uint32_t)(uintptr_t)(OC_LDS uint8_t*)s_dyn4 != 0u) __builtin_trap();  // folds away: the region starts at address 0
+    uint4* const s_lay = reinterpret_cast<uint4*>(s_dyn4 + M::LAY);
+    uint4* const s_lut = reinterpret_cast<uint4*>(s_dyn4 + M::LUT);
+    uint16_t* const s_act = reinterpret_cast<uint16_t*>(s_dyn4 + M::ACT);  // [player][40]
+    uint8_t* const s_fl = s_dyn4 + M::FL;
+    uint8_t* const s_fi = s_dyn4 + M::FI;
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = e < n;
+    const Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains a barrier
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(&g_lut4);
+        const int first = UNIFORM ? (L.old_dynamics() ? 2 * LUT4_KEYS : 0) : 0, count = UNIFORM ? 2 * LUT4_KEYS : 4 * LUT4_KEYS;
+        for (int i = threadIdx.x; i < count; i += BLOCK) {
+            uint4 ent = src[first + i];
+            if (UNIFORM)  // one layout: the entry carries the shaped reward itself
+                ent.w = ent.w == RW4_PLACE ? __float_as_uint(L.rew_placement()) : ent.w == RW4_PLATE ? __float_as_uint(L.rew_soup()) : 0u;
+            s_lut[i] = ent;
+        }
+    }
+    if (UNIFORM && threadIdx.x < 32) {
+        const LayC Cs = load_consts<true>(L);
+        s_dyn4[M::CT + threadIdx.x] = (uint8_t)cook_of(Cs, OC_O_SOUP | threadIdx.x);
+    }
+    if (MODE == 1) {
+        if (threadIdx.x < 36) {  // the LUT's LDS address is folded into the offsets
+            s_act[threadIdx.x] = (uint16_t)(M::LUT + (threadIdx.x / 6 == 5 ? 0 : LUT4_KEYS * 16));
+            s_act[40 + threadIdx.x] = (uint16_t)(M::LUT + (threadIdx.x % 6 == 5 ? 0 : LUT4_KEYS * 16));
+        }
+        build_joint_table(L, W, reinterpret_cast<uint16_t*>(s_dyn4), s_fl, s_fi);
+    }
+    __syncthreads();
+    if (!active) return;
+    const uint32_t col = (uint32_t)M::CELLS + threadIdx.x * 2u;  // LDS address of this lane's column of cell words
+    const LayC C = load_consts<UNIFORM>(L);
+    const uint32_t lut_var = (uint32_t)M::LUT + (UNIFORM ? 0u : (C.old_dyn ? (uint32_t)LUT4_BYTES : 0u));  // this lane's LUT
+    const uint32_t delta4 = make_delta4(W);
+    Env4<MAXP> s;
+    load_env4<MAXP>(C, L, st, n, e, n_obj, horizon, s, col);
+    const bool two = MODE == 1 || s.pos1 != 0xFFu;
+    auto joint_row = [&]() {  // LDS address of the row of the joint pose (pos0, or0, pos1, or1)
+        const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR];
+        return ((s_fi[s.pos0] * 4u + s.or0) * NP + (s_fi[s.pos1] * 4u + s.or1)) * MVJ_ROW_BYTES;
+    };
+    if (MODE == 1) s.J = joint_row();
+    float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint64_t g = (uint64_t)(env_offset + e);
+    const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
+    float4* rew_k = rewards ? rewards + (int64_t)blockIdx.x * BLOCK : nullptr;  // wave-uniform row pointers
+    const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));  // first lane of this wavefront
+    uint8_t* flg_k = flags ? flags + (int64_t)blockIdx.x * BLOCK + wave_base : nullptr;
+    const uint32_t lane = threadIdx.x & 63u;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t zero = 0;
+
+    // ---- resolve_interacts + env effects + bookkeeping for one step.  fo*: LDS addresses of the faced cells, off*: LUT
+    //      address of (this lane's table, does the player interact), c*: the faced cell words (already read).
+    //      m0..m3: the caller's movement result for this step, overwritten inside the horizon branch when the env is put
+    //      back to its start state — MODE 1: (row of the next pose, its faced cells, row of the pose after that; ja2n = the
+    //      next step's joint action * 2), MODE 0: (pos0, pos1, or0, or1).
+    //      pkb[k]: key byte of pot k's cell read BEFORE this step's interacts (the "pot_states" of mdp.py:1439), MAXP <= 2.
+    constexpr bool PKB = MAXP <= 2;
+    auto cook_time = [&](uint32_t soup) __attribute__((always_inline)) {
+        return UNIFORM ? (uint32_t)*(const OC_LDS uint8_t*)(uintptr_t)((uint32_t)M::CT + (soup & 31u)) : cook_of(C, soup);
+    };
+    auto core = [&](uint32_t fo0, uint32_t fo1, uint32_t off0, uint32_t off1, uint32_t c0, uint32_t c1, uint32_t ja2n,
+                    const uint32_t (&pkb)[MAXP], uint32_t& m0, uint32_t& m1, uint32_t& m2, uint32_t& m3) __attribute__((always_inline)) {
+        // both players against the pre-step cells; player 1 replays on player 0's result when they face the same cell
+        // and player 0 changed it (Q2 of SURVEY 8a)
+        const uint4 e0 = lds_rd128(lut4_addr(off0, s.h0, c0));
+        uint4 e1 = lds_rd128(lut4_addr(off1, s.h1, c1));
+        const uint32_t r0 = interact4(e0, s.h0, c0);
+        uint32_t r1 = interact4(e1, s.h1, c1);
+        uint32_t cw0 = r0 >> 16;  // player 0's faced cell afterwards
+        asm volatile("" : "+v"(r1), "+v"(e1.y), "+v"(e1.w), "+v"(cw0));  // player 1's result is formed here: it must not wait for player 0's
+#if defined(OC_EXPERIMENT) && (OC_EXPERIMENT == 3)
+        if (false) {
+#else
+        if (__builtin_expect((fo0 == fo1) & ((r0 & F4_CHG) != 0u), 0)) {
+#endif
+            e1 = lds_rd128(lut4_addr(off1, s.h1, cw0));
+            r1 = interact4(e1, s.h1, cw0);
+        }
+        lds_wr16(fo0, cw0);
+        lds_wr16(fo1, r1 >> 16);
+        const uint32_t h0_before = s.h0, h1_before = s.h1, dc_before = s.dcount;
+        s.h0 = r0;
+        s.h1 = r1;
+        const uint32_t dd0 = (uint32_t)((int32_t)e0.y >> 24);
+        s.dcount = dc_before + dd0 + (uint32_t)((int32_t)e1.y >> 24);
+        // shaped reward of potting / soup pickup straight from the entries (class -> this lane's layout when the table is mixed)
+        float sh0, sh1;
+        if (UNIFORM) {
+            sh0 = __uint_as_float(e0.w); sh1 = __uint_as_float(e1.w);
+        } else {
+            sh0 = e0.w == RW4_PLACE ? C.rew_place : e0.w == RW4_PLATE ? C.rew_soup : 0.f;
+            sh1 = e1.w == RW4_PLACE ? C.rew_place : e1.w == RW4_PLATE ? C.rew_soup : 0.f;
+        }
+        ep.z += sh0; ep.w += sh1;
+#if !defined(OC_EXPERIMENT) || (OC_EXPERIMENT != 1)
+        if (OUT || rew_k) rew_k[threadIdx.x] = make_float4(0.f, 0.f, sh0, sh1);
+        if (OUT || flg_k) store_flag_byte(flg_k, lane, zero);
+#endif
+        // step_environment_effects (mdp.py:1691-1703): the countdowns; a pot whose countdown ends is marked ready below
+        bool ripe[MAXP];
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            s.rem[k] -= 1u;
+            ripe[k] = s.rem[k] == 0u;
+        }
+        const bool done = s.tleft == 0u;
+        s.tleft -= 1u;
+        // (1) cooking starts (mdp.py:1515-1522): tick 0 now, cooked once by this step's env effects (Q4).  Old dynamics:
+        //     a pot that has just received its third item — or arrived full and idle — starts by itself in the env
+        //     effects, same arithmetic (Q11).
+        uint32_t smask = F4_START;
+        if (OLD) smask |= C.old_dyn ? (uint32_t)F4_PLACE : 0u;
+        bool starts = ((r0 | r1) & smask) != 0u;
+        if (OLD) starts |= s.pending != 0u;
+        if (__builtin_expect(starts, 0)) {
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k) {
+                if (MAXP > 1 && (uint32_t)k >= C.n_pots) break;
+                const uint32_t pa = col + s.poff[k];
+                uint32_t soup = 0;
+                bool go = false;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const uint32_t rr = p ? r1 : r0, fo = p ? fo1 : fo0;
+                    const bool begins = (rr & F4_START) != 0u;
+                    const bool fills = OLD && C.old_dyn && (rr & F4_PLACE) && (rr >> 24) == KB_POT + PC_IDLE3;
+                    if ((begins | fills) && (MAXP == 1 || fo == pa)) { go = true; soup = (rr >> 16) & 0xFFu; }
+                }
+                if (OLD && ((s.pending >> k) & 1u)) { go = true; soup = lds_rd16(pa) & 0xFFu; }
+                if (go) {
+                    const uint32_t cook = cook_time(soup);
+                    s.rem[k] = cook == 0u ? REM_IDLE : cook - 1u;
+                    s.tk[k] = TK_LIVE;
+                    s.exotic &= ~(1u << k);
+                    ripe[k] = false;
+                    lds_wr8(pa + 1u, cook <= 1u ? KB_POT + PC_READY : KB_POT + PC_COOKING);
+                }
+            }
+            if (OLD) s.pending = 0;
+        }
+        // (2) deliveries, possibly useful dish pick-ups, the horizon.  A dish taken from the dispenser can only be
+        //     "useful" when some pot is (pot_states before the interacts) and no dish lies on a counter — before, or
+        //     after player 0's own pick-up.
+        bool dish_ok = min(dc_before, dc_before + dd0) == 0u;
+        if (PKB) {
+            bool any_useful = false;
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k)  // (unused slots read cell 0, whose key byte is no pot class unless it is pot 0)
+                any_useful |= (pkb[k] - (KB_POT + PC_IDLE1) <= (uint32_t)(PC_READY - PC_IDLE1)) & (pkb[k] != KB_POT + PC_IDLE3);
+            dish_ok &= any_useful;
+        }
+        const uint32_t gate = dish_ok ? (uint32_t)(F4_SERVE | F4_TAKE_DISH) : (uint32_t)F4_SERVE;
+        bool slow = (((r0 | r1) & gate) != 0u) | done;
+#if defined(OC_EXPERIMENT) && (OC_EXPERIMENT == 2)
+        slow = done;
+#endif
+        if (__builtin_expect(slow, 0)) {
+            const uint32_t hb0 = (h0_before >> 8) & 0xFFu, hb1 = (h1_before >> 8) & 0xFFu, hn0 = (r0 >> 8) & 0xFFu;
+            // pot_states before any interact (mdp.py:1439): ready / cooking / 1..2 idle items <=> class not in {empty, idle 3}
+            uint32_t useful_pots = 0;
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k) {
+                if (MAXP > 1 && (uint32_t)k >= C.n_pots) break;
+                uint32_t kb;
+                if (PKB) {
+                    kb = pkb[k];
+                } else {  // the cells hold the classes after this step's interacts; a pot a player has just changed had
+                          // the class of that player's faced cell word before (player 0's first)
+                    const uint32_t pa = col + s.poff[k];
+                    kb = lds_rd16(pa) >> 8;
+                    kb = ((r1 & F4_POTBITS) && fo1 == pa) ? (c1 >> 8) : kb;
+                    kb = ((r0 & F4_POTBITS) && fo0 == pa) ? (c0 >> 8) : kb;
+                }
+                useful_pots += (kb != KB_POT + PC_EMPTY && kb != KB_POT + PC_IDLE3) ? 1u : 0u;
+            }
+            // is_dish_pickup_useful (mdp.py:2180-2204): live hands / counters, stale pots
+            const bool du0 = two & (((hb1 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_before == 0u);
+            const bool du1 = two & (((hn0 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_before + dd0 == 0u);
+            float4 r;
+            r.z = (((r0 & F4_TAKE_DISH) != 0u) & du0) ? C.rew_dish : 0.f;
+            r.w = (((r1 & F4_TAKE_DISH) != 0u) & du1) ? C.rew_dish : 0.f;
+            r.x = (r0 & F4_SERVE) ? L.value(recipe_idx(hb0) & 15u) : 0.f;  // deliver_soup (mdp.py:1631-1642)
+            r.y = (r1 & F4_SERVE) ? L.value(recipe_idx(hb1) & 15u) : 0.f;
+            ep.x += r.x; ep.y += r.y; ep.z += r.z; ep.w += r.w;
+            r.z += sh0; r.w += sh1;
+            if (OUT || rew_k) rew_k[threadIdx.x] = r;
+            if (done) {  // OvercookedEnv.step bookkeeping at the horizon (env.py:266-267, 321-325)
+                uint32_t fl = OC_F_DONE;
+                if (options & OC_OPT_AUTO_RESET) {
+                    env_reset4<MAXP>(C, L, n_obj, horizon, s, col);
+#pragma unroll
+                    for (int k = 0; k < MAXP; ++k) ripe[k] = false;
+                    ep = zero4;
+                    fl |= OC_F_RESET;
+                    if (MODE == 1) {  // redo the look-ahead from the start pose
+                        m0 = joint_row();
+                        m1 = lds_rd32(m0 + 72u);
+                        m2 = lds_rd16(m0 + ja2n);
+                    } else {
+                        m0 = s.pos0; m1 = s.pos1; m2 = s.or0; m3 = s.or1;
+                    }
+                } else {
+                    s.tleft = 0u;
+                    s.over += 1u;
+                }
+                if (OUT || flg_k) store_flag_byte(flg_k, lane, fl);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k)  // a finished countdown turns the pot ready (the lanes concerned only)
+            if (ripe[k]) lds_wr8(col + s.poff[k] + 1u, KB_POT + PC_READY);
+        if (OUT || rew_k) rew_k += n;
+        if (OUT || flg_k) flg_k += n;
+    };
+
+    Phx4 w = {0, 0, 0, 0};  // the Philox block of the step being looked at
+#define OC_JA_AT(T, FIRST)                                                                                   \
+    ([&]() __attribute__((always_inline)) {                                                                  \
+        const uint64_t t_ = (uint64_t)(T);                                                                   \
+        if ((FIRST) || ((uint32_t)t_ & 7u) == 0u) w = philox_words(t_ >> 3, g_lo, g_hi, seed_lo, seed_hi);   \
+        return joint_action_of(w, (uint32_t)t_ & 7u);                                                        \
+    }())
+
+    if (MODE == 1) {
+        // Software pipeline over the move table: while step k resolves its interacts, the reads for step k + 1 (faced
+        // cells of the next pose, the pose after that, who interacts) are already in flight.  State carried:
+        //   Jc = row of the pose at step k, fa = its faced-cell offsets, off0/off1 = LUT addresses for step k's actions,
+        //   Jn = row of the pose at step k + 1.
+        uint32_t Jc = s.J;
+        uint32_t ja2 = OC_JA_AT(t0, true) * 2u;
+        uint32_t fa = lds_rd32(Jc + 72u), Jn = lds_rd16(Jc + ja2);
+        uint32_t off0 = lds_rd16((uint32_t)M::ACT + ja2), off1 = lds_rd16((uint32_t)M::ACT + 80u + ja2);
+        auto pstep = [&](uint32_t ja2n) __attribute__((always_inline)) {  // ja2n: 2 * joint action of the NEXT step
+            const uint32_t fo0 = col + (fa & 0xFFFFu), fo1 = col + (fa >> 16);
+            const uint32_t c0 = lds_rd16(fo0), c1 = lds_rd16(fo1);
+            uint32_t pkb[MAXP];
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k) pkb[k] = PKB ? (uint32_t)*(const OC_LDS uint8_t*)(uintptr_t)(col + s.poff[k] + 1u) : 0u;
+            uint32_t fa_n = lds_rd32(Jn + 72u), Jnn = lds_rd16(Jn + ja2n);
+            const uint32_t off0n = lds_rd16((uint32_t)M::ACT + ja2n), off1n = lds_rd16((uint32_t)M::ACT + 80u + ja2n);
+            uint32_t Jcn = Jn, unused = 0;
+            core(fo0, fo1, off0, off1, c0, c1, ja2n, pkb, Jcn, fa_n, Jnn, unused);
+            Jc = Jcn; Jn = Jnn; fa = fa_n; off0 = off0n; off1 = off1n;
+        };
+        int k = 0;
+        const int head_end = min(n_steps, (int)((8u - ((uint32_t)t0 & 7u)) & 7u));
+        // (the look-ahead call for the last head step loads the block the unrolled loop starts with; with no head, the
+        //  prologue's ja_at(t0) did)
+        for (; k < head_end; ++k) pstep(OC_JA_AT(t0 + k + 1, false) * 2u);  // up to the next block boundary
+        for (; n_steps - k >= 8; k += 8) {  // whole Philox blocks, unrolled; the look-ahead digit of step 7 is the next block's first
+            const Phx4 nb = philox_words(((uint64_t)(t0 + k) >> 3) + 1u, g_lo, g_hi, seed_lo, seed_hi);
+            pstep(__umulhi(w.w0 * 36u, 36u) * 2u);
+            pstep(__umulhi(w.w1, 36u) * 2u);
+            pstep(__umulhi(w.w1 * 36u, 36u) * 2u);
+            pstep(__umulhi(w.w2, 36u) * 2u);
+            pstep(__umulhi(w.w2 * 36u, 36u) * 2u);
+            pstep(__umulhi(w.w3, 36u) * 2u);
+            pstep(__umulhi(w.w3 * 36u, 36u) * 2u);
+            pstep(__umulhi(nb.w0, 36u) * 2u);
+            w = nb;
+        }
+        for (; k < n_steps; ++k) pstep(OC_JA_AT(t0 + k + 1, false) * 2u);  // the tail
+        // joint pose -> cells / orientations
+        const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR], Jidx = Jc / MVJ_ROW_BYTES, P0 = Jidx / NP, P1 = Jidx - P0 * NP;
+        s.pos0 = s_fl[P0 >> 2]; s.or0 = P0 & 3u; s.pos1 = s_fl[P1 >> 2]; s.or1 = P1 & 3u;
+    } else {
+        auto astep = [&](uint32_t a0, uint32_t a1) __attribute__((always_inline)) {
+            const uint32_t f0 = step_cell(s.pos0, s.or0, delta4), f1 = two ? step_cell(s.pos1, s.or1, delta4) : f0;
+            const uint32_t m0 = a0 < 4u ? step_cell(s.pos0, a0, delta4) : s.pos0;
+            const uint32_t m1 = (two & (a1 < 4u)) ? step_cell(s.pos1, a1, delta4) : (two ? s.pos1 : s.pos0);
+            const uint32_t fo0 = col + f0 * (BLOCK * 2u), fo1 = col + f1 * (BLOCK * 2u);
+            const uint32_t off0 = lut_var + (a0 == OC_A_INTERACT ? 0u : (uint32_t)(LUT4_KEYS * 16));
+            const uint32_t off1 = lut_var + ((two & (a1 == OC_A_INTERACT)) ? 0u : (uint32_t)(LUT4_KEYS * 16));
+            const uint32_t c0 = lds_rd16(fo0), c1 = lds_rd16(fo1);
+            const uint32_t cm0 = lds_rd16(col + m0 * (BLOCK * 2u)), cm1 = lds_rd16(col + m1 * (BLOCK * 2u));
+            uint32_t pkb[MAXP];
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k) pkb[k] = PKB ? (uint32_t)*(const OC_LDS uint8_t*)(uintptr_t)(col + s.poff[k] + 1u) : 0u;
+            // resolve_movement (mdp.py:1644-1727): decided on the pre-step terrain, applied after the interacts
+            const bool mv0 = a0 < 4u, mv1 = two & (a1 < 4u);
+            const uint32_t np0 = (mv0 & ((cm0 >> 8) < 30u)) ? m0 : s.pos0, np1 = (mv1 & ((cm1 >> 8) < 30u)) ? m1 : s.pos1;
+            const bool collide = two & ((np0 == np1) | ((np0 == s.pos1) & (np1 == s.pos0)));
+            const uint32_t q0 = collide ? s.pos0 : np0, q1 = collide ? s.pos1 : np1;
+            const uint32_t o0 = mv0 ? a0 : s.or0, o1 = mv1 ? a1 : s.or1;
+            uint32_t p0 = q0, p1 = q1, d0 = o0, d1 = o1;
+            core(fo0, fo1, off0, off1, c0, c1, 0u, pkb, p0, p1, d0, d1);
+            s.pos0 = p0; s.pos1 = p1; s.or0 = d0; s.or1 = d1;
+        };
+        int k = 0;
+        const int head_end = min(n_steps, (int)((8u - ((uint32_t)t0 & 7u)) & 7u));
+        for (int phase = 0; phase < 2; ++phase) {
+            const int upto = phase == 0 ? head_end : n_steps;
+            for (; k < upto; ++k) {  // rolled steps: up to the next block boundary, and the tail
+                const uint32_t ja = OC_JA_AT(t0 + k, k == 0);
+                const uint32_t a0 = ja / 6u;
+                astep(a0, ja - 6u * a0);
+            }
+            if (phase == 0) {
+                for (; n_steps - k >= 8; k += 8) {  // whole Philox blocks, unrolled
+                    w = philox_words((uint64_t)(t0 + k) >> 3, g_lo, g_hi, seed_lo, seed_hi);
+#pragma unroll
+                    for (int wd = 0; wd < 4; ++wd) {
+                        uint32_t x = wd == 0 ? w.w0 : wd == 1 ? w.w1 : wd == 2 ? w.w2 : w.w3;
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            const uint32_t a0 = __umulhi(x, 6u);
+                            x *= 6u;
+                            const uint32_t a1 = __umulhi(x, 6u);
+                            x *= 6u;
+                            astep(a0, a1);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#undef OC_JA_AT
+    store_env4<MAXP>(C, L, st, n, e, n_obj, horizon, s, col);
+    if (ep_returns) ep_returns[e] = ep;
+}

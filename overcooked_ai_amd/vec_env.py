@@ -40,6 +40,7 @@ class VecOvercookedEnv:
         self.lane_per_env = False  # rollout_random: force the one-lane-per-env kernel (testing / comparison)
         self.lane_pair = False     # rollout_random: force the lane-pair kernel where the table allows it
         self.predicate_interact = False  # rollout_random: lane-per-env kernel with the predicate-network interact
+        self.rollout_v3 = False          # rollout_random: k_rollout3 instead of k_rollout4 (cross-checks)
         self.seed = int(seed)
         self.env_offset = int(env_offset)
         self.t_global = 0  # global step counter feeding the Philox counter of rollout_random
@@ -67,10 +68,12 @@ class VecOvercookedEnv:
         self._batch = _lib.OcBatch(
             d_layouts=self.d_layouts.data_ptr(),
             d_layout_id=self.layout_id.data_ptr() if self.layout_id is not None else None,
-            n_envs=self.n_envs, n_layouts=len(self.table), width=self.width, height=self.height,
-            max_pots=self.table.max_pots,
-            batch_flags=_lib.BATCH_TWO_PLAYERS if all(s.num_players == 2 for s in self.table.specs) else 0)
+            n_envs=self.n_envs, n_layouts=len(self.table), width=self.width, height=self.height)
         self._bref = ctypes.byref(self._batch)
+        # kernel-variant hints (max pots, two players everywhere, max free cells) from the host copy of the table
+        host_table = np.ascontiguousarray(self.table.records)
+        _lib.check(self.lib.oc_batch_hints(host_table.ctypes.data, len(self.table), self._bref), "oc_batch_hints")
+        assert self._batch.max_pots == self.table.max_pots
         self._plans = {}
         self._phi_tables = {}
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
@@ -91,7 +94,8 @@ class VecOvercookedEnv:
     @property
     def options(self):
         return ((_lib.OPT_AUTO_RESET if self.auto_reset else 0) | (_lib.OPT_LANE_PER_ENV if self.lane_per_env else 0)
-                | (_lib.OPT_LANE_PAIR if self.lane_pair else 0) | (_lib.OPT_PREDICATE_INTERACT if self.predicate_interact else 0))
+                | (_lib.OPT_LANE_PAIR if self.lane_pair else 0) | (_lib.OPT_PREDICATE_INTERACT if self.predicate_interact else 0)
+                | (_lib.OPT_ROLLOUT_V3 if self.rollout_v3 else 0))
 
     def spec_of(self, e):
         return self.table.specs[0 if self.layout_id is None else int(self.layout_id_host[e])]

@@ -116,7 +116,7 @@ def test_reference_golden_trajectory(manifest, gpu):
     assert total == d["ep_rewards"][: n - 1].sum()
 
 
-@pytest.mark.parametrize("kernel", ["lane_per_env", "lane_pair", "predicate_interact"])
+@pytest.mark.parametrize("kernel", ["lane_per_env", "rollout_v3", "lane_pair", "predicate_interact"])
 @pytest.mark.parametrize("name", ROLLOUT_CONFIGS)
 def test_golden_rollouts_fused(name, kernel, manifest, gpu):
     """Both fused Philox rollout kernels against episodes run through the reference's OvercookedEnv.step."""
@@ -217,7 +217,7 @@ def test_step_vs_oracle_random_states(n_envs, gpu):
         assert (fl_o & 2).any() or n_envs == 1
 
 
-@pytest.mark.parametrize("kernel", ["lane_per_env", "lane_pair", "predicate_interact"])
+@pytest.mark.parametrize("kernel", ["lane_per_env", "rollout_v3", "lane_pair", "predicate_interact"])
 def test_full_size_rollout_vs_oracle(kernel, gpu):
     """BASELINE config 2 at full size: 65 536 cramped_room envs, random policy, horizon 400 with auto-reset."""
     from overcooked_ai_amd.layouts import spec_from_name
@@ -265,7 +265,7 @@ def test_full_size_rollout_vs_oracle(kernel, gpu):
     assert torch.equal(shard.state, env3.state[:, a:b])
 
 
-@pytest.mark.parametrize("kernel", ["lane_per_env", "lane_pair", "predicate_interact"])
+@pytest.mark.parametrize("kernel", ["lane_per_env", "rollout_v3", "lane_pair", "predicate_interact"])
 def test_mixed_layout_batch_vs_oracle(kernel, gpu):
     """BASELINE config 4 (one GPU's shard): env e uses canonical layout e % 5, all padded to 9x5."""
     from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
@@ -343,9 +343,10 @@ def test_every_registry_layout_vs_oracle(gpu):
         env = make_env(spec, n, gpu, horizon=400, auto_reset=True, seed=3)
         st_o = st.copy()
         rew_o, _ = orc.rollout_random(st_o, 60, horizon=400, options=1, seed=3)
-        for kernel in ("lane_per_env", "lane_pair", "predicate_interact"):  # lane_pair falls back where it does not apply
+        for kernel in ("lane_per_env", "rollout_v3", "lane_pair", "predicate_interact"):  # lane_pair falls back where it does not apply
             env.lane_per_env, env.lane_pair, env.predicate_interact = (kernel == "lane_per_env", kernel == "lane_pair",
                                                                        kernel == "predicate_interact")
+            env.rollout_v3 = kernel == "rollout_v3"
             env.set_packed_state(st)
             env.t_global = 0
             rew = torch.zeros((60, n, 4), dtype=torch.float32, device=gpu)
@@ -721,8 +722,8 @@ def test_no_out_of_bounds_writes_with_ragged_batches(gpu):
         K = 7
         r_raw, rew = guarded((K, n, 4), torch.float32); bufs.append((r_raw, rew))
         f_raw, fl = guarded((K, n), torch.uint8); bufs.append((f_raw, fl))
-        for mode in (None, "lane_per_env", "lane_pair", "predicate_interact"):
-            for m in ("lane_per_env", "lane_pair", "predicate_interact"):
+        for mode in (None, "lane_per_env", "rollout_v3", "lane_pair", "predicate_interact"):
+            for m in ("lane_per_env", "rollout_v3", "lane_pair", "predicate_interact"):
                 setattr(env, m, m == mode)
             env.rollout_random(K, rew, fl)
         s_raw, st_out = guarded(tuple(env.state.shape), torch.uint8); bufs.append((s_raw, st_out))
