@@ -284,7 +284,7 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         const bool two = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0;
         const bool joint = uniform && two && b->max_free_cells >= 2 && b->max_free_cells <= (uint32_t)JOINT_MAX_FLOOR;
         const bool old = (b->batch_flags & OC_BATCH_NEW_DYNAMICS) == 0;  // some layout may use old dynamics
-        const size_t cell_bytes = (size_t)n_obj * 16 * BLOCK * sizeof(uint16_t);
+        const size_t cell_bytes = ((size_t)n_obj * 16 + 1) * BLOCK * sizeof(uint16_t);  // + one spare word per lane
         const dim3 grid4(grid_for(b->n_envs)), block4(BLOCK);
         const bool out = d_rewards != nullptr && d_flags != nullptr;
 #define GO4(U, MP, LL, MODE, OUT, OLD, ...)                                                                         \

@@ -40,8 +40,11 @@ constexpr uint32_t KB_COUNTER = OC_T_COUNTER * 30u, KB_POT = OC_T_POT * 30u;
 enum { F4_TAKE_DISH = 1, F4_PLACE = 2, F4_PLATE = 4, F4_START = 8, F4_SERVE = 16, F4_CHG = 128 };
 constexpr uint32_t F4_POTBITS = F4_PLACE | F4_PLATE | F4_START;
 constexpr int LUT4_KEYS = 240, LUT4_BYTES = 2 * LUT4_KEYS * 16;  // keys 240..479: the "does not interact" copy (all no-ops)
-constexpr uint32_t REM_IDLE = 0x40000000u;  // countdown of a pot that is not cooking
-constexpr uint32_t TK_LIVE = 0xFFFFFFFFu;   // tick register: "derive the tick from the countdown when storing"
+// Countdown register of a pot.  Cooking: steps until it is ready.  Never cooking during this launch: REM_IDLE minus the
+// steps run (stays a large positive number: a launch runs at most 2^30 steps).  Cooked or started during the launch: at
+// most the longest cook time, or negative once it is ready — rem_live() tells these two cases apart when the state is stored.
+constexpr uint32_t REM_IDLE = 0x7FFFFF00u;
+__device__ __forceinline__ bool rem_live(uint32_t rem) { return (int32_t)rem < 0x100; }
 
 struct Lut4Entry { uint32_t sel, cst, add, rew; };
 enum { RW4_NONE = 0, RW4_PLACE = 1, RW4_PLATE = 2 };
@@ -102,7 +105,7 @@ struct Env4 {
     uint32_t tleft, over;            // timestep = horizon - 1 - tleft + over (over > 0: running past the horizon)
     uint32_t dcount;                 // loose dishes on counters
     uint32_t rem[MAXP];              // steps until the pot is ready (REM_IDLE when it is not cooking)
-    uint32_t tk[MAXP];               // wire tick byte, or TK_LIVE
+    uint32_t tk[MAXP];               // wire tick byte the pot arrived with (its tick when the countdown never ran)
     uint32_t poff[MAXP];             // byte offset of the pot's cell word in this lane's LDS column
     uint32_t exotic;                 // bit k: pot k arrived holding an ingredient-less soup object (kept as "empty")
     uint32_t pending;                // bit k: old dynamics, pot k arrived idle with 3 items: it starts in the first step's env effects
@@ -171,7 +174,7 @@ __device__ __forceinline__ void load_env4(const LayC& C, const Lay L, const uint
             const uint32_t pc = pot_class(C, o, tkb);
             if (o == OC_O_SOUP) { s.exotic |= 1u << k; o = 0; }  // a soup object without ingredients behaves as an empty pot
             if (C.old_dyn && pc == PC_IDLE3) s.pending |= 1u << k;
-            s.tk[k] = pc == PC_COOKING ? TK_LIVE : tkb;
+            s.tk[k] = tkb;
             s.rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) : REM_IDLE;
             lds_wr16(col + s.poff[k], o | ((KB_POT + pc) << 8));
         }
@@ -193,14 +196,15 @@ __device__ __forceinline__ void store_env4(const LayC& C, const Lay L, uint4* __
         if ((uint32_t)k < C.n_pots) {
             const uint32_t cw = lds_rd16(col + s.poff[k]), o = cw & 0xFFu, pc = (cw >> 8) - KB_POT;
             uint32_t tkb = s.tk[k];
-            if (tkb == TK_LIVE) {
+            const bool live = rem_live(s.rem[k]);
+            if (live) {
                 const uint32_t cook = cook_of(C, o);
                 tkb = (pc == PC_COOKING ? cook - s.rem[k] : cook) + 1u;
             }
             if (pc < PC_COOKING) tkb = 0;  // empty or idle
             if (k < 4) h.z |= tkb << (8 * (k & 3));
             else h.w |= tkb << (8 * (k & 3));
-            if (o == 0u && ((s.exotic >> k) & 1u)) { pot_fix_cell[k] = L.pot_cell(k); pot_fix_obj[k] = OC_O_SOUP; }
+            if (o == 0u && ((s.exotic >> k) & 1u) && !live) { pot_fix_cell[k] = L.pot_cell(k); pot_fix_obj[k] = OC_O_SOUP; }
         }
     }
     st[e] = h;
@@ -396,145 +400,197 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
     //      m0..m3: the caller's movement result for this step, overwritten inside the horizon branch when the env is put
     //      back to its start state — MODE 1: (row of the next pose, its faced cells, row of the pose after that; ja2n = the
     //      next step's joint action * 2), MODE 0: (pos0, pos1, or0, or1).
-    //      pkb[k]: key byte of pot k's cell read BEFORE this step's interacts (the "pot_states" of mdp.py:1439), MAXP <= 2.
-    constexpr bool PKB = MAXP <= 2;
+    //      pw[k]: pot k's cell word read BEFORE this step's interacts (its class is the "pot_states" of mdp.py:1439),
+    //      cookv[k]: the cook time of what that pot holds (FAST_START only), MAXP <= 2.
+    constexpr bool PW = MAXP <= 2;
+    constexpr bool FAST_START = UNIFORM && MAXP == 1 && !OLD;  // a cooking start is two instructions of the straight line
     auto cook_time = [&](uint32_t soup) __attribute__((always_inline)) {
         return UNIFORM ? (uint32_t)*(const OC_LDS uint8_t*)(uintptr_t)((uint32_t)M::CT + (soup & 31u)) : cook_of(C, soup);
     };
+    // some recipe of the batch's layout cooks in zero steps (FAST_START handles that start in the rare branch)
+    bool zero_cook = false;
+    if (FAST_START) {
+#pragma unroll
+        for (int no = 0; no <= 3; ++no)
+#pragma unroll
+            for (int nt = 0; nt + no <= 3; ++nt)
+                if (no + nt > 0) zero_cook |= ((C.cook[nt] >> (8 * no)) & 0xFFu) == 0u;
+    }
+    //      MODE 1 also prefetches the next step's faced cells (nc0, nc1) and pot words (npw) as soon as this step's cell
+    //      writes are issued — m1 holds the next pose's faced-cell offsets on entry.
+    const uint32_t dummy = col + (uint32_t)n_obj * 16u * (BLOCK * 2u);  // a spare cell word per lane (one row past the grid)
+    auto rd_pots = [&](uint32_t (&out)[MAXP]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) out[k] = PW ? lds_rd16(col + s.poff[k]) : 0u;
+    };
     auto core = [&](uint32_t fo0, uint32_t fo1, uint32_t off0, uint32_t off1, uint32_t c0, uint32_t c1, uint32_t ja2n,
-                    const uint32_t (&pkb)[MAXP], uint32_t& m0, uint32_t& m1, uint32_t& m2, uint32_t& m3) __attribute__((always_inline)) {
-        // both players against the pre-step cells; player 1 replays on player 0's result when they face the same cell
-        // and player 0 changed it (Q2 of SURVEY 8a)
+                    const uint32_t (&pw)[MAXP], uint32_t& m0, uint32_t& m1, uint32_t& m2, uint32_t& m3, uint32_t& nc0,
+                    uint32_t& nc1, uint32_t (&npw)[MAXP]) __attribute__((always_inline)) {
+        // ---- the straight line: everything a step does when nothing rare happens -------------------------------------
+        uint32_t cookv = 0;
+        if (FAST_START) cookv = cook_time(pw[0]);  // cook time of what the pot holds, should somebody start it
+        // both players against the pre-step cells (resolve_interacts, mdp.py:1432-1579)
         const uint4 e0 = lds_rd128(lut4_addr(off0, s.h0, c0));
         uint4 e1 = lds_rd128(lut4_addr(off1, s.h1, c1));
         const uint32_t r0 = interact4(e0, s.h0, c0);
         uint32_t r1 = interact4(e1, s.h1, c1);
-        uint32_t cw0 = r0 >> 16;  // player 0's faced cell afterwards
-        asm volatile("" : "+v"(r1), "+v"(e1.y), "+v"(e1.w), "+v"(cw0));  // player 1's result is formed here: it must not wait for player 0's
-#if defined(OC_EXPERIMENT) && (OC_EXPERIMENT == 3)
-        if (false) {
-#else
-        if (__builtin_expect((fo0 == fo1) & ((r0 & F4_CHG) != 0u), 0)) {
-#endif
-            e1 = lds_rd128(lut4_addr(off1, s.h1, cw0));
-            r1 = interact4(e1, s.h1, cw0);
-        }
+        const uint32_t cw0 = r0 >> 16;  // player 0's faced cell afterwards
         lds_wr16(fo0, cw0);
         lds_wr16(fo1, r1 >> 16);
         const uint32_t h0_before = s.h0, h1_before = s.h1, dc_before = s.dcount;
-        s.h0 = r0;
-        s.h1 = r1;
-        const uint32_t dd0 = (uint32_t)((int32_t)e0.y >> 24);
-        s.dcount = dc_before + dd0 + (uint32_t)((int32_t)e1.y >> 24);
-        // shaped reward of potting / soup pickup straight from the entries (class -> this lane's layout when the table is mixed)
-        float sh0, sh1;
-        if (UNIFORM) {
-            sh0 = __uint_as_float(e0.w); sh1 = __uint_as_float(e1.w);
-        } else {
-            sh0 = e0.w == RW4_PLACE ? C.rew_place : e0.w == RW4_PLATE ? C.rew_soup : 0.f;
-            sh1 = e1.w == RW4_PLACE ? C.rew_place : e1.w == RW4_PLATE ? C.rew_soup : 0.f;
-        }
-        ep.z += sh0; ep.w += sh1;
-#if !defined(OC_EXPERIMENT) || (OC_EXPERIMENT != 1)
-        if (OUT || rew_k) rew_k[threadIdx.x] = make_float4(0.f, 0.f, sh0, sh1);
-        if (OUT || flg_k) store_flag_byte(flg_k, lane, zero);
-#endif
-        // step_environment_effects (mdp.py:1691-1703): the countdowns; a pot whose countdown ends is marked ready below
+        const uint32_t dc_mid = dc_before + (uint32_t)((int32_t)e0.y >> 24);  // loose dishes after player 0's interact
+        uint32_t dcount = dc_mid + (uint32_t)((int32_t)e1.y >> 24);
+        // step_environment_effects (mdp.py:1691-1703): the countdowns; a finished one turns the pot ready — every lane
+        // stores, the others into their spare cell word.  begin_cooking (mdp.py:1515-1522) = load the countdown: tick 0
+        // now, cooked once by this step's env effects (Q4).
+        uint32_t rem_before[MAXP];
         bool ripe[MAXP];
 #pragma unroll
         for (int k = 0; k < MAXP; ++k) {
+            rem_before[k] = s.rem[k];
+            if (FAST_START) s.rem[k] = ((r0 | r1) & F4_START) ? cookv : s.rem[k];
             s.rem[k] -= 1u;
             ripe[k] = s.rem[k] == 0u;
+            if (MAXP <= 2 || (uint32_t)k < C.n_pots) lds_wr8(ripe[k] ? col + s.poff[k] + 1u : dummy, KB_POT + PC_READY);
         }
+        if (MODE == 1) {  // the next step's cells: everything this step writes to the grid has been issued
+            nc0 = lds_rd16(col + (m1 & 0xFFFFu));
+            nc1 = lds_rd16(col + (m1 >> 16));
+            rd_pots(npw);
+        }
+        // shaped reward of potting / soup pickup straight from the entries (class -> this lane's layout when the table is mixed)
+        auto shaped_of = [&](uint32_t w) __attribute__((always_inline)) {
+            return UNIFORM ? __uint_as_float(w) : (w == RW4_PLACE ? C.rew_place : w == RW4_PLATE ? C.rew_soup : 0.f);
+        };
+        const float sh0 = shaped_of(e0.w);
+        float sh1 = shaped_of(e1.w);
         const bool done = s.tleft == 0u;
         s.tleft -= 1u;
-        // (1) cooking starts (mdp.py:1515-1522): tick 0 now, cooked once by this step's env effects (Q4).  Old dynamics:
-        //     a pot that has just received its third item — or arrived full and idle — starts by itself in the env
-        //     effects, same arithmetic (Q11).
-        uint32_t smask = F4_START;
-        if (OLD) smask |= C.old_dyn ? (uint32_t)F4_PLACE : 0u;
-        bool starts = ((r0 | r1) & smask) != 0u;
-        if (OLD) starts |= s.pending != 0u;
-        if (__builtin_expect(starts, 0)) {
-#pragma unroll
-            for (int k = 0; k < MAXP; ++k) {
-                if (MAXP > 1 && (uint32_t)k >= C.n_pots) break;
-                const uint32_t pa = col + s.poff[k];
-                uint32_t soup = 0;
-                bool go = false;
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const uint32_t rr = p ? r1 : r0, fo = p ? fo1 : fo0;
-                    const bool begins = (rr & F4_START) != 0u;
-                    const bool fills = OLD && C.old_dyn && (rr & F4_PLACE) && (rr >> 24) == KB_POT + PC_IDLE3;
-                    if ((begins | fills) && (MAXP == 1 || fo == pa)) { go = true; soup = (rr >> 16) & 0xFFu; }
-                }
-                if (OLD && ((s.pending >> k) & 1u)) { go = true; soup = lds_rd16(pa) & 0xFFu; }
-                if (go) {
-                    const uint32_t cook = cook_time(soup);
-                    s.rem[k] = cook == 0u ? REM_IDLE : cook - 1u;
-                    s.tk[k] = TK_LIVE;
-                    s.exotic &= ~(1u << k);
-                    ripe[k] = false;
-                    lds_wr8(pa + 1u, cook <= 1u ? KB_POT + PC_READY : KB_POT + PC_COOKING);
-                }
-            }
-            if (OLD) s.pending = 0;
-        }
-        // (2) deliveries, possibly useful dish pick-ups, the horizon.  A dish taken from the dispenser can only be
-        //     "useful" when some pot is (pot_states before the interacts) and no dish lies on a counter — before, or
-        //     after player 0's own pick-up.
-        bool dish_ok = min(dc_before, dc_before + dd0) == 0u;
-        if (PKB) {
+        // ---- ONE branch for everything rare (~0.5 % of the lane-steps); it only corrects state afterwards -----------
+        //  * player 1 faces the cell player 0 has just changed: its interact is redone on the new cell (Q2 of SURVEY 8a)
+        //  * deliveries (recipe value), dish pick-ups that may be useful, the horizon; cooking starts where the straight
+        //    line does not do them
+        // A dish taken from the dispenser can only be "useful" when some pot is (pot_states before the interacts) and no
+        // dish lies on a counter — before, or after player 0's own pick-up.
+        const bool conflict = (fo0 == fo1) & ((r0 & F4_CHG) != 0u);
+        bool dish_ok = min(dc_before, dc_mid) == 0u;
+        if (PW) {
             bool any_useful = false;
 #pragma unroll
-            for (int k = 0; k < MAXP; ++k)  // (unused slots read cell 0, whose key byte is no pot class unless it is pot 0)
-                any_useful |= (pkb[k] - (KB_POT + PC_IDLE1) <= (uint32_t)(PC_READY - PC_IDLE1)) & (pkb[k] != KB_POT + PC_IDLE3);
+            for (int k = 0; k < MAXP; ++k) {  // (unused slots read cell 0, whose key byte is no pot class unless it is pot 0)
+                const uint32_t kb = pw[k] >> 8;
+                any_useful |= (kb - (KB_POT + PC_IDLE1) <= (uint32_t)(PC_READY - PC_IDLE1)) & (kb != KB_POT + PC_IDLE3);
+            }
             dish_ok &= any_useful;
         }
-        const uint32_t gate = dish_ok ? (uint32_t)(F4_SERVE | F4_TAKE_DISH) : (uint32_t)F4_SERVE;
-        bool slow = (((r0 | r1) & gate) != 0u) | done;
+        uint32_t gate = dish_ok ? (uint32_t)(F4_SERVE | F4_TAKE_DISH) : (uint32_t)F4_SERVE;
+        if (!FAST_START || zero_cook) gate |= F4_START;
+        if (OLD) gate |= C.old_dyn ? (uint32_t)F4_PLACE : 0u;  // old dynamics: the third item starts the pot (Q11)
+        bool rare = (((r0 | r1) & gate) != 0u) | done | conflict;
+        if (OLD) rare |= s.pending != 0u;
 #if defined(OC_EXPERIMENT) && (OC_EXPERIMENT == 2)
-        slow = done;
+        rare = done | conflict;
+#elif defined(OC_EXPERIMENT) && (OC_EXPERIMENT == 3)
+        rare = (((r0 | r1) & gate) != 0u) | done;
+#elif defined(OC_EXPERIMENT) && (OC_EXPERIMENT == 4)
+        rare = done;
 #endif
-        if (__builtin_expect(slow, 0)) {
-            const uint32_t hb0 = (h0_before >> 8) & 0xFFu, hb1 = (h1_before >> 8) & 0xFFu, hn0 = (r0 >> 8) & 0xFFu;
-            // pot_states before any interact (mdp.py:1439): ready / cooking / 1..2 idle items <=> class not in {empty, idle 3}
-            uint32_t useful_pots = 0;
-#pragma unroll
-            for (int k = 0; k < MAXP; ++k) {
-                if (MAXP > 1 && (uint32_t)k >= C.n_pots) break;
-                uint32_t kb;
-                if (PKB) {
-                    kb = pkb[k];
-                } else {  // the cells hold the classes after this step's interacts; a pot a player has just changed had
-                          // the class of that player's faced cell word before (player 0's first)
-                    const uint32_t pa = col + s.poff[k];
-                    kb = lds_rd16(pa) >> 8;
-                    kb = ((r1 & F4_POTBITS) && fo1 == pa) ? (c1 >> 8) : kb;
-                    kb = ((r0 & F4_POTBITS) && fo0 == pa) ? (c0 >> 8) : kb;
-                }
-                useful_pots += (kb != KB_POT + PC_EMPTY && kb != KB_POT + PC_IDLE3) ? 1u : 0u;
+        uint32_t nh0 = r0, nh1 = r1;  // the hands after the step
+        float add0 = sh0, add1 = sh1; // what the episode's shaped returns gain
+        float4 rw = make_float4(0.f, 0.f, sh0, sh1);  // this step's reward quad and flag byte: stored ONCE, after the branch
+        uint32_t fl = 0;                              // (a second store to the same address would wait for the first)
+        if (__builtin_expect(rare, 0)) {
+            bool grid_changed = false;  // something below wrote to the grid after the prefetch
+            if (conflict) {
+                e1 = lds_rd128(lut4_addr(off1, h1_before, cw0));
+                r1 = interact4(e1, h1_before, cw0);
+                nh1 = r1;
+                lds_wr16(fo1, r1 >> 16);
+                dcount = dc_mid + (uint32_t)((int32_t)e1.y >> 24);
+                sh1 = shaped_of(e1.w);
+                add1 = sh1;
+                grid_changed = true;
             }
-            // is_dish_pickup_useful (mdp.py:2180-2204): live hands / counters, stale pots
-            const bool du0 = two & (((hb1 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_before == 0u);
-            const bool du1 = two & (((hn0 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_before + dd0 == 0u);
-            float4 r;
-            r.z = (((r0 & F4_TAKE_DISH) != 0u) & du0) ? C.rew_dish : 0.f;
-            r.w = (((r1 & F4_TAKE_DISH) != 0u) & du1) ? C.rew_dish : 0.f;
-            r.x = (r0 & F4_SERVE) ? L.value(recipe_idx(hb0) & 15u) : 0.f;  // deliver_soup (mdp.py:1631-1642)
-            r.y = (r1 & F4_SERVE) ? L.value(recipe_idx(hb1) & 15u) : 0.f;
-            ep.x += r.x; ep.y += r.y; ep.z += r.z; ep.w += r.w;
-            r.z += sh0; r.w += sh1;
-            if (OUT || rew_k) rew_k[threadIdx.x] = r;
+            // cooking starts.  Old dynamics: a pot that has just received its third item — or arrived full and idle —
+            // starts by itself in the env effects, same arithmetic (Q11).
+            uint32_t smask = F4_START;
+            if (OLD) smask |= C.old_dyn ? (uint32_t)F4_PLACE : 0u;
+            bool starts = ((r0 | r1) & smask) != 0u;
+            if (OLD) starts |= s.pending != 0u;
+            if (starts || conflict) {
+#pragma unroll
+                for (int k = 0; k < MAXP; ++k) {
+                    if (MAXP > 1 && (uint32_t)k >= C.n_pots) break;
+                    const uint32_t pa = col + s.poff[k];
+                    uint32_t soup = 0;
+                    bool go = false;
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const uint32_t rr = p ? r1 : r0, fo = p ? fo1 : fo0;
+                        const bool begins = (rr & F4_START) != 0u;
+                        const bool fills = OLD && C.old_dyn && (rr & F4_PLACE) && (rr >> 24) == KB_POT + PC_IDLE3;
+                        if ((begins | fills) && (MAXP == 1 || fo == pa)) { go = true; soup = (rr >> 16) & 0xFFu; }
+                    }
+                    if (OLD && ((s.pending >> k) & 1u)) { go = true; soup = lds_rd16(pa) & 0xFFu; }
+                    // (the straight line may have loaded or not loaded the countdown from player 1's stale interact: redo)
+                    uint32_t cook = 0;
+                    if (go) cook = cook_time(soup);
+                    s.rem[k] = (go ? cook : rem_before[k]) - 1u;
+                    ripe[k] = s.rem[k] == 0u;
+                    if (go) {  // (cook == 0: ready at once, never ticks)
+                        s.exotic &= ~(1u << k);
+                        lds_wr8(pa + 1u, (cook == 0u || ripe[k]) ? KB_POT + PC_READY : KB_POT + PC_COOKING);
+                        grid_changed = true;
+                    } else if (ripe[k]) {
+                        lds_wr8(pa + 1u, KB_POT + PC_READY);
+                        grid_changed = true;
+                    }
+                }
+                if (OLD) s.pending = 0;
+            }
+            // deliveries and dish pick-ups
+            const uint32_t hb0 = (h0_before >> 8) & 0xFFu, hb1 = (h1_before >> 8) & 0xFFu, hn0 = (r0 >> 8) & 0xFFu;
+            if ((r0 | r1) & (F4_SERVE | F4_TAKE_DISH)) {
+                // pot_states before any interact (mdp.py:1439): ready / cooking / 1..2 idle items <=> class not in {empty, idle 3}
+                uint32_t useful_pots = 0;
+#pragma unroll
+                for (int k = 0; k < MAXP; ++k) {
+                    if (MAXP > 1 && (uint32_t)k >= C.n_pots) break;
+                    uint32_t kb;
+                    if (PW) {
+                        kb = pw[k] >> 8;
+                    } else {  // the cells hold the classes after this step's interacts; a pot a player has just changed
+                              // had the class of that player's faced cell word before (player 0's first)
+                        const uint32_t pa = col + s.poff[k];
+                        kb = lds_rd16(pa) >> 8;
+                        kb = ((r1 & F4_POTBITS) && fo1 == pa) ? ((conflict ? cw0 : c1) >> 8) : kb;
+                        kb = ((r0 & F4_POTBITS) && fo0 == pa) ? (c0 >> 8) : kb;
+                    }
+                    useful_pots += (kb != KB_POT + PC_EMPTY && kb != KB_POT + PC_IDLE3) ? 1u : 0u;
+                }
+                // is_dish_pickup_useful (mdp.py:2180-2204): live hands / counters, stale pots
+                const bool du0 = two & (((hb1 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_before == 0u);
+                const bool du1 = two & (((hn0 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_mid == 0u);
+                float4 r;
+                r.z = (((r0 & F4_TAKE_DISH) != 0u) & du0) ? C.rew_dish : 0.f;
+                r.w = (((r1 & F4_TAKE_DISH) != 0u) & du1) ? C.rew_dish : 0.f;
+                r.x = (r0 & F4_SERVE) ? L.value(recipe_idx(hb0) & 15u) : 0.f;  // deliver_soup (mdp.py:1631-1642)
+                r.y = (r1 & F4_SERVE) ? L.value(recipe_idx(hb1) & 15u) : 0.f;
+                ep.x += r.x; ep.y += r.y; ep.z += r.z; ep.w += r.w;
+                rw = make_float4(r.x, r.y, r.z + sh0, r.w + sh1);
+            } else {
+                rw.w = sh1;
+            }
             if (done) {  // OvercookedEnv.step bookkeeping at the horizon (env.py:266-267, 321-325)
-                uint32_t fl = OC_F_DONE;
+                fl = OC_F_DONE;
                 if (options & OC_OPT_AUTO_RESET) {
                     env_reset4<MAXP>(C, L, n_obj, horizon, s, col);
-#pragma unroll
-                    for (int k = 0; k < MAXP; ++k) ripe[k] = false;
-                    ep = zero4;
+                    nh0 = nh1 = 0;
+                    dcount = 0;
+                    ep = zero4;        // the episode ends with this step: its returns restart from zero,
+                    add0 = add1 = 0.f; // and this step's shaped rewards are not carried into the next one
                     fl |= OC_F_RESET;
+                    grid_changed = true;
                     if (MODE == 1) {  // redo the look-ahead from the start pose
                         m0 = joint_row();
                         m1 = lds_rd32(m0 + 72u);
@@ -546,12 +602,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                     s.tleft = 0u;
                     s.over += 1u;
                 }
-                if (OUT || flg_k) store_flag_byte(flg_k, lane, fl);
+            }
+            if (MODE == 1 && grid_changed) {  // read the next step's cells again
+                nc0 = lds_rd16(col + (m1 & 0xFFFFu));
+                nc1 = lds_rd16(col + (m1 >> 16));
+                rd_pots(npw);
             }
         }
-#pragma unroll
-        for (int k = 0; k < MAXP; ++k)  // a finished countdown turns the pot ready (the lanes concerned only)
-            if (ripe[k]) lds_wr8(col + s.poff[k] + 1u, KB_POT + PC_READY);
+#if !defined(OC_EXPERIMENT) || (OC_EXPERIMENT != 1)
+        if (OUT || rew_k) rew_k[threadIdx.x] = rw;
+        if (OUT || flg_k) store_flag_byte(flg_k, lane, fl);
+#endif
+        s.h0 = nh0;
+        s.h1 = nh1;
+        s.dcount = dcount;
+        ep.z += add0; ep.w += add1;
         if (OUT || rew_k) rew_k += n;
         if (OUT || flg_k) flg_k += n;
     };
@@ -573,17 +638,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         uint32_t ja2 = OC_JA_AT(t0, true) * 2u;
         uint32_t fa = lds_rd32(Jc + 72u), Jn = lds_rd16(Jc + ja2);
         uint32_t off0 = lds_rd16((uint32_t)M::ACT + ja2), off1 = lds_rd16((uint32_t)M::ACT + 80u + ja2);
+        uint32_t c0 = lds_rd16(col + (fa & 0xFFFFu)), c1 = lds_rd16(col + (fa >> 16));  // the faced cells of step k
+        uint32_t pw[MAXP];
+        rd_pots(pw);
         auto pstep = [&](uint32_t ja2n) __attribute__((always_inline)) {  // ja2n: 2 * joint action of the NEXT step
             const uint32_t fo0 = col + (fa & 0xFFFFu), fo1 = col + (fa >> 16);
-            const uint32_t c0 = lds_rd16(fo0), c1 = lds_rd16(fo1);
-            uint32_t pkb[MAXP];
-#pragma unroll
-            for (int k = 0; k < MAXP; ++k) pkb[k] = PKB ? (uint32_t)*(const OC_LDS uint8_t*)(uintptr_t)(col + s.poff[k] + 1u) : 0u;
             uint32_t fa_n = lds_rd32(Jn + 72u), Jnn = lds_rd16(Jn + ja2n);
             const uint32_t off0n = lds_rd16((uint32_t)M::ACT + ja2n), off1n = lds_rd16((uint32_t)M::ACT + 80u + ja2n);
-            uint32_t Jcn = Jn, unused = 0;
-            core(fo0, fo1, off0, off1, c0, c1, ja2n, pkb, Jcn, fa_n, Jnn, unused);
-            Jc = Jcn; Jn = Jnn; fa = fa_n; off0 = off0n; off1 = off1n;
+            uint32_t Jcn = Jn, unused = 0, nc0 = 0, nc1 = 0, npw[MAXP];
+            core(fo0, fo1, off0, off1, c0, c1, ja2n, pw, Jcn, fa_n, Jnn, unused, nc0, nc1, npw);
+            Jc = Jcn; Jn = Jnn; fa = fa_n; off0 = off0n; off1 = off1n; c0 = nc0; c1 = nc1;
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k) pw[k] = npw[k];
         };
         int k = 0;
         const int head_end = min(n_steps, (int)((8u - ((uint32_t)t0 & 7u)) & 7u));
@@ -616,9 +682,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             const uint32_t off1 = lut_var + ((two & (a1 == OC_A_INTERACT)) ? 0u : (uint32_t)(LUT4_KEYS * 16));
             const uint32_t c0 = lds_rd16(fo0), c1 = lds_rd16(fo1);
             const uint32_t cm0 = lds_rd16(col + m0 * (BLOCK * 2u)), cm1 = lds_rd16(col + m1 * (BLOCK * 2u));
-            uint32_t pkb[MAXP];
-#pragma unroll
-            for (int k = 0; k < MAXP; ++k) pkb[k] = PKB ? (uint32_t)*(const OC_LDS uint8_t*)(uintptr_t)(col + s.poff[k] + 1u) : 0u;
+            uint32_t pw[MAXP];
+            rd_pots(pw);
             // resolve_movement (mdp.py:1644-1727): decided on the pre-step terrain, applied after the interacts
             const bool mv0 = a0 < 4u, mv1 = two & (a1 < 4u);
             const uint32_t np0 = (mv0 & ((cm0 >> 8) < 30u)) ? m0 : s.pos0, np1 = (mv1 & ((cm1 >> 8) < 30u)) ? m1 : s.pos1;
@@ -626,7 +691,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             const uint32_t q0 = collide ? s.pos0 : np0, q1 = collide ? s.pos1 : np1;
             const uint32_t o0 = mv0 ? a0 : s.or0, o1 = mv1 ? a1 : s.or1;
             uint32_t p0 = q0, p1 = q1, d0 = o0, d1 = o1;
-            core(fo0, fo1, off0, off1, c0, c1, 0u, pkb, p0, p1, d0, d1);
+            uint32_t nc0 = 0, nc1 = 0, npw[MAXP];
+            core(fo0, fo1, off0, off1, c0, c1, 0u, pw, p0, p1, d0, d1, nc0, nc1, npw);
             s.pos0 = p0; s.pos1 = p1; s.or0 = d0; s.or1 = d1;
         };
         int k = 0;

@@ -14,8 +14,9 @@ env = VecOvercookedEnv(os.environ.get("LAYOUT", "cramped_room"), n, horizon=400,
 mode = os.environ.get("MODE", "")
 if mode:
     setattr(env, mode, True)
-rew = torch.zeros((100, n, 4), dtype=torch.float32, device=dev)
-fl = torch.zeros((100, n), dtype=torch.uint8, device=dev)
+T = int(os.environ.get("STEPS", "100"))
+rew = torch.zeros((T, n, 4), dtype=torch.float32, device=dev)
+fl = torch.zeros((T, n), dtype=torch.uint8, device=dev)
 for _ in range(12):
-    env.rollout_random(100, rew, fl)
+    env.rollout_random(T, rew, fl)
 torch.cuda.synchronize()
