@@ -105,6 +105,14 @@ class OvercookedEnv:
         for key, src in (("cumulative_sparse_rewards_by_agent", "sparse_reward_by_agent"),
                          ("cumulative_shaped_rewards_by_agent", "shaped_reward_by_agent")):
             self.game_stats[key] = self.game_stats[key] + np.asarray(infos[src])
+        mask = getattr(infos, "event_mask", None)
+        if mask is not None:  # the kernel's event bit mask: visit only what happened (bit 2 * event + agent)
+            while mask:
+                low = mask & -mask
+                k = low.bit_length() - 1
+                self.game_stats[EVENT_TYPES[k >> 1]][k & 1].append(t)
+                mask ^= low
+            return
         for name, flags in infos["event_infos"].items():
             for agent, happened in enumerate(flags):
                 if happened:

@@ -27,6 +27,9 @@ EVENT_TYPES = [  # mdp.py:1027-1058
 ]
 
 
+_ACTION_INDEX = {a: i for i, a in enumerate(Action.INDEX_TO_ACTION)}
+
+
 def events_from_mask(mask, num_players=2):
     """u64 event mask (bit 2*k + p) -> the reference's event_infos dict {event: [bool] * num_players}."""
     mask = int(mask)
@@ -35,6 +38,69 @@ def events_from_mask(mask, num_players=2):
 
 def default_device():
     return os.environ.get("OC_AMD_DEVICE", "cuda:0")
+
+
+class _Infos(dict):
+    """The infos dict of get_state_transition (same keys as the reference's) that also remembers the kernel's event bit
+    mask, so that OvercookedEnv._update_game_stats need not walk 25 x 2 flags."""
+    __slots__ = ("event_mask",)
+
+
+class _SingleEnvPort:
+    """One env stepped by the HIP kernel with no Python objects in between: the single-state calls of the drop-in API
+    (`get_state_transition`, hence `OvercookedEnv.step`) write the packed state and the joint action into ONE pinned host
+    buffer, launch `oc_step` on pointers INTO that buffer (pinned host memory is mapped into the GPU's address space, so
+    the kernel reads its inputs and writes next state, rewards, flags and the event mask over PCIe: no staging copies,
+    no device allocation) and wait on the stream once."""
+
+    def __init__(self, mdp):
+        import ctypes
+
+        import torch
+
+        from . import _lib
+        from .state import SingleStateCodec
+
+        self.env = mdp._env(1)  # owns the device copy of the layout table and the OcBatch
+        env = self.env
+        self.lib, self.bref = env.lib, env._bref
+        self.n_state = env.n_planes * 16
+        self.codec = SingleStateCodec(mdp.spec, env.n_planes)
+        off = lambda x: (x + 15) & ~15
+        self.o_in, self.o_act = 0, off(self.n_state)
+        self.o_out = self.o_act + 16
+        self.o_rew = self.o_out + off(self.n_state)
+        self.o_flag, self.o_ev = self.o_rew + 16, self.o_rew + 32
+        total = self.o_ev + 16
+        self.pinned = torch.zeros((total,), dtype=torch.uint8).pin_memory()
+        self.np = self.pinned.numpy()
+        self.mv = memoryview(self.np)
+        self.mv_in = self.mv[self.o_in:self.o_in + self.n_state]
+        self.mv_out = self.mv[self.o_out:self.o_out + self.n_state]
+        self.rew = self.np[self.o_rew:self.o_rew + 16].view(np.float32)
+        self.ev = self.np[self.o_ev:self.o_ev + 8].view(np.uint64)
+        base = self.pinned.data_ptr()
+        self.ptrs = tuple(ctypes.c_void_p(base + o) for o in (self.o_in, self.o_out, self.o_act, self.o_rew, self.o_flag, self.o_ev))
+        self.stream = torch.cuda.Stream(device=env.device)
+        self.stream_ptr = ctypes.c_void_p(self.stream.cuda_stream)
+        self.device = env.device
+        self.torch = torch
+        self.num_players = mdp.num_players
+
+    def transition(self, state, a0, a1):
+        """(next_state, rewards float32[4], event mask int) or None when the state needs the general path."""
+        if not self.codec.pack(state, self.mv_in):
+            return None
+        mv = self.mv
+        mv[self.o_act] = a0
+        mv[self.o_act + 1] = a1
+        p = self.ptrs
+        rc = self.lib.oc_step(self.bref, p[0], p[1], p[2], p[3], p[4], None, p[5], 65535, 0, self.stream_ptr)
+        if rc:
+            from . import _lib
+            _lib.check(rc, "oc_step")
+        self.stream.synchronize()
+        return self.codec.unpack(self.mv_out), self.rew, int(self.ev[0])
 
 
 class OvercookedGridworld:
@@ -74,6 +140,7 @@ class OvercookedGridworld:
         self.terrain_pos_dict = {c: spec.cells_of(c) for c in " XOTPDS"}
         self._device = device
         self._envs = {}
+        self._single = None
 
     # ---------------------------------------------------------------- construction (mdp.py:1150-1222)
     @staticmethod
@@ -232,8 +299,37 @@ class OvercookedGridworld:
                           "sparse_reward_by_agent": sp, "shaped_reward_by_agent": sh})
         return nxt, infos
 
+    def _port(self):
+        if self._single is None:
+            self._single = _SingleEnvPort(self)
+        return self._single
+
+    def _fast_transition(self, state, joint_action):
+        """One env through the pinned-buffer port; None -> the general batched path (which also raises the reference's
+        errors for illegal actions / invalid states)."""
+        if len(joint_action) != self.num_players:
+            return None
+        try:
+            a0 = _ACTION_INDEX[joint_action[0]]
+            a1 = _ACTION_INDEX[joint_action[1]] if self.num_players == 2 else 4
+        except (KeyError, TypeError):
+            return None
+        out = self._port().transition(state, a0, a1)
+        if out is None:
+            return None
+        nxt, rew, mask = out
+        n = self.num_players
+        infos = _Infos(event_infos=events_from_mask(mask, n),
+                       sparse_reward_by_agent=[_num(v) for v in rew[0:n]],
+                       shaped_reward_by_agent=[_num(v) for v in rew[2:2 + n]])
+        infos.event_mask = mask
+        return nxt, infos
+
     def get_state_transition(self, state, joint_action, display_phi=False, motion_planner=None):
         """(new_state, infos) exactly like mdp.py:1375-1430; the input state is not modified."""
+        fast = self._fast_transition(state, joint_action)
+        if fast is not None and not display_phi:
+            return fast
         nxt, infos = self.get_state_transitions([state], [joint_action])
         if display_phi:  # mdp.py:1421-1429; the motion planner's distances are built in (planner.py)
             phi = self.potential_functions([state, nxt[0]])

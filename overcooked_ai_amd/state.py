@@ -565,3 +565,136 @@ def canonical_state_dict(state):
         "all_orders": [tuple(sorted(o["ingredients"])) for o in d.get("all_orders", [])],
         "timestep": d.get("timestep", 0),
     }
+
+
+# ------------------------------------------------------------------------------------------------
+# one env, no dict round trip: the single-state calls of the drop-in API (OvercookedGridworld.get_state_transition,
+# OvercookedEnv.step) go through this codec; anything it does not recognise falls back to pack_states / unpack_states,
+# which validate like the reference's _check_valid_state and raise the matching errors
+# ------------------------------------------------------------------------------------------------
+class SingleStateCodec:
+    def __init__(self, spec, n_planes):
+        self.spec, self.n_planes = spec, n_planes
+        self.W, self.H = spec.width, spec.height
+        self.terrain = [c for row in spec.terrain_mtx for c in row]
+        self.pot_slot = {y * self.W + x: k for k, (x, y) in enumerate(spec.cells_of("P"))}
+        self.xy = [(c % self.W, c // self.W) for c in range(self.W * self.H)]
+        self.or_index = Direction.DIRECTION_TO_INDEX
+        self.or_of = Direction.INDEX_TO_DIRECTION
+        self.num_players = spec.num_players
+        all_orders = spec.start_all_orders or [{"ingredients": ["onion"] * a + ["tomato"] * b}
+                                               for n in (1, 2, 3) for a in range(n, -1, -1) for b in [n - a]]
+        self.bonus_orders = _norm_orders(spec.start_bonus_orders)
+        self.all_orders = _norm_orders(all_orders)
+        self._zeros = bytes(16 * n_planes)
+        self._soup = {}  # soup code -> (ingredient names, cook time)
+        for code in range(O_SOUP, O_SOUP + 32):
+            n = (code >> 3) & 3
+            ings = ["tomato" if (code >> i) & 1 else "onion" for i in range(n)]
+            self._soup[code] = (ings, _cook_time_of(spec, ings) if n else None)
+        self._soup_code = {tuple(v[0]): k for k, v in self._soup.items() if (k & 7) >> ((k >> 3) & 3) == 0}
+
+    # -- state -> bytes -----------------------------------------------------------------------
+    def _code(self, obj, in_pot):
+        """Object code, or None when the object is outside what the fast path handles."""
+        if type(obj) is ObjectState:
+            return _SIMPLE_CODE.get(obj.name)
+        if type(obj) is SoupState:
+            code = self._soup_code.get(tuple(obj._ingredients))
+            if code is None:
+                return None
+            if not in_pot and (not obj._ingredients or obj._cooking_tick != self._soup[code][1]
+                               or getattr(obj, "_finished", False)):
+                return None  # soups outside pots are fully cooked; get_soup(finished=True) resolves in the slow path
+            return code
+        return None
+
+    def pack(self, state, buf):
+        """Write `state` (an OvercookedState of this package) into the 16 * n_planes bytes of `buf`; False = use the
+        general path (unknown types, anything invalid: it raises the proper error)."""
+        if type(state) is not OvercookedState or len(state.players) != self.num_players:
+            return False
+        W, terrain = self.W, self.terrain
+        buf[:] = self._zeros  # buf: a writable memoryview / bytearray of exactly 16 * n_planes bytes
+        seen = []
+        for p, pl in enumerate(state.players):
+            x, y = pl.position
+            if not (0 <= x < W and 0 <= y < self.H):
+                return False
+            c = y * W + x
+            if terrain[c] != " " or c in seen:
+                return False
+            seen.append(c)
+            buf[3 * p] = c
+            buf[3 * p + 1] = self.or_index[pl.orientation]
+            held = pl.held_object
+            if held is not None:
+                code = self._code(held, False)
+                if code is None or held.position != (x, y):
+                    return False
+                buf[3 * p + 2] = code
+        if self.num_players == 1:
+            buf[3] = 0xFF
+        t = state.timestep
+        if not 0 <= t < 65536:
+            return False
+        buf[6], buf[7] = t & 0xFF, t >> 8
+        for (x, y), obj in state.objects.items():
+            if not (0 <= x < W and 0 <= y < self.H) or obj.position != (x, y):
+                return False
+            c = y * W + x
+            tc = terrain[c]
+            if tc == " " or c in seen:
+                return False
+            seen.append(c)
+            in_pot = tc == "P"
+            code = self._code(obj, in_pot)
+            if code is None:
+                return False
+            if in_pot:
+                if code < O_SOUP:
+                    return False
+                tick = obj._cooking_tick
+                ct = self._soup[code][1]
+                if tick >= 0 and (ct is None or tick > ct):
+                    return False
+                buf[8 + self.pot_slot[c]] = tick + 1
+            buf[16 + c] = code  # plane 1 + (c >> 4), byte c & 15 of a one-env array
+        return True
+
+    # -- bytes -> state -----------------------------------------------------------------------
+    def _obj(self, code, pos, tick=None):
+        if code < O_SOUP:
+            o = ObjectState.__new__(ObjectState)
+            o.name, o._position = _SIMPLE_NAME[code], pos
+            return o
+        ings, ct = self._soup[code]
+        if tick is None:
+            tick = ct  # soups outside pots are cooked
+        o = SoupState.__new__(SoupState)
+        o.name, o._position = "soup", pos
+        o._ingredients, o._cooking_tick, o._cook_time = list(ings), tick, (None if tick < 0 else ct)
+        return o
+
+    def unpack(self, buf):
+        xy = self.xy
+        players = []
+        for p in range(self.num_players):
+            pos = xy[buf[3 * p]]
+            code = buf[3 * p + 2]
+            pl = PlayerState.__new__(PlayerState)
+            pl.position, pl.orientation = pos, self.or_of[buf[3 * p + 1]]
+            pl.held_object = self._obj(code, pos) if code else None
+            players.append(pl)
+        objects = {}
+        cells = buf[16:16 + self.W * self.H]
+        if any(cells):
+            for c, code in enumerate(cells):
+                if code:
+                    tick = buf[8 + self.pot_slot[c]] - 1 if c in self.pot_slot else None
+                    objects[xy[c]] = self._obj(code, xy[c], tick)
+        st = OvercookedState.__new__(OvercookedState)
+        st.players, st.objects = tuple(players), objects
+        st._bonus_orders, st._all_orders = self.bonus_orders, self.all_orders
+        st.timestep = buf[6] | (buf[7] << 8)
+        return st

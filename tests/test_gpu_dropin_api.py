@@ -262,3 +262,25 @@ def test_vec_multi_agent_random_start_states():
         assert np.array_equal(env.venv.get_packed_state(), st), t
         assert np.array_equal(env.phi_cur.cpu().numpy(), O.potential(orc, st, pp)), t
         assert np.array_equal(ob.cpu().numpy().astype(np.int32), orc.encode_lossless(st, horizon=horizon)), t
+
+
+def test_infinite_order_bonus_delivery():
+    """tutorial_3 ships order_bonus = inf: delivering its bonus order pays an infinite sparse reward in the reference
+    (get_recipe_value, mdp.py:1595-1602) — the drop-in API must return inf, not crash on int(inf)."""
+    from overcooked_ai_amd import Action, Direction, OvercookedEnv, OvercookedGridworld
+    from overcooked_ai_amd.state import OvercookedState, PlayerState, SoupState
+
+    mdp = OvercookedGridworld.from_layout_name("tutorial_3")
+    ct = mdp.spec.recipe_time((1, 2))
+    soup = SoupState((5, 1), ["onion", "tomato", "tomato"], ct, ct)
+    state = OvercookedState([PlayerState((5, 3), Direction.NORTH), PlayerState((5, 1), Direction.EAST, soup)], {},
+                            bonus_orders=mdp.start_bonus_orders, all_orders=mdp.start_all_orders)
+    new_state, infos = mdp.get_state_transition(state, (Action.STAY, Action.INTERACT))
+    assert infos["sparse_reward_by_agent"] == [0, float("inf")] and not new_state.players[1].has_object()
+    # the same through the batched general path and through OvercookedEnv.step
+    _, infos_b = mdp.get_state_transitions([state], [(Action.STAY, Action.INTERACT)])
+    assert infos_b[0]["sparse_reward_by_agent"] == [0, float("inf")]
+    env = OvercookedEnv.from_mdp(mdp, horizon=10, info_level=0)
+    env.state = state
+    _, reward, _, info = env.step((Action.STAY, Action.INTERACT))
+    assert reward == float("inf") and info["sparse_r_by_agent"] == [0, float("inf")]
