@@ -159,6 +159,25 @@ typedef struct OcBatch {
  */
 int oc_batch_hints(const OcLayout* h_layouts, int n_layouts, OcBatch* batch);
 
+/*
+ * How a finished env is restarted by OC_OPT_AUTO_RESET (and by oc_multi_agent_step): NULL = the standard start state
+ * (get_standard_start_state, mdp.py:1297-1305); otherwise the start_state_fn of
+ * OvercookedGridworld.get_random_start_state_fn(random_start_pos, rnd_obj_prob_thresh) (mdp.py:1307-1369) as
+ * OvercookedEnv.reset uses it (env.py:288-319), drawn inside the step kernel with the stream documented at
+ * oc_reset_random for global env g = env_offset + e and
+ *      epoch of a restart at step k of the call = epoch + k      (k = 0 for single-step entry points),
+ * so a caller that passes epoch = 1 + (steps executed so far) never reuses the draws of its initial
+ * oc_reset_random(epoch 0).  Supported by the table-driven kernels (oc_step without d_events, oc_step_many,
+ * oc_rollout_random without OC_OPT_ROLLOUT_V3 / LANE_PAIR / PREDICATE_INTERACT, oc_multi_agent_step).
+ */
+typedef struct OcStartSpec {
+    uint64_t seed;
+    int64_t env_offset;          /* global index of local env 0 (oc_rollout_random: must equal its env_offset argument) */
+    uint32_t epoch;
+    int32_t random_start_pos;    /* 0 / 1 */
+    double rnd_obj_prob_thresh;  /* 0 .. 1 */
+} OcStartSpec;
+
 int oc_abi_version(void);
 size_t oc_layout_size(void); /* == sizeof(OcLayout) == 256 */
 const char* oc_last_error(void);
@@ -182,7 +201,7 @@ int oc_state_planes(int width, int height);
  */
 int oc_step(const OcBatch* batch, const void* d_state_in, void* d_state_out, const uint8_t* d_actions,
             float* d_rewards, uint8_t* d_flags, float* d_ep_returns, uint64_t* d_events, int horizon,
-            uint32_t options, void* stream);
+            uint32_t options, const OcStartSpec* start, void* stream);
 
 /*
  * oc_step_many — n_steps consecutive oc_step transitions (in place) in ONE launch: step k consumes
@@ -191,7 +210,7 @@ int oc_step(const OcBatch* batch, const void* d_state_in, void* d_state_out, con
  * AgentEvaluator._check_trajectories_dynamics, benchmarking.py:366).  Results are those of n_steps oc_step calls.
  */
 int oc_step_many(const OcBatch* batch, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
-                 float* d_ep_returns, int n_steps, int horizon, uint32_t options, void* stream);
+                 float* d_ep_returns, int n_steps, int horizon, uint32_t options, const OcStartSpec* start, void* stream);
 
 /*
  * oc_rollout_random — n_steps transitions per launch under the uniform random policy
@@ -208,7 +227,7 @@ int oc_step_many(const OcBatch* batch, void* d_state, const uint8_t* d_actions, 
  */
 int oc_rollout_random(const OcBatch* batch, void* d_state, float* d_rewards, uint8_t* d_flags,
                       float* d_ep_returns, int horizon, uint32_t options, uint64_t seed,
-                      int64_t env_offset, int64_t t0, int n_steps, void* stream);
+                      int64_t env_offset, int64_t t0, int n_steps, const OcStartSpec* start, void* stream);
 
 /*
  * oc_encode_lossless — the 26-layer observation of both players.
@@ -260,13 +279,14 @@ int oc_shape_rewards(const OcBatch* batch, const float* d_rewards, const uint8_t
  * oc_potential on s' (when d_phi_tables != NULL: use_phi) -> oc_shape_rewards -> copy of the episode returns ->
  * oc_reset of the finished envs (mask = d_done) -> oc_encode_lossless of the states the next step starts from
  * (when d_obs != NULL).  Arguments as in those entry points; d_done is required.  Two-player tables with at most two
- * pots run everything before the encoding as one kernel (k_train_step) with identical results.
+ * pots run everything before the encoding as one kernel (k_train_step) with identical results.  With `start`, finished
+ * envs restart from drawn start states and d_phi_cur receives the potential of those.
  */
 int oc_multi_agent_step(const OcBatch* batch, void* d_state, const uint8_t* d_actions, float* d_rewards,
                         uint8_t* d_flags, float* d_ep_returns, float* d_ep_returns_out, const uint8_t* d_plan_blob,
                         const uint32_t* d_plan_off, const uint8_t* d_phi_tables, double* d_phi_next,
                         double* d_phi_cur, const double* d_phi_start, double reward_shaping_factor, double* d_shaped,
-                        uint8_t* d_done, void* d_obs, int obs_dtype, int horizon, void* stream);
+                        uint8_t* d_done, void* d_obs, int obs_dtype, int horizon, const OcStartSpec* start, void* stream);
 
 /*
  * oc_reset_random — randomized start states drawn on the GPU.

@@ -164,6 +164,17 @@ def mdp_from_layout_dict(layout, **overrides):
     return m
 
 
+class OracleStartSpec(ctypes.Structure):
+    _fields_ = [("seed", ctypes.c_uint64), ("env_offset", ctypes.c_int64), ("epoch", ctypes.c_uint32),
+                ("random_start_pos", ctypes.c_int32), ("rnd_obj_prob_thresh", ctypes.c_double)]
+
+
+def start_spec(seed=0, env_offset=0, epoch=0, random_start_pos=False, rnd_obj_prob_thresh=0.0):
+    """start_state_fn of a batch for Oracle.step / rollout_random (restarts at the horizon draw from it)."""
+    return OracleStartSpec(int(seed), int(env_offset), int(epoch) & 0xFFFFFFFF, int(bool(random_start_pos)),
+                           float(rnd_obj_prob_thresh))
+
+
 class Oracle:
     """A table of oracle MDPs sharing one grid shape, operating on wire-format state arrays.
 
@@ -210,7 +221,7 @@ class Oracle:
         assert rc == 0
         return state
 
-    def step(self, state, actions, horizon=400, options=0, layout_id=None, ep_returns=None):
+    def step(self, state, actions, horizon=400, options=0, layout_id=None, ep_returns=None, start=None):
         """Returns (next_state, rewards[n,4] f32, flags[n] u8). `state` is not modified."""
         n = state.shape[1]
         assert state.shape == (self.n_planes, n, 16) and state.dtype == np.uint8
@@ -225,12 +236,12 @@ class Oracle:
                                _ptr(out, ctypes.c_uint8), _ptr(actions, ctypes.c_uint8), _ptr(rewards, ctypes.c_float),
                                _ptr(flags, ctypes.c_uint8), _ptr(ep_returns, ctypes.c_float),
                                _ptr(self.last_events, ctypes.c_uint64), ctypes.c_int64(n),
-                               int(horizon), ctypes.c_uint32(options))
+                               int(horizon), ctypes.c_uint32(options), ctypes.byref(start) if start is not None else None)
         assert rc == 0
         return out, rewards, flags
 
     def rollout_random(self, state, n_steps, horizon=400, options=0, seed=0, env_offset=0, t0=0, layout_id=None,
-                       ep_returns=None, want_outputs=True):
+                       ep_returns=None, want_outputs=True, start=None):
         """In-place n_steps random-policy steps. Returns (rewards[T,n,4], flags[T,n]) or (None, None)."""
         n = state.shape[1]
         lid = self._lid(layout_id, n)
@@ -240,7 +251,7 @@ class Oracle:
                                          _ptr(rewards, ctypes.c_float), _ptr(flags, ctypes.c_uint8),
                                          _ptr(ep_returns, ctypes.c_float), ctypes.c_int64(n), int(horizon),
                                          ctypes.c_uint32(options), ctypes.c_uint64(seed), ctypes.c_int64(env_offset),
-                                         ctypes.c_int64(t0), int(n_steps))
+                                         ctypes.c_int64(t0), int(n_steps), ctypes.byref(start) if start is not None else None)
         assert rc == 0
         return rewards, flags
 

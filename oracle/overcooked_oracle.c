@@ -539,8 +539,22 @@ static void pack_state(const OracleMdp* m, const State* s, uint8_t* planes, int6
 #define F_RESET 0x04
 #define OPT_AUTO_RESET 0x1u
 
+/* start_state_fn of a batch: NULL = get_standard_start_state, else get_random_start_state_fn(random_start_pos,
+ * rnd_obj_prob_thresh) (mdp.py:1307-1369) with the draws of oc_reset_random (include/oc_amd.h, OcStartSpec) */
+typedef struct OracleStartSpec {
+    uint64_t seed;
+    int64_t env_offset;
+    uint32_t epoch;
+    int32_t random_start_pos;
+    double rnd_obj_prob_thresh;
+} OracleStartSpec;
+
+static void random_start_state(const OracleMdp* m, State* s, uint64_t seed, uint64_t g, uint32_t epoch,
+                               int random_start_pos, uint64_t thresh);
+
 static void env_step_one(const OracleMdp* m, State* s, const int* ja, float* rew4, uint8_t* flag, float* ep4,
-                         int horizon, uint32_t options, uint64_t* events) {
+                         int horizon, uint32_t options, uint64_t* events, const OracleStartSpec* ss, uint64_t g,
+                         uint32_t epoch) {
     double sparse[2], shaped[2];
     uint8_t f = 0;
     uint64_t ev = 0;
@@ -562,8 +576,12 @@ static void env_step_one(const OracleMdp* m, State* s, const int* ja, float* rew
     }
     if (s->timestep >= horizon) { /* is_done, env.py:321-325 */
         f |= F_DONE;
-        if (options & OPT_AUTO_RESET) {
-            standard_start_state(m, s);
+        if (options & OPT_AUTO_RESET) { /* OvercookedEnv.reset, env.py:288-319: start_state_fn() or the standard state */
+            if (ss)
+                random_start_state(m, s, ss->seed, g, epoch, ss->random_start_pos,
+                                   (uint64_t)(ss->rnd_obj_prob_thresh * 4294967296.0));
+            else
+                standard_start_state(m, s);
             if (ep4) ep4[0] = ep4[1] = ep4[2] = ep4[3] = 0.f;
             f |= F_RESET;
         }
@@ -573,7 +591,7 @@ static void env_step_one(const OracleMdp* m, State* s, const int* ja, float* rew
 
 int oracle_step(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, const uint8_t* state_in,
                 uint8_t* state_out, const uint8_t* actions, float* rewards, uint8_t* flags, float* ep_returns,
-                uint64_t* events, int64_t n_envs, int horizon, uint32_t options) {
+                uint64_t* events, int64_t n_envs, int horizon, uint32_t options, const OracleStartSpec* ss) {
     (void)n_mdps;
     for (int64_t e = 0; e < n_envs; ++e) {
         const OracleMdp* m = &mdps[layout_id ? layout_id[e] : 0];
@@ -581,7 +599,8 @@ int oracle_step(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, co
         unpack_state(m, state_in, n_envs, e, &s);
         int ja[2] = {actions[2 * e], actions[2 * e + 1]};
         env_step_one(m, &s, ja, rewards ? rewards + 4 * e : 0, flags ? flags + e : 0, ep_returns ? ep_returns + 4 * e : 0,
-                     horizon, options, events ? events + e : 0);
+                     horizon, options, events ? events + e : 0, ss, ss ? (uint64_t)(ss->env_offset + e) : 0,
+                     ss ? ss->epoch : 0);
         pack_state(m, &s, state_out, n_envs, e);
     }
     return 0;
@@ -659,7 +678,7 @@ int oracle_set_threads(int n) { /* returns the number of threads that will be us
 
 int oracle_rollout_random(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, uint8_t* state, float* rewards,
                           uint8_t* flags, float* ep_returns, int64_t n_envs, int horizon, uint32_t options,
-                          uint64_t seed, int64_t env_offset, int64_t t0, int n_steps) {
+                          uint64_t seed, int64_t env_offset, int64_t t0, int n_steps, const OracleStartSpec* ss) {
     (void)n_mdps;
     /* envs are independent (no cross-env data flow in mdp.py): with OpenMP the env loop spreads over the host cores set
      * by oracle_set_threads (default 1) — used only by bench.py's cpu_baseline to report an all-cores figure */
@@ -676,7 +695,7 @@ int oracle_rollout_random(const OracleMdp* mdps, int n_mdps, const uint16_t* lay
             draw_actions(seed, g, (uint64_t)(t0 + k), &ja[0], &ja[1]);
             env_step_one(m, &s, ja, rewards ? rewards + 4 * ((int64_t)k * n_envs + e) : 0,
                          flags ? flags + ((int64_t)k * n_envs + e) : 0, ep_returns ? ep_returns + 4 * e : 0, horizon,
-                         options, 0);
+                         options, 0, ss, g, ss ? ss->epoch + (uint32_t)k : 0); /* restart at step k: epoch + k */
         }
         pack_state(m, &s, state, n_envs, e);
     }

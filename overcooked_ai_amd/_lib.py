@@ -36,6 +36,16 @@ class OcBatch(ctypes.Structure):
     ]
 
 
+class OcStartSpec(ctypes.Structure):
+    _fields_ = [
+        ("seed", ctypes.c_uint64),
+        ("env_offset", ctypes.c_int64),
+        ("epoch", ctypes.c_uint32),
+        ("random_start_pos", ctypes.c_int32),
+        ("rnd_obj_prob_thresh", ctypes.c_double),
+    ]
+
+
 class OcAmdError(RuntimeError):
     pass
 
@@ -69,11 +79,12 @@ def load():
     L.oc_batch_hints.restype = i32
     L.oc_batch_hints.argtypes = [vp, i32, bp]
     L.oc_step.restype = i32
-    L.oc_step.argtypes = [bp, vp, vp, vp, vp, vp, vp, vp, i32, u32, vp]
+    sp = ctypes.POINTER(OcStartSpec)
+    L.oc_step.argtypes = [bp, vp, vp, vp, vp, vp, vp, vp, i32, u32, sp, vp]
     L.oc_step_many.restype = i32
-    L.oc_step_many.argtypes = [bp, vp, vp, vp, vp, vp, i32, i32, u32, vp]
+    L.oc_step_many.argtypes = [bp, vp, vp, vp, vp, vp, i32, i32, u32, sp, vp]
     L.oc_rollout_random.restype = i32
-    L.oc_rollout_random.argtypes = [bp, vp, vp, vp, vp, i32, u32, u64, i64, i64, i32, vp]
+    L.oc_rollout_random.argtypes = [bp, vp, vp, vp, vp, i32, u32, u64, i64, i64, i32, sp, vp]
     L.oc_encode_lossless.restype = i32
     L.oc_encode_lossless.argtypes = [bp, vp, vp, i32, i32, vp]
     L.oc_featurize.restype = i32
@@ -82,7 +93,7 @@ def load():
     L.oc_potential.argtypes = [bp, vp, vp, vp, vp, vp, vp]
     L.oc_phi_table_size.restype = i32
     L.oc_multi_agent_step.restype = i32
-    L.oc_multi_agent_step.argtypes = [bp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_double, vp, vp, vp, i32, i32, vp]
+    L.oc_multi_agent_step.argtypes = [bp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_double, vp, vp, vp, i32, i32, sp, vp]
     L.oc_shape_rewards.restype = i32
     L.oc_shape_rewards.argtypes = [bp, vp, vp, vp, vp, vp, ctypes.c_double, vp, vp, vp]
     L.oc_reset_random.restype = i32

@@ -32,11 +32,11 @@
 namespace {
 
 #include "common.hpp"
+#include "reset.hpp"
 #include "step_predicate.hpp"
 #include "step_table.hpp"
 #include "step_lut4.hpp"
 #include "rollout_pair.hpp"
-#include "reset.hpp"
 #include "encode.hpp"
 #include "featurize.hpp"
 #include "potential.hpp"
@@ -97,6 +97,21 @@ inline int enc_lds_budget() {
     return v;
 }
 
+// OcStartSpec -> kernel argument; false when the spec is malformed
+bool start_args(const OcStartSpec* sp, StartArgs* sa) {
+    memset(sa, 0, sizeof(*sa));
+    if (!sp) return true;
+    if (!(sp->rnd_obj_prob_thresh >= 0.0 && sp->rnd_obj_prob_thresh <= 1.0)) return false;
+    sa->enabled = 1;
+    sa->seed_lo = (uint32_t)sp->seed;
+    sa->seed_hi = (uint32_t)(sp->seed >> 32);
+    sa->epoch = sp->epoch;
+    sa->env_offset = sp->env_offset;
+    sa->thresh = (uint64_t)(sp->rnd_obj_prob_thresh * 4294967296.0);  // floor(thresh * 2^32); 1.0 -> 2^32: always
+    sa->random_start_pos = sp->random_start_pos != 0;
+    return true;
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
 // SIMDs of the current device (4 per CU); cached per thread
@@ -131,7 +146,7 @@ inline int64_t simd_count() {
 template <bool EVENTS>
 void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_state_out, const uint8_t* d_actions,
                  float* d_rewards, uint8_t* d_flags, float* d_ep_returns, uint64_t* d_events, int horizon,
-                 uint32_t options, hipStream_t s, int n_steps = 1) {
+                 uint32_t options, hipStream_t s, const StartArgs& sa, int n_steps = 1) {
     const bool uniform = b->n_layouts == 1;
     const bool lds = b->n_layouts <= LDS_LAYOUT_MAX;
     const bool small = b->max_pots >= 1 && b->max_pots <= 2;
@@ -144,7 +159,7 @@ void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_st
         if (!want_lds(k_step3<U, MP, LL, ##__VA_ARGS__>, smem)) break;                                               \
         hipLaunchKernelGGL((k_step3<U, MP, LL, ##__VA_ARGS__>), grid, block, smem, s, b->d_layouts, b->n_layouts, b->d_layout_id,   \
                            (const uint4*)d_state_in, (uint4*)d_state_out, d_actions, (float4*)d_rewards, d_flags,    \
-                           (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options, n_steps);            \
+                           (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options, n_steps, sa);        \
     } while (0)
         if (uniform && fast && b->max_pots == 1) GO3(true, 1, true, true);
         else if (uniform && fast && small) GO3(true, 2, true, true);
@@ -199,9 +214,14 @@ int oc_batch_hints(const OcLayout* h_layouts, int n_layouts, OcBatch* batch) {
 }
 
 int oc_step(const OcBatch* b, const void* d_state_in, void* d_state_out, const uint8_t* d_actions, float* d_rewards,
-            uint8_t* d_flags, float* d_ep_returns, uint64_t* d_events, int horizon, uint32_t options, void* stream) {
+            uint8_t* d_flags, float* d_ep_returns, uint64_t* d_events, int horizon, uint32_t options,
+            const OcStartSpec* start, void* stream) {
     int n_obj = 0;
     if (int rc = check_batch(b, &n_obj)) return rc;
+    StartArgs sa;
+    if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_step: start.rnd_obj_prob_thresh must be in [0, 1]");
+    if (start && (d_events || (options & OC_OPT_PREDICATE_INTERACT)))
+        return fail(OC_EINVAL, "oc_step: drawn start states need the table-driven kernel (no d_events / PREDICATE_INTERACT)");
     if (!d_state_in || !d_state_out || !d_actions || !d_rewards || !d_flags)
         return fail(OC_EINVAL, "oc_step: NULL state/actions/rewards/flags pointer");
     if (horizon < 1 || horizon > 65535) return fail(OC_EINVAL, "oc_step: horizon must be in 1..65535");
@@ -209,16 +229,20 @@ int oc_step(const OcBatch* b, const void* d_state_in, void* d_state_out, const u
     hipStream_t s = (hipStream_t)stream;
     if (d_events)
         launch_step<true>(b, n_obj, d_state_in, d_state_out, d_actions, d_rewards, d_flags, d_ep_returns, d_events,
-                          horizon, options, s);
+                          horizon, options, s, sa);
     else
         launch_step<false>(b, n_obj, d_state_in, d_state_out, d_actions, d_rewards, d_flags, d_ep_returns, nullptr,
-                           horizon, options, s);
+                           horizon, options, s, sa);
     return check_launch("oc_step");
 }
 
 int oc_step_many(const OcBatch* b, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
-                 float* d_ep_returns, int n_steps, int horizon, uint32_t options, void* stream) {
+                 float* d_ep_returns, int n_steps, int horizon, uint32_t options, const OcStartSpec* start, void* stream) {
     if (n_steps < 0) return fail(OC_EINVAL, "oc_step_many: n_steps < 0");
+    StartArgs sa;
+    if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_step_many: start.rnd_obj_prob_thresh must be in [0, 1]");
+    if (start && (options & OC_OPT_PREDICATE_INTERACT))
+        return fail(OC_EINVAL, "oc_step_many: drawn start states need the table-driven kernel");
     int n_obj = 0;
     if (int rc = check_batch(b, &n_obj)) return rc;
     if (!d_state || !d_actions || !d_rewards || !d_flags)
@@ -227,13 +251,13 @@ int oc_step_many(const OcBatch* b, void* d_state, const uint8_t* d_actions, floa
     if (b->n_envs == 0 || n_steps == 0) return OC_OK;
     if (!(options & OC_OPT_PREDICATE_INTERACT)) {  // all K transitions in one launch, the envs stay on chip in between
         launch_step<false>(b, n_obj, d_state, d_state, d_actions, d_rewards, d_flags, d_ep_returns, nullptr, horizon,
-                           options, (hipStream_t)stream, n_steps);
+                           options, (hipStream_t)stream, sa, n_steps);
         return check_launch("oc_step_many");
     }
     for (int k = 0; k < n_steps; ++k) {
         const int64_t off = (int64_t)k * b->n_envs;
         if (int rc = oc_step(b, d_state, d_state, d_actions + 2 * off, d_rewards + 4 * off, d_flags + off, d_ep_returns,
-                             nullptr, horizon, options, stream))
+                             nullptr, horizon, options, nullptr, stream))
             return rc;
     }
     return OC_OK;
@@ -241,9 +265,14 @@ int oc_step_many(const OcBatch* b, void* d_state, const uint8_t* d_actions, floa
 
 int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t* d_flags, float* d_ep_returns,
                       int horizon, uint32_t options, uint64_t seed, int64_t env_offset, int64_t t0, int n_steps,
-                      void* stream) {
+                      const OcStartSpec* start, void* stream) {
     int n_obj = 0;
     if (int rc = check_batch(b, &n_obj)) return rc;
+    StartArgs sa;
+    if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_rollout_random: start.rnd_obj_prob_thresh must be in [0, 1]");
+    if (start && (options & (OC_OPT_ROLLOUT_V3 | OC_OPT_LANE_PAIR | OC_OPT_PREDICATE_INTERACT)))
+        return fail(OC_EINVAL, "oc_rollout_random: drawn start states need the default kernel (k_rollout4)");
+    if (start && start->env_offset != env_offset) return fail(OC_EINVAL, "oc_rollout_random: start.env_offset differs from env_offset");
     if (!d_state) return fail(OC_EINVAL, "oc_rollout_random: NULL state pointer");
     if (horizon < 1 || horizon > 65535) return fail(OC_EINVAL, "oc_rollout_random: horizon must be in 1..65535");
     if (n_steps < 0 || n_steps > (1 << 30)) return fail(OC_EINVAL, "oc_rollout_random: n_steps must be in 0..2^30");
@@ -294,7 +323,7 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         hipLaunchKernelGGL((k_rollout4<U, MP, LL, MODE, OUT, OLD, ##__VA_ARGS__>), grid4, block4, smem4, s, b->d_layouts, \
                            b->n_layouts, b->d_layout_id, (uint4*)d_state, (float4*)d_rewards, d_flags,              \
                            (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options, (uint32_t)seed,     \
-                           (uint32_t)(seed >> 32), env_offset, t0, n_steps);                                        \
+                           (uint32_t)(seed >> 32), env_offset, t0, n_steps, sa);                                    \
     } while (0)
         if (joint && b->max_pots == 1 && out && !old && b->max_free_cells <= 6) GO4(true, 1, true, 1, true, false, 6);
         else if (joint && b->max_pots == 1) GO4(true, 1, true, 1, false, true, JOINT_MAX_FLOOR);
@@ -426,8 +455,10 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
                         float* d_ep_returns, float* d_ep_returns_out, const uint8_t* d_plan_blob,
                         const uint32_t* d_plan_off, const uint8_t* d_phi_tables, double* d_phi_next, double* d_phi_cur,
                         const double* d_phi_start, double reward_shaping_factor, double* d_shaped, uint8_t* d_done,
-                        void* d_obs, int obs_dtype, int horizon, void* stream) {
+                        void* d_obs, int obs_dtype, int horizon, const OcStartSpec* start, void* stream) {
     if (!d_done) return fail(OC_EINVAL, "oc_multi_agent_step: d_done is required (it is the reset mask)");
+    StartArgs sa;
+    if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_multi_agent_step: start.rnd_obj_prob_thresh must be in [0, 1]");
     {
         int n_obj = 0;
         if (int rc = check_batch(b, &n_obj)) return rc;
@@ -451,7 +482,7 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
                            b->n_layouts, b->d_layout_id, (uint4*)d_state, d_actions, (float4*)d_rewards, d_flags,     \
                            (float4*)d_ep_returns, (float4*)d_ep_returns_out, d_plan_blob, d_plan_off, d_phi_tables,   \
                            d_phi_next, d_phi_cur, d_phi_start, reward_shaping_factor, d_shaped, d_done, b->n_envs,    \
-                           b->width, b->height, n_obj, horizon);                                                      \
+                           b->width, b->height, n_obj, horizon, sa);                                                  \
     } while (0)
                 if (uniform && fast && b->max_pots == 1) GOT(true, 1, true, true);
                 else if (uniform && fast) GOT(true, 2, true, true);
@@ -465,7 +496,7 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
             return OC_OK;
         }
     }
-    if (int rc = oc_step(b, d_state, d_state, d_actions, d_rewards, d_flags, d_ep_returns, nullptr, horizon, 0u, stream)) return rc;
+    if (int rc = oc_step(b, d_state, d_state, d_actions, d_rewards, d_flags, d_ep_returns, nullptr, horizon, 0u, nullptr, stream)) return rc;
     if (d_phi_tables) {
         if (int rc = oc_potential(b, d_plan_blob, d_plan_off, d_phi_tables, d_state, d_phi_next, stream)) return rc;
     }
@@ -477,7 +508,16 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
                            (hipStream_t)stream) != hipSuccess)
             return fail(OC_ELAUNCH, "oc_multi_agent_step: copy of the episode returns failed");
     }
-    if (int rc = oc_reset(b, d_state, d_done, d_ep_returns, stream)) return rc;
+    if (start) {  // finished envs restart from drawn states; d_phi_cur = the potential of what every env starts the next step from
+        if (int rc = oc_reset_random(b, d_state, d_done, d_ep_returns, start->seed, start->env_offset, start->epoch,
+                                     start->random_start_pos, start->rnd_obj_prob_thresh, stream))
+            return rc;
+        if (d_phi_tables) {
+            if (int rc = oc_potential(b, d_plan_blob, d_plan_off, d_phi_tables, d_state, d_phi_cur, stream)) return rc;
+        }
+    } else {
+        if (int rc = oc_reset(b, d_state, d_done, d_ep_returns, stream)) return rc;
+    }
     if (d_obs) return oc_encode_lossless(b, d_state, d_obs, obs_dtype, horizon, stream);
     return OC_OK;
 }

@@ -38,23 +38,30 @@ __global__ __launch_bounds__(BLOCK) void k_reset(const OcLayout* __restrict__ g_
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t RESET_KEY_TWEAK = 0x52535421u;  // "RST!"
 
-__global__ __launch_bounds__(BLOCK) void k_reset_random(const OcLayout* __restrict__ g_layouts,
-                                                        const uint16_t* __restrict__ layout_id, uint4* st,
-                                                        const uint8_t* __restrict__ mask,
-                                                        float4* __restrict__ ep_returns, int64_t n, int n_obj,
-                                                        uint32_t seed_lo, uint32_t seed_hi, int64_t env_offset,
-                                                        uint32_t epoch, int random_start_pos, uint64_t thresh) {
-    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= n) return;
-    if (mask && !mask[e]) return;
-    const uint32_t lid = layout_id ? layout_id[e] : 0u;
-    const Lay L{reinterpret_cast<const uint8_t*>(g_layouts) + (size_t)lid * 256u};
-    const uint64_t g = (uint64_t)(env_offset + e);
+// What a randomized start consists of; players face NORTH, nothing lies on the counters, timestep 0.
+struct StartDraw {
+    uint32_t pos0, pos1;          // cells (pos1 = 0xFF on one-player layouts)
+    uint32_t held[2];             // object codes
+    uint32_t ticks[2];            // header bytes 8..15: cooking_tick + 1 per pot slot
+    uint8_t pot_obj[OC_MAX_POTS]; // soup code per pot slot (0 = empty)
+};
+
+// Launch-time description of the start_state_fn (include/oc_amd.h, OcStartSpec), by value in kernel arguments.
+struct StartArgs {
+    uint32_t enabled, seed_lo, seed_hi, epoch;
+    int64_t env_offset;
+    uint64_t thresh;  // floor(rnd_obj_prob_thresh * 2^32)
+    int32_t random_start_pos;
+};
+
+__device__ __forceinline__ StartDraw draw_start(const Lay L, uint64_t g, uint32_t epoch, uint32_t seed_lo, uint32_t seed_hi,
+                                                int random_start_pos, uint64_t thresh) {
+    StartDraw d;
     const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
     const uint32_t k1 = seed_hi ^ RESET_KEY_TWEAK;
     const uint32_t cells = L.u8(L_NCELLS), np = L.n_players();
     uint32_t r[4];
-    uint32_t pos0 = L.u8(L_START_POS), pos1 = L.u8(L_START_POS + 1);
+    d.pos0 = L.u8(L_START_POS); d.pos1 = L.u8(L_START_POS + 1);
     if (random_start_pos) {
         uint32_t n_floor = 0;
         for (uint32_t c = 0; c < cells; ++c) n_floor += (L.terrain(c) & 7u) == OC_T_FLOOR ? 1u : 0u;
@@ -71,16 +78,15 @@ __global__ __launch_bounds__(BLOCK) void k_reset_random(const OcLayout* __restri
         uint32_t seen = 0;
         for (uint32_t c = 0; c < cells; ++c) {
             if ((L.terrain(c) & 7u) != OC_T_FLOOR) continue;
-            if (seen == a) pos0 = c;
-            if (seen == b) pos1 = c;
+            if (seen == a) d.pos0 = c;
+            if (seen == b) d.pos1 = c;
             ++seen;
         }
     }
-    uint32_t held[2] = {0u, 0u};
-    uint32_t ticks[2] = {0u, 0u};  // header bytes 8..15
-    uint8_t pot_obj[OC_MAX_POTS];
+    d.held[0] = d.held[1] = 0u;
+    d.ticks[0] = d.ticks[1] = 0u;
     const uint32_t n_pots = L.n_pots();
-    for (uint32_t k = 0; k < (uint32_t)OC_MAX_POTS; ++k) pot_obj[k] = 0;
+    for (uint32_t k = 0; k < (uint32_t)OC_MAX_POTS; ++k) d.pot_obj[k] = 0;
     auto soup_code = [](uint32_t n_on, uint32_t n_to) {  // onions first, then tomatoes (SoupState.get_soup, mdp.py:664-693)
         return OC_O_SOUP | ((n_on + n_to) << 3) | (((1u << n_to) - 1u) << n_on);
     };
@@ -89,25 +95,41 @@ __global__ __launch_bounds__(BLOCK) void k_reset_random(const OcLayout* __restri
             philox4x32_10(epoch, g_lo, g_hi, 1u + i, seed_lo, k1, r);
             if ((uint64_t)r[0] < thresh) {
                 const uint32_t n_on = 1u + __umulhi(r[2], 3u), n_to = __umulhi(r[3], 4u - n_on);
-                held[i] = r[1] < 858993459u ? (uint32_t)OC_O_DISH : r[1] < 3435973836u ? (uint32_t)OC_O_ONION : soup_code(n_on, n_to);
+                d.held[i] = r[1] < 858993459u ? (uint32_t)OC_O_DISH : r[1] < 3435973836u ? (uint32_t)OC_O_ONION : soup_code(n_on, n_to);
             }
         }
         for (uint32_t k = 0; k < n_pots; ++k) {
             philox4x32_10(epoch, g_lo, g_hi, 3u + k, seed_lo, k1, r);
             if ((uint64_t)r[0] < thresh) {
                 const uint32_t n_on = 1u + __umulhi(r[1], 3u), n_to = __umulhi(r[2], 4u - n_on);
-                pot_obj[k] = (uint8_t)soup_code(n_on, n_to);
-                if ((uint64_t)r[3] < thresh) ticks[k >> 2] |= 1u << (8u * (k & 3u));  // cooking_tick 0 -> stored 1
+                d.pot_obj[k] = (uint8_t)soup_code(n_on, n_to);
+                if ((uint64_t)r[3] < thresh) d.ticks[k >> 2] |= 1u << (8u * (k & 3u));  // cooking_tick 0 -> stored 1
             }
         }
     }
-    if (np < 2u) pos1 = 0xFFu;
-    st[e] = make_uint4(pos0 | (held[0] << 16) | (pos1 << 24), np == 2u ? (held[1] << 8) : 0u, ticks[0], ticks[1]);
+    if (np < 2u) d.pos1 = 0xFFu;
+    return d;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_reset_random(const OcLayout* __restrict__ g_layouts,
+                                                        const uint16_t* __restrict__ layout_id, uint4* st,
+                                                        const uint8_t* __restrict__ mask,
+                                                        float4* __restrict__ ep_returns, int64_t n, int n_obj,
+                                                        uint32_t seed_lo, uint32_t seed_hi, int64_t env_offset,
+                                                        uint32_t epoch, int random_start_pos, uint64_t thresh) {
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= n) return;
+    if (mask && !mask[e]) return;
+    const uint32_t lid = layout_id ? layout_id[e] : 0u;
+    const Lay L{reinterpret_cast<const uint8_t*>(g_layouts) + (size_t)lid * 256u};
+    const StartDraw d = draw_start(L, (uint64_t)(env_offset + e), epoch, seed_lo, seed_hi, random_start_pos, thresh);
+    const uint32_t np = L.n_players(), n_pots = L.n_pots();
+    st[e] = make_uint4(d.pos0 | (d.held[0] << 16) | (d.pos1 << 24), np == 2u ? (d.held[1] << 8) : 0u, d.ticks[0], d.ticks[1]);
     for (int p = 0; p < n_obj; ++p) {
         uint32_t w[4] = {0u, 0u, 0u, 0u};
         for (uint32_t k = 0; k < n_pots; ++k) {
             const uint32_t c = L.pot_cell((int)k);
-            if ((int)(c >> 4) == p) w[(c >> 2) & 3u] |= (uint32_t)pot_obj[k] << (8u * (c & 3u));
+            if ((int)(c >> 4) == p) w[(c >> 2) & 3u] |= (uint32_t)d.pot_obj[k] << (8u * (c & 3u));
         }
         st[(int64_t)(1 + p) * n + e] = make_uint4(w[0], w[1], w[2], w[3]);
     }

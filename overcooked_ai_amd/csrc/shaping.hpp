@@ -50,7 +50,7 @@ __global__ __launch_bounds__(BLOCK) void k_train_step(const OcLayout* __restrict
                                                       const uint8_t* __restrict__ phi_tables, double* __restrict__ phi_next,
                                                       double* __restrict__ phi_cur, const double* __restrict__ phi_start,
                                                       double factor, double* __restrict__ shaped, uint8_t* __restrict__ done,
-                                                      int64_t n, int W, int H, int n_obj, int horizon) {
+                                                      int64_t n, int W, int H, int n_obj, int horizon, StartArgs sa) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) uint16_t s_cells3[];  // [n_obj * 16][BLOCK]
     __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];  // one 256-byte record when the batch has one layout
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(BLOCK) void k_train_step(const OcLayout* __restrict
     } else {
         env_step3<MAXP, FAST ? 2 : 0>(C, L, lut, cells, s, delta4, a0, a1, r,
                                       FAST ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull);
-        fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, 0u, r, ep);
+        fl = finish_step3<MAXP>(C, L, n_obj, cells, s, horizon, 0u, r, ep, sa, 0, 0);
     }
     const bool is_done = (fl & OC_F_DONE) != 0u;
     const double sparse = (double)r.x + (double)r.y;
@@ -94,8 +94,19 @@ __global__ __launch_bounds__(BLOCK) void k_train_step(const OcLayout* __restrict
     reinterpret_cast<double2*>(shaped)[e] = make_double2(sparse + factor * d0, sparse + factor * d1);
     done[e] = is_done ? 1 : 0;
     if (ep_out) ep_out[e] = ep;
-    if (is_done) {
-        env_reset3<MAXP>(L, n_obj, s, cells);
+    if (is_done) {  // the next episode: the standard start state, or one drawn from the batch's start_state_fn
+        if (sa.enabled) {
+            env_reset3_draw<MAXP>(C, L, n_obj, s, cells, draw_start(L, (uint64_t)(sa.env_offset + e), sa.epoch, sa.seed_lo,
+                                                                    sa.seed_hi, sa.random_start_pos, sa.thresh));
+            if (phi_tables) {  // phi(s) of the next step is the potential of THAT state
+                const Phi T{phi_tables + (size_t)lid * PHI_BYTES};
+                phi_cur[e] = potential2_core(L, T, plan_blob + plan_off[lid], (uint32_t)(W * H), 2u, s.pos0, s.or0, s.held0,
+                                             s.pos1, s.or1, s.held1, s.ps[0], MAXP > 1 ? s.ps[MAXP - 1] : 0u, s.tk[0],
+                                             MAXP > 1 ? s.tk[MAXP - 1] : 0u);
+            }
+        } else {
+            env_reset3<MAXP>(L, n_obj, s, cells);
+        }
         ep = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     store_env3<MAXP>(C, L, st, n, e, n_obj, s, cells);

@@ -330,6 +330,25 @@ __device__ __forceinline__ void store_flag_byte(uint8_t* row, uint32_t lane_off,
     asm volatile("global_store_byte %0, %1, %2" : : "v"(lane_off), "v"(v), "s"(row) : "memory");
 }
 
+// a randomized start (get_random_start_state_fn, mdp.py:1307-1369) drawn by draw_start, in Env4 / key-byte form
+template <int MAXP>
+__device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int n_obj, int horizon, Env4<MAXP>& s, uint32_t col,
+                                                const StartDraw& d) {
+    env_reset4<MAXP>(C, L, n_obj, horizon, s, col);
+    s.pos0 = d.pos0; s.pos1 = d.pos1;
+    s.h0 = d.held[0] << 8; s.h1 = d.held[1] << 8;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        if ((uint32_t)k < C.n_pots) {
+            const uint32_t o = d.pot_obj[k], tkb = (d.ticks[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            const uint32_t pc = pot_class(C, o, tkb);
+            s.tk[k] = tkb;
+            s.rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) : REM_IDLE;
+            lds_wr16(col + s.poff[k], o | ((KB_POT + pc) << 8));
+        }
+    }
+}
+
 // MODE 0: arithmetic movement, any table; MODE 1: JOINT move table (one two-player layout with <= NF free cells)
 // OLD: some layout of the table may use old dynamics (auto-start of full pots in the env effects)
 template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR>
@@ -338,7 +357,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                                                     float4* __restrict__ rewards, uint8_t* __restrict__ flags,
                                                     float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,
                                                     int horizon, uint32_t options, uint32_t seed_lo, uint32_t seed_hi,
-                                                    int64_t env_offset, int64_t t0, int n_steps) {
+                                                    int64_t env_offset, int64_t t0, int n_steps, StartArgs sa) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn4[];
     using M = Lds4<UNIFORM, LAY_LDS, MODE, NF>;
     if ((uint32_t)(uintptr_t)(OC_LDS uint8_t*)s_dyn4 != 0u) __builtin_trap();  // folds away: the region starts at address 0
@@ -393,7 +412,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
     uint8_t* flg_k = flags ? flags + (int64_t)blockIdx.x * BLOCK + wave_base : nullptr;
     const uint32_t lane = threadIdx.x & 63u;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const uint32_t zero = 0;
+    uint32_t step_k = 0;  // index of the step within this launch (wave-uniform): the epoch offset of a restart
 
     // ---- resolve_interacts + env effects + bookkeeping for one step.  fo*: LDS addresses of the faced cells, off*: LUT
     //      address of (this lane's table, does the player interact), c*: the faced cell words (already read).
@@ -584,8 +603,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             if (done) {  // OvercookedEnv.step bookkeeping at the horizon (env.py:266-267, 321-325)
                 fl = OC_F_DONE;
                 if (options & OC_OPT_AUTO_RESET) {
-                    env_reset4<MAXP>(C, L, n_obj, horizon, s, col);
-                    nh0 = nh1 = 0;
+                    if (sa.enabled) {  // the batch's start_state_fn: drawn from (seed, global env, epoch of this step)
+                        env_reset4_draw<MAXP>(C, L, n_obj, horizon, s, col,
+                                              draw_start(L, g, sa.epoch + step_k, sa.seed_lo, sa.seed_hi, sa.random_start_pos, sa.thresh));
+                        nh0 = s.h0; nh1 = s.h1;
+                    } else {
+                        env_reset4<MAXP>(C, L, n_obj, horizon, s, col);
+                        nh0 = nh1 = 0;
+                    }
                     dcount = 0;
                     ep = zero4;        // the episode ends with this step: its returns restart from zero,
                     add0 = add1 = 0.f; // and this step's shaped rewards are not carried into the next one
@@ -619,6 +644,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         ep.z += add0; ep.w += add1;
         if (OUT || rew_k) rew_k += n;
         if (OUT || flg_k) flg_k += n;
+        step_k += 1u;
     };
 
     Phx4 w = {0, 0, 0, 0};  // the Philox block of the step being looked at

@@ -362,15 +362,38 @@ __device__ __forceinline__ void env_reset3(const Lay L, int n_obj, Env3<MAXP>& s
     for (int c = 0; c < n_obj * 16; ++c) reinterpret_cast<uint8_t*>(cells + c * BLOCK)[0] = 0;  // clear objects, keep terrain
 }
 
+// a randomized start (get_random_start_state_fn, mdp.py:1307-1369) drawn by draw_start, in Env3 form
 template <int MAXP>
-__device__ __forceinline__ uint32_t finish_step3(const Lay L, int n_obj, uint16_t* cells, Env3<MAXP>& s, int horizon,
-                                                 uint32_t options, const float4& r, float4& ep) {
+__device__ __forceinline__ void env_reset3_draw(const LayC& C, const Lay L, int n_obj, Env3<MAXP>& s, uint16_t* cells,
+                                                const StartDraw& d) {
+    env_reset3<MAXP>(L, n_obj, s, cells);
+    s.pos0 = d.pos0; s.pos1 = d.pos1;
+    s.held0 = d.held[0]; s.held1 = d.held[1];
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        if ((uint32_t)k < C.n_pots) {
+            s.ps[k] = d.pot_obj[k];
+            s.tk[k] = (d.ticks[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            s.pc[k] = pot_class(C, s.ps[k], s.tk[k]);
+        }
+    }
+}
+
+// sa / g / epoch: the start_state_fn of the batch (disabled: the standard start state), this env's global index and the
+// epoch of a restart at this step
+template <int MAXP>
+__device__ __forceinline__ uint32_t finish_step3(const LayC& C, const Lay L, int n_obj, uint16_t* cells, Env3<MAXP>& s,
+                                                 int horizon, uint32_t options, const float4& r, float4& ep,
+                                                 const StartArgs& sa, uint64_t g, uint32_t epoch) {
     ep.x += r.x; ep.y += r.y; ep.z += r.z; ep.w += r.w;
     uint32_t fl = 0;
     if (__builtin_expect((int)s.t >= horizon, 0)) {  // once per episode: keep the restart out of the straight-line path
         fl |= OC_F_DONE;
         if (options & OC_OPT_AUTO_RESET) {
-            env_reset3<MAXP>(L, n_obj, s, cells);
+            if (sa.enabled)
+                env_reset3_draw<MAXP>(C, L, n_obj, s, cells, draw_start(L, g, epoch, sa.seed_lo, sa.seed_hi, sa.random_start_pos, sa.thresh));
+            else
+                env_reset3<MAXP>(L, n_obj, s, cells);
             ep = make_float4(0.f, 0.f, 0.f, 0.f);
             fl |= OC_F_RESET;
         }
@@ -425,6 +448,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
     float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     const uint64_t g = (uint64_t)(env_offset + e);
     const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
+    const StartArgs no_sa = {0, 0, 0, 0, 0, 0, 0};  // (restarts from drawn start states: k_rollout4)
     uint32_t rnd[4] = {0, 0, 0, 0};
     // outputs of step k live at [k][e]: a wave-uniform base per step (SALU) + this lane's 32-bit offset
     float4* const rew_blk = rewards ? rewards + (int64_t)blockIdx.x * BLOCK : nullptr;
@@ -450,7 +474,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
         x *= 6u;                                                                                         \
         float4 r;                                                                                        \
         env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask, s_move);               \
-        const uint32_t fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);             \
+        const uint32_t fl = finish_step3<MAXP>(C, L, n_obj, cells, s, horizon, options, r, ep, no_sa, 0, 0);\
         if (OUT || rew_k) { rew_k[threadIdx.x] = r; rew_k += n; }                                        \
         if (OUT || flg_k) { flg_k[threadIdx.x] = (uint8_t)fl; flg_k += n; }                              \
     }
@@ -467,7 +491,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
                 draw_actions(rnd, s8, a0, a1);
                 float4 r;
                 env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask, s_move);
-                const uint32_t fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);
+                const uint32_t fl = finish_step3<MAXP>(C, L, n_obj, cells, s, horizon, options, r, ep, no_sa, 0, 0);
                 if (OUT || rew_k) { rew_k[threadIdx.x] = r; rew_k += n; }
                 if (OUT || flg_k) { flg_k[threadIdx.x] = (uint8_t)fl; flg_k += n; }
             }
@@ -493,7 +517,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
             draw_actions(rnd, s8, a0, a1);
             float4 r;
             env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask, s_move);
-            const uint32_t fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);
+            const uint32_t fl = finish_step3<MAXP>(C, L, n_obj, cells, s, horizon, options, r, ep, no_sa, 0, 0);
             if (rew_blk) (rew_blk + (int64_t)k * n)[threadIdx.x] = r;
             if (flg_blk) (flg_blk + (int64_t)k * n)[threadIdx.x] = (uint8_t)fl;
         }
@@ -511,7 +535,7 @@ __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_
                                                  uint4* st_out, const uint8_t* __restrict__ actions,
                                                  float4* __restrict__ rewards, uint8_t* __restrict__ flags,
                                                  float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,
-                                                 int horizon, uint32_t options, int n_steps) {
+                                                 int horizon, uint32_t options, int n_steps, StartArgs sa) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_cells3[];  // [n_obj * 16][BLOCK]
     __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];  // one 256-byte record when the batch has one layout
     __shared__ uint2 s_lut[2 * LUT_ENTRIES];
@@ -526,6 +550,7 @@ __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_
     const uint32_t delta4 = make_delta4(W);
     Env3<MAXP> s;
     load_env3<MAXP>(C, L, st_in, n, e, n_obj, s, cells);
+    const uint64_t g = (uint64_t)(sa.env_offset + e);
     const uint64_t floor_mask = FAST ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull;
     float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     // n_steps transitions with the caller's actions [n_steps][n][2] (oc_step: one; oc_step_many: K in one launch, the
@@ -544,7 +569,7 @@ __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_
             fl = OC_F_BAD_ACTION;  // get_state_transition raises ValueError (mdp.py:1394-1398): leave the env untouched
         } else {
             env_step3<MAXP, FAST ? 2 : 0>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask);
-            fl = finish_step3<MAXP>(L, n_obj, cells, s, horizon, options, r, ep);
+            fl = finish_step3<MAXP>(C, L, n_obj, cells, s, horizon, options, r, ep, sa, g, sa.epoch + (uint32_t)k);
         }
         rew_k[threadIdx.x] = r;
         flg_k[threadIdx.x] = (uint8_t)fl;

@@ -36,7 +36,9 @@ class VecOvercookedMultiAgent:
 
         self._torch, self._lib = torch, _lib
         venv_kwargs.pop("auto_reset", None)
-        self.venv = VecOvercookedEnv(layouts, n_envs, horizon=horizon, device=device, auto_reset=False, **venv_kwargs)
+        self.venv = VecOvercookedEnv(layouts, n_envs, horizon=horizon, device=device, auto_reset=False,
+                                     random_start_pos=random_start_pos, rnd_obj_prob_thresh=rnd_obj_prob_thresh,
+                                     **venv_kwargs)
         v = self.venv
         self.n_envs, self.horizon, self.use_phi, self.gamma = v.n_envs, v.horizon, bool(use_phi), float(gamma)
         self._initial_reward_shaping_factor = self.reward_shaping_factor = reward_shaping_factor
@@ -61,8 +63,8 @@ class VecOvercookedMultiAgent:
             lid = v.layout_id_host if v.layout_id is not None else np.zeros(self.n_envs, np.int64)
             first = [int(np.nonzero(lid == l)[0][0]) if (lid == l).any() else 0 for l in range(len(v.table))]
             self.phi_start.copy_(self.phi_cur[torch.as_tensor(first, device=dev)])
-        if self._random_starts:
-            self.reset()
+        if self._random_starts and self.use_phi:  # the fresh batch already holds drawn start states (epoch 0)
+            v.potential(self.gamma, out=self.phi_cur)
 
     def _obs_buffer(self):
         if self._obs is None or self._obs.dtype != self.obs_dtype:
@@ -98,7 +100,7 @@ class VecOvercookedMultiAgent:
         if actions.dtype != torch.uint8 or actions.shape != (self.n_envs, 2) or not actions.is_contiguous() \
                 or actions.device != v.state.device:
             raise ValueError("actions must be a contiguous uint8 [n_envs, 2] tensor on %s" % v.device)
-        obs = self._obs_buffer() if (self.obs_kind == "ppo" and not self._random_starts) else None
+        obs = self._obs_buffer() if self.obs_kind == "ppo" else None
         code = {torch.uint8: self._lib.OBS_U8, torch.float32: self._lib.OBS_F32}[self.obs_dtype]
         if self.use_phi:
             if self._phi_args is None:
@@ -112,12 +114,9 @@ class VecOvercookedMultiAgent:
                        v._ep_ptr, self.ep_returns.data_ptr(), plan, off, tables, self.phi_next.data_ptr(),
                        self.phi_cur.data_ptr(), self.phi_start.data_ptr(), float(self.reward_shaping_factor),
                        self.shaped.data_ptr(), self.done.data_ptr(), obs.data_ptr() if obs is not None else None, code,
-                       self.horizon)
+                       self.horizon, v._start_spec())  # random starts: finished envs restart from drawn states in the same call
         self._lib.check(rc, "oc_multi_agent_step")
-        if self._random_starts:  # finished envs were restarted from the standard state: redraw them, then observe
-            v.reset(mask=self.done, random_start_pos=self.random_start_pos, rnd_obj_prob_thresh=self.rnd_obj_prob_thresh)
-            if self.use_phi:
-                v.potential(self.gamma, out=self.phi_cur)  # == phi(s') where the episode goes on, phi(new start) elsewhere
+        v.steps_done += 1
         infos = {"sparse_r_by_agent": v.rewards[:, 0:2], "shaped_r_by_agent": v.rewards[:, 2:4], "flags": v.flags,
                  "ep_returns": self.ep_returns}  # episode totals so far; final where done (the reset cleared the live ones)
         if self.use_phi:

@@ -26,7 +26,7 @@ def as_layout_table(layouts, pad_to=None):
 
 class VecOvercookedEnv:
     def __init__(self, layouts, n_envs, horizon=400, device="cuda", layout_id=None, auto_reset=False, seed=0,
-                 env_offset=0, pad_to=None, track_returns=True):
+                 env_offset=0, pad_to=None, track_returns=True, random_start_pos=False, rnd_obj_prob_thresh=0.0):
         self.lib = _lib.load()
         self.table = as_layout_table(layouts, pad_to)
         self.n_envs = int(n_envs)
@@ -45,6 +45,11 @@ class VecOvercookedEnv:
         self.env_offset = int(env_offset)
         self.t_global = 0  # global step counter feeding the Philox counter of rollout_random
         self.reset_epoch = 0  # counter of randomized resets (oc_reset_random's epoch)
+        # start_state_fn = get_random_start_state_fn(random_start_pos, rnd_obj_prob_thresh) (mdp.py:1307-1369): when set,
+        # reset() and every restart inside the step kernels (auto_reset) draw the start state instead of the standard one
+        self.random_start_pos, self.rnd_obj_prob_thresh = bool(random_start_pos), float(rnd_obj_prob_thresh)
+        self.steps_done = 0  # batched steps executed: epoch base of the in-kernel restarts (1 + steps_done + k)
+        self._start = _lib.OcStartSpec()
         self.width, self.height = self.table.width, self.table.height
         self.n_planes = self.table.n_planes
         assert self.lib.oc_state_planes(self.width, self.height) == self.n_planes
@@ -97,14 +102,30 @@ class VecOvercookedEnv:
                 | (_lib.OPT_LANE_PAIR if self.lane_pair else 0) | (_lib.OPT_PREDICATE_INTERACT if self.predicate_interact else 0)
                 | (_lib.OPT_ROLLOUT_V3 if self.rollout_v3 else 0))
 
+    @property
+    def random_starts(self):
+        return self.random_start_pos or self.rnd_obj_prob_thresh > 0.0
+
+    def _start_spec(self):
+        """OcStartSpec* for the next launch (None = restarts from the standard start state)."""
+        if not self.random_starts:
+            return None
+        sp = self._start
+        sp.seed, sp.env_offset, sp.epoch = self.seed, self.env_offset, (1 + self.steps_done) & 0xFFFFFFFF
+        sp.random_start_pos, sp.rnd_obj_prob_thresh = int(self.random_start_pos), self.rnd_obj_prob_thresh
+        return ctypes.byref(sp)
+
     def spec_of(self, e):
         return self.table.specs[0 if self.layout_id is None else int(self.layout_id_host[e])]
 
     # ------------------------------------------------------------------ env API
-    def reset(self, mask=None, random_start_pos=False, rnd_obj_prob_thresh=0.0):
+    def reset(self, mask=None, random_start_pos=None, rnd_obj_prob_thresh=None):
         """Start states for all envs, or those with mask != 0 (u8/bool tensor [n_envs]): the standard start state
-        (mdp.py:1297) by default; with random_start_pos / rnd_obj_prob_thresh the randomized start states of
-        get_random_start_state_fn (mdp.py:1307-1369), drawn on the GPU from (seed, global env index, reset epoch)."""
+        (mdp.py:1297), or — with random_start_pos / rnd_obj_prob_thresh, which default to the env's own — the randomized
+        start states of get_random_start_state_fn (mdp.py:1307-1369), drawn on the GPU from (seed, global env index,
+        reset epoch)."""
+        random_start_pos = self.random_start_pos if random_start_pos is None else random_start_pos
+        rnd_obj_prob_thresh = self.rnd_obj_prob_thresh if rnd_obj_prob_thresh is None else rnd_obj_prob_thresh
         d_mask = None
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
@@ -142,9 +163,10 @@ class VecOvercookedEnv:
         out = self._state_ptr if state_out is None else state_out.data_ptr()
         rc = self._launch(self.lib.oc_step, self._bref, self._state_ptr, out, actions.data_ptr(), self._rewards_ptr,
                           self._flags_ptr, self._ep_ptr, events_out.data_ptr() if events_out is not None else None,
-                          self.horizon, self.options)
+                          self.horizon, self.options, self._start_spec() if self.auto_reset else None)
         if rc:
             _lib.check(rc, "oc_step")
+        self.steps_done += 1
         return self.rewards, self.flags
 
     def step_many(self, actions, rewards_out, flags_out):
@@ -155,8 +177,10 @@ class VecOvercookedEnv:
         self._check(rewards_out, torch.float32, K * self.n_envs * 4, "rewards_out")
         self._check(flags_out, torch.uint8, K * self.n_envs, "flags_out")
         rc = self._launch(self.lib.oc_step_many, self._bref, self._state_ptr, actions.data_ptr(), rewards_out.data_ptr(),
-                          flags_out.data_ptr(), self._ep_ptr, int(K), self.horizon, self.options)
+                          flags_out.data_ptr(), self._ep_ptr, int(K), self.horizon, self.options,
+                          self._start_spec() if self.auto_reset else None)
         _lib.check(rc, "oc_step_many")
+        self.steps_done += int(K)
         return rewards_out, flags_out
 
     def rollout_random(self, n_steps, rewards_out=None, flags_out=None):
@@ -172,9 +196,11 @@ class VecOvercookedEnv:
                 rewards_out.data_ptr() if rewards_out is not None else None,
                 flags_out.data_ptr() if flags_out is not None else None,
                 self.ep_returns.data_ptr() if self.ep_returns is not None else None,
-                self.horizon, self.options, self.seed, self.env_offset, self.t_global, int(n_steps), self._stream())
+                self.horizon, self.options, self.seed, self.env_offset, self.t_global, int(n_steps),
+                self._start_spec() if self.auto_reset else None, self._stream())
         _lib.check(rc, "oc_rollout_random")
         self.t_global += int(n_steps)
+        self.steps_done += int(n_steps)
         return rewards_out, flags_out
 
     def encode_lossless(self, dtype=torch.uint8, out=None, state=None):

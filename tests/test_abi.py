@@ -23,7 +23,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
     for s in syms:
         assert getattr(L, s) is not None
-    assert L.oc_abi_version() == 1
+    assert L.oc_abi_version() == 2
     assert L.oc_layout_size() == 256
     assert L.oc_state_planes(5, 4) == 3 and L.oc_state_planes(9, 5) == 4 and L.oc_state_planes(14, 9) == 9
 
@@ -37,12 +37,34 @@ def test_batch_struct_layout_matches_header():
     assert _lib.OcBatch.width.offset == 28 and _lib.OcBatch.height.offset == 32 and _lib.OcBatch.max_pots.offset == 36
 
 
+def test_batch_hints_from_a_host_table():
+    """oc_batch_hints derives the kernel-variant hints from a HOST copy of the layout table (no GPU involved)."""
+    import numpy as np
+
+    from overcooked_ai_amd import _lib
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    L = _lib.load()
+    for names, pots, free, flags in ((["cramped_room"], 1, 6, 3), (["asymmetric_advantages", "cramped_room"], 2, None, 3),
+                                     (["cramped_room_old_dynamics" if False else "cramped_room"], 1, 6, 3)):
+        table = LayoutTable([spec_from_name(nm) for nm in names], pad_to=(9, 5) if len(names) > 1 else None)
+        rec = np.ascontiguousarray(table.records)
+        b = _lib.OcBatch()
+        assert L.oc_batch_hints(rec.ctypes.data, len(table), ctypes.byref(b)) == 0
+        want_free = max(sum(row.count(" ") for row in s.terrain_mtx) for s in table.specs)
+        assert b.max_pots == pots == table.max_pots and b.batch_flags == flags and b.max_free_cells == want_free
+        if free is not None:
+            assert b.max_free_cells == free
+    assert ctypes.sizeof(_lib.OcStartSpec) == 32 and _lib.OcStartSpec.rnd_obj_prob_thresh.offset == 24
+    assert L.oc_batch_hints(None, 1, None) == -1
+
+
 def test_argument_validation_without_gpu():
     """Argument errors are detected on the host before any launch, so they are testable without a GPU."""
     from overcooked_ai_amd import _lib
 
     L = _lib.load()
-    assert L.oc_step(None, None, None, None, None, None, None, None, 400, 0, None) == -1
+    assert L.oc_step(None, None, None, None, None, None, None, None, 400, 0, None, None) == -1
     assert b"batch is NULL" in L.oc_last_error()
     b = _lib.OcBatch(d_layouts=None, d_layout_id=None, n_envs=4, n_layouts=1, width=5, height=4)
     assert L.oc_reset(ctypes.byref(b), None, None, None, None) == -1

@@ -394,10 +394,10 @@ def test_abi_argument_errors(gpu):
 
     env = make_env("cramped_room", 8, gpu)
     L = _lib.load()
-    rc = L.oc_step(env._bref, None, None, None, None, None, None, None, 400, 0, None)
+    rc = L.oc_step(env._bref, None, None, None, None, None, None, None, 400, 0, None, None)
     assert rc == -1 and b"NULL" in L.oc_last_error()
     rc = L.oc_step(env._bref, env.state.data_ptr(), env.state.data_ptr(), env.flags.data_ptr(),
-                   env.rewards.data_ptr(), env.flags.data_ptr(), None, None, 0, 0, None)
+                   env.rewards.data_ptr(), env.flags.data_ptr(), None, None, 0, 0, None, None)
     assert rc == -1 and b"horizon" in L.oc_last_error()
     bad = _lib.OcBatch(d_layouts=env.d_layouts.data_ptr(), d_layout_id=None, n_envs=8, n_layouts=2, width=5, height=4,
                        max_pots=1)
@@ -784,3 +784,69 @@ def test_step_many_equals_single_steps_with_illegal_actions_and_resets(gpu):
         assert torch.equal(many.state, one.state) and torch.equal(many.ep_returns, one.ep_returns)
         assert np.array_equal(many.get_packed_state(), st) and np.array_equal(many.ep_returns.cpu().numpy(), ep)
         assert (fl & 2).any() and (fl & 4).any()
+
+
+@pytest.mark.parametrize("layouts", ["cramped_room", "asymmetric_advantages", "mixed"])
+def test_random_starts_inside_the_fused_auto_reset(layouts, gpu):
+    """start_state_fn = get_random_start_state_fn(random_start_pos, rnd_obj_prob_thresh) (mdp.py:1307-1369) as
+    OvercookedEnv.reset uses it (env.py:288-319): every restart at the horizon, inside the step kernels, draws a new
+    start state (OcStartSpec) — rollout (k_rollout4), step and step_many (k_step3) against the oracle's restatement,
+    across several episode boundaries, with staggered timesteps so that envs restart at different steps."""
+    from oracle import oracle as O
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    n, horizon, seed, off = 5000, 23, 11, 1000
+    if layouts == "mixed":
+        table = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+        lid = (np.arange(n) * 3 % 5).astype(np.uint16)
+    else:
+        table = LayoutTable([spec_from_name(layouts)])
+        lid = None
+    orc = oracle_for(table.specs)
+    kw = dict(random_start_pos=True, rnd_obj_prob_thresh=0.35)
+    env = make_env(table, n, gpu, horizon=horizon, auto_reset=True, seed=seed, env_offset=off, layout_id=lid, **kw)
+    st = orc.reset_random(orc.new_state(n), seed=seed, env_offset=off, epoch=0, layout_id=lid, **kw)
+    assert np.array_equal(env.get_packed_state(), st)
+    stagger = (np.arange(n) % horizon).astype(np.uint8)  # envs reach the horizon at different steps
+    st[0, :, 6] = stagger
+    env.set_packed_state(st)
+    ep_o = np.zeros((n, 4), np.float32)
+    steps_done = 0
+    # fused rollout: 3 launches of 31 steps = 4 horizons
+    for launch in range(3):
+        T = 31
+        rew = torch.zeros((T, n, 4), dtype=torch.float32, device=gpu)
+        fl = torch.zeros((T, n), dtype=torch.uint8, device=gpu)
+        env.rollout_random(T, rew, fl)
+        rew_o, fl_o = orc.rollout_random(st, T, horizon=horizon, options=1, seed=seed, env_offset=off, t0=steps_done,
+                                         layout_id=lid, ep_returns=ep_o,
+                                         start=O.start_spec(seed, off, 1 + steps_done, **kw))
+        steps_done += T
+        assert np.array_equal(fl.cpu().numpy(), fl_o) and (fl_o & 4).sum() >= n, launch
+        assert np.array_equal(env.get_packed_state(), st), launch
+        assert np.array_equal(rew.cpu().numpy(), rew_o) and np.array_equal(env.ep_returns.cpu().numpy(), ep_o)
+    # the step API, one call per step, then K steps in one call
+    rng = np.random.default_rng(3)
+    for t in range(horizon + 3):
+        acts = rng.integers(0, 6, size=(n, 2)).astype(np.uint8)
+        r, f = env.step(torch.from_numpy(acts).to(gpu))
+        st, r_o, f_o = orc.step(st, acts, horizon=horizon, options=1, layout_id=lid, ep_returns=ep_o,
+                                start=O.start_spec(seed, off, 1 + steps_done, **kw))
+        steps_done += 1
+        assert np.array_equal(env.get_packed_state(), st) and np.array_equal(f.cpu().numpy(), f_o), t
+        assert np.array_equal(r.cpu().numpy(), r_o)
+    K = horizon + 5
+    acts_k = rng.integers(0, 6, size=(K, n, 2)).astype(np.uint8)
+    rew_k = torch.zeros((K, n, 4), dtype=torch.float32, device=gpu)
+    fl_k = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
+    env.step_many(torch.from_numpy(acts_k).to(gpu), rew_k, fl_k)
+    for k in range(K):
+        st, r_o, f_o = orc.step(st, acts_k[k], horizon=horizon, options=1, layout_id=lid, ep_returns=ep_o,
+                                start=O.start_spec(seed, off, 1 + steps_done + k, **kw))
+        assert np.array_equal(rew_k[k].cpu().numpy(), r_o) and np.array_equal(fl_k[k].cpu().numpy(), f_o), k
+    assert np.array_equal(env.get_packed_state(), st) and np.array_equal(env.ep_returns.cpu().numpy(), ep_o)
+    # kernels that cannot draw start states refuse instead of silently restarting from the standard state
+    from overcooked_ai_amd._lib import OcAmdError
+    env.rollout_v3 = True
+    with pytest.raises(OcAmdError):
+        env.rollout_random(3)
