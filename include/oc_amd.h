@@ -178,6 +178,23 @@ typedef struct OcStartSpec {
     double rnd_obj_prob_thresh;  /* 0 .. 1 */
 } OcStartSpec;
 
+/*
+ * Where the event_infos of a call go (EVENT_TYPES, mdp.py:1027-1058; log_object_* / is_*_useful / is_potting_*,
+ * mdp.py:2121-2308); NULL = no event logging.  Bit 2*k + p of a mask is event_infos[EVENT_TYPES[k]][p].
+ *   d_events       [n_steps][n_envs] u64: the mask of every step, or NULL
+ *   d_counts       [n_envs][25] u32: how often each event happened in the env's RUNNING episode — player 0 in bits
+ *                  0..15, player 1 in bits 16..31 (the lengths of game_stats[event][player], env.py:382-401; what
+ *                  RLlib reports per agent, human_aware_rl/rllib/rllib.py:453-483).  Accumulated across calls by the
+ *                  step kernels; zeroed when the env is auto-reset.  Or NULL
+ *   d_counts_done  [n_envs][25] u32: the counts of the last FINISHED episode (ep_game_stats), written at the step that
+ *                  ends it, or NULL
+ */
+typedef struct OcEventSink {
+    uint64_t* d_events;
+    uint32_t* d_counts;
+    uint32_t* d_counts_done;
+} OcEventSink;
+
 int oc_abi_version(void);
 size_t oc_layout_size(void); /* == sizeof(OcLayout) == 256 */
 const char* oc_last_error(void);
@@ -196,12 +213,13 @@ int oc_state_planes(int width, int height);
  *   d_ep_returns   [n_envs][4] float running sums of d_rewards over the episode
  *                  (game_stats cumulative_*_rewards_by_agent, env.py:387-392), or NULL
  *   d_events       [n_envs] u64 event_infos of this step (EVENT_TYPES, mdp.py:1027-1058): bit 2*k + p is
- *                  event_infos[EVENT_TYPES[k]][p]; or NULL to skip event logging
+ *                  event_infos[EVENT_TYPES[k]][p]; or NULL (shorthand for an OcEventSink with only d_events)
+ *   events         per-episode event counters / masks (OcEventSink), or NULL
  *   horizon        done when timestep >= horizon (1..65535)
  */
 int oc_step(const OcBatch* batch, const void* d_state_in, void* d_state_out, const uint8_t* d_actions,
             float* d_rewards, uint8_t* d_flags, float* d_ep_returns, uint64_t* d_events, int horizon,
-            uint32_t options, const OcStartSpec* start, void* stream);
+            uint32_t options, const OcStartSpec* start, const OcEventSink* events, void* stream);
 
 /*
  * oc_step_many — n_steps consecutive oc_step transitions (in place) in ONE launch: step k consumes
@@ -210,7 +228,8 @@ int oc_step(const OcBatch* batch, const void* d_state_in, void* d_state_out, con
  * AgentEvaluator._check_trajectories_dynamics, benchmarking.py:366).  Results are those of n_steps oc_step calls.
  */
 int oc_step_many(const OcBatch* batch, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
-                 float* d_ep_returns, int n_steps, int horizon, uint32_t options, const OcStartSpec* start, void* stream);
+                 float* d_ep_returns, int n_steps, int horizon, uint32_t options, const OcStartSpec* start,
+                 const OcEventSink* events, void* stream);
 
 /*
  * oc_rollout_random — n_steps transitions per launch under the uniform random policy
@@ -227,7 +246,8 @@ int oc_step_many(const OcBatch* batch, void* d_state, const uint8_t* d_actions, 
  */
 int oc_rollout_random(const OcBatch* batch, void* d_state, float* d_rewards, uint8_t* d_flags,
                       float* d_ep_returns, int horizon, uint32_t options, uint64_t seed,
-                      int64_t env_offset, int64_t t0, int n_steps, const OcStartSpec* start, void* stream);
+                      int64_t env_offset, int64_t t0, int n_steps, const OcStartSpec* start,
+                      const OcEventSink* events, void* stream);
 
 /*
  * oc_encode_lossless — the 26-layer observation of both players.
@@ -286,7 +306,8 @@ int oc_multi_agent_step(const OcBatch* batch, void* d_state, const uint8_t* d_ac
                         uint8_t* d_flags, float* d_ep_returns, float* d_ep_returns_out, const uint8_t* d_plan_blob,
                         const uint32_t* d_plan_off, const uint8_t* d_phi_tables, double* d_phi_next,
                         double* d_phi_cur, const double* d_phi_start, double reward_shaping_factor, double* d_shaped,
-                        uint8_t* d_done, void* d_obs, int obs_dtype, int horizon, const OcStartSpec* start, void* stream);
+                        uint8_t* d_done, void* d_obs, int obs_dtype, int horizon, const OcStartSpec* start,
+                        const OcEventSink* events, void* stream);
 
 /*
  * oc_reset_random — randomized start states drawn on the GPU.

@@ -46,6 +46,10 @@ class OcStartSpec(ctypes.Structure):
     ]
 
 
+class OcEventSink(ctypes.Structure):
+    _fields_ = [("d_events", ctypes.c_void_p), ("d_counts", ctypes.c_void_p), ("d_counts_done", ctypes.c_void_p)]
+
+
 class OcAmdError(RuntimeError):
     pass
 
@@ -80,11 +84,12 @@ def load():
     L.oc_batch_hints.argtypes = [vp, i32, bp]
     L.oc_step.restype = i32
     sp = ctypes.POINTER(OcStartSpec)
-    L.oc_step.argtypes = [bp, vp, vp, vp, vp, vp, vp, vp, i32, u32, sp, vp]
+    ep = ctypes.POINTER(OcEventSink)
+    L.oc_step.argtypes = [bp, vp, vp, vp, vp, vp, vp, vp, i32, u32, sp, ep, vp]
     L.oc_step_many.restype = i32
-    L.oc_step_many.argtypes = [bp, vp, vp, vp, vp, vp, i32, i32, u32, sp, vp]
+    L.oc_step_many.argtypes = [bp, vp, vp, vp, vp, vp, i32, i32, u32, sp, ep, vp]
     L.oc_rollout_random.restype = i32
-    L.oc_rollout_random.argtypes = [bp, vp, vp, vp, vp, i32, u32, u64, i64, i64, i32, sp, vp]
+    L.oc_rollout_random.argtypes = [bp, vp, vp, vp, vp, i32, u32, u64, i64, i64, i32, sp, ep, vp]
     L.oc_encode_lossless.restype = i32
     L.oc_encode_lossless.argtypes = [bp, vp, vp, i32, i32, vp]
     L.oc_featurize.restype = i32
@@ -93,7 +98,7 @@ def load():
     L.oc_potential.argtypes = [bp, vp, vp, vp, vp, vp, vp]
     L.oc_phi_table_size.restype = i32
     L.oc_multi_agent_step.restype = i32
-    L.oc_multi_agent_step.argtypes = [bp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_double, vp, vp, vp, i32, i32, sp, vp]
+    L.oc_multi_agent_step.argtypes = [bp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_double, vp, vp, vp, i32, i32, sp, ep, vp]
     L.oc_shape_rewards.restype = i32
     L.oc_shape_rewards.argtypes = [bp, vp, vp, vp, vp, vp, ctypes.c_double, vp, vp, vp]
     L.oc_reset_random.restype = i32

@@ -112,6 +112,17 @@ bool start_args(const OcStartSpec* sp, StartArgs* sa) {
     return true;
 }
 
+EvArgs ev_args(const OcEventSink* sink, uint64_t* d_events, uint32_t clear_on_done = 0) {
+    EvArgs ea = {d_events, nullptr, nullptr, clear_on_done};
+    if (sink) {
+        if (sink->d_events) ea.events = sink->d_events;
+        ea.counts = sink->d_counts;
+        ea.counts_done = sink->d_counts_done;
+    }
+    return ea;
+}
+inline bool ev_on(const EvArgs& ea) { return ea.events || ea.counts; }
+
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
 // SIMDs of the current device (4 per CU); cached per thread
@@ -146,26 +157,26 @@ inline int64_t simd_count() {
 template <bool EVENTS>
 void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_state_out, const uint8_t* d_actions,
                  float* d_rewards, uint8_t* d_flags, float* d_ep_returns, uint64_t* d_events, int horizon,
-                 uint32_t options, hipStream_t s, const StartArgs& sa, int n_steps = 1) {
+                 uint32_t options, hipStream_t s, const StartArgs& sa, const EvArgs& ea, int n_steps = 1) {
     const bool uniform = b->n_layouts == 1;
     const bool lds = b->n_layouts <= LDS_LAYOUT_MAX;
     const bool small = b->max_pots >= 1 && b->max_pots <= 2;
     const bool fast = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0 && b->width * b->height <= 64;
     const size_t smem = (size_t)n_obj * 8 * BLOCK * sizeof(uint32_t);
     const dim3 grid(grid_for(b->n_envs)), block(BLOCK);
-    if (!EVENTS && !(options & OC_OPT_PREDICATE_INTERACT)) {
-#define GO3(U, MP, LL, ...)                                                                                          \
+    if (!(options & OC_OPT_PREDICATE_INTERACT)) {
+#define GO3(U, MP, LL, F)                                                                                            \
     do {                                                                                                             \
-        if (!want_lds(k_step3<U, MP, LL, ##__VA_ARGS__>, smem)) break;                                               \
-        hipLaunchKernelGGL((k_step3<U, MP, LL, ##__VA_ARGS__>), grid, block, smem, s, b->d_layouts, b->n_layouts, b->d_layout_id,   \
+        if (!want_lds(k_step3<U, MP, LL, F, EVENTS>, smem)) break;                                                   \
+        hipLaunchKernelGGL((k_step3<U, MP, LL, F, EVENTS>), grid, block, smem, s, b->d_layouts, b->n_layouts, b->d_layout_id,   \
                            (const uint4*)d_state_in, (uint4*)d_state_out, d_actions, (float4*)d_rewards, d_flags,    \
-                           (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options, n_steps, sa);        \
+                           (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options, n_steps, sa, ea);    \
     } while (0)
         if (uniform && fast && b->max_pots == 1) GO3(true, 1, true, true);
         else if (uniform && fast && small) GO3(true, 2, true, true);
-        else if (uniform) { if (b->max_pots == 1) GO3(true, 1, true); else if (small) GO3(true, 2, true); else GO3(true, 8, true); }
-        else if (lds) { if (small) GO3(false, 2, true); else GO3(false, 8, true); }
-        else { if (small) GO3(false, 2, false); else GO3(false, 8, false); }
+        else if (uniform) { if (b->max_pots == 1) GO3(true, 1, true, false); else if (small) GO3(true, 2, true, false); else GO3(true, 8, true, false); }
+        else if (lds) { if (small) GO3(false, 2, true, false); else GO3(false, 8, true, false); }
+        else { if (small) GO3(false, 2, false, false); else GO3(false, 8, false, false); }
 #undef GO3
         return;
     }
@@ -174,7 +185,7 @@ void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_st
         if (!want_lds(k_step<U, MP, LL, EVENTS>, smem)) break;                                              \
         hipLaunchKernelGGL((k_step<U, MP, LL, EVENTS>), grid, block, smem, s, b->d_layouts, b->n_layouts,   \
                            b->d_layout_id, (const uint4*)d_state_in, (uint4*)d_state_out, d_actions,        \
-                           (float4*)d_rewards, d_flags, (float4*)d_ep_returns, d_events, b->n_envs,         \
+                           (float4*)d_rewards, d_flags, (float4*)d_ep_returns, ea.events, b->n_envs,        \
                            b->width, n_obj, horizon, options);                                              \
     } while (0)
     if (uniform) { if (small) GO(true, 2, true); else GO(true, 8, true); }
@@ -215,34 +226,39 @@ int oc_batch_hints(const OcLayout* h_layouts, int n_layouts, OcBatch* batch) {
 
 int oc_step(const OcBatch* b, const void* d_state_in, void* d_state_out, const uint8_t* d_actions, float* d_rewards,
             uint8_t* d_flags, float* d_ep_returns, uint64_t* d_events, int horizon, uint32_t options,
-            const OcStartSpec* start, void* stream) {
+            const OcStartSpec* start, const OcEventSink* events, void* stream) {
     int n_obj = 0;
     if (int rc = check_batch(b, &n_obj)) return rc;
     StartArgs sa;
     if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_step: start.rnd_obj_prob_thresh must be in [0, 1]");
-    if (start && (d_events || (options & OC_OPT_PREDICATE_INTERACT)))
-        return fail(OC_EINVAL, "oc_step: drawn start states need the table-driven kernel (no d_events / PREDICATE_INTERACT)");
+    const EvArgs ea = ev_args(events, d_events);
+    if (options & OC_OPT_PREDICATE_INTERACT) {
+        if (start) return fail(OC_EINVAL, "oc_step: drawn start states need the table-driven kernel (no PREDICATE_INTERACT)");
+        if (ea.counts) return fail(OC_EINVAL, "oc_step: event counters need the table-driven kernel (no PREDICATE_INTERACT)");
+    }
     if (!d_state_in || !d_state_out || !d_actions || !d_rewards || !d_flags)
         return fail(OC_EINVAL, "oc_step: NULL state/actions/rewards/flags pointer");
     if (horizon < 1 || horizon > 65535) return fail(OC_EINVAL, "oc_step: horizon must be in 1..65535");
     if (b->n_envs == 0) return OC_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (d_events)
-        launch_step<true>(b, n_obj, d_state_in, d_state_out, d_actions, d_rewards, d_flags, d_ep_returns, d_events,
-                          horizon, options, s, sa);
+    if (ev_on(ea))
+        launch_step<true>(b, n_obj, d_state_in, d_state_out, d_actions, d_rewards, d_flags, d_ep_returns, ea.events,
+                          horizon, options, s, sa, ea);
     else
         launch_step<false>(b, n_obj, d_state_in, d_state_out, d_actions, d_rewards, d_flags, d_ep_returns, nullptr,
-                           horizon, options, s, sa);
+                           horizon, options, s, sa, ea);
     return check_launch("oc_step");
 }
 
 int oc_step_many(const OcBatch* b, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
-                 float* d_ep_returns, int n_steps, int horizon, uint32_t options, const OcStartSpec* start, void* stream) {
+                 float* d_ep_returns, int n_steps, int horizon, uint32_t options, const OcStartSpec* start,
+                 const OcEventSink* events, void* stream) {
     if (n_steps < 0) return fail(OC_EINVAL, "oc_step_many: n_steps < 0");
     StartArgs sa;
     if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_step_many: start.rnd_obj_prob_thresh must be in [0, 1]");
-    if (start && (options & OC_OPT_PREDICATE_INTERACT))
-        return fail(OC_EINVAL, "oc_step_many: drawn start states need the table-driven kernel");
+    const EvArgs ea = ev_args(events, nullptr);
+    if ((start || ev_on(ea)) && (options & OC_OPT_PREDICATE_INTERACT))
+        return fail(OC_EINVAL, "oc_step_many: drawn start states / event logging need the table-driven kernel");
     int n_obj = 0;
     if (int rc = check_batch(b, &n_obj)) return rc;
     if (!d_state || !d_actions || !d_rewards || !d_flags)
@@ -250,14 +266,18 @@ int oc_step_many(const OcBatch* b, void* d_state, const uint8_t* d_actions, floa
     if (horizon < 1 || horizon > 65535) return fail(OC_EINVAL, "oc_step_many: horizon must be in 1..65535");
     if (b->n_envs == 0 || n_steps == 0) return OC_OK;
     if (!(options & OC_OPT_PREDICATE_INTERACT)) {  // all K transitions in one launch, the envs stay on chip in between
-        launch_step<false>(b, n_obj, d_state, d_state, d_actions, d_rewards, d_flags, d_ep_returns, nullptr, horizon,
-                           options, (hipStream_t)stream, sa, n_steps);
+        if (ev_on(ea))
+            launch_step<true>(b, n_obj, d_state, d_state, d_actions, d_rewards, d_flags, d_ep_returns, nullptr, horizon,
+                              options, (hipStream_t)stream, sa, ea, n_steps);
+        else
+            launch_step<false>(b, n_obj, d_state, d_state, d_actions, d_rewards, d_flags, d_ep_returns, nullptr, horizon,
+                               options, (hipStream_t)stream, sa, ea, n_steps);
         return check_launch("oc_step_many");
     }
     for (int k = 0; k < n_steps; ++k) {
         const int64_t off = (int64_t)k * b->n_envs;
         if (int rc = oc_step(b, d_state, d_state, d_actions + 2 * off, d_rewards + 4 * off, d_flags + off, d_ep_returns,
-                             nullptr, horizon, options, nullptr, stream))
+                             nullptr, horizon, options, nullptr, nullptr, stream))
             return rc;
     }
     return OC_OK;
@@ -265,13 +285,14 @@ int oc_step_many(const OcBatch* b, void* d_state, const uint8_t* d_actions, floa
 
 int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t* d_flags, float* d_ep_returns,
                       int horizon, uint32_t options, uint64_t seed, int64_t env_offset, int64_t t0, int n_steps,
-                      const OcStartSpec* start, void* stream) {
+                      const OcStartSpec* start, const OcEventSink* events, void* stream) {
     int n_obj = 0;
     if (int rc = check_batch(b, &n_obj)) return rc;
     StartArgs sa;
     if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_rollout_random: start.rnd_obj_prob_thresh must be in [0, 1]");
-    if (start && (options & (OC_OPT_ROLLOUT_V3 | OC_OPT_LANE_PAIR | OC_OPT_PREDICATE_INTERACT)))
-        return fail(OC_EINVAL, "oc_rollout_random: drawn start states need the default kernel (k_rollout4)");
+    const EvArgs ea = ev_args(events, nullptr);
+    if ((start || ev_on(ea)) && (options & (OC_OPT_ROLLOUT_V3 | OC_OPT_LANE_PAIR | OC_OPT_PREDICATE_INTERACT)))
+        return fail(OC_EINVAL, "oc_rollout_random: drawn start states / event logging need the default kernel (k_rollout4)");
     if (start && start->env_offset != env_offset) return fail(OC_EINVAL, "oc_rollout_random: start.env_offset differs from env_offset");
     if (!d_state) return fail(OC_EINVAL, "oc_rollout_random: NULL state pointer");
     if (horizon < 1 || horizon > 65535) return fail(OC_EINVAL, "oc_rollout_random: horizon must be in 1..65535");
@@ -316,16 +337,22 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         const size_t cell_bytes = ((size_t)n_obj * 16 + 1) * BLOCK * sizeof(uint16_t);  // + one spare word per lane
         const dim3 grid4(grid_for(b->n_envs)), block4(BLOCK);
         const bool out = d_rewards != nullptr && d_flags != nullptr;
-#define GO4(U, MP, LL, MODE, OUT, OLD, ...)                                                                         \
+#define GO4(U, MP, LL, MODE, OUT, OLD, NF, ...)                                                                     \
     do {                                                                                                            \
-        const size_t smem4 = (size_t)Lds4<U, LL, MODE, ##__VA_ARGS__>::CELLS + cell_bytes;                          \
-        if (!want_lds(k_rollout4<U, MP, LL, MODE, OUT, OLD, ##__VA_ARGS__>, smem4)) break;                          \
-        hipLaunchKernelGGL((k_rollout4<U, MP, LL, MODE, OUT, OLD, ##__VA_ARGS__>), grid4, block4, smem4, s, b->d_layouts, \
+        const size_t smem4 = (size_t)Lds4<U, LL, MODE, NF>::CELLS + cell_bytes;                                     \
+        if (!want_lds(k_rollout4<U, MP, LL, MODE, OUT, OLD, NF, ##__VA_ARGS__>, smem4)) break;                      \
+        hipLaunchKernelGGL((k_rollout4<U, MP, LL, MODE, OUT, OLD, NF, ##__VA_ARGS__>), grid4, block4, smem4, s, b->d_layouts, \
                            b->n_layouts, b->d_layout_id, (uint4*)d_state, (float4*)d_rewards, d_flags,              \
                            (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options, (uint32_t)seed,     \
-                           (uint32_t)(seed >> 32), env_offset, t0, n_steps, sa);                                    \
+                           (uint32_t)(seed >> 32), env_offset, t0, n_steps, sa, ea);                                \
     } while (0)
-        if (joint && b->max_pots == 1 && out && !old && b->max_free_cells <= 6) GO4(true, 1, true, 1, true, false, 6);
+        if (ev_on(ea)) {  // event logging: the general instances
+            if (joint && b->max_pots == 1) GO4(true, 1, true, 1, false, true, JOINT_MAX_FLOOR, true);
+            else if (uniform) { if (small) GO4(true, 2, true, 0, false, true, 0, true); else GO4(true, 8, true, 0, false, true, 0, true); }
+            else if (lds) { if (small) GO4(false, 2, true, 0, false, true, 0, true); else GO4(false, 8, true, 0, false, true, 0, true); }
+            else { if (small) GO4(false, 2, false, 0, false, true, 0, true); else GO4(false, 8, false, 0, false, true, 0, true); }
+        }
+        else if (joint && b->max_pots == 1 && out && !old && b->max_free_cells <= 6) GO4(true, 1, true, 1, true, false, 6);
         else if (joint && b->max_pots == 1) GO4(true, 1, true, 1, false, true, JOINT_MAX_FLOOR);
         else if (joint && small) GO4(true, 2, true, 1, false, true, JOINT_MAX_FLOOR);
         else if (joint) GO4(true, 8, true, 1, false, true, JOINT_MAX_FLOOR);
@@ -455,10 +482,12 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
                         float* d_ep_returns, float* d_ep_returns_out, const uint8_t* d_plan_blob,
                         const uint32_t* d_plan_off, const uint8_t* d_phi_tables, double* d_phi_next, double* d_phi_cur,
                         const double* d_phi_start, double reward_shaping_factor, double* d_shaped, uint8_t* d_done,
-                        void* d_obs, int obs_dtype, int horizon, const OcStartSpec* start, void* stream) {
+                        void* d_obs, int obs_dtype, int horizon, const OcStartSpec* start, const OcEventSink* events,
+                        void* stream) {
     if (!d_done) return fail(OC_EINVAL, "oc_multi_agent_step: d_done is required (it is the reset mask)");
     StartArgs sa;
     if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_multi_agent_step: start.rnd_obj_prob_thresh must be in [0, 1]");
+    const EvArgs ea = ev_args(events, nullptr, 1u);
     {
         int n_obj = 0;
         if (int rc = check_batch(b, &n_obj)) return rc;
@@ -477,12 +506,16 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
                 const dim3 grid(grid_for(b->n_envs)), block(BLOCK);
 #define GOT(U, MP, LL, F)                                                                                             \
     do {                                                                                                              \
-        if (!want_lds(k_train_step<U, MP, LL, F>, smem)) break;                                                       \
-        hipLaunchKernelGGL((k_train_step<U, MP, LL, F>), grid, block, smem, (hipStream_t)stream, b->d_layouts,        \
+        if (ev_on(ea)) { GOT_(U, MP, LL, F, true); } else { GOT_(U, MP, LL, F, false); }                              \
+    } while (0)
+#define GOT_(U, MP, LL, F, EV)                                                                                        \
+    do {                                                                                                              \
+        if (!want_lds(k_train_step<U, MP, LL, F, EV>, smem)) break;                                                   \
+        hipLaunchKernelGGL((k_train_step<U, MP, LL, F, EV>), grid, block, smem, (hipStream_t)stream, b->d_layouts,    \
                            b->n_layouts, b->d_layout_id, (uint4*)d_state, d_actions, (float4*)d_rewards, d_flags,     \
                            (float4*)d_ep_returns, (float4*)d_ep_returns_out, d_plan_blob, d_plan_off, d_phi_tables,   \
                            d_phi_next, d_phi_cur, d_phi_start, reward_shaping_factor, d_shaped, d_done, b->n_envs,    \
-                           b->width, b->height, n_obj, horizon, sa);                                                  \
+                           b->width, b->height, n_obj, horizon, sa, ea);                                              \
     } while (0)
                 if (uniform && fast && b->max_pots == 1) GOT(true, 1, true, true);
                 else if (uniform && fast) GOT(true, 2, true, true);
@@ -490,13 +523,30 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
                 else if (lds) GOT(false, 2, true, false);
                 else GOT(false, 2, false, false);
 #undef GOT
+#undef GOT_
                 if (int rc = check_launch("oc_multi_agent_step")) return rc;
             }
             if (d_obs) return oc_encode_lossless(b, d_state, d_obs, obs_dtype, horizon, stream);
             return OC_OK;
         }
     }
-    if (int rc = oc_step(b, d_state, d_state, d_actions, d_rewards, d_flags, d_ep_returns, nullptr, horizon, 0u, nullptr, stream)) return rc;
+    {  // the general sequence: oc_step (finished envs are restarted below: their counters clear at the DONE step)
+        int n_obj = 0;
+        if (int rc = check_batch(b, &n_obj)) return rc;
+        if (!d_state || !d_actions || !d_rewards || !d_flags) return fail(OC_EINVAL, "oc_multi_agent_step: NULL state/actions/rewards/flags pointer");
+        if (horizon < 1 || horizon > 65535) return fail(OC_EINVAL, "oc_multi_agent_step: horizon must be in 1..65535");
+        if (b->n_envs > 0) {
+            StartArgs none;
+            start_args(nullptr, &none);
+            if (ev_on(ea))
+                launch_step<true>(b, n_obj, d_state, d_state, d_actions, d_rewards, d_flags, d_ep_returns, nullptr, horizon, 0u,
+                                  (hipStream_t)stream, none, ea);
+            else
+                launch_step<false>(b, n_obj, d_state, d_state, d_actions, d_rewards, d_flags, d_ep_returns, nullptr, horizon, 0u,
+                                   (hipStream_t)stream, none, ea);
+            if (int rc = check_launch("oc_multi_agent_step")) return rc;
+        }
+    }
     if (d_phi_tables) {
         if (int rc = oc_potential(b, d_plan_blob, d_plan_off, d_phi_tables, d_state, d_phi_next, stream)) return rc;
     }

@@ -54,6 +54,32 @@ struct StartArgs {
     int32_t random_start_pos;
 };
 
+// Where the event_infos of a launch go (include/oc_amd.h, OcEventSink), by value in kernel arguments.
+struct EvArgs {
+    uint64_t* events;       // [n_steps][n_envs] masks, or NULL
+    uint32_t* counts;       // [n_envs][25] running counts of the current episode (player 0: bits 0..15, player 1: 16..31), or NULL
+    uint32_t* counts_done;  // [n_envs][25] counts of the last finished episode, or NULL
+    uint32_t clear_on_done; // the caller restarts finished envs itself right after this launch (oc_multi_agent_step)
+};
+constexpr int N_EVENT_TYPES = 25;
+
+// add one step's events to the env's counters; at the end of an episode publish them and start from zero
+__device__ __forceinline__ void count_events(const EvArgs& ea, int64_t e, uint64_t ev, bool episode_ends, bool restarts) {
+    if (!ea.counts) return;
+    uint32_t* c = ea.counts + e * N_EVENT_TYPES;
+    while (ev) {
+        const int b = __ffsll((long long)ev) - 1;
+        c[b >> 1] += 1u << (16 * (b & 1));  // this lane owns the env: a plain read-modify-write
+        ev &= ev - 1ull;
+    }
+    if (episode_ends) {
+        for (int k = 0; k < N_EVENT_TYPES; ++k) {
+            if (ea.counts_done) ea.counts_done[e * N_EVENT_TYPES + k] = c[k];
+            if (restarts || ea.clear_on_done) c[k] = 0;
+        }
+    }
+}
+
 __device__ __forceinline__ StartDraw draw_start(const Lay L, uint64_t g, uint32_t epoch, uint32_t seed_lo, uint32_t seed_hi,
                                                 int random_start_pos, uint64_t thresh) {
     StartDraw d;

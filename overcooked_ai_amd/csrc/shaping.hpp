@@ -40,7 +40,7 @@ __global__ __launch_bounds__(BLOCK) void k_shape_rewards(const float4* __restric
 // Same outputs, bit for bit, as the sequence oc_step / oc_potential / oc_shape_rewards / copy / oc_reset that
 // oc_multi_agent_step enqueues for every other table (tests/test_gpu_parity.py compares the two).
 // ------------------------------------------------------------------------------------------
-template <bool UNIFORM, int MAXP, bool LAY_LDS, bool FAST>
+template <bool UNIFORM, int MAXP, bool LAY_LDS, bool FAST, bool EVENTS = false>
 __global__ __launch_bounds__(BLOCK) void k_train_step(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                       const uint16_t* __restrict__ layout_id, uint4* st,
                                                       const uint8_t* __restrict__ actions, float4* __restrict__ rewards,
@@ -50,7 +50,8 @@ __global__ __launch_bounds__(BLOCK) void k_train_step(const OcLayout* __restrict
                                                       const uint8_t* __restrict__ phi_tables, double* __restrict__ phi_next,
                                                       double* __restrict__ phi_cur, const double* __restrict__ phi_start,
                                                       double factor, double* __restrict__ shaped, uint8_t* __restrict__ done,
-                                                      int64_t n, int W, int H, int n_obj, int horizon, StartArgs sa) {
+                                                      int64_t n, int W, int H, int n_obj, int horizon, StartArgs sa,
+                                                      EvArgs ea) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) uint16_t s_cells3[];  // [n_obj * 16][BLOCK]
     __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];  // one 256-byte record when the batch has one layout
@@ -75,10 +76,16 @@ __global__ __launch_bounds__(BLOCK) void k_train_step(const OcLayout* __restrict
     if (a0 > 5u || a1 > 5u) {
         fl = OC_F_BAD_ACTION;  // the env stays untouched (mdp.py:1394-1398 raises)
     } else {
-        env_step3<MAXP, FAST ? 2 : 0>(C, L, lut, cells, s, delta4, a0, a1, r,
-                                      FAST ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull);
+        uint64_t ev = 0;
+        env_step3<MAXP, FAST ? 2 : 0, EVENTS>(C, L, lut, cells, s, delta4, a0, a1, r,
+                                              FAST ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull, nullptr, &ev);
         fl = finish_step3<MAXP>(C, L, n_obj, cells, s, horizon, 0u, r, ep, sa, 0, 0);
+        if (EVENTS) {
+            if (ea.events) ea.events[e] = ev;
+            count_events(ea, e, ev, (fl & OC_F_DONE) != 0u, true);  // finished envs restart below
+        }
     }
+    if (EVENTS && ea.events && (fl & OC_F_BAD_ACTION)) ea.events[e] = 0;
     const bool is_done = (fl & OC_F_DONE) != 0u;
     const double sparse = (double)r.x + (double)r.y;
     double d0 = (double)r.z, d1 = (double)r.w;

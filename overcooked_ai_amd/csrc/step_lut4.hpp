@@ -351,13 +351,14 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
 
 // MODE 0: arithmetic movement, any table; MODE 1: JOINT move table (one two-player layout with <= NF free cells)
 // OLD: some layout of the table may use old dynamics (auto-start of full pots in the env effects)
-template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR>
+// EV: event_infos are logged (per-step masks and / or per-episode counters, EvArgs)
+template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_rollout4(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                     const uint16_t* __restrict__ layout_id, uint4* st,
                                                     float4* __restrict__ rewards, uint8_t* __restrict__ flags,
                                                     float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,
                                                     int horizon, uint32_t options, uint32_t seed_lo, uint32_t seed_hi,
-                                                    int64_t env_offset, int64_t t0, int n_steps, StartArgs sa) {
+                                                    int64_t env_offset, int64_t t0, int n_steps, StartArgs sa, EvArgs ea) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn4[];
     using M = Lds4<UNIFORM, LAY_LDS, MODE, NF>;
     if ((uint32_t)(uintptr_t)(OC_LDS uint8_t*)s_dyn4 != 0u) __builtin_trap();  // folds away: the region starts at address 0
@@ -633,6 +634,43 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                 nc1 = lds_rd16(col + (m1 >> 16));
                 rd_pots(npw);
             }
+        }
+        if (EV) {  // event_infos of the step (mdp.py:2121-2308), from the outcomes above
+            uint64_t ev = 0;
+            const bool acted = (((r0 | r1) & 0xFFu) != 0u) | ((((r0 ^ h0_before) | (r1 ^ h1_before)) & 0xFF00u) != 0u);
+            if (acted) {
+                const uint32_t hb0 = (h0_before >> 8) & 0xFFu, hb1 = (h1_before >> 8) & 0xFFu, hn0 = (r0 >> 8) & 0xFFu;
+                const uint32_t hn1 = (r1 >> 8) & 0xFFu, cc1 = conflict ? cw0 : c1;
+                uint32_t useful_pots = 0, n_full = 0;
+#pragma unroll
+                for (int k = 0; k < MAXP; ++k) {
+                    if (MAXP > 1 && (uint32_t)k >= C.n_pots) break;
+                    uint32_t kb;
+                    if (PW) {
+                        kb = pw[k] >> 8;
+                    } else {
+                        const uint32_t pa = col + s.poff[k];
+                        kb = lds_rd16(pa) >> 8;
+                        kb = ((r1 & F4_POTBITS) && fo1 == pa) ? (cc1 >> 8) : kb;
+                        kb = ((r0 & F4_POTBITS) && fo0 == pa) ? (c0 >> 8) : kb;
+                    }
+                    useful_pots += (kb != KB_POT + PC_EMPTY && kb != KB_POT + PC_IDLE3) ? 1u : 0u;
+                    n_full += kb >= KB_POT + PC_IDLE3 ? 1u : 0u;
+                }
+                const bool du0 = two & (((hb1 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_before == 0u);
+                const bool du1 = two & (((hn0 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_mid == 0u);
+                const uint32_t t0_ = ((c0 >> 8) * 137u) >> 12, t1_ = ((cc1 >> 8) * 137u) >> 12;  // key byte / 30 = terrain type
+                const bool disp0 = (t0_ == OC_T_ONION_DISP) | (t0_ == OC_T_TOMATO_DISP) | (t0_ == OC_T_DISH_DISP);
+                const bool disp1 = (t1_ == OC_T_ONION_DISP) | (t1_ == OC_T_TOMATO_DISP) | (t1_ == OC_T_DISH_DISP);
+                ev = interact_events<0>(C, t0_, hb0, c0 & 0xFFu, ((r0 & F4_CHG) != 0u) & (t0_ == OC_T_COUNTER),
+                                        disp0 & (hb0 == 0u) & (hn0 != 0u), (r0 & F4_PLACE) != 0u, (r0 & F4_PLATE) != 0u,
+                                        (r0 & F4_SERVE) != 0u, hb1, du0, n_full, two) |
+                     interact_events<1>(C, t1_, hb1, cc1 & 0xFFu, ((r1 & F4_CHG) != 0u) & (t1_ == OC_T_COUNTER),
+                                        disp1 & (hb1 == 0u) & (hn1 != 0u), (r1 & F4_PLACE) != 0u, (r1 & F4_PLATE) != 0u,
+                                        (r1 & F4_SERVE) != 0u, hn0, du1, n_full, two);
+            }
+            if (ea.events) ea.events[(int64_t)step_k * n + e] = ev;
+            count_events(ea, e, ev, done, (options & OC_OPT_AUTO_RESET) != 0u);
         }
 #if !defined(OC_EXPERIMENT) || (OC_EXPERIMENT != 1)
         if (OUT || rew_k) rew_k[threadIdx.x] = rw;

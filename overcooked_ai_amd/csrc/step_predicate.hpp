@@ -15,6 +15,53 @@ enum {
 __device__ __forceinline__ uint64_t evbit(bool cond, int k, int p) { return cond ? (1ull << (2 * k + p)) : 0ull; }
 
 // ------------------------------------------------------------------------------------------
+// event_infos of ONE player's interact (log_object_pickup / drop / potting and their usefulness predicates,
+// mdp.py:2121-2308; EVENT_TYPES, mdp.py:1027-1058) from the outcome of the interact, whichever formulation produced it:
+//   type     terrain type of the faced cell,  h / o  hand and faced object BEFORE the interact (o: the soup for a pot)
+//   swapX    counter pick-up or drop,  take  something taken from a dispenser,  place / plate / serve  as named
+//   other_h  the other player's LIVE hand,  dish_useful  is_dish_pickup_useful for this player,  n_full  pots that are
+//   cooking, ready or hold max_num_ingredients items (pot_states before any interact),  n_pots  pots of the layout
+// ------------------------------------------------------------------------------------------
+template <int P>
+__device__ __forceinline__ uint64_t interact_events(const LayC& C, uint32_t type, uint32_t h, uint32_t o, bool swapX,
+                                                    bool take, bool place, bool plate, bool serve, uint32_t other_h,
+                                                    bool dish_useful, uint32_t n_full, bool two) {
+    const bool hz = h == 0u;
+    const uint32_t n = (o >> 3) & 3u;
+    const bool isD = type == OC_T_DISH_DISP;
+    const bool all_full = C.n_pots == n_full;
+    const bool other_dish = other_h == OC_O_DISH, other_onion = other_h == OC_O_ONION;
+    const bool ing_pick_useful = two & !(all_full & !other_dish);
+    const bool ing_drop_useful = two & all_full & !other_dish;
+    const bool dish_drop_useful = two & (n_full == 0u) & !other_onion;
+    const bool pickX = swapX & hz, dropX = swapX & !hz;
+    const bool takeO = take & (type == OC_T_ONION_DISP), takeD = take & isD;
+    uint64_t e = 0;
+    const bool pk_on = (pickX & (o == OC_O_ONION)) | takeO, pk_to = pickX & (o == OC_O_TOMATO);
+    const bool pk_di = (pickX & (o == OC_O_DISH)) | takeD;
+    e |= evbit(pk_on, EV_ONION_PICKUP, P) | evbit(pk_on & ing_pick_useful, EV_USEFUL_ONION_PICKUP, P);
+    e |= evbit(pk_to, EV_TOMATO_PICKUP, P) | evbit(pk_to & ing_pick_useful, EV_USEFUL_TOMATO_PICKUP, P);
+    e |= evbit(pk_di, EV_DISH_PICKUP, P) | evbit(pk_di & dish_useful, EV_USEFUL_DISH_PICKUP, P);
+    e |= evbit((pickX & ((o & OC_O_SOUP) != 0u)) | plate, EV_SOUP_PICKUP, P);
+    e |= evbit(dropX & (h == OC_O_ONION), EV_ONION_DROP, P) | evbit(dropX & (h == OC_O_ONION) & ing_drop_useful, EV_USEFUL_ONION_DROP, P);
+    e |= evbit(dropX & (h == OC_O_TOMATO), EV_TOMATO_DROP, P) | evbit(dropX & (h == OC_O_TOMATO) & ing_drop_useful, EV_USEFUL_TOMATO_DROP, P);
+    e |= evbit(dropX & (h == OC_O_DISH), EV_DISH_DROP, P) | evbit(dropX & (h == OC_O_DISH) & dish_drop_useful, EV_USEFUL_DISH_DROP, P);
+    e |= evbit(dropX & ((h & OC_O_SOUP) != 0u), EV_SOUP_DROP, P);
+    e |= evbit(serve, EV_SOUP_DELIVERY, P);
+    // potting: class nibble of (old soup, ingredient): 1 optimal, 2 viable, 4 catastrophic, 8 useless
+    const uint32_t nt = __popc(o & 7u), no = n - nt, pi = no + 3u * nt;  // old soup has <= 2 ingredients here
+    const uint32_t pw = pi < 4u ? C.pclass[0] : C.pclass[1];
+    const uint32_t tom = h == OC_O_TOMATO ? 1u : 0u;
+    const uint32_t nib = (pw >> (8u * (pi & 3u) + 4u * tom)) & 0xFu;
+    e |= evbit(place, EV_POTTING_ONION, P) >> (10u * tom);  // EV_POTTING_TOMATO = EV_POTTING_ONION - 5
+    e |= evbit(place & ((nib & 1u) != 0u), EV_OPTIMAL_ONION_POTTING, P) << (2u * tom);
+    e |= evbit(place & ((nib & 2u) != 0u), EV_VIABLE_ONION_POTTING, P) << (2u * tom);
+    e |= evbit(place & ((nib & 4u) != 0u), EV_CATASTROPHIC_ONION_POTTING, P) << (2u * tom);
+    e |= evbit(place & ((nib & 8u) != 0u), EV_USELESS_ONION_POTTING, P) << (2u * tom);
+    return e;
+}
+
+// ------------------------------------------------------------------------------------------
 // INTERACT of player P (resolve_interacts, mdp.py:1432-1579) as a pure function of its inputs, written
 // without data-dependent branches: every outcome is a predicate, the new hand / cell / tick are selects.
 //   h, other_h   this player's hand and the other player's LIVE hand
@@ -90,37 +137,7 @@ __device__ __forceinline__ IOut interact(const LayC& C, const Lay L, bool act, u
     r.sparse = serve ? value : 0.f;
     r.ev = 0;
     if (EVENTS) {
-        // log_object_pickup / drop / potting and their usefulness predicates (mdp.py:2121-2308)
-        const bool all_full = C.n_pots == n_full;
-        const bool other_dish = other_h == OC_O_DISH, other_onion = other_h == OC_O_ONION;
-        const bool ing_pick_useful = two & !(all_full & !other_dish);
-        const bool ing_drop_useful = two & all_full & !other_dish;
-        const bool dish_drop_useful = two & (n_full == 0u) & !other_onion;
-        const bool pickX = swapX & hz, dropX = swapX & !hz;
-        const bool takeO = take & (type == OC_T_ONION_DISP), takeD = take & isD;
-        uint64_t e = 0;
-        const bool pk_on = (pickX & (o == OC_O_ONION)) | takeO, pk_to = pickX & (o == OC_O_TOMATO);
-        const bool pk_di = (pickX & (o == OC_O_DISH)) | takeD;
-        e |= evbit(pk_on, EV_ONION_PICKUP, P) | evbit(pk_on & ing_pick_useful, EV_USEFUL_ONION_PICKUP, P);
-        e |= evbit(pk_to, EV_TOMATO_PICKUP, P) | evbit(pk_to & ing_pick_useful, EV_USEFUL_TOMATO_PICKUP, P);
-        e |= evbit(pk_di, EV_DISH_PICKUP, P) | evbit(pk_di & dish_useful, EV_USEFUL_DISH_PICKUP, P);
-        e |= evbit((pickX & ((o & OC_O_SOUP) != 0u)) | plate, EV_SOUP_PICKUP, P);
-        e |= evbit(dropX & (h == OC_O_ONION), EV_ONION_DROP, P) | evbit(dropX & (h == OC_O_ONION) & ing_drop_useful, EV_USEFUL_ONION_DROP, P);
-        e |= evbit(dropX & (h == OC_O_TOMATO), EV_TOMATO_DROP, P) | evbit(dropX & (h == OC_O_TOMATO) & ing_drop_useful, EV_USEFUL_TOMATO_DROP, P);
-        e |= evbit(dropX & (h == OC_O_DISH), EV_DISH_DROP, P) | evbit(dropX & (h == OC_O_DISH) & dish_drop_useful, EV_USEFUL_DISH_DROP, P);
-        e |= evbit(dropX & ((h & OC_O_SOUP) != 0u), EV_SOUP_DROP, P);
-        e |= evbit(serve, EV_SOUP_DELIVERY, P);
-        // potting: class nibble of (old soup, ingredient): 1 optimal, 2 viable, 4 catastrophic, 8 useless
-        const uint32_t nt = __popc(o & 7u), no = n - nt, pi = no + 3u * nt;  // old soup has <= 2 ingredients here
-        const uint32_t pw = pi < 4u ? C.pclass[0] : C.pclass[1];
-        const uint32_t tom = h == OC_O_TOMATO ? 1u : 0u;
-        const uint32_t nib = (pw >> (8u * (pi & 3u) + 4u * tom)) & 0xFu;
-        e |= evbit(place, EV_POTTING_ONION, P) >> (10u * tom);  // EV_POTTING_TOMATO = EV_POTTING_ONION - 5
-        e |= evbit(place & ((nib & 1u) != 0u), EV_OPTIMAL_ONION_POTTING, P) << (2u * tom);
-        e |= evbit(place & ((nib & 2u) != 0u), EV_VIABLE_ONION_POTTING, P) << (2u * tom);
-        e |= evbit(place & ((nib & 4u) != 0u), EV_CATASTROPHIC_ONION_POTTING, P) << (2u * tom);
-        e |= evbit(place & ((nib & 8u) != 0u), EV_USELESS_ONION_POTTING, P) << (2u * tom);
-        r.ev = e;
+        r.ev = interact_events<P>(C, type, h, o, swapX, take, place, plate, serve, other_h, dish_useful, n_full, two);
     }
     return r;
 }

@@ -186,18 +186,26 @@ __device__ __forceinline__ Probe3 probe3(const uint16_t* cells, const Env3<MAXP>
     return q;
 }
 
-template <int MAXP, int FAST>
+template <int MAXP, int FAST, bool EVENTS = false>
 __device__ __forceinline__ void step3_main(const LayC& C, const Lay L, const uint8_t* s_lut, uint16_t* cells,
                                            Env3<MAXP>& s, uint32_t a0, uint32_t a1, const Probe3& q, float4& r,
-                                           uint64_t floor_mask) {
+                                           uint64_t floor_mask, uint64_t* ev = nullptr) {
     const bool two = FAST >= 1 || s.pos1 != 0xFFu;
     const bool mv0 = a0 < 4u, mv1 = two & (a1 < 4u);
     const uint32_t f0 = q.f0, f1 = q.f1, c_f0 = q.c_f0, c_f1 = q.c_f1;
 
     // pot_states before any interact (mdp.py:1439): ready / cooking / 1..2 idle items  <=>  class not in {empty, idle 3}
-    uint32_t useful_pots = 0;
+    uint32_t useful_pots = 0, n_full = 0;
 #pragma unroll
-    for (int k = 0; k < MAXP; ++k) useful_pots += ((s.pc[k] != PC_EMPTY) & (s.pc[k] != PC_IDLE3)) ? 1u : 0u;
+    for (int k = 0; k < MAXP; ++k) {
+        useful_pots += ((s.pc[k] != PC_EMPTY) & (s.pc[k] != PC_IDLE3)) ? 1u : 0u;
+        if (EVENTS) n_full += (((uint32_t)k < C.n_pots) & (s.pc[k] >= PC_IDLE3)) ? 1u : 0u;
+    }
+    uint32_t ps_before[MAXP];
+    if (EVENTS) {
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) ps_before[k] = s.ps[k];
+    }
 
     const bool act0 = a0 == OC_A_INTERACT, act1 = two & (a1 == OC_A_INTERACT);
     const uint32_t h0_before = s.held0, h1_before = s.held1;
@@ -219,6 +227,31 @@ __device__ __forceinline__ void step3_main(const LayC& C, const Lay L, const uin
     const bool du1 = two & (((s.held0 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (s.dcount == 0);
     const float sh1 = ((r1.flags & LF_PLACE) ? C.rew_place : 0.f) + ((r1.flags & LF_PLATE) ? C.rew_soup : 0.f) +
                       ((((r1.flags & LF_TAKE_DISH) != 0u) & du1) ? C.rew_dish : 0.f);
+    if (EVENTS) {  // event_infos (mdp.py:2121-2308) from the two outcomes
+        auto faced = [&](uint32_t c16, const uint32_t (&ps)[MAXP]) {  // the object an interact sees: the soup for a pot
+            uint32_t o = c16 & 0xFFu;
+            if (((c16 >> 8) & 7u) == OC_T_POT) {
+#pragma unroll
+                for (int k = 0; k < MAXP; ++k) o = (c16 >> 11) == (uint32_t)k ? ps[k] : o;
+            }
+            return o;
+        };
+        uint32_t ps_mid[MAXP];  // pots after player 0 (what a replayed player 1 saw)
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) ps_mid[k] = s.ps[k];
+        const uint32_t t0_ = act0 ? (c_f0 >> 8) & 7u : 7u, t1_ = act1 ? (c_f1 >> 8) & 7u : 7u;
+        const uint32_t o0 = faced(c_f0, ps_before), o1 = conflict ? faced(c_f1_live, ps_mid) : faced(c_f1, ps_before);
+        const bool disp0 = (t0_ == OC_T_ONION_DISP) | (t0_ == OC_T_TOMATO_DISP) | (t0_ == OC_T_DISH_DISP);
+        const bool disp1 = (t1_ == OC_T_ONION_DISP) | (t1_ == OC_T_TOMATO_DISP) | (t1_ == OC_T_DISH_DISP);
+        const int32_t dc_before = s.dcount - r0.ddelta;
+        const bool du0e = two & (((h1_before == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_before == 0);
+        *ev = interact_events<0>(C, t0_, h0_before, o0, (r0.flags & LF_SWAP) != 0u, disp0 & (h0_before == 0u) & (r0.new_h != 0u),
+                                 (r0.flags & LF_PLACE) != 0u, (r0.flags & LF_PLATE) != 0u, (r0.flags & LF_SERVE) != 0u,
+                                 h1_before, du0e, n_full, two) |
+              interact_events<1>(C, t1_, h1_before, o1, (r1.flags & LF_SWAP) != 0u, disp1 & (h1_before == 0u) & (r1.new_h != 0u),
+                                 (r1.flags & LF_PLACE) != 0u, (r1.flags & LF_PLATE) != 0u, (r1.flags & LF_SERVE) != 0u,
+                                 s.held0, du1, n_full, two);
+    }
     s.held1 = r1.new_h;
     s.dcount += r1.ddelta;
     apply_pot3<MAXP>(s, r1);
@@ -269,12 +302,12 @@ __device__ __forceinline__ void step3_env(const LayC& C, Env3<MAXP>& s) {
     }
 }
 
-template <int MAXP, int FAST = 0>
+template <int MAXP, int FAST = 0, bool EVENTS = false>
 __device__ __forceinline__ void env_step3(const LayC& C, const Lay L, const uint8_t* s_lut, uint16_t* cells,
                                           Env3<MAXP>& s, uint32_t delta4, uint32_t a0, uint32_t a1, float4& r,
-                                          uint64_t floor_mask = 0, const uint8_t* s_move = nullptr) {
+                                          uint64_t floor_mask = 0, const uint8_t* s_move = nullptr, uint64_t* ev = nullptr) {
     const Probe3 q = probe3<MAXP, FAST>(cells, s, delta4, a0, a1, s_move);
-    step3_main<MAXP, FAST>(C, L, s_lut, cells, s, a0, a1, q, r, floor_mask);
+    step3_main<MAXP, FAST, EVENTS>(C, L, s_lut, cells, s, a0, a1, q, r, floor_mask, ev);
     step3_env<MAXP>(C, s);
 }
 
@@ -529,13 +562,13 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
 // k_step3: transitions with caller-supplied actions (one per launch for oc_step, K for oc_step_many), table-driven
 // interact (no event logging;
 // oc_step with d_events != NULL uses k_step, whose predicate-network interact produces the event bits)
-template <bool UNIFORM, int MAXP, bool LAY_LDS, bool FAST = false>
+template <bool UNIFORM, int MAXP, bool LAY_LDS, bool FAST = false, bool EVENTS = false>
 __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                  const uint16_t* __restrict__ layout_id, const uint4* st_in,
                                                  uint4* st_out, const uint8_t* __restrict__ actions,
                                                  float4* __restrict__ rewards, uint8_t* __restrict__ flags,
                                                  float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,
-                                                 int horizon, uint32_t options, int n_steps, StartArgs sa) {
+                                                 int horizon, uint32_t options, int n_steps, StartArgs sa, EvArgs ea) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_cells3[];  // [n_obj * 16][BLOCK]
     __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];  // one 256-byte record when the batch has one layout
     __shared__ uint2 s_lut[2 * LUT_ENTRIES];
@@ -568,9 +601,15 @@ __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_
         if (__builtin_expect(a0 > 5u || a1 > 5u, 0)) {
             fl = OC_F_BAD_ACTION;  // get_state_transition raises ValueError (mdp.py:1394-1398): leave the env untouched
         } else {
-            env_step3<MAXP, FAST ? 2 : 0>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask);
+            uint64_t ev = 0;
+            env_step3<MAXP, FAST ? 2 : 0, EVENTS>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask, nullptr, &ev);
             fl = finish_step3<MAXP>(C, L, n_obj, cells, s, horizon, options, r, ep, sa, g, sa.epoch + (uint32_t)k);
+            if (EVENTS) {
+                if (ea.events) ea.events[(int64_t)k * n + e] = ev;
+                count_events(ea, e, ev, (fl & OC_F_DONE) != 0u, (fl & OC_F_RESET) != 0u);
+            }
         }
+        if (EVENTS && ea.events && (fl & OC_F_BAD_ACTION)) ea.events[(int64_t)k * n + e] = 0;
         rew_k[threadIdx.x] = r;
         flg_k[threadIdx.x] = (uint8_t)fl;
         rew_k += n;

@@ -95,7 +95,7 @@ class _SingleEnvPort:
         mv[self.o_act] = a0
         mv[self.o_act + 1] = a1
         p = self.ptrs
-        rc = self.lib.oc_step(self.bref, p[0], p[1], p[2], p[3], p[4], None, p[5], 65535, 0, None, self.stream_ptr)
+        rc = self.lib.oc_step(self.bref, p[0], p[1], p[2], p[3], p[4], None, p[5], 65535, 0, None, None, self.stream_ptr)
         if rc:
             from . import _lib
             _lib.check(rc, "oc_step")

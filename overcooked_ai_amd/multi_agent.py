@@ -114,7 +114,8 @@ class VecOvercookedMultiAgent:
                        v._ep_ptr, self.ep_returns.data_ptr(), plan, off, tables, self.phi_next.data_ptr(),
                        self.phi_cur.data_ptr(), self.phi_start.data_ptr(), float(self.reward_shaping_factor),
                        self.shaped.data_ptr(), self.done.data_ptr(), obs.data_ptr() if obs is not None else None, code,
-                       self.horizon, v._start_spec())  # random starts: finished envs restart from drawn states in the same call
+                       self.horizon, v._start_spec(),  # random starts: finished envs restart from drawn states in the same call
+                       v._event_sink() if v.event_counts is not None else None)
         self._lib.check(rc, "oc_multi_agent_step")
         v.steps_done += 1
         infos = {"sparse_r_by_agent": v.rewards[:, 0:2], "shaped_r_by_agent": v.rewards[:, 2:4], "flags": v.flags,

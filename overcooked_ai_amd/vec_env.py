@@ -26,7 +26,8 @@ def as_layout_table(layouts, pad_to=None):
 
 class VecOvercookedEnv:
     def __init__(self, layouts, n_envs, horizon=400, device="cuda", layout_id=None, auto_reset=False, seed=0,
-                 env_offset=0, pad_to=None, track_returns=True, random_start_pos=False, rnd_obj_prob_thresh=0.0):
+                 env_offset=0, pad_to=None, track_returns=True, random_start_pos=False, rnd_obj_prob_thresh=0.0,
+                 track_events=False):
         self.lib = _lib.load()
         self.table = as_layout_table(layouts, pad_to)
         self.n_envs = int(n_envs)
@@ -75,6 +76,13 @@ class VecOvercookedEnv:
             d_layout_id=self.layout_id.data_ptr() if self.layout_id is not None else None,
             n_envs=self.n_envs, n_layouts=len(self.table), width=self.width, height=self.height)
         self._bref = ctypes.byref(self._batch)
+        # per-episode event counters (game_stats lengths, env.py:382-401): [n_envs, 25] int32, player 0 in the low half-word
+        self.event_counts = self.event_counts_done = None
+        self._sink = _lib.OcEventSink()
+        if track_events:
+            self.event_counts = torch.zeros((self.n_envs, 25), dtype=torch.int32, device=dev)
+            self.event_counts_done = torch.zeros((self.n_envs, 25), dtype=torch.int32, device=dev)
+            self._sink.d_counts, self._sink.d_counts_done = self.event_counts.data_ptr(), self.event_counts_done.data_ptr()
         # kernel-variant hints (max pots, two players everywhere, max free cells) from the host copy of the table
         host_table = np.ascontiguousarray(self.table.records)
         _lib.check(self.lib.oc_batch_hints(host_table.ctypes.data, len(self.table), self._bref), "oc_batch_hints")
@@ -114,6 +122,25 @@ class VecOvercookedEnv:
         sp.seed, sp.env_offset, sp.epoch = self.seed, self.env_offset, (1 + self.steps_done) & 0xFFFFFFFF
         sp.random_start_pos, sp.rnd_obj_prob_thresh = int(self.random_start_pos), self.rnd_obj_prob_thresh
         return ctypes.byref(sp)
+
+    def _event_sink(self, events_out=None):
+        """OcEventSink* for the next launch: the per-episode counters when tracking is on, plus an optional per-step mask
+        buffer (int64 [n_steps, n_envs]); None = no event logging."""
+        if self.event_counts is None and events_out is None:
+            return None
+        self._sink.d_events = events_out.data_ptr() if events_out is not None else None
+        return ctypes.byref(self._sink)
+
+    def event_stats(self, finished=False):
+        """{event name: int32 tensor [n_envs, 2]}: how often each event happened per player in the running episode, or
+        (finished=True) in each env's last finished episode — the lengths of the reference's game_stats lists."""
+        from .mdp import EVENT_TYPES
+
+        c = self.event_counts_done if finished else self.event_counts
+        if c is None:
+            raise ValueError("construct the env with track_events=True")
+        both = torch.stack([c & 0xFFFF, (c >> 16) & 0xFFFF], dim=-1)
+        return {name: both[:, k] for k, name in enumerate(EVENT_TYPES)}
 
     def spec_of(self, e):
         return self.table.specs[0 if self.layout_id is None else int(self.layout_id_host[e])]
@@ -163,29 +190,35 @@ class VecOvercookedEnv:
         out = self._state_ptr if state_out is None else state_out.data_ptr()
         rc = self._launch(self.lib.oc_step, self._bref, self._state_ptr, out, actions.data_ptr(), self._rewards_ptr,
                           self._flags_ptr, self._ep_ptr, events_out.data_ptr() if events_out is not None else None,
-                          self.horizon, self.options, self._start_spec() if self.auto_reset else None)
+                          self.horizon, self.options, self._start_spec() if self.auto_reset else None,
+                          self._event_sink() if self.event_counts is not None else None)
         if rc:
             _lib.check(rc, "oc_step")
         self.steps_done += 1
         return self.rewards, self.flags
 
-    def step_many(self, actions, rewards_out, flags_out):
+    def step_many(self, actions, rewards_out, flags_out, events_out=None):
         """K consecutive steps enqueued from C: actions uint8 [K, n_envs, 2] -> rewards_out float32 [K, n_envs, 4],
-        flags_out uint8 [K, n_envs]."""
+        flags_out uint8 [K, n_envs]; events_out: optional int64 [K, n_envs] event masks."""
         K = actions.shape[0]
+        if events_out is not None:
+            self._check(events_out, torch.int64, int(K) * self.n_envs, "events_out")
         self._check(actions, torch.uint8, K * self.n_envs * 2, "actions")
         self._check(rewards_out, torch.float32, K * self.n_envs * 4, "rewards_out")
         self._check(flags_out, torch.uint8, K * self.n_envs, "flags_out")
         rc = self._launch(self.lib.oc_step_many, self._bref, self._state_ptr, actions.data_ptr(), rewards_out.data_ptr(),
                           flags_out.data_ptr(), self._ep_ptr, int(K), self.horizon, self.options,
-                          self._start_spec() if self.auto_reset else None)
+                          self._start_spec() if self.auto_reset else None, self._event_sink(events_out))
         _lib.check(rc, "oc_step_many")
         self.steps_done += int(K)
         return rewards_out, flags_out
 
-    def rollout_random(self, n_steps, rewards_out=None, flags_out=None):
+    def rollout_random(self, n_steps, rewards_out=None, flags_out=None, events_out=None):
         """n_steps fused random-policy transitions in one launch (Philox actions, see include/oc_amd.h).
-        rewards_out: float32 [n_steps, n_envs, 4] or None; flags_out: uint8 [n_steps, n_envs] or None."""
+        rewards_out: float32 [n_steps, n_envs, 4] or None; flags_out: uint8 [n_steps, n_envs] or None; events_out:
+        int64 [n_steps, n_envs] event masks or None."""
+        if events_out is not None:
+            self._check(events_out, torch.int64, int(n_steps) * self.n_envs, "events_out")
         if rewards_out is not None:
             self._check(rewards_out, torch.float32, int(n_steps) * self.n_envs * 4, "rewards_out")
         if flags_out is not None:
@@ -197,7 +230,7 @@ class VecOvercookedEnv:
                 flags_out.data_ptr() if flags_out is not None else None,
                 self.ep_returns.data_ptr() if self.ep_returns is not None else None,
                 self.horizon, self.options, self.seed, self.env_offset, self.t_global, int(n_steps),
-                self._start_spec() if self.auto_reset else None, self._stream())
+                self._start_spec() if self.auto_reset else None, self._event_sink(events_out), self._stream())
         _lib.check(rc, "oc_rollout_random")
         self.t_global += int(n_steps)
         self.steps_done += int(n_steps)

@@ -64,7 +64,7 @@ def test_argument_validation_without_gpu():
     from overcooked_ai_amd import _lib
 
     L = _lib.load()
-    assert L.oc_step(None, None, None, None, None, None, None, None, 400, 0, None, None) == -1
+    assert L.oc_step(None, None, None, None, None, None, None, None, 400, 0, None, None, None) == -1
     assert b"batch is NULL" in L.oc_last_error()
     b = _lib.OcBatch(d_layouts=None, d_layout_id=None, n_envs=4, n_layouts=1, width=5, height=4)
     assert L.oc_reset(ctypes.byref(b), None, None, None, None) == -1

@@ -284,3 +284,41 @@ def test_infinite_order_bonus_delivery():
     env.state = state
     _, reward, _, info = env.step((Action.STAY, Action.INTERACT))
     assert reward == float("inf") and info["sparse_r_by_agent"] == [0, float("inf")]
+
+
+def test_vec_multi_agent_event_counters():
+    """The batched training env keeps the per-agent event counters RLlib reports (rllib.py:453-483, env.py:382-401):
+    fused kernel (k_train_step) and the general sequence, against the oracle's event_infos summed per episode."""
+    import torch
+
+    from oracle import oracle as O
+    from overcooked_ai_amd import VecOvercookedMultiAgent
+    from overcooked_ai_amd.layouts import LayoutSpec, spec_from_name
+
+    dev = torch.device("cuda:0")
+    seven = LayoutSpec({"grid": "XPPPPPX\nO 1 2 O\nX     X\nXDPSPTX", "onion_time": 3, "tomato_time": 5,
+                        "onion_value": 7, "tomato_value": 4})
+    for spec in (spec_from_name("cramped_room"), seven):
+        n, horizon = 1500, 30
+        env = VecOvercookedMultiAgent(spec, n, horizon=horizon, use_phi=False, reward_shaping_factor=1.0, device=dev,
+                                      track_events=True)
+        orc = O.Oracle([O.mdp_from_layout_dict(spec.to_layout_dict())])
+        st = orc.reset(orc.new_state(n))
+        counts = np.zeros((n, 25, 2), np.int64)
+        done_counts = np.zeros((n, 25, 2), np.int64)
+        gen = torch.Generator(device=dev).manual_seed(3)
+        for t in range(75):
+            acts = torch.randint(0, 6, (n, 2), dtype=torch.uint8, device=dev, generator=gen)
+            env.step(acts)
+            st, _, f = orc.step(st, acts.cpu().numpy(), horizon=horizon, options=0)
+            ev = orc.last_events
+            counts += ((ev[:, None] >> np.arange(50, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.int64).reshape(n, 25, 2)
+            fin = (f & 1) != 0
+            done_counts[fin] = counts[fin]
+            counts[fin] = 0
+            st = orc.reset(st, mask=fin.astype(np.uint8))
+        assert np.array_equal(env.venv.get_packed_state(), st)
+        got = env.venv.event_counts.cpu().numpy().astype(np.int64)
+        assert np.array_equal(np.stack([got & 0xFFFF, (got >> 16) & 0xFFFF], -1), counts) and counts.sum() > 0
+        gd = env.venv.event_counts_done.cpu().numpy().astype(np.int64)
+        assert np.array_equal(np.stack([gd & 0xFFFF, (gd >> 16) & 0xFFFF], -1), done_counts) and done_counts.sum() > 0

@@ -48,8 +48,11 @@ def u8(t):
     return t.cpu().numpy()
 
 
+@pytest.mark.parametrize("interact", ["table", "predicate"])
 @pytest.mark.parametrize("name", TRANSITION_CONFIGS)
-def test_golden_transitions(name, manifest, gpu):
+def test_golden_transitions(name, interact, manifest, gpu):
+    """8 400 (state, joint action) -> (next state, rewards, event_infos) transitions of the reference per configuration,
+    through oc_step with event logging: the table-driven kernel (k_step3) and the predicate-network one (k_step)."""
     from overcooked_ai_amd.layouts import LayoutSpec
 
     cfg = manifest["configs"][name]["transitions"]
@@ -57,6 +60,7 @@ def test_golden_transitions(name, manifest, gpu):
     d = np.load(os.path.join(GOLDEN, "transitions_%s.npz" % name))
     n = d["actions"].shape[0]
     env = make_env(spec, n, gpu, horizon=65535)
+    env.predicate_interact = interact == "predicate"
     env.set_packed_state(d["state_in"])
     ev = torch.zeros((n,), dtype=torch.int64, device=gpu)
     rew, flags = env.step(torch.from_numpy(d["actions"]).to(gpu), events_out=ev)
@@ -394,10 +398,10 @@ def test_abi_argument_errors(gpu):
 
     env = make_env("cramped_room", 8, gpu)
     L = _lib.load()
-    rc = L.oc_step(env._bref, None, None, None, None, None, None, None, 400, 0, None, None)
+    rc = L.oc_step(env._bref, None, None, None, None, None, None, None, 400, 0, None, None, None)
     assert rc == -1 and b"NULL" in L.oc_last_error()
     rc = L.oc_step(env._bref, env.state.data_ptr(), env.state.data_ptr(), env.flags.data_ptr(),
-                   env.rewards.data_ptr(), env.flags.data_ptr(), None, None, 0, 0, None, None)
+                   env.rewards.data_ptr(), env.flags.data_ptr(), None, None, 0, 0, None, None, None)
     assert rc == -1 and b"horizon" in L.oc_last_error()
     bad = _lib.OcBatch(d_layouts=env.d_layouts.data_ptr(), d_layout_id=None, n_envs=8, n_layouts=2, width=5, height=4,
                        max_pots=1)
@@ -850,3 +854,105 @@ def test_random_starts_inside_the_fused_auto_reset(layouts, gpu):
     env.rollout_v3 = True
     with pytest.raises(OcAmdError):
         env.rollout_random(3)
+
+
+@pytest.mark.parametrize("layouts", ["cramped_room", "counter_circuit", "mixed"])
+def test_event_masks_and_episode_counters_on_the_fast_paths(layouts, gpu):
+    """event_infos / game_stats without the slow kernel: k_rollout4 and k_step3 emit the per-step event
+    masks and keep per-env, per-episode counters (OcEventSink) — masks equal the oracle's event_infos of every step,
+    the counters equal the popcount sums per episode, are published when the episode ends and restart from zero."""
+    from oracle import oracle as O
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    n, horizon, seed = 3000, 40, 5
+    if layouts == "mixed":
+        table = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+        lid = (np.arange(n) % 5).astype(np.uint16)
+    else:
+        table = LayoutTable([spec_from_name(layouts)])
+        lid = None
+    orc = oracle_for(table.specs)
+    env = make_env(table, n, gpu, horizon=horizon, auto_reset=True, seed=seed, layout_id=lid, track_events=True,
+                   random_start_pos=True, rnd_obj_prob_thresh=0.5)  # random starts: events from the first steps on
+    st = env.get_packed_state()
+    counts = np.zeros((n, 25, 2), np.int64)
+    done_counts = np.zeros((n, 25, 2), np.int64)
+
+    def account(ev_o, flags_o):
+        bits = ((ev_o[:, None] >> np.arange(50, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.int64).reshape(n, 25, 2)
+        counts[:] += bits
+        fin = (flags_o & 1) != 0
+        done_counts[fin] = counts[fin]
+        counts[(flags_o & 4) != 0] = 0
+
+    def check_counters():
+        got = env.event_counts.cpu().numpy().astype(np.int64)
+        assert np.array_equal(np.stack([got & 0xFFFF, (got >> 16) & 0xFFFF], -1), counts)
+        gd = env.event_counts_done.cpu().numpy().astype(np.int64)
+        assert np.array_equal(np.stack([gd & 0xFFFF, (gd >> 16) & 0xFFFF], -1), done_counts)
+
+    steps = 0
+    T = 55  # crosses the horizon once
+    ev = torch.zeros((T, n), dtype=torch.int64, device=gpu)
+    env.rollout_random(T, None, None, events_out=ev)
+    ev_np = ev.cpu().numpy().view(np.uint64)
+    for k in range(T):
+        acts = O.random_actions(seed, 0, k, n)
+        st, _, f_o = orc.step(st, acts, horizon=horizon, options=1, layout_id=lid,
+                              start=O.start_spec(seed, 0, 1 + steps, True, 0.5))
+        steps += 1
+        assert np.array_equal(ev_np[k], orc.last_events), k
+        account(orc.last_events, f_o)
+    assert np.array_equal(env.get_packed_state(), st) and counts.sum() > 0 and done_counts.sum() > 0
+    check_counters()
+    # the step API: one step with a mask, then K steps in one call
+    rng = np.random.default_rng(2)
+    acts = rng.integers(0, 6, size=(n, 2)).astype(np.uint8)
+    ev1 = torch.zeros((n,), dtype=torch.int64, device=gpu)
+    _, f = env.step(torch.from_numpy(acts).to(gpu), events_out=ev1)
+    st, _, f_o = orc.step(st, acts, horizon=horizon, options=1, layout_id=lid, start=O.start_spec(seed, 0, 1 + steps, True, 0.5))
+    steps += 1
+    assert np.array_equal(ev1.cpu().numpy().view(np.uint64), orc.last_events) and np.array_equal(f.cpu().numpy(), f_o)
+    account(orc.last_events, f_o)
+    K = 45
+    acts_k = rng.integers(0, 6, size=(K, n, 2)).astype(np.uint8)
+    rew_k = torch.zeros((K, n, 4), dtype=torch.float32, device=gpu)
+    fl_k = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
+    ev_k = torch.zeros((K, n), dtype=torch.int64, device=gpu)
+    env.step_many(torch.from_numpy(acts_k).to(gpu), rew_k, fl_k, events_out=ev_k)
+    ev_np = ev_k.cpu().numpy().view(np.uint64)
+    for k in range(K):
+        st, _, f_o = orc.step(st, acts_k[k], horizon=horizon, options=1, layout_id=lid,
+                              start=O.start_spec(seed, 0, 1 + steps + k, True, 0.5))
+        assert np.array_equal(ev_np[k], orc.last_events), k
+        account(orc.last_events, f_o)
+    assert np.array_equal(env.get_packed_state(), st)
+    check_counters()
+    stats = env.event_stats(finished=True)
+    assert set(stats) == set(__import__("overcooked_ai_amd").EVENT_TYPES) and stats["onion_pickup"].shape == (n, 2)
+
+
+def test_episode_counters_equal_reference_game_stats(gpu):
+    """The counters against the reference itself: the lengths of info["episode"]["ep_game_stats"][event][agent]
+    (env.py:363-401) of the recorded OvercookedEnv episodes."""
+    import json
+
+    from overcooked_ai_amd import EVENT_TYPES
+    from overcooked_ai_amd.layouts import LayoutSpec
+
+    with open(os.path.join(GOLDEN, "env_episodes.json")) as f:
+        episodes = json.load(f)
+    for name, ep in episodes.items():
+        spec = LayoutSpec(ep["layout"])
+        env = make_env(spec, 2, gpu, horizon=ep["horizon"], auto_reset=True, track_events=True)
+        acts = np.array([s["actions"] for s in ep["steps"]], np.uint8)[:, None, :].repeat(2, axis=1)
+        K = acts.shape[0]
+        rew = torch.zeros((K, 2, 4), dtype=torch.float32, device=gpu)
+        fl = torch.zeros((K, 2), dtype=torch.uint8, device=gpu)
+        env.step_many(torch.from_numpy(acts).to(gpu), rew, fl)
+        assert int(fl[-1, 0]) & 1, name
+        stats = env.event_stats(finished=True)
+        for ev_name in EVENT_TYPES:
+            want = [len(x) for x in ep["episode"]["ep_game_stats"][ev_name]]
+            assert stats[ev_name][0].tolist() == want, (name, ev_name)
+        assert not env.event_counts.any()  # restarted: the running episode has no events yet
