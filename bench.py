@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--lane-per-env", action="store_true", help="force the one-lane-per-env rollout kernel")
     ap.add_argument("--lane-pair", action="store_true", help="force the two-lanes-per-env rollout kernel")
     ap.add_argument("--predicate-interact", action="store_true", help="lane-per-env kernel with the predicate-network interact (v2)")
+    ap.add_argument("--rollout-v3", action="store_true", help="the previous table-driven rollout kernel (k_rollout3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the step-API and encode side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -281,6 +282,7 @@ def main():
         env.lane_per_env = args.lane_per_env
         env.lane_pair = args.lane_pair
         env.predicate_interact = args.predicate_interact
+        env.rollout_v3 = args.rollout_v3
     fuse = max(1, args.fuse)  # launch shape: independent of --steps (a 20-step --steps must not shrink the launches)
     rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
@@ -331,11 +333,12 @@ def main():
 
     value = float(world) * n * total_steps / wall_max
 
-    # roofline of the dominant kernel (k_rollout3): algorithmic HBM bytes per launch / median launch duration
+    # roofline of the dominant kernel (k_rollout4): algorithmic HBM bytes per launch / median launch duration
     state_bytes = S_CRAMPED if args.layout == "cramped_room" else 4 * ((env.n_planes * 16) // 4)
     bytes_per_launch = n * (2 * state_bytes + OUT_BYTES * fuse)
     achieved = bytes_per_launch / (launch_med * 1e-3) / 1e9
-    kernel = "k_rollout" if args.predicate_interact else "k_rollout_pair" if args.lane_pair else "k_rollout3"
+    kernel = ("k_rollout" if args.predicate_interact else "k_rollout_pair" if args.lane_pair
+              else "k_rollout3" if args.rollout_v3 else "k_rollout4")
     traffic = None
     try:  # PMC HBM bytes per launch measured by tools/profile_round.sh on this same launch shape (profiles/traffic.json)
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
@@ -351,12 +354,14 @@ def main():
     try:  # SQ counters of the same kernel (tools/pmc_rollout.sh): what bounds it is instruction issue, not HBM
         with open(os.path.join(ROOT, "profiles", "sq_counters.json")) as f:
             sq = json.load(f)
-        if kernel == "k_rollout3" and n == N_ENVS_PER_GPU and args.layout == "cramped_room":
+        if kernel == sq.get("kernel", "").split("<")[0] and n == N_ENVS_PER_GPU and args.layout == "cramped_room":
             issue = {"valu_per_env_step": sq["valu_per_env_step"], "salu_per_env_step": sq["salu_per_env_step"],
                      "lds_per_env_step": sq["lds_per_env_step"], "valu_busy_frac": sq["valu_busy_frac"],
                      "wait_frac": sq["wait_any_frac"],
-                     "note": "one wavefront per SIMD at 65 536 envs: a VALU instruction occupies the SIMD for 4 clk, so "
-                             "valu_per_env_step * 4 clk is the floor of a batched step whatever the bytes moved"}
+                     "wave_clk_per_env_step": sq.get("wave_clk_per_env_step"),
+                     "note": "one wavefront per SIMD at 65 536 envs: every instruction of the wavefront issues in turn (~4 clk "
+                             "each), so (VALU + SALU + LDS + VMEM per env-step) * 4 clk is the floor of a batched step "
+                             "whatever the bytes moved"}
     except (OSError, ValueError, KeyError):
         pass
     out = {
@@ -553,7 +558,8 @@ def bench_single_env_api(dev, torch, episodes=3):
     dt = time.perf_counter() - t0
     return {"value": steps / dt, "unit": "env steps/s", "us_per_step": dt / steps * 1e6, "episodes": episodes,
             "reference_python": REFERENCE_PYTHON["value"],
-            "note": "OvercookedEnv.step through the single-env drop-in API (one env, one launch + one D2H per call); "
+            "note": "OvercookedEnv.step through the single-env drop-in API: state and action written into a pinned host buffer "
+                    "the kernel reads and writes in place (no staging copies), one launch + one stream wait per call; "
                     "latency-bound by construction - batch with VecOvercookedEnv for throughput"}
 
 

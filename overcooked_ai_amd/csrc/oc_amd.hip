@@ -329,7 +329,9 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
                                env_offset, t0, n_steps);
         return check_launch("oc_rollout_random");
     }
-    if ((options & (OC_OPT_PREDICATE_INTERACT | OC_OPT_ROLLOUT_V3)) == 0) {
+    // launches of a few steps cannot amortise k_rollout4's prologue (LUT patching, move table): they run k_rollout3
+    const bool short_launch = n_steps < 8 && !start && !ev_on(ea);
+    if ((options & (OC_OPT_PREDICATE_INTERACT | OC_OPT_ROLLOUT_V3)) == 0 && !short_launch) {
         // k_rollout4.  JOINT move table: one two-player layout with at most JOINT_MAX_FLOOR free cells (hint from the caller)
         const bool two = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0;
         const bool joint = uniform && two && b->max_free_cells >= 2 && b->max_free_cells <= (uint32_t)JOINT_MAX_FLOOR;

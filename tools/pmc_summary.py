@@ -4,6 +4,11 @@ import sqlite3
 import sys
 
 args = sys.argv[1:]
+json_out = steps = None
+if "--json" in args:  # --json <path> <steps per launch>: per-env-step counters of the first kernel -> profiles/sq_counters.json
+    i = args.index("--json")
+    json_out, steps = args[i + 1], float(args[i + 2])
+    del args[i:i + 3]
 dirs, kerns = args[:args.index("--")], args[args.index("--") + 1:]
 for kern in kerns:
     vals = {}
@@ -13,6 +18,28 @@ for kern in kerns:
             for name, cnt, mean in db.execute("select counter_name,count(*),avg(counter_value) from pmc_events where name like ? group by counter_name", ("%" + kern + "%",)):
                 vals[name] = mean
     print(kern, {k: int(v) for k, v in sorted(vals.items())})
+    if json_out and "SQ_WAVES" in vals:
+        import json
+
+        w, wc = vals["SQ_WAVES"], vals["SQ_WAVE_CYCLES"]
+        names = set()
+        for d in dirs:
+            for f in glob.glob(d + "/*.db"):
+                names |= {r[0] for r in sqlite3.connect(f).execute("select distinct name from pmc_events where name like ?", ("%" + kern + "%",))}
+        per = lambda k: round(vals.get(k, 0.0) / w / steps, 2)
+        json.dump({
+            "_note": "rocprofv3 --pmc SQ_* passes of tools/prof_rollout.py (tools/pmc_rollout.sh), 65 536 cramped_room envs, %d fused "
+                     "steps per launch; per wavefront and env-step (the launch prologue, e.g. the joint move table build, is included)" % steps,
+            "kernel": sorted(n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] for n in names)[0] if names else kern,
+            "valu_per_env_step": per("SQ_INSTS_VALU"), "salu_per_env_step": per("SQ_INSTS_SALU"),
+            "lds_per_env_step": per("SQ_INSTS_LDS"), "vmem_wr_per_env_step": per("SQ_INSTS_VMEM_WR"),
+            "branches_per_env_step": per("SQ_INSTS_BRANCH"),
+            "wave_clk_per_env_step": round(4 * wc / w / steps, 1),
+            "valu_busy_frac": round(vals.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 3),
+            "wait_any_frac": round(vals.get("SQ_WAIT_ANY", 0.0) / wc, 3),
+            "lds_bank_conflict_per_active_cycle": round(vals.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, vals.get("SQ_LDS_IDX_ACTIVE", 0.0)), 2),
+        }, open(json_out, "w"), indent=1)
+        json_out = None
     if "SQ_WAVES" in vals:
         w, wc = vals["SQ_WAVES"], vals["SQ_WAVE_CYCLES"]
         g = lambda k: vals.get(k, 0.0)
