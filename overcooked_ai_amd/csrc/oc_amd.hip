@@ -354,7 +354,11 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
             else if (lds) { if (small) GO4(false, 2, true, 0, false, true, 0, true); else GO4(false, 8, true, 0, false, true, 0, true); }
             else { if (small) GO4(false, 2, false, 0, false, true, 0, true); else GO4(false, 8, false, 0, false, true, 0, true); }
         }
-        else if (joint && b->max_pots == 1 && out && !old && b->max_free_cells <= 6) GO4(true, 1, true, 1, true, false, 6);
+        else if (joint && b->max_pots == 1 && out && !old && b->max_free_cells <= 6) {
+            // one wavefront per SIMD (or less): read the faced cells a step ahead; more: do not (see PIPE)
+            if (b->n_envs <= simd_count() * 64 * 3 / 2) GO4(true, 1, true, 1, true, false, 6);
+            else GO4(true, 1, true, 1, true, false, 6, false, false);
+        }
         else if (joint && b->max_pots == 1) GO4(true, 1, true, 1, false, true, JOINT_MAX_FLOOR);
         else if (joint && small) GO4(true, 2, true, 1, false, true, JOINT_MAX_FLOOR);
         else if (joint) GO4(true, 8, true, 1, false, true, JOINT_MAX_FLOOR);

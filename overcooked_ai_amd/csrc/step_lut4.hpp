@@ -115,7 +115,11 @@ struct Env4 {
 // address 0 and table offsets ARE addresses: nothing is added per access, constants fold into the DS offset field.
 #define OC_LDS __attribute__((address_space(3)))
 typedef uint32_t oc_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint32_t lds_rd16(uint32_t a) { return *(const OC_LDS uint16_t*)(uintptr_t)a; }
+__device__ __forceinline__ uint32_t lds_rd16(uint32_t a) {
+    const uint32_t v = *(const OC_LDS uint16_t*)(uintptr_t)a;
+    __builtin_assume(v <= 0xFFFFu);  // ds_read_u16 zero-extends: spare the re-masking of values carried across steps
+    return v;
+}
 __device__ __forceinline__ uint32_t lds_rd32(uint32_t a) { return *(const OC_LDS uint32_t*)(uintptr_t)a; }
 __device__ __forceinline__ uint4 lds_rd128(uint32_t a) {
     const oc_u32x4 v = *(const OC_LDS oc_u32x4*)(uintptr_t)a;
@@ -352,7 +356,11 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
 // MODE 0: arithmetic movement, any table; MODE 1: JOINT move table (one two-player layout with <= NF free cells)
 // OLD: some layout of the table may use old dynamics (auto-start of full pots in the env effects)
 // EV: event_infos are logged (per-step masks and / or per-episode counters, EvArgs)
-template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false>
+// PIPE (MODE 1): the next step's faced cells are read one step ahead.  That hides the read behind the tail of the step
+//   when a SIMD holds one wavefront (65 536 envs); with two or more wavefronts per SIMD the extra LDS traffic costs
+//   more than the latency it hides (131 072 cramped_room envs: 0.48 vs 0.65 us per batched step), so big batches turn it off
+template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false,
+          bool PIPE = true>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_rollout4(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                     const uint16_t* __restrict__ layout_id, uint4* st,
                                                     float4* __restrict__ rewards, uint8_t* __restrict__ flags,
@@ -422,8 +430,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
     //      next step's joint action * 2), MODE 0: (pos0, pos1, or0, or1).
     //      pw[k]: pot k's cell word read BEFORE this step's interacts (its class is the "pot_states" of mdp.py:1439),
     //      cookv[k]: the cook time of what that pot holds (FAST_START only), MAXP <= 2.
-    constexpr bool PW = MAXP <= 2;
-    constexpr bool FAST_START = UNIFORM && MAXP == 1 && !OLD;  // a cooking start is two instructions of the straight line
+    // (!PIPE = two or more wavefronts per SIMD: LDS operations are what the step is short of — no pot word / cook time
+    //  reads in the straight line, the rare branch looks them up)
+    constexpr bool PW = MAXP <= 2 && PIPE;
+    constexpr bool FAST_START = UNIFORM && MAXP == 1 && !OLD && PIPE;  // a cooking start is two instructions of the straight line
     auto cook_time = [&](uint32_t soup) __attribute__((always_inline)) {
         return UNIFORM ? (uint32_t)*(const OC_LDS uint8_t*)(uintptr_t)((uint32_t)M::CT + (soup & 31u)) : cook_of(C, soup);
     };
@@ -447,6 +457,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                     const uint32_t (&pw)[MAXP], uint32_t& m0, uint32_t& m1, uint32_t& m2, uint32_t& m3, uint32_t& nc0,
                     uint32_t& nc1, uint32_t (&npw)[MAXP]) __attribute__((always_inline)) {
         // ---- the straight line: everything a step does when nothing rare happens -------------------------------------
+        // (values read with ds_read_u16 a step earlier: tell the compiler they are still 16 bits wide)
+        __builtin_assume(c0 <= 0xFFFFu); __builtin_assume(c1 <= 0xFFFFu);
+        __builtin_assume(off0 <= 0xFFFFu); __builtin_assume(off1 <= 0xFFFFu);
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) __builtin_assume(pw[k] <= 0xFFFFu);
         uint32_t cookv = 0;
         if (FAST_START) cookv = cook_time(pw[0]);  // cook time of what the pot holds, should somebody start it
         // both players against the pre-step cells (resolve_interacts, mdp.py:1432-1579)
@@ -471,9 +486,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             if (FAST_START) s.rem[k] = ((r0 | r1) & F4_START) ? cookv : s.rem[k];
             s.rem[k] -= 1u;
             ripe[k] = s.rem[k] == 0u;
-            if (MAXP <= 2 || (uint32_t)k < C.n_pots) lds_wr8(ripe[k] ? col + s.poff[k] + 1u : dummy, KB_POT + PC_READY);
+            if (PIPE) {
+                if (MAXP <= 2 || (uint32_t)k < C.n_pots) lds_wr8(ripe[k] ? col + s.poff[k] + 1u : dummy, KB_POT + PC_READY);
+            } else if (ripe[k]) {  // only the lanes concerned store
+                lds_wr8(col + s.poff[k] + 1u, KB_POT + PC_READY);
+            }
         }
-        if (MODE == 1) {  // the next step's cells: everything this step writes to the grid has been issued
+        if (MODE == 1 && PIPE) {  // the next step's cells: everything this step writes to the grid has been issued
             nc0 = lds_rd16(col + (m1 & 0xFFFFu));
             nc1 = lds_rd16(col + (m1 >> 16));
             rd_pots(npw);
@@ -629,7 +648,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                     s.over += 1u;
                 }
             }
-            if (MODE == 1 && grid_changed) {  // read the next step's cells again
+            if (MODE == 1 && PIPE && grid_changed) {  // read the next step's cells again
                 nc0 = lds_rd16(col + (m1 & 0xFFFFu));
                 nc1 = lds_rd16(col + (m1 >> 16));
                 rd_pots(npw);
@@ -707,13 +726,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         rd_pots(pw);
         auto pstep = [&](uint32_t ja2n) __attribute__((always_inline)) {  // ja2n: 2 * joint action of the NEXT step
             const uint32_t fo0 = col + (fa & 0xFFFFu), fo1 = col + (fa >> 16);
+            if (!PIPE) {
+                c0 = lds_rd16(fo0);
+                c1 = lds_rd16(fo1);
+                rd_pots(pw);
+            }
             uint32_t fa_n = lds_rd32(Jn + 72u), Jnn = lds_rd16(Jn + ja2n);
             const uint32_t off0n = lds_rd16((uint32_t)M::ACT + ja2n), off1n = lds_rd16((uint32_t)M::ACT + 80u + ja2n);
             uint32_t Jcn = Jn, unused = 0, nc0 = 0, nc1 = 0, npw[MAXP];
             core(fo0, fo1, off0, off1, c0, c1, ja2n, pw, Jcn, fa_n, Jnn, unused, nc0, nc1, npw);
-            Jc = Jcn; Jn = Jnn; fa = fa_n; off0 = off0n; off1 = off1n; c0 = nc0; c1 = nc1;
+            Jc = Jcn; Jn = Jnn; fa = fa_n; off0 = off0n; off1 = off1n;
+            if (PIPE) {
+                c0 = nc0; c1 = nc1;
 #pragma unroll
-            for (int k = 0; k < MAXP; ++k) pw[k] = npw[k];
+                for (int k = 0; k < MAXP; ++k) pw[k] = npw[k];
+            }
         };
         int k = 0;
         const int head_end = min(n_steps, (int)((8u - ((uint32_t)t0 & 7u)) & 7u));

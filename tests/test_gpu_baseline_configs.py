@@ -130,3 +130,25 @@ def test_config4_4096_generated_terrains(kernel, gpu):
         st2, r_o, f_o = orc.step(st, acts, horizon=100, options=1, layout_id=lid)
         assert np.array_equal(env.get_packed_state(), st2) and np.array_equal(r.cpu().numpy(), r_o)
         assert np.array_equal(f.cpu().numpy(), f_o)
+
+
+def test_big_batch_variant_of_the_rollout_kernel(gpu):
+    """More than ~1.5 wavefronts per SIMD (here 131 072 cramped_room envs) selects k_rollout4's lean instance (no
+    one-step-ahead cell reads, cooking starts in the rare branch): same results as the oracle across a restart."""
+    from overcooked_ai_amd.layouts import spec_from_name
+    from overcooked_ai_amd.vec_env import VecOvercookedEnv
+
+    n = 131072
+    spec = spec_from_name("cramped_room")
+    orc = _oracle([spec])
+    env = VecOvercookedEnv(spec, n, device=gpu, auto_reset=True, horizon=70, seed=9)
+    st = orc.reset(orc.new_state(n))
+    ep_o = np.zeros((n, 4), np.float32)
+    T = 100
+    rew = torch.zeros((T, n, 4), dtype=torch.float32, device=gpu)
+    fl = torch.zeros((T, n), dtype=torch.uint8, device=gpu)
+    env.rollout_random(T, rew, fl)
+    rew_o, fl_o = orc.rollout_random(st, T, horizon=70, options=1, seed=9, ep_returns=ep_o)
+    assert np.array_equal(env.get_packed_state(), st) and np.array_equal(fl.cpu().numpy(), fl_o)
+    assert np.array_equal(rew.cpu().numpy(), rew_o) and np.array_equal(env.ep_returns.cpu().numpy(), ep_o)
+    assert (fl_o[69] == 5).all() and np.abs(rew_o).sum() > 0
