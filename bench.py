@@ -176,12 +176,14 @@ class _Timer:
     """Device-side timing of each launch: HIP events on the stream the kernels are launched on (torch's current
     stream — VecOvercookedEnv launches there); wall clock on CPU for the stub."""
 
-    def __init__(self, torch, dev):
+    def __init__(self, torch, dev, reserve=0):
         self.torch, self.gpu, self.dev, self.ev = torch, dev.type == "cuda", dev, []
+        # events are created up front: creating one per launch inside the timed loop costs host time per launch
+        self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(reserve)] if self.gpu else []
 
     def mark(self):
         if self.gpu:
-            e = self.torch.cuda.Event(enable_timing=True)
+            e = self.pool.pop() if self.pool else self.torch.cuda.Event(enable_timing=True)
             e.record()
             self.ev.append(e)
         else:
@@ -304,6 +306,7 @@ def main():
     repeats = plan_repeats(args.steps, fuse, float(est.item()), args.min_seconds)
     total_steps = args.steps * repeats
     launches = total_steps // fuse
+    tm = _Timer(torch, dev, reserve=launches + 1)
 
     tm.sync()
     sharding.barrier()
@@ -398,7 +401,7 @@ def main():
         out["single_env_api"] = bench_single_env_api(dev, torch)
         out["encode"] = bench_encode(dev, torch, VecOvercookedEnv)
         out["training_env"] = bench_training_env(dev, torch)
-    if rank == 0 and not args.no_cpu_baseline and not args.stub:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stub:  # the CPU leg runs at N = 1 only
         out["cpu_baseline"] = cpu_baseline(args.layout, args.cpu_seconds)
         out["cpu_baseline"]["reference_python"] = REFERENCE_PYTHON
     if rank == 0:
@@ -417,7 +420,8 @@ def run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
     if args.config == 3:
         env = VecOvercookedEnv("asymmetric_advantages", n, horizon=HORIZON, device=dev, auto_reset=True, seed=0,
                                env_offset=rank * n)
-        encode, workload, sbytes = True, "asymmetric_advantages x %d envs/GPU, random policy + lossless u8 encoding every step" % n, S_ASYM
+        encode, workload, sbytes = True, ("asymmetric_advantages x %d envs/GPU, random policy (pre-sampled actions in HBM) + lossless "
+                                          "u8 encoding every step (oc_step_encode)" % n), S_ASYM
     elif args.config == 4:
         names = ["cramped_room", "asymmetric_advantages", "coordination_ring", "forced_coordination", "counter_circuit"]
         table = LayoutTable([spec_from_name(nm) for nm in names], pad_to=(9, 5))
@@ -439,10 +443,18 @@ def run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
     obs = torch.empty((n, 2, env.width, env.height, 26), dtype=torch.uint8, device=dev) if encode else None
 
+    if encode:
+        # configs[2]: per iteration one oc_step_encode call = the transition (pre-sampled uniform actions resident in HBM)
+        # + the lossless u8 observation of the resulting state, two kernels back to back
+        acts = torch.randint(0, 6, (256, n, 2), dtype=torch.uint8, device=dev)
+        counter = [0]
+
     def launch():  # one `fuse`-step unit of the workload
-        env.rollout_random(fuse, rew, fl)
-        if encode:
-            env.encode_lossless(torch.uint8, out=obs)
+        if not encode:
+            env.rollout_random(fuse, rew, fl)
+            return
+        env.step_encode(acts[counter[0] % 256], torch.uint8, out=obs)
+        counter[0] += 1
 
     for _ in range(-(-args.warmup // fuse)):
         launch()
@@ -456,7 +468,7 @@ def run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
     sharding.allreduce_max(est)
     repeats = plan_repeats(args.steps, fuse, float(est.item()), args.min_seconds)
     total_steps = args.steps * repeats
-    tm = _Timer(torch, dev)
+    tm = _Timer(torch, dev, reserve=total_steps // fuse + 1)
     tm.sync()
     sharding.barrier()
     tm.sync()

@@ -259,6 +259,20 @@ int oc_encode_lossless(const OcBatch* batch, const void* d_state, void* d_obs, i
                        void* stream);
 
 /*
+ * oc_step_encode — oc_step (in place, caller's actions, auto-reset per `options`, drawn start states per `start`)
+ * followed by oc_encode_lossless of the resulting states, i.e. the step of a training / evaluation loop that feeds the
+ * lossless observation to a policy: OvercookedEnv.step (env.py:244) + lossless_state_encoding_mdp of the state the next
+ * step starts from (env.py:276; human_aware_rl/rllib/rllib.py:257-260).  One C call enqueues the two kernels back to
+ * back on `stream`.  (A single fused kernel — the workgroup that parked a group of envs in LDS steps them there and
+ * builds their observation from the same copy — was built and measured on MI355X: 103 us vs 37 us for 65 536
+ * asymmetric_advantages envs, because the latency-bound step then runs once per 16-env group on one wavefront while the
+ * workgroup's other wavefronts wait)  Arguments as in oc_step / oc_encode_lossless.
+ */
+int oc_step_encode(const OcBatch* batch, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
+                   float* d_ep_returns, void* d_obs, int obs_dtype, int horizon, uint32_t options,
+                   const OcStartSpec* start, void* stream);
+
+/*
  * oc_featurize — the hand-crafted feature vector of both players.
  * Replaces OvercookedGridworld.featurize_state (mdp.py:2579-2898) as called through
  * OvercookedEnv.featurize_state_mdp (env.py:282-286); needs 2-player layouts.

