@@ -749,6 +749,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         for (; k < head_end; ++k) pstep(OC_JA_AT(t0 + k + 1, false) * 2u);  // up to the next block boundary
         for (; n_steps - k >= 8; k += 8) {  // whole Philox blocks, unrolled; the look-ahead digit of step 7 is the next block's first
             const Phx4 nb = philox_words(((uint64_t)(t0 + k) >> 3) + 1u, g_lo, g_hi, seed_lo, seed_hi);
+#if defined(OC_ROLL2)
+            // two steps per iteration, the words rotate through (cur, nxt): one copy of the step pair instead of four
+            uint32_t q0 = w.w0, q1 = w.w1, q2 = w.w2, q3 = w.w3;
+#pragma unroll 1
+            for (int wi = 0; wi < 4; ++wi) {
+                pstep(__umulhi(q0 * 36u, 36u) * 2u);
+                pstep(__umulhi(q1, 36u) * 2u);
+                q0 = q1; q1 = q2; q2 = q3; q3 = nb.w0;
+            }
+#else
             pstep(__umulhi(w.w0 * 36u, 36u) * 2u);
             pstep(__umulhi(w.w1, 36u) * 2u);
             pstep(__umulhi(w.w1 * 36u, 36u) * 2u);
@@ -757,6 +767,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             pstep(__umulhi(w.w3, 36u) * 2u);
             pstep(__umulhi(w.w3 * 36u, 36u) * 2u);
             pstep(__umulhi(nb.w0, 36u) * 2u);
+#endif
             w = nb;
         }
         for (; k < n_steps; ++k) pstep(OC_JA_AT(t0 + k + 1, false) * 2u);  // the tail
