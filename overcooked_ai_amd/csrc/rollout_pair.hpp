@@ -237,7 +237,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_pair(const OcLayout* __restri
     if (!lane1) {
         uint4 h;
         h.x = s.pos | (s.ori << 8) | (s.held << 16) | (pos_o << 24);
-        h.y = ori_o | (held_o << 8) | (s.t << 16);
+        h.y = ori_o | (held_o << 8) | (min(s.t, 0xFFFFu) << 16);  // the wire format's u16 timestep saturates
         h.z = s.tk | (tk_o << 8);
         h.w = 0;
         st[e] = h;

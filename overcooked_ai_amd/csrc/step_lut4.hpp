@@ -189,7 +189,7 @@ template <int MAXP>
 __device__ __forceinline__ void store_env4(const LayC& C, const Lay L, uint4* __restrict__ st, int64_t n, int64_t e,
                                            int n_obj, int horizon, const Env4<MAXP>& s, uint32_t col) {
     uint4 h;
-    const uint32_t t = (uint32_t)horizon - 1u - s.tleft + s.over;
+    const uint32_t t = min((uint32_t)horizon - 1u - s.tleft + s.over, 0xFFFFu);  // the wire format's u16: saturates
     h.x = s.pos0 | (s.or0 << 8) | ((s.h0 & 0xFF00u) << 8) | (s.pos1 << 24);
     h.y = s.or1 | (s.h1 & 0xFF00u) | (t << 16);
     h.z = 0; h.w = 0;

@@ -278,7 +278,7 @@ __device__ __forceinline__ void store_env(const Lay L, uint4* __restrict__ st, i
                                           uint32_t n_pots, const EnvW<MAXP>& s, uint32_t* cellw) {
     uint4 h;
     h.x = s.pos0 | (s.or0 << 8) | (s.held0 << 16) | (s.pos1 << 24);
-    h.y = s.or1 | (s.held1 << 8) | (s.t << 16);
+    h.y = s.or1 | (s.held1 << 8) | (min(s.t, 0xFFFFu) << 16);  // the wire format's u16 timestep saturates
     h.z = 0; h.w = 0;
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {

@@ -15,6 +15,12 @@ MAX_HORIZON = 1e10
 
 
 class OvercookedEnv:
+    """The reference's OvercookedEnv surface (overcooked_env.py:33-405) over the HIP transition.
+
+    One difference in range: the packed state carries the timestep as a u16, so an episode can run for at most
+    65 535 steps (the reference's default horizon, 1e10, means "never done" there and "done at the packing limit"
+    here: step() raises ValueError at timestep 65 536; the batched kernels saturate the stored timestep instead)."""
+
     def __init__(self, mdp_generator_fn, start_state_fn=None, horizon=MAX_HORIZON, mlam_params=None, info_level=0,
                  num_mdp=1, initial_info={}):
         assert callable(mdp_generator_fn), (

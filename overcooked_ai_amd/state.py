@@ -427,7 +427,7 @@ def pack_state_dict(spec, state_dict, out, e):
         hdr[3] = 0xFF
     t = int(state_dict.get("timestep", 0))
     if not 0 <= t < 65536:
-        raise ValueError("timestep out of range")
+        raise ValueError("timestep %d does not fit the packed state (u16): episodes are limited to 65 535 steps" % t)
     hdr[6], hdr[7] = t & 0xFF, t >> 8
     objects = state_dict.get("objects", [])
     if isinstance(objects, dict):

@@ -999,3 +999,33 @@ def test_fused_step_encode_equals_step_then_encode(layout, gpu):
             assert torch.equal(a.state, b.state) and torch.equal(r1, r2) and torch.equal(f1, f2), (layout, random_starts, t)
             assert torch.equal(obs1, obs2) and torch.equal(a.ep_returns, b.ep_returns), (layout, random_starts, t)
         assert (f1 & 2).any() or True
+
+
+@pytest.mark.gpu
+def test_timestep_saturates_at_the_packing_limit(gpu):
+    """The packed state's timestep is a u16: an env that keeps stepping past 65 535 without a reset (no auto-reset, the
+    caller ignores `done`) stores 65 535 from then on instead of wrapping to 0 — every kernel family."""
+    from overcooked_ai_amd.layouts import spec_from_name
+
+    spec = spec_from_name("cramped_room")
+    n = 300
+    rng = np.random.default_rng(11)
+    st = random_packed_states(spec, n, rng)
+    st[0, :, 6], st[0, :, 7] = 0xFC, 0xFF  # timestep 65 532
+    for kernel in ("lane_per_env", "rollout_v3", "lane_pair", "predicate_interact", "step", "step_predicate"):
+        env = make_env(spec, n, gpu, horizon=65535, auto_reset=False, seed=2)
+        env.lane_per_env, env.lane_pair = kernel == "lane_per_env", kernel == "lane_pair"
+        env.predicate_interact = kernel in ("predicate_interact", "step_predicate")
+        env.rollout_v3 = kernel == "rollout_v3"
+        env.set_packed_state(st)
+        if kernel.startswith("step"):
+            for _ in range(12):
+                _, fl = env.step(torch.from_numpy(rng.integers(0, 6, size=(n, 2)).astype(np.uint8)).to(gpu))
+        else:
+            fl = torch.zeros((12, n), dtype=torch.uint8, device=gpu)
+            env.rollout_random(12, None, fl)
+            fl = fl[-1]
+        out = env.get_packed_state()
+        t = out[0, :, 6].astype(np.int64) | (out[0, :, 7].astype(np.int64) << 8)
+        assert (t == 65535).all(), (kernel, t[:8])
+        assert ((u8(fl) & 1) == 1).all(), kernel  # past the horizon: done every step
