@@ -21,36 +21,30 @@ class OvercookedEnv:
     65 535 steps (the reference's default horizon, 1e10, means "never done" there and "done at the packing limit"
     here: step() raises ValueError at timestep 65 536; the batched kernels saturate the stored timestep instead)."""
 
+    _CTOR_KEYS = ("start_state_fn", "horizon", "info_level", "num_mdp")  # what env_params / copy() carry over
+
     def __init__(self, mdp_generator_fn, start_state_fn=None, horizon=MAX_HORIZON, mlam_params=None, info_level=0,
                  num_mdp=1, initial_info={}):
-        assert callable(mdp_generator_fn), (
-            "OvercookedEnv takes in a OvercookedGridworld generator function. If trying to instantiate directly "
-            "from a OvercookedGridworld instance, use the OvercookedEnv.from_mdp method")
-        self.num_mdp = num_mdp
+        if not callable(mdp_generator_fn):
+            raise AssertionError("OvercookedEnv is built from a function that returns an OvercookedGridworld; to wrap "
+                                 "an existing OvercookedGridworld use OvercookedEnv.from_mdp")
+        self.mdp_generator_fn, self.mlam_params = mdp_generator_fn, mlam_params
+        self.start_state_fn, self.horizon, self.info_level, self.num_mdp = start_state_fn, horizon, info_level, num_mdp
         self.variable_mdp = num_mdp > 1
-        self.mdp_generator_fn = mdp_generator_fn
-        self.horizon = horizon
-        self.mlam_params = mlam_params
-        self.start_state_fn = start_state_fn
-        self.info_level = info_level
         self.reset(outside_info=initial_info)
 
     @staticmethod
     def from_mdp(mdp, start_state_fn=None, horizon=MAX_HORIZON, mlam_params=None, info_level=1, num_mdp=None):
-        assert isinstance(mdp, OvercookedGridworld)
-        if num_mdp is not None:
-            assert num_mdp == 1
-        return OvercookedEnv(mdp_generator_fn=lambda _ignored: mdp, start_state_fn=start_state_fn, horizon=horizon,
-                             mlam_params=mlam_params, info_level=info_level, num_mdp=1)
+        assert isinstance(mdp, OvercookedGridworld) and num_mdp in (None, 1)
+        return OvercookedEnv(lambda _outside_info: mdp, start_state_fn, horizon, mlam_params, info_level, 1)
 
     @property
     def env_params(self):
-        return {"start_state_fn": self.start_state_fn, "horizon": self.horizon, "info_level": self.info_level,
-                "num_mdp": self.num_mdp}
+        return {k: getattr(self, k) for k in self._CTOR_KEYS}
 
     def copy(self):
-        return OvercookedEnv(mdp_generator_fn=self.mdp_generator_fn, start_state_fn=self.start_state_fn,
-                             horizon=self.horizon, info_level=self.info_level, num_mdp=self.num_mdp)
+        """A fresh env (reset to a start state) over the same generator and parameters (env.py:236-242)."""
+        return OvercookedEnv(self.mdp_generator_fn, **self.env_params)
 
     # ---------------------------------------------------------------- stepping (API of env.py:244-325)
     def step(self, joint_action, joint_agent_action_info=None, display_phi=False):
@@ -75,16 +69,19 @@ class OvercookedEnv:
         return self.mdp.featurize_state(state, None, num_pots=num_pots, counter_goals=cg)
 
     def reset(self, regen_mdp=True, outside_info={}):
+        """New episode (env.py:288-319): optionally a new mdp from the generator, a start state, empty game_stats."""
         if regen_mdp:
             self.mdp = self.mdp_generator_fn(outside_info)
-        self.state = self.start_state_fn() if self.start_state_fn is not None else self.mdp.get_standard_start_state()
+        start = self.start_state_fn or self.mdp.get_standard_start_state
+        self.state = start()
         n = self.mdp.num_players
         self.game_stats = {name: [[] for _ in range(n)] for name in EVENT_TYPES}
         for key in ("cumulative_sparse_rewards_by_agent", "cumulative_shaped_rewards_by_agent"):
             self.game_stats[key] = np.zeros(n, dtype=np.int64)
 
     def is_done(self):
-        return self.state.timestep >= self.horizon or self.mdp.is_terminal(self.state)
+        out_of_time = self.state.timestep >= self.horizon
+        return out_of_time or self.mdp.is_terminal(self.state)
 
     def _prepare_info_dict(self, joint_agent_action_info, mdp_infos):
         """Per-step info: the keys of env.py:339-361."""

@@ -112,6 +112,13 @@ def test_batched_transitions_and_gym_wrapper():
         ob_main = base_env.lossless_state_encoding_mdp(obs["overcooked_state"])[env.agent_idx]
         assert np.array_equal(obs["both_agent_obs"][0], ob_main)
     assert n == 20 and info["episode"]["ep_length"] == 20 and info["episode"]["policy_agent_idx"] == env.agent_idx
+    # env_params / copy() (env.py:229-242): a copy is a fresh episode over the same generator and parameters
+    assert base_env.env_params == {"start_state_fn": None, "horizon": 20, "info_level": 0, "num_mdp": 1}
+    twin = base_env.copy()
+    assert twin.mdp is base_env.mdp and twin.horizon == 20 and twin.state.timestep == 0 and base_env.state.timestep == 20
+    assert twin.is_done() is False and base_env.is_done() is True
+    with pytest.raises(AssertionError):
+        OvercookedEnv(mdp)  # a gridworld instead of a generator function
 
 
 def test_featurize_state_api_matches_reference_golden():
