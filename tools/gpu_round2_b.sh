@@ -3,7 +3,7 @@
 # 1-rank RCCL smoke, the other BASELINE configs.  Everything lands in gpurun_out/r02b/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r02b
+O=$R/gpurun_out/${OUT_TAG:-r02b}
 mkdir -p $O
 cd $R
 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -2 $O/pytest_gpu.log
@@ -24,3 +24,4 @@ STEPS=400 bash tools/pmc_rollout.sh r02 > /dev/null 2>&1
 cp gpurun_out/pmc_r02.txt gpurun_out/sq_counters_r02.json $O/ 2>/dev/null
 ls -la $O
 head -c 600 $O/bench_driver_cmd.json
+timeout 240 python tools/soak.py --seeds 12 --envs 4096 --steps 500 > $O/soak.log 2>&1; echo "soak rc=$?" >> $O/soak.log; tail -3 $O/soak.log
