@@ -420,8 +420,8 @@ def run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
     if args.config == 3:
         env = VecOvercookedEnv("asymmetric_advantages", n, horizon=HORIZON, device=dev, auto_reset=True, seed=0,
                                env_offset=rank * n)
-        encode, workload, sbytes = True, ("asymmetric_advantages x %d envs/GPU, random policy (pre-sampled actions in HBM) + lossless "
-                                          "u8 encoding every step (oc_step_encode)" % n), S_ASYM
+        encode, workload, sbytes = True, ("asymmetric_advantages x %d envs/GPU, random policy (in-kernel Philox actions) + lossless u8 "
+                                          "encoding of every step into a [steps][envs] trajectory buffer (oc_rollout_encode)" % n), S_ASYM
     elif args.config == 4:
         names = ["cramped_room", "asymmetric_advantages", "coordination_ring", "forced_coordination", "counter_circuit"]
         table = LayoutTable([spec_from_name(nm) for nm in names], pad_to=(9, 5))
@@ -438,23 +438,19 @@ def run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
         env = VecOvercookedEnv(table, n, horizon=HORIZON, device=dev, auto_reset=True, seed=0, env_offset=rank * n,
                                layout_id=lid)
         workload, sbytes = "%d LayoutGenerator 9x5 terrains (reference generator, seed 0; env e -> terrain e %% %d) x %d envs/GPU, random policy" % (K, K, n), 36
-    fuse = 1 if encode else max(1, args.fuse)
+    # configs[2] (the rollout of configs[1] plus oc_encode_lossless every step): ENC_FUSE steps per launch, the
+    # observation of every step kept ([ENC_FUSE][n] u8 trajectory buffer: 7.7 GB at 65 536 9x5 envs)
+    ENC_FUSE = 50
+    fuse = ENC_FUSE if encode else max(1, args.fuse)
     rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
-    obs = torch.empty((n, 2, env.width, env.height, 26), dtype=torch.uint8, device=dev) if encode else None
-
-    if encode:
-        # configs[2]: per iteration one oc_step_encode call = the transition (pre-sampled uniform actions resident in HBM)
-        # + the lossless u8 observation of the resulting state, two kernels back to back
-        acts = torch.randint(0, 6, (256, n, 2), dtype=torch.uint8, device=dev)
-        counter = [0]
+    obs = torch.empty((fuse, n, 2, env.width, env.height, 26), dtype=torch.uint8, device=dev) if encode else None
 
     def launch():  # one `fuse`-step unit of the workload
-        if not encode:
+        if encode:
+            env.rollout_encode(fuse, obs, rew, fl)
+        else:
             env.rollout_random(fuse, rew, fl)
-            return
-        env.step_encode(acts[counter[0] % 256], torch.uint8, out=obs)
-        counter[0] += 1
 
     for _ in range(-(-args.warmup // fuse)):
         launch()
@@ -486,7 +482,22 @@ def run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
     tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
     sharding.allreduce_max(tmax)
     wall = float(tmax.item())
-    unit_bytes = n * (2 * sbytes + OUT_BYTES * fuse) + (n * (sbytes + 2 * env.width * env.height * 26) if encode else 0)
+    unit_bytes = n * (2 * sbytes + OUT_BYTES * fuse) + (fuse * n * 2 * env.width * env.height * 26 if encode else 0)
+    one_step = None
+    if encode:  # the same step with caller-supplied actions, one call per step (oc_step_encode: what a policy in the loop pays)
+        acts = torch.randint(0, 6, (64, n, 2), dtype=torch.uint8, device=dev)
+        ob1 = obs[0]
+        for i in range(20):
+            env.step_encode(acts[i % 64], torch.uint8, out=ob1)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for i in range(300):
+            env.step_encode(acts[i % 64], torch.uint8, out=ob1)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        us = ev0.elapsed_time(ev1) / 300 * 1e3
+        one_step = {"us_per_step": us, "value": n / us * 1e6, "unit": "env steps/s (one GPU)",
+                    "note": "oc_step_encode: caller-supplied actions resident in HBM, one C call per batched step"}
     out = {"metric": "env steps/sec (whole node)", "value": float(world) * n * total_steps / wall, "unit": "env steps/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / total_steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -497,6 +508,8 @@ def run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
                         "frac": unit_bytes / (unit_med * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "bytes_per_launch": unit_bytes, "launch_ms": unit_med,
                         "note": "algorithmic bytes of one %d-step unit (all its kernels) / its median duration from HIP events" % fuse}}
+    if one_step is not None:
+        out["caller_actions_one_step"] = one_step
     if rank == 0:
         emit(out)
     sharding.barrier()

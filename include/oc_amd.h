@@ -91,6 +91,10 @@ extern "C" {
 
 #define OC_OPT_ROLLOUT_V3 0x10u /* oc_rollout_random: the previous table-driven kernel (k_rollout3) instead of k_rollout4
                                   (kept for cross-checking) */
+#define OC_OPT_ONE_KERNEL 0x20u /* oc_rollout_encode / oc_step_encode: take the single-kernel path (k_rollout_encode)
+                                  whenever the table allows it; by default it runs only for batches that give every CU
+                                  a workgroup (it keeps 256 envs per CU on chip; smaller batches are faster through the
+                                  one-step kernels, whose observation kernel spreads over all CUs) */
 
 /* OcBatch.batch_flags */
 #define OC_BATCH_TWO_PLAYERS 0x1u /* every layout of the table has exactly 2 players */
@@ -263,14 +267,35 @@ int oc_encode_lossless(const OcBatch* batch, const void* d_state, void* d_obs, i
  * followed by oc_encode_lossless of the resulting states, i.e. the step of a training / evaluation loop that feeds the
  * lossless observation to a policy: OvercookedEnv.step (env.py:244) + lossless_state_encoding_mdp of the state the next
  * step starts from (env.py:276; human_aware_rl/rllib/rllib.py:257-260).  One C call enqueues the two kernels back to
- * back on `stream`.  (A single fused kernel — the workgroup that parked a group of envs in LDS steps them there and
- * builds their observation from the same copy — was built and measured on MI355X: 103 us vs 37 us for 65 536
- * asymmetric_advantages envs, because the latency-bound step then runs once per 16-env group on one wavefront while the
- * workgroup's other wavefronts wait)  Arguments as in oc_step / oc_encode_lossless.
+ * back on `stream`; with OC_OPT_ONE_KERNEL (and no `start`) it is oc_rollout_encode with n_steps = 1 — a wash for a
+ * single step (36.4 vs 37.2 us on 65 536 asymmetric_advantages envs, 25.1 vs 24.4 us on cramped_room), the gain of the
+ * single kernel comes with several steps per launch.  Arguments as in oc_step / oc_encode_lossless.
  */
 int oc_step_encode(const OcBatch* batch, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
                    float* d_ep_returns, void* d_obs, int obs_dtype, int horizon, uint32_t options,
                    const OcStartSpec* start, void* stream);
+
+/*
+ * oc_rollout_encode — n_steps transitions AND the lossless observation after each of them, in one call: BASELINE
+ * configs[2] (the rollout of configs[1] "plus oc_encode_lossless every step"), i.e. a trajectory of
+ * (reward, flag, observation) per step as a rollout collector (OvercookedEnv.run_agents / get_rollouts, env.py:425-580,
+ * over step 244 + lossless_state_encoding_mdp 276) gathers it.
+ *   d_actions  NULL: the uniform random policy, the Philox stream of oc_rollout_random (seed, env_offset, t0);
+ *              else [n_steps][n_envs][2] action indices as for oc_step_many (illegal: flagged, env untouched)
+ *   d_rewards  [n_steps][n_envs][4] / d_flags [n_steps][n_envs] (may be NULL with the random policy)
+ *   d_obs      observation of step k at (char*)d_obs + k * obs_step_stride: [n_envs][2][W][H][26] of obs_dtype, the state
+ *              the NEXT step starts from (after an auto-reset: the start state), exactly what oc_step_encode emits;
+ *              obs_step_stride in bytes, a multiple of 16; 0 = every step overwrites the same observation
+ *   options    OC_OPT_AUTO_RESET (standard start states), OC_OPT_ONE_KERNEL
+ * One layout, u8 observations, at most two pots, at least two steps and a batch that fills the GPU run as ONE kernel
+ * (k_rollout_encode: the env stays on chip for all steps, every wavefront encodes its own 64 envs through a private
+ * LDS image, no workgroup barrier in the step loop): 30 us per step on 65 536 asymmetric_advantages envs, the rate at
+ * which the observation bytes alone reach HBM (two one-step kernels: 37 us).  Any other case runs the one-step kernels
+ * step by step with identical results.
+ */
+int oc_rollout_encode(const OcBatch* batch, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
+                      float* d_ep_returns, void* d_obs, int obs_dtype, int64_t obs_step_stride, int horizon,
+                      uint32_t options, uint64_t seed, int64_t env_offset, int64_t t0, int n_steps, void* stream);
 
 /*
  * oc_featurize — the hand-crafted feature vector of both players.

@@ -13,13 +13,14 @@ OPT_LANE_PER_ENV = 0x2
 OPT_LANE_PAIR = 0x4
 OPT_PREDICATE_INTERACT = 0x8
 OPT_ROLLOUT_V3 = 0x10
+OPT_ONE_KERNEL = 0x20
 BATCH_TWO_PLAYERS = 0x1
 BATCH_NEW_DYNAMICS = 0x2
 OBS_U8, OBS_F32 = 0, 1
 
 EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_batch_hints", "oc_step", "oc_step_many",
            "oc_rollout_random",
-           "oc_encode_lossless", "oc_step_encode", "oc_featurize", "oc_potential", "oc_phi_table_size", "oc_reset", "oc_reset_random", "oc_shape_rewards", "oc_multi_agent_step")
+           "oc_encode_lossless", "oc_step_encode", "oc_rollout_encode", "oc_featurize", "oc_potential", "oc_phi_table_size", "oc_reset", "oc_reset_random", "oc_shape_rewards", "oc_multi_agent_step")
 
 
 class OcBatch(ctypes.Structure):
@@ -94,6 +95,8 @@ def load():
     L.oc_encode_lossless.argtypes = [bp, vp, vp, i32, i32, vp]
     L.oc_step_encode.restype = i32
     L.oc_step_encode.argtypes = [bp, vp, vp, vp, vp, vp, vp, i32, i32, u32, sp, vp]
+    L.oc_rollout_encode.restype = i32
+    L.oc_rollout_encode.argtypes = [bp, vp, vp, vp, vp, vp, vp, i32, i64, i32, u32, u64, i64, i64, i32, vp]
     L.oc_featurize.restype = i32
     L.oc_featurize.argtypes = [bp, vp, vp, vp, vp, i32, vp]
     L.oc_potential.restype = i32

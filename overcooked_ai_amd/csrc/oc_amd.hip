@@ -10,6 +10,7 @@
 //   rollout_pair.hpp    two lanes per env: k_rollout_pair
 //   reset.hpp           get_standard_start_state mdp.py:1297, get_random_start_state_fn 1307: k_reset, k_reset_random
 //   encode.hpp          lossless_state_encoding mdp.py:2385-2561: k_encode, k_encode_uniform
+//   rollout_encode.hpp  K transitions with the observation of every step in one launch: k_rollout_encode
 //   featurize.hpp       featurize_state mdp.py:2579-2898: k_featurize
 //   potential.hpp       potential_function mdp.py:2920-3238: k_potential, k_potential2
 //   shaping.hpp         OvercookedMultiAgent.step reward, rllib.py:306-329: k_shape_rewards
@@ -38,6 +39,7 @@ namespace {
 #include "step_lut4.hpp"
 #include "rollout_pair.hpp"
 #include "encode.hpp"
+#include "rollout_encode.hpp"
 #include "featurize.hpp"
 #include "potential.hpp"
 #include "shaping.hpp"
@@ -677,10 +679,85 @@ int oc_step_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions, fl
     StartArgs sa;
     if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_step_encode: start.rnd_obj_prob_thresh must be in [0, 1]");
     if (b->n_envs == 0) return OC_OK;
-    if (int rc = oc_step(b, d_state, d_state, d_actions, d_rewards, d_flags, d_ep_returns, nullptr, horizon, options, start,
-                         nullptr, stream))
+    if (!start && !(options & ~(uint32_t)(OC_OPT_AUTO_RESET | OC_OPT_ONE_KERNEL)))  // one kernel where that applies
+        return oc_rollout_encode(b, d_state, d_actions, d_rewards, d_flags, d_ep_returns, d_obs, obs_dtype, 0, horizon, options,
+                                 0, 0, 0, 1, stream);
+    if (int rc = oc_step(b, d_state, d_state, d_actions, d_rewards, d_flags, d_ep_returns, nullptr, horizon,
+                         options & ~(uint32_t)OC_OPT_ONE_KERNEL, start, nullptr, stream))
         return rc;
     return oc_encode_lossless(b, d_state, d_obs, obs_dtype, horizon, stream);
+}
+
+int oc_rollout_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
+                      float* d_ep_returns, void* d_obs, int obs_dtype, int64_t obs_step_stride, int horizon,
+                      uint32_t options, uint64_t seed, int64_t env_offset, int64_t t0, int n_steps, void* stream) {
+    int n_obj = 0;
+    if (int rc = check_batch(b, &n_obj)) return rc;
+    if (!d_state || !d_obs) return fail(OC_EINVAL, "oc_rollout_encode: NULL state / observation pointer");
+    if (obs_dtype != OC_OBS_U8 && obs_dtype != OC_OBS_F32) return fail(OC_EINVAL, "oc_rollout_encode: bad obs_dtype");
+    if (((uintptr_t)d_obs & 15u) != 0 || obs_step_stride < 0 || (obs_step_stride & 15) != 0)
+        return fail(OC_EINVAL, "oc_rollout_encode: d_obs and obs_step_stride must be multiples of 16 bytes");
+    if (horizon < 1 || horizon > 65535) return fail(OC_EINVAL, "oc_rollout_encode: horizon must be in 1..65535");
+    if (n_steps < 0 || n_steps > (1 << 30)) return fail(OC_EINVAL, "oc_rollout_encode: n_steps must be in 0..2^30");
+    if (options & ~(uint32_t)(OC_OPT_AUTO_RESET | OC_OPT_ONE_KERNEL))
+        return fail(OC_EINVAL, "oc_rollout_encode: options other than OC_OPT_AUTO_RESET / OC_OPT_ONE_KERNEL");
+    if (d_actions && (!d_rewards || !d_flags)) return fail(OC_EINVAL, "oc_rollout_encode: caller actions need the rewards and flags arrays");
+    if (b->n_envs == 0 || n_steps == 0) return OC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    // one layout, u8 observations, at most two pots: the whole trajectory in one launch (k_rollout_encode).  The LDS of
+    // a workgroup holds the cell words of its 256 envs, the template, the headers and one image per wavefront.
+    const int cells = b->width * b->height;
+    const size_t env_bytes = (size_t)2 * cells * OC_NUM_LAYERS;
+    // It keeps 256 envs per CU on chip and is bound by what one CU's four wavefronts can encode per step (~27 us for
+    // 9x5), so it pays once every CU has a workgroup: 30 us vs 37 us per step at 65 536 envs, but 27 us vs 18 us at 16 384
+    // (a single step is a wash against the two one-step kernels — 36.4 vs 37.2 us on 9x5, 25.1 vs 24.4 us on 5x4 — and
+    // stays with them unless OC_OPT_ONE_KERNEL asks)
+    const bool fills_gpu = b->n_envs >= (simd_count() / 4) * 192 && n_steps >= 2;
+    const uint32_t step_options = options & (uint32_t)OC_OPT_AUTO_RESET;
+    if ((fills_gpu || (options & OC_OPT_ONE_KERNEL)) && b->n_layouts == 1 && obs_dtype == OC_OBS_U8 && b->max_pots >= 1 &&
+        b->max_pots <= 2 && n_obj <= 3) {
+        int unit = 1;
+        while (((env_bytes * unit) & 15u) != 0) unit *= 2;  // 1, 2 or 4 envs per template
+        const size_t cell_bytes = (size_t)n_obj * 16 * BLOCK * sizeof(uint16_t);
+        const size_t fixed = cell_bytes + env_bytes * unit + (size_t)BLOCK * 16;
+        const size_t budget = 150 * 1024;
+        int gmax = fixed < budget ? (int)((budget - fixed) / (4 * env_bytes)) : 0;
+        if (gmax > 64) gmax = 64;
+        if (gmax >= unit) {
+            const int parts = (64 + gmax - 1) / gmax;           // sub-groups per wavefront, as even as the budget allows
+            int g = (64 + parts - 1) / parts;
+            g = (g + unit - 1) / unit * unit;
+            if (g > gmax) g = gmax / unit * unit;
+            const size_t smem = fixed + 4 * (size_t)g * env_bytes;
+            const bool fast = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0 && cells <= 64;
+            const dim3 grid(grid_for(b->n_envs)), block(BLOCK);
+#define GORE(FAST)                                                                                                     \
+    do {                                                                                                               \
+        if (!want_lds(k_rollout_encode<2, FAST>, smem)) break;                                                         \
+        hipLaunchKernelGGL((k_rollout_encode<2, FAST>), grid, block, smem, s, b->d_layouts, (uint4*)d_state, d_actions, \
+                           (float4*)d_rewards, d_flags, (float4*)d_ep_returns, (uint8_t*)d_obs, obs_step_stride,       \
+                           b->n_envs, b->width, b->height, n_obj, horizon, step_options, (uint32_t)seed,               \
+                           (uint32_t)(seed >> 32), env_offset, t0, n_steps, unit, g);                                  \
+    } while (0)
+            if (fast) GORE(3); else GORE(0);
+#undef GORE
+            return check_launch("oc_rollout_encode");
+        }
+    }
+    // every other table: the same result from the one-step kernels, step by step
+    for (int k = 0; k < n_steps; ++k) {
+        const int64_t off = (int64_t)k * b->n_envs;
+        int rc;
+        if (d_actions)
+            rc = oc_step(b, d_state, d_state, d_actions + 2 * off, d_rewards + 4 * off, d_flags + off, d_ep_returns, nullptr,
+                         horizon, step_options, nullptr, nullptr, stream);
+        else
+            rc = oc_rollout_random(b, d_state, d_rewards ? d_rewards + 4 * off : nullptr, d_flags ? d_flags + off : nullptr,
+                                   d_ep_returns, horizon, step_options, seed, env_offset, t0 + k, 1, nullptr, nullptr, stream);
+        if (rc) return rc;
+        if ((rc = oc_encode_lossless(b, d_state, (uint8_t*)d_obs + (int64_t)k * obs_step_stride, obs_dtype, horizon, stream))) return rc;
+    }
+    return OC_OK;
 }
 
 }  // extern "C"

@@ -42,6 +42,7 @@ class VecOvercookedEnv:
         self.lane_pair = False     # rollout_random: force the lane-pair kernel where the table allows it
         self.predicate_interact = False  # rollout_random: lane-per-env kernel with the predicate-network interact
         self.rollout_v3 = False          # rollout_random: k_rollout3 instead of k_rollout4 (cross-checks)
+        self.one_kernel = False          # step_encode / rollout_encode: the single-kernel path whatever the batch size
         self.seed = int(seed)
         self.env_offset = int(env_offset)
         self.t_global = 0  # global step counter feeding the Philox counter of rollout_random
@@ -198,8 +199,9 @@ class VecOvercookedEnv:
         return self.rewards, self.flags
 
     def step_encode(self, actions, dtype=torch.uint8, out=None):
-        """step(actions) followed by encode_lossless of the resulting states, as one C call (oc_step_encode: one fused
-        kernel for single two-player layouts with at most two pots).  Returns (rewards, flags, obs)."""
+        """step(actions) followed by encode_lossless of the resulting states, as one C call (oc_step_encode: one kernel
+        for a single layout with at most two pots, u8 observations and a batch that fills the GPU — or `one_kernel` —
+        else the two kernels back to back).  Returns (rewards, flags, obs)."""
         code = {torch.uint8: _lib.OBS_U8, torch.float32: _lib.OBS_F32}[dtype]
         if out is None:
             out = torch.empty((self.n_envs, 2, self.width, self.height, 26), dtype=dtype, device=self.device)
@@ -209,7 +211,8 @@ class VecOvercookedEnv:
                 or actions.device != self.state.device:
             raise ValueError("actions must be a contiguous uint8 [n_envs, 2] tensor on %s" % self.device)
         rc = self._launch(self.lib.oc_step_encode, self._bref, self._state_ptr, actions.data_ptr(), self._rewards_ptr,
-                          self._flags_ptr, self._ep_ptr, out.data_ptr(), code, self.horizon, self.options,
+                          self._flags_ptr, self._ep_ptr, out.data_ptr(), code, self.horizon,
+                          self.options | (_lib.OPT_ONE_KERNEL if self.one_kernel else 0),
                           self._start_spec() if self.auto_reset else None)
         _lib.check(rc, "oc_step_encode")
         self.steps_done += 1
@@ -253,6 +256,54 @@ class VecOvercookedEnv:
         self.t_global += int(n_steps)
         self.steps_done += int(n_steps)
         return rewards_out, flags_out
+
+    def rollout_encode(self, n_steps, obs_out, rewards_out=None, flags_out=None, actions=None, dtype=torch.uint8):
+        """n_steps transitions with the lossless observation after every step, one C call (oc_rollout_encode; a single
+        kernel for one layout / u8 / at most two pots).  actions: None = the random policy of rollout_random (same Philox
+        stream), or uint8 [n_steps, n_envs, 2].  obs_out: [n_steps, n_envs, 2, W, H, 26] (the whole trajectory) or
+        [n_envs, 2, W, H, 26] (every step overwrites it: only the last observation survives).  rewards_out float32
+        [n_steps, n_envs, 4] / flags_out uint8 [n_steps, n_envs] (required with caller actions)."""
+        K = int(n_steps)
+        code = {torch.uint8: _lib.OBS_U8, torch.float32: _lib.OBS_F32}[dtype]
+        per_step = self.n_envs * 2 * self.width * self.height * 26
+        if obs_out.dim() == 6:
+            self._check(obs_out, dtype, K * per_step, "obs_out")
+            stride = per_step * obs_out.element_size()
+        else:
+            self._check(obs_out, dtype, per_step, "obs_out")
+            stride = 0
+        if actions is not None:
+            self._check(actions, torch.uint8, K * self.n_envs * 2, "actions")
+        if rewards_out is not None:
+            self._check(rewards_out, torch.float32, K * self.n_envs * 4, "rewards_out")
+        if flags_out is not None:
+            self._check(flags_out, torch.uint8, K * self.n_envs, "flags_out")
+        if actions is not None and (rewards_out is None or flags_out is None):
+            raise ValueError("caller actions need rewards_out and flags_out")
+        if self.random_starts or stride % 16 != 0:  # drawn start states / odd strides: the one-step calls, step by step
+            for k in range(K):
+                obs_k = obs_out[k] if stride else obs_out
+                if actions is None:
+                    self.rollout_random(1, None if rewards_out is None else rewards_out[k:k + 1],
+                                        None if flags_out is None else flags_out[k:k + 1])
+                else:
+                    r, f = self.step(actions[k])
+                    rewards_out[k].copy_(r)
+                    flags_out[k].copy_(f)
+                self.encode_lossless(dtype, out=obs_k)
+            return obs_out, rewards_out, flags_out
+        rc = self._launch(self.lib.oc_rollout_encode, self._bref, self._state_ptr,
+                          actions.data_ptr() if actions is not None else None,
+                          rewards_out.data_ptr() if rewards_out is not None else None,
+                          flags_out.data_ptr() if flags_out is not None else None, self._ep_ptr, obs_out.data_ptr(), code,
+                          stride, self.horizon,
+                          (_lib.OPT_AUTO_RESET if self.auto_reset else 0) | (_lib.OPT_ONE_KERNEL if self.one_kernel else 0),
+                          self.seed, self.env_offset, self.t_global, K)
+        _lib.check(rc, "oc_rollout_encode")
+        if actions is None:
+            self.t_global += K
+        self.steps_done += K
+        return obs_out, rewards_out, flags_out
 
     def encode_lossless(self, dtype=torch.uint8, out=None, state=None):
         """[n_envs, 2, W, H, 26] observation (mdp.py:2385); out[:, i] is the encoding for player i."""

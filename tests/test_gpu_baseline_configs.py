@@ -73,6 +73,33 @@ def test_config2_asymmetric_advantages_step_plus_encoding(gpu):
     assert (fl_o >= 0).all() and np.array_equal(env.get_packed_state(), st)
 
 
+def test_config2_one_kernel_trajectory(gpu):
+    """bench.py --config 3 as it runs now: oc_rollout_encode (k_rollout_encode) at 65 536 asymmetric_advantages envs —
+    40 steps across the horizon in ONE launch, observations of all steps in a trajectory buffer; rewards, flags, final
+    state and sampled observations against the C oracle."""
+    from overcooked_ai_amd.layouts import spec_from_name
+
+    spec = spec_from_name("asymmetric_advantages")
+    orc = _oracle([spec])
+    env = _env(spec, gpu, horizon=400, seed=0)
+    st = orc.reset(orc.new_state(N))
+    st[0, :, 6] = 380 & 0xFF
+    st[0, :, 7] = 380 >> 8
+    env.set_packed_state(st)
+    K = 40
+    rew = torch.zeros((K, N, 4), dtype=torch.float32, device=gpu)
+    fl = torch.zeros((K, N), dtype=torch.uint8, device=gpu)
+    obs = torch.empty((K, N, 2, env.width, env.height, 26), dtype=torch.uint8, device=gpu)
+    env.rollout_encode(K, obs, rew, fl)
+    rew_h, fl_h = rew.cpu().numpy(), fl.cpu().numpy()
+    for it in range(K):
+        rew_o, fl_o = orc.rollout_random(st, 1, horizon=400, options=1, seed=0, t0=it)
+        assert np.array_equal(fl_h[it], fl_o[0]) and np.array_equal(rew_h[it], rew_o[0]), it
+        if it % 8 == 7 or it in (19, 20):
+            assert np.array_equal(obs[it].cpu().numpy().astype(np.int32), orc.encode_lossless(st, horizon=400)), it
+    assert (fl_h[19] & 4).all() and np.array_equal(env.get_packed_state(), st)
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_config3_five_layout_mix(kernel, gpu):
     """bench.py --config 4: 65 536 envs, env e -> layout e % 5 of the canonical five padded to 9x5."""

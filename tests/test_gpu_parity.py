@@ -981,6 +981,7 @@ def test_fused_step_encode_equals_step_then_encode(layout, gpu):
         kw = dict(random_start_pos=True, rnd_obj_prob_thresh=0.4) if random_starts else {}
         a = make_env(table, n, gpu, horizon=horizon, auto_reset=True, seed=6, layout_id=lid, **kw)
         b = make_env(table, n, gpu, horizon=horizon, auto_reset=True, seed=6, layout_id=lid, **kw)
+        a.one_kernel = True  # k_rollout_encode with one step where the table allows it (no drawn starts, u8)
         st = np.concatenate([random_packed_states(table.specs[l if lid is not None else 0], int(((lid == l).sum() if lid is not None else n)), rng,
                                                   timestep_max=horizon - 1) for l in (range(5) if lid is not None else [0])], axis=1)
         if lid is not None:  # envs of layout l in the order they appear
@@ -1029,3 +1030,79 @@ def test_timestep_saturates_at_the_packing_limit(gpu):
         t = out[0, :, 6].astype(np.int64) | (out[0, :, 7].astype(np.int64) << 8)
         assert (t == 65535).all(), (kernel, t[:8])
         assert ((u8(fl) & 1) == 1).all(), kernel  # past the horizon: done every step
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["cramped_room", "asymmetric_advantages", "counter_circuit", "coordination_ring",
+                                    "cramped_room_old_dynamics", "mixed", "seven_pots"])
+def test_rollout_with_observations_equals_the_one_step_kernels(layout, gpu):
+    """oc_rollout_encode (BASELINE configs[2]: K transitions and the lossless observation after every step in one call;
+    one kernel for single-layout / u8 / <= 2-pot batches, the one-step kernels step by step otherwise) == K x
+    (oc_rollout_random or oc_step, then oc_encode_lossless), bit for bit: per-step rewards, flags and observations, the
+    final state and episode returns — random policy and caller actions with illegal entries, across two horizons with
+    auto-reset, ragged batch (partly filled last wavefront, empty wavefronts), trajectory buffer and single buffer; the
+    first steps are also checked against the C oracle directly."""
+    from overcooked_ai_amd.layouts import LayoutSpec, LayoutTable, spec_from_name
+
+    n, horizon, K = 5004, 17, 40  # a multiple of 4 (16-byte observation rows), not of 64
+    lid = None
+    if layout == "mixed":
+        table = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+        lid = (np.arange(n) % 5).astype(np.uint16)
+    elif layout == "seven_pots":
+        table = LayoutTable([LayoutSpec({"grid": "\n".join(["XPPPPPX", "O 1 2 O", "X     X", "XDPSPTX"]), "onion_time": 3,
+                                         "tomato_time": 5, "onion_value": 7, "tomato_value": 4})])
+    elif layout == "cramped_room_old_dynamics":
+        table = LayoutTable([spec_from_name("cramped_room", old_dynamics=True)])
+    else:
+        table = LayoutTable([spec_from_name(layout)])
+    rng = np.random.default_rng(9)
+    st = np.concatenate([random_packed_states(table.specs[l if lid is not None else 0], int(((lid == l).sum() if lid is not None else n)), rng,
+                                              timestep_max=horizon - 1) for l in (range(5) if lid is not None else [0])], axis=1)
+    if lid is not None:
+        order = np.argsort(np.argsort(lid, kind="stable"), kind="stable")
+        st = st[:, order]
+    W, H = table.width, table.height
+    for mode in ("random", "actions", "single_buffer"):
+        a = make_env(table, n, gpu, horizon=horizon, auto_reset=True, seed=21, layout_id=lid)
+        b = make_env(table, n, gpu, horizon=horizon, auto_reset=True, seed=21, layout_id=lid)
+        a.one_kernel = True  # the batch is far too small to pick k_rollout_encode by itself
+        a.set_packed_state(st)
+        b.set_packed_state(st)
+        acts = None
+        if mode == "actions":
+            acts_np = rng.integers(0, 6, size=(K, n, 2)).astype(np.uint8)
+            acts_np[rng.integers(0, K, size=30), rng.integers(0, n, size=30), rng.integers(0, 2, size=30)] = 9
+            acts = torch.from_numpy(acts_np).to(gpu)
+        obs_b = torch.zeros((K, n, 2, W, H, 26), dtype=torch.uint8, device=gpu)
+        rew_b = torch.zeros((K, n, 4), dtype=torch.float32, device=gpu)
+        fl_b = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
+        for k in range(K):
+            if acts is None:
+                b.rollout_random(1, rew_b[k:k + 1], fl_b[k:k + 1])
+            else:
+                r, f = b.step(acts[k])
+                rew_b[k].copy_(r)
+                fl_b[k].copy_(f)
+            b.encode_lossless(torch.uint8, out=obs_b[k])
+        rew_a = torch.full((K, n, 4), -1.0, dtype=torch.float32, device=gpu)
+        fl_a = torch.full((K, n), 0xEE, dtype=torch.uint8, device=gpu)
+        if mode == "single_buffer":
+            obs_a = torch.full((n + 64, 2, W, H, 26), 0xAB, dtype=torch.uint8, device=gpu)  # + guard rows
+            a.rollout_encode(K, obs_a[:n], rew_a, fl_a)
+            assert torch.equal(obs_a[:n], obs_b[-1]), (layout, mode)
+            assert (obs_a[n:] == 0xAB).all(), (layout, mode, "write past the observation")
+        else:
+            obs_a = torch.full((K, n, 2, W, H, 26), 0xAB, dtype=torch.uint8, device=gpu)
+            a.rollout_encode(K, obs_a, rew_a, fl_a, actions=acts)
+            for k in range(K):
+                assert torch.equal(obs_a[k], obs_b[k]), (layout, mode, k)
+        assert torch.equal(rew_a, rew_b) and torch.equal(fl_a, fl_b), (layout, mode)
+        assert torch.equal(a.state, b.state) and torch.equal(a.ep_returns, b.ep_returns), (layout, mode)
+        assert (u8(fl_a) & 4).any(), "no auto-reset inside the window"
+        if mode == "random":  # the oracle itself on the first steps
+            orc = oracle_for(table.specs)
+            st_o = st.copy()
+            for k in range(6):
+                orc.rollout_random(st_o, 1, horizon=horizon, options=1, seed=21, t0=k, layout_id=lid, want_outputs=False)
+                assert np.array_equal(u8(obs_a[k]).astype(np.int32), orc.encode_lossless(st_o, horizon=horizon, layout_id=lid)), (layout, k)
