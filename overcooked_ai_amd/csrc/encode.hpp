@@ -31,6 +31,26 @@ __device__ __forceinline__ void enc_object_layers(T* item, uint32_t o, bool in_p
     else if (o == OC_O_TOMATO) item[24] = (T)1;
 }
 
+// The same layers without branches: four stores whatever the object is.  Unused ones store 0 into layers 20 / 21,
+// which no other object of the same cell can own (a cell holds at most one object; a player stands on a floor cell,
+// which holds none).  A wavefront executes the union of its lanes' paths, so this is what the scatter loops call.
+//   soup idle in a pot:  [16] = onions, [17] = tomatoes                       (mdp.py:2490-2497)
+//   any other soup:      [18] = onions, [19] = tomatoes, [20] = time left (cooking in a pot), [21] = done (2499-2525)
+//   dish / onion / tomato: [22] / [23] / [24] = 1                            (2527-2534)
+template <typename T>
+__device__ __forceinline__ void enc_object_writes(T* item, uint32_t o, bool in_pot, uint32_t tk, uint32_t ct) {
+    const bool soup = (o & OC_O_SOUP) != 0u;
+    const uint32_t n = (o >> 3) & 3u, nt = __popc(o & 7u), no = n - nt;
+    const bool idle = soup & in_pot & (tk == 0u);
+    const bool hot = soup & !idle;
+    const uint32_t first = soup ? (idle ? 16u : 18u) : (o == OC_O_DISH ? 22u : o == OC_O_ONION ? 23u : 24u);
+    item[first] = (T)(soup ? no : 1u);
+    item[soup ? first + 1u : 20u] = (T)(soup ? nt : 0u);
+    const uint32_t ticks = tk - 1u;
+    item[20] = (T)((hot & in_pot) ? ct - ticks : 0u);
+    item[21] = (T)(hot ? (in_pot ? (ticks >= ct ? 1u : 0u) : 1u) : 0u);
+}
+
 template <typename T, bool LAY_LDS>
 __global__ __launch_bounds__(BLOCK) void k_encode(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                   const uint16_t* __restrict__ layout_id,
@@ -188,7 +208,6 @@ __global__ __launch_bounds__(BLOCK) void k_encode_uniform(const OcLayout* __rest
 
     const int64_t n_groups = (n + epg - 1) / epg;
     const int obj_dwords = (n_planes - 1) * 4;
-    const int tasks_per_env = obj_dwords + 2;
     for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const int64_t e0 = g * epg;
         const int ne = (int)min((int64_t)epg, n - e0);
@@ -205,43 +224,40 @@ __global__ __launch_bounds__(BLOCK) void k_encode_uniform(const OcLayout* __rest
             s_state[(i % ne) * n_planes + (i / ne)] = st[(int64_t)(i / ne) * n + e0 + (i % ne)];
         __syncthreads();
 
-        // dynamic values: players, objects
-        for (int q = threadIdx.x; q < ne * tasks_per_env; q += BLOCK) {
-            const int le = q / tasks_per_env;
-            const int j = q - le * tasks_per_env;
+        // dynamic values.  A wavefront executes the union of its lanes' paths: players and objects run in separate
+        // loops and an object's layers are written without branches (enc_object_writes).
+        for (int t = threadIdx.x; t < 2 * ne; t += BLOCK) {  // players (mdp.py:2468-2479, ordering 2423-2434)
+            const int le = t >> 1, pl = t & 1;
             const uint8_t* se = reinterpret_cast<const uint8_t*>(s_state + le * n_planes);
-            T* env_img = img + (size_t)le * items_per_env * OC_NUM_LAYERS;
-            if (j < obj_dwords) {
-                const uint32_t w = reinterpret_cast<const uint32_t*>(se + 16)[j];
-                if (w != 0u) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const uint32_t o = (w >> (8 * b)) & 0xFFu;
-                        if (o) {
-                            const uint32_t c = 4u * (uint32_t)j + (uint32_t)b;
-                            const uint32_t y = (c * inv_w) >> 16, x = c - y * (uint32_t)W, i = x * (uint32_t)H + y;
-                            const uint32_t tc = L.terrain(c);
-                            const bool in_pot = (tc & 7u) == OC_T_POT;
-                            uint32_t tk = 0, ct = 0;
-                            if (in_pot) { tk = se[8 + (tc >> 3)]; ct = L.cook_time(recipe_idx(o)); }
-                            enc_object_layers<T>(env_img + (size_t)i * OC_NUM_LAYERS, o, in_pot, tk, ct);
-                            enc_object_layers<T>(env_img + ((size_t)cells + i) * OC_NUM_LAYERS, o, in_pot, tk, ct);
-                        }
-                    }
-                }
-            } else {
-                const int pl = j - obj_dwords;
-                const uint32_t pos = se[3 * pl], ori = se[3 * pl + 1], held = se[3 * pl + 2];
-                if (pos != 0xFFu) {
-                    const uint32_t y = (pos * inv_w) >> 16, x = pos - y * (uint32_t)W, i = x * (uint32_t)H + y;
-#pragma unroll
-                    for (int v = 0; v < 2; ++v) {
-                        T* item = env_img + ((size_t)v * cells + i) * OC_NUM_LAYERS;
-                        const int k = (pl == v) ? 0 : 1;  // the view's own player comes first (mdp.py:2422-2434)
-                        item[k] = (T)1;
-                        item[2 + 4 * k + ori] = (T)1;
-                        if (held) enc_object_layers<T>(item, held, false, 0u, 0u);
-                    }
+            const uint32_t pos = se[3 * pl], ori = se[3 * pl + 1], held = se[3 * pl + 2];
+            if (pos != 0xFFu) {
+                const uint32_t y = (pos * inv_w) >> 16, x = pos - y * (uint32_t)W, i = x * (uint32_t)H + y;
+                T* own = img + ((size_t)le * items_per_env + (size_t)pl * cells + i) * OC_NUM_LAYERS;
+                T* other = img + ((size_t)le * items_per_env + (size_t)(1 - pl) * cells + i) * OC_NUM_LAYERS;
+                own[0] = (T)1; own[2 + ori] = (T)1;
+                other[1] = (T)1; other[6 + ori] = (T)1;
+                if (held) { enc_object_writes<T>(own, held, false, 0u, 0u); enc_object_writes<T>(other, held, false, 0u, 0u); }
+            }
+        }
+        for (int q = threadIdx.x; q < ne * obj_dwords; q += BLOCK) {  // objects on the grid (mdp.py:2482-2534)
+            const int le = q / obj_dwords;
+            const int j = q - le * obj_dwords;
+            const uint8_t* se = reinterpret_cast<const uint8_t*>(s_state + le * n_planes);
+            uint32_t w = reinterpret_cast<const uint32_t*>(se + 16)[j];
+            if (w != 0u) {
+                T* env_img = img + (size_t)le * items_per_env * OC_NUM_LAYERS;
+                while (w != 0u) {
+                    const uint32_t b4 = (uint32_t)(__ffs((int)w) - 1) >> 3;  // lowest non-empty cell of the dword
+                    const uint32_t o = (w >> (8u * b4)) & 0xFFu;
+                    w &= ~(0xFFu << (8u * b4));
+                    const uint32_t c = 4u * (uint32_t)j + b4;
+                    const uint32_t y = (c * inv_w) >> 16, x = c - y * (uint32_t)W, i = x * (uint32_t)H + y;
+                    const uint32_t tc = L.terrain(c);
+                    const bool in_pot = (tc & 7u) == OC_T_POT;
+                    const uint32_t tk = se[8 + (tc >> 3)];
+                    const uint32_t ct = L.cook_time(recipe_idx(o) & 15u);
+                    enc_object_writes<T>(env_img + (size_t)i * OC_NUM_LAYERS, o, in_pot, tk, ct);
+                    enc_object_writes<T>(env_img + ((size_t)cells + i) * OC_NUM_LAYERS, o, in_pot, tk, ct);
                 }
             }
         }

@@ -21,25 +21,6 @@
 // both well under the time HBM needs for the observation bytes (9x5: 153 MB per step), which is what bounds the loop.
 // Actions: Philox (the stream of oc_rollout_random) or caller-supplied [K][n][2].
 // ------------------------------------------------------------------------------------------
-// The object layers of one item (26 bytes of one cell of one view), as enc_object_layers writes them, without branches:
-// four byte stores whatever the object is.  Unused ones store 0 into layers 20 / 21, which no other object of the same
-// cell can own (a cell holds at most one object; a player stands on a floor cell, which holds none).
-//   soup idle in a pot:  [16] = onions, [17] = tomatoes                       (mdp.py:2490-2497)
-//   any other soup:      [18] = onions, [19] = tomatoes, [20] = time left (cooking in a pot), [21] = done (2499-2525)
-//   dish / onion / tomato: [22] / [23] / [24] = 1                            (2527-2534)
-__device__ __forceinline__ void enc_object_writes(uint8_t* item, uint32_t o, bool in_pot, uint32_t tk, uint32_t ct) {
-    const bool soup = (o & OC_O_SOUP) != 0u;
-    const uint32_t n = (o >> 3) & 3u, nt = __popc(o & 7u), no = n - nt;
-    const bool idle = soup & in_pot & (tk == 0u);
-    const bool hot = soup & !idle;
-    const uint32_t first = soup ? (idle ? 16u : 18u) : (o == OC_O_DISH ? 22u : o == OC_O_ONION ? 23u : 24u);
-    item[first] = (uint8_t)(soup ? no : 1u);
-    item[soup ? first + 1u : 20u] = (uint8_t)(soup ? nt : 0u);
-    const uint32_t ticks = tk - 1u;
-    item[20] = (uint8_t)((hot & in_pot) ? ct - ticks : 0u);
-    item[21] = (uint8_t)(hot ? (in_pot ? (ticks >= ct ? 1u : 0u) : 1u) : 0u);
-}
-
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -201,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_encode(const OcLayout* __rest
                     T* other = imgT + ((size_t)le * items_per_env + (size_t)(1 - pl) * cells_n + i) * OC_NUM_LAYERS;  // the other view
                     own[0] = (T)1; own[2 + ori] = (T)1;
                     other[1] = (T)1; other[6 + ori] = (T)1;
-                    if (held) { enc_object_writes(own, held, false, 0u, 0u); enc_object_writes(other, held, false, 0u, 0u); }
+                    if (held) { enc_object_writes<T>(own, held, false, 0u, 0u); enc_object_writes<T>(other, held, false, 0u, 0u); }
                 }
             }
             // objects on the grid (mdp.py:2482-2534): lane = (env, object dword), slots of 8 or 16 dwords per env
@@ -227,8 +208,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_encode(const OcLayout* __rest
                                 const bool in_pot = (tc & 7u) == OC_T_POT;
                                 const uint32_t tk = (tkw >> (8u * ((tc >> 3) & 3u))) & 0xFFu;
                                 const uint32_t ct = L.cook_time(recipe_idx(o) & 15u);
-                                enc_object_writes(env_img + (size_t)i * OC_NUM_LAYERS, o, in_pot, tk, ct);
-                                enc_object_writes(env_img + ((size_t)cells_n + i) * OC_NUM_LAYERS, o, in_pot, tk, ct);
+                                enc_object_writes<T>(env_img + (size_t)i * OC_NUM_LAYERS, o, in_pot, tk, ct);
+                                enc_object_writes<T>(env_img + ((size_t)cells_n + i) * OC_NUM_LAYERS, o, in_pot, tk, ct);
                             }
                         }
                     }
