@@ -281,8 +281,9 @@ class VecOvercookedEnv:
         if actions is not None and (rewards_out is None or flags_out is None):
             raise ValueError("caller actions need rewards_out and flags_out")
         if self.random_starts or stride % 16 != 0:  # drawn start states / odd strides: the one-step calls, step by step
+            tmp = torch.empty_like(obs_out[0]) if stride % 16 != 0 else None  # rows of odd sizes: encode into an aligned buffer
             for k in range(K):
-                obs_k = obs_out[k] if stride else obs_out
+                obs_k = tmp if tmp is not None else (obs_out[k] if stride else obs_out)
                 if actions is None:
                     self.rollout_random(1, None if rewards_out is None else rewards_out[k:k + 1],
                                         None if flags_out is None else flags_out[k:k + 1])
@@ -291,6 +292,8 @@ class VecOvercookedEnv:
                     rewards_out[k].copy_(r)
                     flags_out[k].copy_(f)
                 self.encode_lossless(dtype, out=obs_k)
+                if tmp is not None:
+                    obs_out[k].copy_(tmp)
             return obs_out, rewards_out, flags_out
         rc = self._launch(self.lib.oc_rollout_encode, self._bref, self._state_ptr,
                           actions.data_ptr() if actions is not None else None,

@@ -1106,3 +1106,37 @@ def test_rollout_with_observations_equals_the_one_step_kernels(layout, gpu):
             for k in range(6):
                 orc.rollout_random(st_o, 1, horizon=horizon, options=1, seed=21, t0=k, layout_id=lid, want_outputs=False)
                 assert np.array_equal(u8(obs_a[k]).astype(np.int32), orc.encode_lossless(st_o, horizon=horizon, layout_id=lid)), (layout, k)
+
+
+@pytest.mark.gpu
+def test_rollout_with_observations_edge_sizes(gpu):
+    """k_rollout_encode on batches that leave wavefronts empty or partly filled (1, 63, 65, 257 envs), without auto-reset
+    past the horizon, and without reward / flag outputs."""
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    rng = np.random.default_rng(13)
+    for layout, n in (("cramped_room", 1), ("cramped_room", 63), ("asymmetric_advantages", 68), ("cramped_room", 257),
+                      ("coordination_ring", 260), ("coordination_ring", 257)):  # (257 x 1300 B rows: the step-by-step path)
+        table = LayoutTable([spec_from_name(layout)])
+        st = random_packed_states(table.specs[0], n, rng, timestep_max=9)
+        W, H, K = table.width, table.height, 14
+        for auto_reset, outputs in ((True, True), (False, True), (True, False)):
+            a = make_env(table, n, gpu, horizon=10, auto_reset=auto_reset, seed=5)
+            b = make_env(table, n, gpu, horizon=10, auto_reset=auto_reset, seed=5)
+            a.one_kernel = True
+            a.set_packed_state(st)
+            b.set_packed_state(st)
+            obs_a = torch.full((K, n, 2, W, H, 26), 0xAB, dtype=torch.uint8, device=gpu)
+            obs_b = torch.zeros_like(obs_a)
+            rew_a = torch.zeros((K, n, 4), dtype=torch.float32, device=gpu) if outputs else None
+            fl_a = torch.zeros((K, n), dtype=torch.uint8, device=gpu) if outputs else None
+            rew_b = torch.zeros((K, n, 4), dtype=torch.float32, device=gpu)
+            fl_b = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
+            a.rollout_encode(K, obs_a, rew_a, fl_a)
+            for k in range(K):
+                b.rollout_random(1, rew_b[k:k + 1], fl_b[k:k + 1])
+                obs_b[k].copy_(b.encode_lossless(torch.uint8))
+            assert torch.equal(obs_a, obs_b) and torch.equal(a.state, b.state), (layout, n, auto_reset, outputs)
+            assert torch.equal(a.ep_returns, b.ep_returns), (layout, n, auto_reset, outputs)
+            if outputs:
+                assert torch.equal(rew_a, rew_b) and torch.equal(fl_a, fl_b), (layout, n, auto_reset)
