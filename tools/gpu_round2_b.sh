@@ -19,22 +19,9 @@ rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch -- python3 $R/bench.py --gpu
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o write -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_write.log 2>&1
 python $R/tools/summarize_prof.py $O $O/r02_driver_cmd_rocprof.txt > /dev/null 2>$O/summarize.err
 rm -rf $O/trace $O/pmc_fetch $O/pmc_write
-# configs[2] through oc_rollout_encode: kernel trace + WRITE_SIZE of the same command
+# configs[2] through oc_rollout_encode: kernel trace of the same command (WRITE_SIZE wraps on its multi-GB launches: not collected)
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c3trace -o c3 -- python3 $R/bench.py --config 3 --steps 400 --warmup 400 > $O/bench_config3_trace.log 2>&1
 find /tmp/c3trace -name "*kernel_stats.csv" -exec cp {} $O/r02_config3_kernel_stats.csv \;
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/c3write -o c3w -- python3 $R/bench.py --config 3 --steps 400 --warmup 400 > $O/bench_config3_write.log 2>&1
-python3 - <<'PY' > $O/r02_config3_write_size.txt 2>&1
-import csv, glob, collections
-tot = collections.defaultdict(lambda: [0, 0.0])
-for f in glob.glob("/tmp/c3write/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if r.get("Counter_Name") == "WRITE_SIZE":
-            k = r["Kernel_Name"].split("(")[0]
-            tot[k][0] += 1
-            tot[k][1] += float(r["Counter_Value"])
-for k, (c, v) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:6]:
-    print("%-80s dispatches %6d  WRITE_SIZE mean %.1f KiB = %.1f MB per dispatch" % (k[:80], c, v / c, v / c * 1024 / 1e6))
-PY
 cd $R
 STEPS=400 bash tools/pmc_rollout.sh r02 > /dev/null 2>&1
 cp gpurun_out/pmc_r02.txt gpurun_out/sq_counters_r02.json $O/ 2>/dev/null
