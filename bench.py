@@ -508,6 +508,24 @@ def run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
                         "frac": unit_bytes / (unit_med * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "bytes_per_launch": unit_bytes, "launch_ms": unit_med,
                         "note": "algorithmic bytes of one %d-step unit (all its kernels) / its median duration from HIP events" % fuse}}
+    if encode:  # the f32 variant of the observation (what the reference's RLlib wrapper casts to): 10 steps per launch
+        del obs
+        K32 = 10
+        obs32 = torch.empty((K32, n, 2, env.width, env.height, 26), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            env.rollout_encode(K32, obs32, rew[:K32], fl[:K32], dtype=torch.float32)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(20):
+            env.rollout_encode(K32, obs32, rew[:K32], fl[:K32], dtype=torch.float32)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        us = ev0.elapsed_time(ev1) / (20 * K32) * 1e3
+        b32 = n * 2 * env.width * env.height * 26 * 4
+        out["f32_observations"] = {"us_per_step": us, "value": n / us * 1e6, "unit": "env steps/s (one GPU)",
+                                   "achieved_GBs": b32 / us / 1e3, "frac": b32 / us / 1e3 / HBM_PEAK_GBS,
+                                   "note": "oc_rollout_encode with f32 observations, %d steps per launch into a [steps][envs] buffer" % K32}
+        del obs32
     if one_step is not None:
         out["caller_actions_one_step"] = one_step
     if rank == 0:

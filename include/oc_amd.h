@@ -287,7 +287,7 @@ int oc_step_encode(const OcBatch* batch, void* d_state, const uint8_t* d_actions
  *              the NEXT step starts from (after an auto-reset: the start state), exactly what oc_step_encode emits;
  *              obs_step_stride in bytes, a multiple of 16; 0 = every step overwrites the same observation
  *   options    OC_OPT_AUTO_RESET (standard start states), OC_OPT_ONE_KERNEL
- * One layout, u8 observations, at most two pots, at least two steps and a batch that fills the GPU run as ONE kernel
+ * One layout, at most two pots, at least two steps and a batch that fills the GPU run as ONE kernel
  * (k_rollout_encode: the env stays on chip for all steps, every wavefront encodes its own 64 envs through a private
  * LDS image, no workgroup barrier in the step loop): 30 us per step on 65 536 asymmetric_advantages envs, the rate at
  * which the observation bytes alone reach HBM (two one-step kernels: 37 us).  Any other case runs the one-step kernels

@@ -708,15 +708,14 @@ int oc_rollout_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions,
     // one layout, u8 observations, at most two pots: the whole trajectory in one launch (k_rollout_encode).  The LDS of
     // a workgroup holds the cell words of its 256 envs, the template, the headers and one image per wavefront.
     const int cells = b->width * b->height;
-    const size_t env_bytes = (size_t)2 * cells * OC_NUM_LAYERS;
+    const size_t env_bytes = (size_t)2 * cells * OC_NUM_LAYERS * (obs_dtype == OC_OBS_U8 ? 1 : 4);
     // It keeps 256 envs per CU on chip and is bound by what one CU's four wavefronts can encode per step (~27 us for
     // 9x5), so it pays once every CU has a workgroup: 30 us vs 37 us per step at 65 536 envs, but 27 us vs 18 us at 16 384
     // (a single step is a wash against the two one-step kernels — 36.4 vs 37.2 us on 9x5, 25.1 vs 24.4 us on 5x4 — and
     // stays with them unless OC_OPT_ONE_KERNEL asks)
     const bool fills_gpu = b->n_envs >= (simd_count() / 4) * 192 && n_steps >= 2;
     const uint32_t step_options = options & (uint32_t)OC_OPT_AUTO_RESET;
-    if ((fills_gpu || (options & OC_OPT_ONE_KERNEL)) && b->n_layouts == 1 && obs_dtype == OC_OBS_U8 && b->max_pots >= 1 &&
-        b->max_pots <= 2 && n_obj <= 3) {
+    if ((fills_gpu || (options & OC_OPT_ONE_KERNEL)) && b->n_layouts == 1 && b->max_pots >= 1 && b->max_pots <= 2 && n_obj <= 3) {
         int unit = 1;
         while (((env_bytes * unit) & 15u) != 0) unit *= 2;  // 1, 2 or 4 envs per template
         const size_t cell_bytes = (size_t)n_obj * 16 * BLOCK * sizeof(uint16_t);
@@ -732,15 +731,16 @@ int oc_rollout_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions,
             const size_t smem = fixed + 4 * (size_t)g * env_bytes;
             const bool fast = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0 && cells <= 64;
             const dim3 grid(grid_for(b->n_envs)), block(BLOCK);
-#define GORE(FAST)                                                                                                     \
+#define GORE(FAST, T)                                                                                                  \
     do {                                                                                                               \
-        if (!want_lds(k_rollout_encode<2, FAST>, smem)) break;                                                         \
-        hipLaunchKernelGGL((k_rollout_encode<2, FAST>), grid, block, smem, s, b->d_layouts, (uint4*)d_state, d_actions, \
-                           (float4*)d_rewards, d_flags, (float4*)d_ep_returns, (uint8_t*)d_obs, obs_step_stride,       \
-                           b->n_envs, b->width, b->height, n_obj, horizon, step_options, (uint32_t)seed,               \
-                           (uint32_t)(seed >> 32), env_offset, t0, n_steps, unit, g);                                  \
+        if (!want_lds(k_rollout_encode<2, FAST, T>, smem)) break;                                                      \
+        hipLaunchKernelGGL((k_rollout_encode<2, FAST, T>), grid, block, smem, s, b->d_layouts, (uint4*)d_state,        \
+                           d_actions, (float4*)d_rewards, d_flags, (float4*)d_ep_returns, (uint8_t*)d_obs,             \
+                           obs_step_stride, b->n_envs, b->width, b->height, n_obj, horizon, step_options,              \
+                           (uint32_t)seed, (uint32_t)(seed >> 32), env_offset, t0, n_steps, unit, g);                  \
     } while (0)
-            if (fast) GORE(3); else GORE(0);
+            if (obs_dtype == OC_OBS_U8) { if (fast) GORE(3, uint8_t); else GORE(0, uint8_t); }
+            else { if (fast) GORE(3, float); else GORE(0, float); }
 #undef GORE
             return check_launch("oc_rollout_encode");
         }

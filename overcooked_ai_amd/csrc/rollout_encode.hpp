@@ -5,7 +5,7 @@
 // ------------------------------------------------------------------------------------------
 // k_rollout_encode: BASELINE configs[2] as SURVEY.md 8d-3 states it — the rollout of configs[1] (in-kernel Philox
 // actions, auto-reset, rewards / flags every step) plus lossless_state_encoding (mdp.py:2385-2561) of every env after
-// every step, for a batch with ONE layout and u8 observations.
+// every step, for a batch with ONE layout (u8 or f32 observations).
 //
 // One launch of a one-step kernel is a ~6 us latency chain and the observation kernel has ~6 us of fill time of its
 // own; stepping inside the persistent observation kernel once per 19-env group was measured slower.
@@ -27,16 +27,15 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int MAXP, int FAST>
+template <int MAXP, int FAST, typename T>
 __global__ __launch_bounds__(BLOCK) void k_rollout_encode(const OcLayout* __restrict__ g_layouts, uint4* st,
                                                           const uint8_t* __restrict__ actions,
                                                           float4* __restrict__ rewards, uint8_t* __restrict__ flags,
-                                                          float4* __restrict__ ep_returns, uint8_t* __restrict__ obs,
+                                                          float4* __restrict__ ep_returns, uint8_t* __restrict__ obs_bytes,
                                                           int64_t obs_step_stride, int64_t n, int W, int H, int n_obj,
                                                           int horizon, uint32_t options, uint32_t seed_lo,
                                                           uint32_t seed_hi, int64_t env_offset, int64_t t0, int n_steps,
                                                           int unit, int group_envs) {
-    typedef uint8_t T;
     extern __shared__ __attribute__((aligned(16))) uint16_t s_cells3[];  // [n_obj * 16][BLOCK], then template / headers / images
     __shared__ uint4 s_lay[16];
     __shared__ uint2 s_lut[2 * LUT_ENTRIES];
@@ -158,7 +157,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_encode(const OcLayout* __rest
         wave_fence();
 
         // ---- lossless_state_encoding of this wavefront's envs, G at a time through its private LDS image
-        uint8_t* obs_k = obs + (int64_t)k * obs_step_stride;
+        uint8_t* obs_k = obs_bytes + (int64_t)k * obs_step_stride;
         for (int l0 = 0; l0 < n_wave; l0 += group_envs) {
             const int ne = min(group_envs, n_wave - l0);
             const int n_units = (ne + unit - 1) / unit;

@@ -1140,3 +1140,30 @@ def test_rollout_with_observations_edge_sizes(gpu):
             assert torch.equal(a.ep_returns, b.ep_returns), (layout, n, auto_reset, outputs)
             if outputs:
                 assert torch.equal(rew_a, rew_b) and torch.equal(fl_a, fl_b), (layout, n, auto_reset)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["cramped_room", "asymmetric_advantages", "counter_circuit"])
+def test_rollout_with_float32_observations(layout, gpu):
+    """k_rollout_encode<float>: the f32 observation of every step == oc_encode_lossless(f32) after each one-step call."""
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    n, horizon, K = 1000, 11, 25
+    table = LayoutTable([spec_from_name(layout)])
+    rng = np.random.default_rng(17)
+    st = random_packed_states(table.specs[0], n, rng, timestep_max=horizon - 1)
+    W, H = table.width, table.height
+    a = make_env(table, n, gpu, horizon=horizon, auto_reset=True, seed=3)
+    b = make_env(table, n, gpu, horizon=horizon, auto_reset=True, seed=3)
+    a.one_kernel = True
+    a.set_packed_state(st)
+    b.set_packed_state(st)
+    obs_a = torch.full((K, n, 2, W, H, 26), -7.0, dtype=torch.float32, device=gpu)
+    rew_a = torch.zeros((K, n, 4), dtype=torch.float32, device=gpu)
+    fl_a = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
+    a.rollout_encode(K, obs_a, rew_a, fl_a, dtype=torch.float32)
+    rew_b, fl_b = torch.zeros_like(rew_a), torch.zeros_like(fl_a)
+    for k in range(K):
+        b.rollout_random(1, rew_b[k:k + 1], fl_b[k:k + 1])
+        assert torch.equal(obs_a[k], b.encode_lossless(torch.float32)), (layout, k)
+    assert torch.equal(rew_a, rew_b) and torch.equal(fl_a, fl_b) and torch.equal(a.state, b.state)
