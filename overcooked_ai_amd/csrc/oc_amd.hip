@@ -721,26 +721,41 @@ int oc_rollout_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions,
         const size_t cell_bytes = (size_t)n_obj * 16 * BLOCK * sizeof(uint16_t);
         const size_t fixed = cell_bytes + env_bytes * unit + (size_t)BLOCK * 16;
         const size_t budget = 150 * 1024;
-        int gmax = fixed < budget ? (int)((budget - fixed) / (4 * env_bytes)) : 0;
+        // eight wavefronts (four of them helpers that only encode) when eight images of at least 8 envs fit: small grids,
+        // where four wavefronts cannot encode 256 envs in the time HBM takes them (5x4 u8: 14.4 vs 17.4 us per step); 9x5
+        // is at the write ceiling either way (30.1 vs 30.4 us), f32 loses with one-env images (128 vs 117 us)
+        static const int forced_nw = []() { const char* e = getenv("OC_ROLLOUT_ENCODE_WAVES"); return e ? atoi(e) : 0; }();  // tuning runs
+        int nw = 8;
+        int gmax = fixed < budget ? (int)((budget - fixed) / (nw * env_bytes)) : 0;
+        if (((gmax < 8 || gmax < unit) && forced_nw != 8) || forced_nw == 4) {
+            nw = 4;
+            gmax = fixed < budget ? (int)((budget - fixed) / (nw * env_bytes)) : 0;
+        }
         if (gmax > 64) gmax = 64;
         if (gmax >= unit) {
-            const int parts = (64 + gmax - 1) / gmax;           // sub-groups per wavefront, as even as the budget allows
-            int g = (64 + parts - 1) / parts;
+            const int span = nw == 8 ? 32 : 64;                  // envs one wavefront encodes per step
+            const int parts = (span + gmax - 1) / gmax;          // its sub-groups, as even as the budget allows
+            int g = (span + parts - 1) / parts;
             g = (g + unit - 1) / unit * unit;
             if (g > gmax) g = gmax / unit * unit;
-            const size_t smem = fixed + 4 * (size_t)g * env_bytes;
+            const size_t smem = fixed + (size_t)nw * g * env_bytes;
             const bool fast = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0 && cells <= 64;
-            const dim3 grid(grid_for(b->n_envs)), block(BLOCK);
-#define GORE(FAST, T)                                                                                                  \
+            const dim3 grid(grid_for(b->n_envs));
+#define GORE(FAST, T, NW)                                                                                              \
     do {                                                                                                               \
-        if (!want_lds(k_rollout_encode<2, FAST, T>, smem)) break;                                                      \
-        hipLaunchKernelGGL((k_rollout_encode<2, FAST, T>), grid, block, smem, s, b->d_layouts, (uint4*)d_state,        \
-                           d_actions, (float4*)d_rewards, d_flags, (float4*)d_ep_returns, (uint8_t*)d_obs,             \
-                           obs_step_stride, b->n_envs, b->width, b->height, n_obj, horizon, step_options,              \
-                           (uint32_t)seed, (uint32_t)(seed >> 32), env_offset, t0, n_steps, unit, g);                  \
+        if (!want_lds(k_rollout_encode<2, FAST, T, NW>, smem)) break;                                                  \
+        hipLaunchKernelGGL((k_rollout_encode<2, FAST, T, NW>), grid, dim3(NW * 64), smem, s, b->d_layouts,             \
+                           (uint4*)d_state, d_actions, (float4*)d_rewards, d_flags, (float4*)d_ep_returns,             \
+                           (uint8_t*)d_obs, obs_step_stride, b->n_envs, b->width, b->height, n_obj, horizon,           \
+                           step_options, (uint32_t)seed, (uint32_t)(seed >> 32), env_offset, t0, n_steps, unit, g);    \
     } while (0)
-            if (obs_dtype == OC_OBS_U8) { if (fast) GORE(3, uint8_t); else GORE(0, uint8_t); }
-            else { if (fast) GORE(3, float); else GORE(0, float); }
+#define GORE_T(FAST, NW)                                                                                               \
+    do {                                                                                                               \
+        if (obs_dtype == OC_OBS_U8) GORE(FAST, uint8_t, NW); else GORE(FAST, float, NW);                               \
+    } while (0)
+            if (nw == 8) { if (fast) GORE_T(3, 8); else GORE_T(0, 8); }
+            else { if (fast) GORE_T(3, 4); else GORE_T(0, 4); }
+#undef GORE_T
 #undef GORE
             return check_launch("oc_rollout_encode");
         }

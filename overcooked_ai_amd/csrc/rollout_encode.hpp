@@ -16,8 +16,8 @@
 //   * per sub-group of G envs: copy the static-layer template into the wavefront's private LDS image (16-byte moves),
 //     scatter the dynamic values (one task per player and per non-empty object dword, as in k_encode_uniform), stream
 //     the image to its place in obs[step] as contiguous 16-byte stores.
-// No workgroup barrier in the step loop: LDS operations of one wavefront execute in order, so the phases need only a
-// compiler-level fence.  The transition costs ~1 300 clk per step, the observation of 64 envs ~10 000 clk of issue —
+// No workgroup barrier between the phases: LDS operations of one wavefront execute in order, so they need only a
+// compiler-level fence.  (NW = 8 adds four helper wavefronts that share the encoding, with two barriers per step.)  The transition costs ~1 300 clk per step, the observation of 64 envs ~10 000 clk of issue —
 // both well under the time HBM needs for the observation bytes (9x5: 153 MB per step), which is what bounds the loop.
 // Actions: Philox (the stream of oc_rollout_random) or caller-supplied [K][n][2].
 // ------------------------------------------------------------------------------------------
@@ -27,8 +27,8 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int MAXP, int FAST, typename T>
-__global__ __launch_bounds__(BLOCK) void k_rollout_encode(const OcLayout* __restrict__ g_layouts, uint4* st,
+template <int MAXP, int FAST, typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void k_rollout_encode(const OcLayout* __restrict__ g_layouts, uint4* st,
                                                           const uint8_t* __restrict__ actions,
                                                           float4* __restrict__ rewards, uint8_t* __restrict__ flags,
                                                           float4* __restrict__ ep_returns, uint8_t* __restrict__ obs_bytes,
@@ -40,6 +40,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_encode(const OcLayout* __rest
     __shared__ uint4 s_lay[16];
     __shared__ uint2 s_lut[2 * LUT_ENTRIES];
     __shared__ uint8_t s_move[FAST == 3 ? 64 * 8 : 8];
+    __shared__ uint64_t s_urgent[4];  // (NW = 8) per owner wavefront: which of its envs are in their last 40 steps
+    static_assert(NW == 4 || NW == 8, "four owner wavefronts, optionally four helpers");
     const int cells_n = W * H;
     const int items_per_env = 2 * cells_n;
     const size_t env_bytes = (size_t)items_per_env * OC_NUM_LAYERS * sizeof(T);
@@ -53,8 +55,12 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_encode(const OcLayout* __rest
     T* tmpl = reinterpret_cast<T*>(s_tmpl);
     const uint32_t inv_w = 65536u / (uint32_t)W + 1u;
 
-    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const bool active = e < n;
+    // NW = 8: lanes 256..511 are four helper wavefronts.  They own no env; wavefront 4 + w encodes every other sub-group
+    // of owner wavefront w's envs (between two workgroup barriers per step), halving what a wavefront does per step.
+    const bool owner = NW == 4 || threadIdx.x < BLOCK;
+    const int ow = wave & 3, part = wave >> 2;
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + (threadIdx.x & (BLOCK - 1));
+    const bool active = owner && e < n;
     // caller actions: the first step's are requested before the tables are staged, step k + 1's while step k is encoded
     uint32_t a01_next = (actions && active && n_steps > 0) ? reinterpret_cast<const uint16_t*>(actions)[e] : 0u;
     for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
@@ -85,12 +91,12 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_encode(const OcLayout* __rest
             base[((size_t)cells_n + i) * OC_NUM_LAYERS + layer] = (T)1;
         }
     }
-    __syncthreads();  // the last workgroup barrier: from here on every wavefront runs by itself
-    const int64_t wave_e0 = (int64_t)blockIdx.x * BLOCK + (int64_t)wave * 64;
-    const int n_wave = (int)max((int64_t)0, min((int64_t)64, n - wave_e0));  // envs of this wavefront
-    if (n_wave == 0) return;
+    __syncthreads();  // NW = 4: the last workgroup barrier, from here on every wavefront runs by itself
+    const int64_t wave_e0 = (int64_t)blockIdx.x * BLOCK + (int64_t)ow * 64;
+    const int n_wave = (int)max((int64_t)0, min((int64_t)64, n - wave_e0));  // envs of the owner wavefront
+    if (NW == 4 && n_wave == 0) return;
 
-    uint16_t* cells = s_cells3 + threadIdx.x;
+    uint16_t* cells = s_cells3 + (threadIdx.x & (BLOCK - 1));
     const LayC C = load_consts<true>(L);
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut) + (C.old_dyn ? LUT_ENTRIES * 8 : 0);
     const uint32_t delta4 = make_delta4(W);
@@ -107,8 +113,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_encode(const OcLayout* __rest
     uint32_t rnd[4] = {0, 0, 0, 0};
     const int obj_dwords = n_obj * 4;
     const int tasks_per_env = obj_dwords + 2;
-    const uint16_t* wcells = s_cells3 + wave * 64;  // cell c of the wavefront's env l: wcells[c * BLOCK + l]
-    const uint4* whdr = s_hdr + wave * 64;
+    const uint16_t* wcells = s_cells3 + ow * 64;  // cell c of the owner wavefront's env l: wcells[c * BLOCK + l]
+    const uint4* whdr = s_hdr + ow * 64;
 
     for (int k = 0; k < n_steps; ++k) {
         // ---- the transition (get_state_transition + OvercookedEnv.step bookkeeping), as k_rollout3 / k_step3 do it
@@ -153,12 +159,18 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_encode(const OcLayout* __rest
             s_hdr[threadIdx.x] = h;
             urgent = (horizon - (int)s.t) < 40;
         }
-        const uint64_t urgent_mask = __ballot(urgent);
-        wave_fence();
+        uint64_t urgent_mask = __ballot(urgent);
+        if (NW == 8) {
+            if (owner && lane == 0) s_urgent[ow] = urgent_mask;
+            __syncthreads();  // the step's cell words and headers are in LDS for the helpers
+            urgent_mask = s_urgent[ow];
+        } else {
+            wave_fence();
+        }
 
         // ---- lossless_state_encoding of this wavefront's envs, G at a time through its private LDS image
         uint8_t* obs_k = obs_bytes + (int64_t)k * obs_step_stride;
-        for (int l0 = 0; l0 < n_wave; l0 += group_envs) {
+        for (int l0 = part * group_envs; l0 < n_wave; l0 += (NW / 4) * group_envs) {
             const int ne = min(group_envs, n_wave - l0);
             const int n_units = (ne + unit - 1) / unit;
             for (int i = lane; i < unit_chunks; i += 64) {
@@ -247,6 +259,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_encode(const OcLayout* __rest
                     reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(img) + (size_t)n16 * 16)[lane];
             wave_fence();
         }
+        if (NW == 8) __syncthreads();  // the helpers are done reading before the next step writes
     }
     if (active) {
         store_env3<MAXP>(C, L, st, n, e, n_obj, s, cells);
