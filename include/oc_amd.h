@@ -286,7 +286,8 @@ int oc_step_encode(const OcBatch* batch, void* d_state, const uint8_t* d_actions
  *   d_obs      observation of step k at (char*)d_obs + k * obs_step_stride: [n_envs][2][W][H][26] of obs_dtype, the state
  *              the NEXT step starts from (after an auto-reset: the start state), exactly what oc_step_encode emits;
  *              obs_step_stride in bytes, a multiple of 16; 0 = every step overwrites the same observation
- *   options    OC_OPT_AUTO_RESET (standard start states), OC_OPT_ONE_KERNEL
+ *   options    OC_OPT_AUTO_RESET, OC_OPT_ONE_KERNEL;  start: as for oc_rollout_random (NULL = standard start states; a
+ *              restart at step k draws from epoch start->epoch + k)
  * One layout, at most two pots, at least two steps and a batch that fills the GPU run as ONE kernel
  * (k_rollout_encode: the env stays on chip for all steps, every wavefront encodes its own 64 envs through a private
  * LDS image, no workgroup barrier in the step loop): 30 us per step on 65 536 asymmetric_advantages envs, the rate at
@@ -295,7 +296,8 @@ int oc_step_encode(const OcBatch* batch, void* d_state, const uint8_t* d_actions
  */
 int oc_rollout_encode(const OcBatch* batch, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
                       float* d_ep_returns, void* d_obs, int obs_dtype, int64_t obs_step_stride, int horizon,
-                      uint32_t options, uint64_t seed, int64_t env_offset, int64_t t0, int n_steps, void* stream);
+                      uint32_t options, uint64_t seed, int64_t env_offset, int64_t t0, int n_steps,
+                      const OcStartSpec* start, void* stream);
 
 /*
  * oc_featurize — the hand-crafted feature vector of both players.

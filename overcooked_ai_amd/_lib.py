@@ -96,7 +96,7 @@ def load():
     L.oc_step_encode.restype = i32
     L.oc_step_encode.argtypes = [bp, vp, vp, vp, vp, vp, vp, i32, i32, u32, sp, vp]
     L.oc_rollout_encode.restype = i32
-    L.oc_rollout_encode.argtypes = [bp, vp, vp, vp, vp, vp, vp, i32, i64, i32, u32, u64, i64, i64, i32, vp]
+    L.oc_rollout_encode.argtypes = [bp, vp, vp, vp, vp, vp, vp, i32, i64, i32, u32, u64, i64, i64, i32, sp, vp]
     L.oc_featurize.restype = i32
     L.oc_featurize.argtypes = [bp, vp, vp, vp, vp, i32, vp]
     L.oc_potential.restype = i32

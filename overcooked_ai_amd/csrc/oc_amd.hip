@@ -682,7 +682,7 @@ int oc_step_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions, fl
     if (b->n_envs == 0) return OC_OK;
     if (!start && !(options & ~(uint32_t)(OC_OPT_AUTO_RESET | OC_OPT_ONE_KERNEL)))  // one kernel where that applies
         return oc_rollout_encode(b, d_state, d_actions, d_rewards, d_flags, d_ep_returns, d_obs, obs_dtype, 0, horizon, options,
-                                 0, 0, 0, 1, stream);
+                                 0, 0, 0, 1, nullptr, stream);
     if (int rc = oc_step(b, d_state, d_state, d_actions, d_rewards, d_flags, d_ep_returns, nullptr, horizon,
                          options & ~(uint32_t)OC_OPT_ONE_KERNEL, start, nullptr, stream))
         return rc;
@@ -691,9 +691,12 @@ int oc_step_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions, fl
 
 int oc_rollout_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags,
                       float* d_ep_returns, void* d_obs, int obs_dtype, int64_t obs_step_stride, int horizon,
-                      uint32_t options, uint64_t seed, int64_t env_offset, int64_t t0, int n_steps, void* stream) {
+                      uint32_t options, uint64_t seed, int64_t env_offset, int64_t t0, int n_steps,
+                      const OcStartSpec* start, void* stream) {
     int n_obj = 0;
     if (int rc = check_batch(b, &n_obj)) return rc;
+    StartArgs sa;
+    if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_rollout_encode: start.rnd_obj_prob_thresh must be in [0, 1]");
     if (!d_state || !d_obs) return fail(OC_EINVAL, "oc_rollout_encode: NULL state / observation pointer");
     if (obs_dtype != OC_OBS_U8 && obs_dtype != OC_OBS_F32) return fail(OC_EINVAL, "oc_rollout_encode: bad obs_dtype");
     if (((uintptr_t)d_obs & 15u) != 0 || obs_step_stride < 0 || (obs_step_stride & 15) != 0)
@@ -747,7 +750,7 @@ int oc_rollout_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions,
         hipLaunchKernelGGL((k_rollout_encode<2, FAST, T, NW>), grid, dim3(NW * 64), smem, s, b->d_layouts,             \
                            (uint4*)d_state, d_actions, (float4*)d_rewards, d_flags, (float4*)d_ep_returns,             \
                            (uint8_t*)d_obs, obs_step_stride, b->n_envs, b->width, b->height, n_obj, horizon,           \
-                           step_options, (uint32_t)seed, (uint32_t)(seed >> 32), env_offset, t0, n_steps, unit, g);    \
+                           step_options, (uint32_t)seed, (uint32_t)(seed >> 32), env_offset, t0, n_steps, unit, g, sa); \
     } while (0)
 #define GORE_T(FAST, NW)                                                                                               \
     do {                                                                                                               \
@@ -763,13 +766,16 @@ int oc_rollout_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions,
     // every other table: the same result from the one-step kernels, step by step
     for (int k = 0; k < n_steps; ++k) {
         const int64_t off = (int64_t)k * b->n_envs;
+        OcStartSpec sk;
+        if (start) { sk = *start; sk.epoch = start->epoch + (uint32_t)k; }  // a restart at step k draws from epoch + k
+        const OcStartSpec* spk = start ? &sk : nullptr;
         int rc;
         if (d_actions)
             rc = oc_step(b, d_state, d_state, d_actions + 2 * off, d_rewards + 4 * off, d_flags + off, d_ep_returns, nullptr,
-                         horizon, step_options, nullptr, nullptr, stream);
+                         horizon, step_options, spk, nullptr, stream);
         else
             rc = oc_rollout_random(b, d_state, d_rewards ? d_rewards + 4 * off : nullptr, d_flags ? d_flags + off : nullptr,
-                                   d_ep_returns, horizon, step_options, seed, env_offset, t0 + k, 1, nullptr, nullptr, stream);
+                                   d_ep_returns, horizon, step_options, seed, env_offset, t0 + k, 1, spk, nullptr, stream);
         if (rc) return rc;
         if ((rc = oc_encode_lossless(b, d_state, (uint8_t*)d_obs + (int64_t)k * obs_step_stride, obs_dtype, horizon, stream))) return rc;
     }

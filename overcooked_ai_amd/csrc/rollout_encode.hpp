@@ -35,7 +35,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_encode(const OcLayout* __re
                                                           int64_t obs_step_stride, int64_t n, int W, int H, int n_obj,
                                                           int horizon, uint32_t options, uint32_t seed_lo,
                                                           uint32_t seed_hi, int64_t env_offset, int64_t t0, int n_steps,
-                                                          int unit, int group_envs) {
+                                                          int unit, int group_envs, StartArgs sa) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_cells3[];  // [n_obj * 16][BLOCK], then template / headers / images
     __shared__ uint4 s_lay[16];
     __shared__ uint2 s_lut[2 * LUT_ENTRIES];
@@ -109,7 +109,6 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_encode(const OcLayout* __re
     const uint64_t floor_mask = FAST == 2 ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull;
     const uint64_t g = (uint64_t)(env_offset + e);
     const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
-    const StartArgs no_sa = {0, 0, 0, 0, 0, 0, 0};
     uint32_t rnd[4] = {0, 0, 0, 0};
     const int obj_dwords = n_obj * 4;
     const int tasks_per_env = obj_dwords + 2;
@@ -140,7 +139,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_encode(const OcLayout* __re
                 fl = OC_F_BAD_ACTION;  // mdp.py:1394-1398 raises: the env stays untouched
             } else {
                 env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask, s_move);
-                fl = finish_step3<MAXP>(C, L, n_obj, cells, s, horizon, options, r, ep, no_sa, 0, 0);
+                fl = finish_step3<MAXP>(C, L, n_obj, cells, s, horizon, options, r, ep, sa, g, sa.epoch + (uint32_t)k);
             }
             if (rewards) rewards[(int64_t)k * n + e] = r;
             if (flags) flags[(int64_t)k * n + e] = (uint8_t)fl;

@@ -280,7 +280,7 @@ class VecOvercookedEnv:
             self._check(flags_out, torch.uint8, K * self.n_envs, "flags_out")
         if actions is not None and (rewards_out is None or flags_out is None):
             raise ValueError("caller actions need rewards_out and flags_out")
-        if self.random_starts or stride % 16 != 0:  # drawn start states / odd strides: the one-step calls, step by step
+        if stride % 16 != 0:  # rows of odd sizes: the one-step calls, step by step
             tmp = torch.empty_like(obs_out[0]) if stride % 16 != 0 else None  # rows of odd sizes: encode into an aligned buffer
             for k in range(K):
                 obs_k = tmp if tmp is not None else (obs_out[k] if stride else obs_out)
@@ -301,7 +301,7 @@ class VecOvercookedEnv:
                           flags_out.data_ptr() if flags_out is not None else None, self._ep_ptr, obs_out.data_ptr(), code,
                           stride, self.horizon,
                           (_lib.OPT_AUTO_RESET if self.auto_reset else 0) | (_lib.OPT_ONE_KERNEL if self.one_kernel else 0),
-                          self.seed, self.env_offset, self.t_global, K)
+                          self.seed, self.env_offset, self.t_global, K, self._start_spec() if self.auto_reset else None)
         _lib.check(rc, "oc_rollout_encode")
         if actions is None:
             self.t_global += K

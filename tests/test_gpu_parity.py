@@ -1167,3 +1167,44 @@ def test_rollout_with_float32_observations(layout, gpu):
         b.rollout_random(1, rew_b[k:k + 1], fl_b[k:k + 1])
         assert torch.equal(obs_a[k], b.encode_lossless(torch.float32)), (layout, k)
     assert torch.equal(rew_a, rew_b) and torch.equal(fl_a, fl_b) and torch.equal(a.state, b.state)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["cramped_room", "asymmetric_advantages", "mixed"])
+def test_rollout_with_observations_and_drawn_start_states(layout, gpu):
+    """oc_rollout_encode with an OcStartSpec (the env's start_state_fn = get_random_start_state_fn, mdp.py:1307-1369):
+    restarts inside the launch draw the same states as the one-step kernels do (epoch = spec.epoch + step index)."""
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    n, horizon, K = 3000, 9, 30
+    lid = None
+    if layout == "mixed":
+        table = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+        lid = (np.arange(n) % 5).astype(np.uint16)
+    else:
+        table = LayoutTable([spec_from_name(layout)])
+    W, H = table.width, table.height
+    kw = dict(horizon=horizon, auto_reset=True, seed=8, layout_id=lid, random_start_pos=True, rnd_obj_prob_thresh=0.5)
+    rng = np.random.default_rng(2)
+    for with_actions in (False, True):
+        a, b = make_env(table, n, gpu, **kw), make_env(table, n, gpu, **kw)
+        a.one_kernel = True
+        a.reset()
+        b.reset()
+        assert torch.equal(a.state, b.state)
+        acts = torch.from_numpy(rng.integers(0, 6, size=(K, n, 2)).astype(np.uint8)).to(gpu) if with_actions else None
+        obs_a = torch.full((K, n, 2, W, H, 26), 0xAB, dtype=torch.uint8, device=gpu)
+        rew_a = torch.zeros((K, n, 4), dtype=torch.float32, device=gpu)
+        fl_a = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
+        a.rollout_encode(K, obs_a, rew_a, fl_a, actions=acts)
+        rew_b, fl_b = torch.zeros_like(rew_a), torch.zeros_like(fl_a)
+        for k in range(K):
+            if acts is None:
+                b.rollout_random(1, rew_b[k:k + 1], fl_b[k:k + 1])
+            else:
+                r, f = b.step(acts[k])
+                rew_b[k].copy_(r)
+                fl_b[k].copy_(f)
+            assert torch.equal(obs_a[k], b.encode_lossless(torch.uint8)), (layout, with_actions, k)
+        assert torch.equal(rew_a, rew_b) and torch.equal(fl_a, fl_b) and torch.equal(a.state, b.state), (layout, with_actions)
+        assert (u8(fl_a) & 4).sum() >= 3 * n, "several restarts per env inside the launch"
