@@ -210,6 +210,9 @@ class VecOvercookedEnv:
         if actions.dtype != torch.uint8 or actions.shape != (self.n_envs, 2) or not actions.is_contiguous() \
                 or actions.device != self.state.device:
             raise ValueError("actions must be a contiguous uint8 [n_envs, 2] tensor on %s" % self.device)
+        if self.event_counts is not None:  # per-episode event counters ride on oc_step's OcEventSink
+            r, f = self.step(actions)
+            return r, f, self.encode_lossless(dtype, out=out)
         rc = self._launch(self.lib.oc_step_encode, self._bref, self._state_ptr, actions.data_ptr(), self._rewards_ptr,
                           self._flags_ptr, self._ep_ptr, out.data_ptr(), code, self.horizon,
                           self.options | (_lib.OPT_ONE_KERNEL if self.one_kernel else 0),
@@ -262,7 +265,8 @@ class VecOvercookedEnv:
         kernel for one layout / u8 / at most two pots).  actions: None = the random policy of rollout_random (same Philox
         stream), or uint8 [n_steps, n_envs, 2].  obs_out: [n_steps, n_envs, 2, W, H, 26] (the whole trajectory) or
         [n_envs, 2, W, H, 26] (every step overwrites it: only the last observation survives).  rewards_out float32
-        [n_steps, n_envs, 4] / flags_out uint8 [n_steps, n_envs] (required with caller actions)."""
+        [n_steps, n_envs, 4] / flags_out uint8 [n_steps, n_envs] (required with caller actions).  With track_events the
+        one-step calls run step by step (the event counters ride on their OcEventSink)."""
         K = int(n_steps)
         code = {torch.uint8: _lib.OBS_U8, torch.float32: _lib.OBS_F32}[dtype]
         per_step = self.n_envs * 2 * self.width * self.height * 26
@@ -280,8 +284,8 @@ class VecOvercookedEnv:
             self._check(flags_out, torch.uint8, K * self.n_envs, "flags_out")
         if actions is not None and (rewards_out is None or flags_out is None):
             raise ValueError("caller actions need rewards_out and flags_out")
-        if stride % 16 != 0:  # rows of odd sizes: the one-step calls, step by step
-            tmp = torch.empty_like(obs_out[0]) if stride % 16 != 0 else None  # rows of odd sizes: encode into an aligned buffer
+        if stride % 16 != 0 or self.event_counts is not None:  # rows of odd sizes / event counters: the one-step calls, step by step
+            tmp = torch.empty_like(obs_out[0]) if stride and stride % 16 != 0 else None  # rows of odd sizes: encode into an aligned buffer
             for k in range(K):
                 obs_k = tmp if tmp is not None else (obs_out[k] if stride else obs_out)
                 if actions is None:

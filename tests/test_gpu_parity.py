@@ -1208,3 +1208,25 @@ def test_rollout_with_observations_and_drawn_start_states(layout, gpu):
             assert torch.equal(obs_a[k], b.encode_lossless(torch.uint8)), (layout, with_actions, k)
         assert torch.equal(rew_a, rew_b) and torch.equal(fl_a, fl_b) and torch.equal(a.state, b.state), (layout, with_actions)
         assert (u8(fl_a) & 4).sum() >= 3 * n, "several restarts per env inside the launch"
+
+
+@pytest.mark.gpu
+def test_event_counters_follow_step_encode_and_rollout_encode(gpu):
+    """track_events: step_encode / rollout_encode keep the per-episode event counters exactly as step / rollout_random do."""
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    table = LayoutTable([spec_from_name("cramped_room")])
+    n, K = 2048, 40
+    kw = dict(horizon=25, auto_reset=True, seed=4, track_events=True)
+    a, b = make_env(table, n, gpu, **kw), make_env(table, n, gpu, **kw)
+    obs = torch.empty((K, n, 2, table.width, table.height, 26), dtype=torch.uint8, device=gpu)
+    a.rollout_encode(K, obs)
+    b.rollout_random(K)
+    assert torch.equal(a.state, b.state) and torch.equal(a.event_counts, b.event_counts)
+    assert torch.equal(a.event_counts_done, b.event_counts_done) and int(a.event_counts_done.sum()) > 0
+    acts = torch.randint(0, 6, (n, 2), dtype=torch.uint8, device=gpu)
+    for _ in range(30):
+        a.step_encode(acts)
+        b.step(acts)
+    assert torch.equal(a.state, b.state) and torch.equal(a.event_counts, b.event_counts)
+    assert torch.equal(a.event_counts_done, b.event_counts_done)
