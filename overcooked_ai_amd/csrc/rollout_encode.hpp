@@ -1,11 +1,11 @@
-// rollout_encode.hpp — random-policy rollout WITH the lossless observation of every step: k_rollout_encode
+// rollout_encode.hpp — K transitions WITH the lossless observation of every step: k_rollout_encode
 // Part of liboc_amd.so: included by oc_amd.hip inside its anonymous namespace, after step_table.hpp and encode.hpp.
 #pragma once
 
 // ------------------------------------------------------------------------------------------
 // k_rollout_encode: BASELINE configs[2] as SURVEY.md 8d-3 states it — the rollout of configs[1] (in-kernel Philox
 // actions, auto-reset, rewards / flags every step) plus lossless_state_encoding (mdp.py:2385-2561) of every env after
-// every step, for a batch with ONE layout (u8 or f32 observations).
+// every step — for a batch with ONE layout, u8 or f32 observations, random policy or caller-supplied actions.
 //
 // One launch of a one-step kernel is a ~6 us latency chain and the observation kernel has ~6 us of fill time of its
 // own; stepping inside the persistent observation kernel once per 19-env group was measured slower.
@@ -14,12 +14,13 @@
 //   * the wire-format header of each env (players, timestep, pot ticks) goes to a 16-byte LDS slot, the pots' soup
 //     codes back into their cell words — then any lane can read any env of its wavefront;
 //   * per sub-group of G envs: copy the static-layer template into the wavefront's private LDS image (16-byte moves),
-//     scatter the dynamic values (one task per player and per non-empty object dword, as in k_encode_uniform), stream
-//     the image to its place in obs[step] as contiguous 16-byte stores.
+//     scatter the dynamic values (players and objects in separate loops, branch-free layer writes: a wavefront executes
+//     the union of its lanes' paths), stream the image to its place in obs[step] as contiguous 16-byte stores.
 // No workgroup barrier between the phases: LDS operations of one wavefront execute in order, so they need only a
-// compiler-level fence.  (NW = 8 adds four helper wavefronts that share the encoding, with two barriers per step.)  The transition costs ~1 300 clk per step, the observation of 64 envs ~10 000 clk of issue —
-// both well under the time HBM needs for the observation bytes (9x5: 153 MB per step), which is what bounds the loop.
-// Actions: Philox (the stream of oc_rollout_random) or caller-supplied [K][n][2].
+// compiler-level fence.  The transition costs ~1 300 clk per step; copy + scatter of a 9x5 wavefront ~22 us without the
+// output stores, just under the ~28 us HBM needs for the 153 MB of a step — the loop runs at the encoder's write rate.
+// NW = 8 (small grids, where four wavefronts cannot keep up with HBM) adds four helper wavefronts that own no env and
+// encode every other sub-group, between two workgroup barriers per step.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -106,12 +107,10 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_encode(const OcLayout* __re
         load_env3<MAXP>(C, L, st, n, e, n_obj, s, cells);
         if (ep_returns) ep = ep_returns[e];
     }
-    const uint64_t floor_mask = FAST == 2 ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull;
     const uint64_t g = (uint64_t)(env_offset + e);
     const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
     uint32_t rnd[4] = {0, 0, 0, 0};
     const int obj_dwords = n_obj * 4;
-    const int tasks_per_env = obj_dwords + 2;
     const uint16_t* wcells = s_cells3 + ow * 64;  // cell c of the owner wavefront's env l: wcells[c * BLOCK + l]
     const uint4* whdr = s_hdr + ow * 64;
 
@@ -138,7 +137,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_encode(const OcLayout* __re
             if (__builtin_expect(a0 > 5u || a1 > 5u, 0)) {
                 fl = OC_F_BAD_ACTION;  // mdp.py:1394-1398 raises: the env stays untouched
             } else {
-                env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask, s_move);
+                env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, 0ull, s_move);
                 fl = finish_step3<MAXP>(C, L, n_obj, cells, s, horizon, options, r, ep, sa, g, sa.epoch + (uint32_t)k);
             }
             if (rewards) rewards[(int64_t)k * n + e] = r;
