@@ -5,7 +5,7 @@
 Every seed draws a fresh table of generated layouts (random shapes, feature densities, tomatoes, recipe parameters,
 old dynamics), random start states from oc_reset_random, and runs fused rollouts (all three kernel families in turn)
 and explicit-action steps with event masks across the auto-reset boundary; states, rewards, flags, event masks,
-encodings, features and potentials are compared bit for bit with the oracle."""
+encodings (also as oc_rollout_encode trajectories), features and potentials are compared bit for bit with the oracle."""
 import argparse
 import os
 import sys
@@ -98,6 +98,29 @@ def main():
         total += n * K
         enc = env.encode_lossless(torch.uint8).cpu().numpy().astype(np.int32)
         assert np.array_equal(enc, orc.encode_lossless(st, horizon=horizon, layout_id=lid)), ("encode", seed)
+        # K transitions with the observation of every step in one call (oc_rollout_encode; k_rollout_encode where the
+        # table allows it), random policy, against the oracle step by step
+        if all(s.num_players == 2 for s in specs):
+            K = int(rng.integers(2, 24))
+            n2 = min(n, 1024)  # (the trajectory buffer: K x n2 observations)
+            e2 = VecOvercookedEnv(table, n2, horizon=horizon, device=dev, layout_id=None if lid is None else lid[:n2],
+                                  auto_reset=True, seed=seed)
+            e2.one_kernel = True
+            st2 = np.ascontiguousarray(st[:, :n2])
+            e2.set_packed_state(st2)
+            e2.t_global = 5
+            dt = torch.uint8 if seed % 2 else torch.float32
+            obs = torch.zeros((K, n2, 2, table.width, table.height, 26), dtype=dt, device=dev)
+            rew = torch.zeros((K, n2, 4), dtype=torch.float32, device=dev)
+            fl = torch.zeros((K, n2), dtype=torch.uint8, device=dev)
+            e2.rollout_encode(K, obs, rew, fl, dtype=dt)
+            lid2 = None if lid is None else lid[:n2]
+            for k in range(K):
+                r_o, f_o = orc.rollout_random(st2, 1, horizon=horizon, options=1, seed=seed, t0=5 + k, layout_id=lid2)
+                assert np.array_equal(rew[k].cpu().numpy(), r_o[0]) and np.array_equal(fl[k].cpu().numpy(), f_o[0]), ("rollout_encode outputs", seed, k)
+                assert np.array_equal(obs[k].cpu().numpy().astype(np.int32), orc.encode_lossless(st2, horizon=horizon, layout_id=lid2)), ("rollout_encode obs", seed, k)
+            assert np.array_equal(e2.get_packed_state(), st2), ("rollout_encode state", seed)
+            total += n2 * K
         if all(s.num_players == 2 for s in specs):
             cg = "all" if seed % 2 else "none"
             assert np.array_equal(env.featurize(counter_goals=cg, num_pots=seed % 4).cpu().numpy(),
