@@ -19,8 +19,8 @@ BATCH_NEW_DYNAMICS = 0x2
 OBS_U8, OBS_F32 = 0, 1
 
 EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_batch_hints", "oc_step", "oc_step_many",
-           "oc_rollout_random",
-           "oc_encode_lossless", "oc_step_encode", "oc_rollout_encode", "oc_featurize", "oc_potential", "oc_phi_table_size", "oc_reset", "oc_reset_random", "oc_shape_rewards", "oc_multi_agent_step")
+           "oc_rollout_random", "oc_encode_lossless", "oc_step_encode", "oc_rollout_encode", "oc_featurize", "oc_potential",
+           "oc_phi_table_size", "oc_reset", "oc_reset_random", "oc_shape_rewards", "oc_multi_agent_step")
 
 
 class OcBatch(ctypes.Structure):

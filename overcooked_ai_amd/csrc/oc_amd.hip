@@ -373,8 +373,15 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         else if (joint && b->max_pots == 1) GO4(true, 1, true, 1, false, true, JOINT_MAX_FLOOR);
         else if (joint && small) GO4(true, 2, true, 1, false, true, JOINT_MAX_FLOOR);
         else if (joint) GO4(true, 8, true, 1, false, true, JOINT_MAX_FLOOR);
-        else if (uniform && !old && out && small) { if (b->max_pots == 1) GO4(true, 1, true, 0, true, false, 0); else GO4(true, 2, true, 0, true, false, 0); }
-        else if (uniform) { if (b->max_pots == 1) GO4(true, 1, true, 0, false, true, 0); else if (small) GO4(true, 2, true, 0, false, true, 0); else GO4(true, 8, true, 0, false, true, 0); }
+        else if (uniform && !old && out && small) {
+            if (b->max_pots == 1) GO4(true, 1, true, 0, true, false, 0);
+            else GO4(true, 2, true, 0, true, false, 0);
+        }
+        else if (uniform) {
+            if (b->max_pots == 1) GO4(true, 1, true, 0, false, true, 0);
+            else if (small) GO4(true, 2, true, 0, false, true, 0);
+            else GO4(true, 8, true, 0, false, true, 0);
+        }
         else if (lds) { if (small) GO4(false, 2, true, 0, false, true, 0); else GO4(false, 8, true, 0, false, true, 0); }
         else { if (small) GO4(false, 2, false, 0, false, true, 0); else GO4(false, 8, false, 0, false, true, 0); }
 #undef GO4
