@@ -107,7 +107,9 @@ class OvercookedEnv:
         t = self.state.timestep
         for key, src in (("cumulative_sparse_rewards_by_agent", "sparse_reward_by_agent"),
                          ("cumulative_shaped_rewards_by_agent", "shaped_reward_by_agent")):
-            self.game_stats[key] = self.game_stats[key] + np.asarray(infos[src])
+            r = infos[src]
+            if any(r):  # (most steps pay nothing)
+                self.game_stats[key] = self.game_stats[key] + np.asarray(r)
         mask = getattr(infos, "event_mask", None)
         if mask is not None:  # the kernel's event bit mask: visit only what happened (bit 2 * event + agent)
             while mask:

@@ -33,6 +33,10 @@ _ACTION_INDEX = {a: i for i, a in enumerate(Action.INDEX_TO_ACTION)}
 def events_from_mask(mask, num_players=2):
     """u64 event mask (bit 2*k + p) -> the reference's event_infos dict {event: [bool] * num_players}."""
     mask = int(mask)
+    if mask == 0:  # most steps: nothing happened
+        if num_players == 2:
+            return {name: [False, False] for name in EVENT_TYPES}
+        return {name: [False] * num_players for name in EVENT_TYPES}
     return {name: [bool((mask >> (2 * k + p)) & 1) for p in range(num_players)] for k, name in enumerate(EVENT_TYPES)}
 
 
@@ -319,9 +323,10 @@ class OvercookedGridworld:
             return None
         nxt, rew, mask = out
         n = self.num_players
+        r = rew.tolist()  # four Python floats; all-zero on most steps
         infos = _Infos(event_infos=events_from_mask(mask, n),
-                       sparse_reward_by_agent=[_num(v) for v in rew[0:n]],
-                       shaped_reward_by_agent=[_num(v) for v in rew[2:2 + n]])
+                       sparse_reward_by_agent=[0] * n if not (r[0] or r[1]) else [_num(v) for v in r[0:n]],
+                       shaped_reward_by_agent=[0] * n if not (r[2] or r[3]) else [_num(v) for v in r[2:2 + n]])
         infos.event_mask = mask
         return nxt, infos
 
