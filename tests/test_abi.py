@@ -72,6 +72,24 @@ def test_argument_validation_without_gpu():
     b = _lib.OcBatch(d_layouts=4096, d_layout_id=None, n_envs=4, n_layouts=1, width=40, height=40)
     assert L.oc_reset(ctypes.byref(b), 4096, None, None, None) == -1
     assert b"grid shape" in L.oc_last_error()
+    # oc_rollout_encode / oc_step_encode: pointer, alignment, option and range checks come before any launch
+    b = _lib.OcBatch(d_layouts=4096, d_layout_id=None, n_envs=4, n_layouts=1, width=5, height=4)
+    br = ctypes.byref(b)
+    assert L.oc_rollout_encode(br, 4096, None, None, None, None, None, 0, 0, 400, 1, 0, 0, 0, 3, None, None) == -1
+    assert b"NULL state / observation" in L.oc_last_error()
+    assert L.oc_rollout_encode(br, 4096, None, None, None, None, 4096, 0, 24, 400, 1, 0, 0, 0, 3, None, None) == -1
+    assert b"multiples of 16" in L.oc_last_error()
+    assert L.oc_rollout_encode(br, 4096, None, None, None, None, 4096, 7, 0, 400, 1, 0, 0, 0, 3, None, None) == -1
+    assert b"obs_dtype" in L.oc_last_error()
+    assert L.oc_rollout_encode(br, 4096, None, None, None, None, 4096, 0, 0, 400, 0x8, 0, 0, 0, 3, None, None) == -1
+    assert b"options" in L.oc_last_error()
+    assert L.oc_rollout_encode(br, 4096, None, None, None, None, 4096, 0, 0, 70000, 1, 0, 0, 0, 3, None, None) == -1
+    assert b"horizon" in L.oc_last_error()
+    assert L.oc_rollout_encode(br, 4096, 4096, None, None, None, 4096, 0, 0, 400, 1, 0, 0, 0, 3, None, None) == -1
+    assert b"caller actions need" in L.oc_last_error()
+    assert L.oc_rollout_encode(br, 4096, None, None, None, None, 4096, 0, 0, 400, 1, 0, 0, 0, 0, None, None) == 0  # no steps: nothing to do
+    assert L.oc_step_encode(br, 4096, 4096, 4096, 4096, None, None, 0, 400, 1, None, None) == -1
+    assert b"NULL pointer" in L.oc_last_error()
 
 
 def test_product_never_imports_the_oracle():
