@@ -25,7 +25,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 N_ENVS_PER_GPU = 65536
 HORIZON = 400
-DEFAULT_FUSE = HORIZON  # env steps per oc_rollout_random launch: one whole episode
+# env steps per oc_rollout_random launch: five whole episodes.  A launch pays ~21 us before its first step and after its
+# last (joint move table build, LUT staging, state load / store, the gap to the next launch): 14 % of a 400-step launch
+# (128 us), 3.7 % of a 2 000-step one (554 us) — measured 203.9 / 222.6 / 230.3 / 236.5 / 241.7 G env-steps/s at 400 / 800 /
+# 1 200 / 2 000 / 4 000 steps per launch.  2 000 keeps the per-launch outputs at 2.2 GB (PMC counters verified there).
+DEFAULT_FUSE = 5 * HORIZON
 
 # SURVEY.md §8d algorithmic bytes.  S = minimal state of cramped_room (2 players x 3 B + 14 non-floor cells
 # + 1 pot tick + 2 B timestep -> 24 B), outputs 17 B per env-step, actions generated in-kernel (0 B).
@@ -39,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--fuse", type=int, default=DEFAULT_FUSE, help="env steps fused per oc_rollout_random launch (default: one 400-step episode)")
+    ap.add_argument("--fuse", type=int, default=DEFAULT_FUSE, help="env steps fused per oc_rollout_random launch (default: five 400-step episodes)")
     ap.add_argument("--envs", type=int, default=N_ENVS_PER_GPU, help="envs per GPU")
     ap.add_argument("--layout", default="cramped_room")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
@@ -291,7 +295,7 @@ def main():
     tm = _Timer(torch, dev)
 
     # warm-up: at least the W steps asked for, rounded up to whole launches of the timed shape (so every launch of the
-    # kernel in a profile of this command is the same 400-step launch), then 3 more that calibrate R
+    # kernel in a profile of this command is the same `fuse`-step launch), then 3 more that calibrate R
     warm_launches = max(1, -(-args.warmup // fuse))
     for _ in range(warm_launches):
         env.rollout_random(fuse, rew, fl)

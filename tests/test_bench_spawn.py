@@ -34,13 +34,15 @@ def test_plan_repeats():
 
 
 def test_self_spawn_two_ranks_gloo():
+    import bench
+
     out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--stub", "--envs", "64",
                 "--min-seconds", "0.02"])
     assert out["n_gpus"] == 2 and out["data"] == "stub" and out["steps"] == 20 and out["warmup"] == 5
-    assert out["timed_steps"] == 20 * out["repeats"] and out["timed_steps"] % 400 == 0
+    assert out["timed_steps"] == 20 * out["repeats"] and out["timed_steps"] % bench.DEFAULT_FUSE == 0
     assert len(out["ms_per_step_by_rank"]) == 2 and all(x > 0 for x in out["ms_per_step_by_rank"])
     # the stub writes 1/16 into every reward slot: the all-reduced sums prove both ranks took part
-    assert out["aggregate"]["sparse_return_last_launch"] == 2 * 400 * 64 * 2 / 16
+    assert out["aggregate"]["sparse_return_last_launch"] == 2 * bench.DEFAULT_FUSE * 64 * 2 / 16
     assert out["aggregate"]["reduced_over"] == "gloo all-reduce"
     assert abs(out["value"] - 2 * 64 * out["timed_steps"] / out["timed_region_s"]) < 1e-6 * out["value"]
 
