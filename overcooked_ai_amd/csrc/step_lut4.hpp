@@ -252,46 +252,59 @@ __device__ __forceinline__ void env_reset4(const LayC& C, const Lay L, int n_obj
 // ------------------------------------------------------------------------------------------
 constexpr int MVJ_ROW = 38, MVJ_ROW_BYTES = MVJ_ROW * 2, JOINT_MAX_FLOOR = 7;
 
-__device__ __forceinline__ void build_joint_table(const Lay L, int W, uint16_t* mvj, uint8_t* s_fl, uint8_t* s_fi) {
+// Built by every workgroup at launch (~2 us): the free cells are ranked by the first wavefront (ballot + prefix count),
+// the single-player moves SP[pose][action] = (cell, pose) after _move_if_direction by 168 lanes, and a joint row then
+// only combines two of them per entry (collision test + index arithmetic).  `sp` = 2 * 28 * 6 bytes of scratch LDS.
+__device__ __forceinline__ void build_joint_table(const Lay L, int W, uint16_t* mvj, uint8_t* s_fl, uint8_t* s_fi, uint8_t* sp) {
     const int nc = (int)L.u8(L_NCELLS);
-    if (threadIdx.x == 0) {
-        int nf = 0;
-        for (int c = 0; c < nc; ++c) {
-            s_fi[c] = 0xFF;
-            if ((L.terrain((uint32_t)c) & 7u) == OC_T_FLOOR && nf < JOINT_MAX_FLOOR) { s_fi[c] = (uint8_t)nf; s_fl[nf++] = (uint8_t)c; }
+    if (threadIdx.x < 64) {  // free cells in row-major order: s_fi[cell] = rank (0xFF: not free / beyond the table), s_fl[rank] = cell
+        int base = 0;
+        for (int c0 = 0; c0 < nc; c0 += 64) {
+            const int c = c0 + (int)threadIdx.x;
+            const bool fl = c < nc && (L.terrain((uint32_t)c) & 7u) == OC_T_FLOOR;
+            const uint64_t m = __ballot(fl);
+            const int rank = base + __popcll(m & ((1ull << threadIdx.x) - 1ull));
+            if (c < nc) s_fi[c] = (fl && rank < JOINT_MAX_FLOOR) ? (uint8_t)rank : (uint8_t)0xFF;
+            if (fl && rank < JOINT_MAX_FLOOR) s_fl[rank] = (uint8_t)c;
+            base += __popcll(m);
         }
-        s_fl[JOINT_MAX_FLOOR] = (uint8_t)nf;
+        if (threadIdx.x == 0) s_fl[JOINT_MAX_FLOOR] = (uint8_t)min(base, JOINT_MAX_FLOOR);
     }
     __syncthreads();
     const int nf = s_fl[JOINT_MAX_FLOOR], NP = 4 * nf, NJ = NP * NP;
+    auto ahead = [&](int c, int d) {  // cell in direction d, or c itself when that leaves the grid
+        const int t = c + (d == 0 ? -W : d == 1 ? W : d == 2 ? 1 : -1);
+        return (t >= 0 && t < nc) ? t : c;
+    };
+    if ((int)threadIdx.x < NP * 6) {  // one player alone: _move_if_direction (mdp.py:1718-1727)
+        const int P = threadIdx.x / 6, a = threadIdx.x - P * 6;
+        const int c = s_fl[P >> 2], o = P & 3;
+        const int t = a < 4 ? ahead(c, a) : c;
+        const int q = (a < 4 && s_fi[t] != 0xFF) ? t : c;
+        sp[2 * threadIdx.x] = (uint8_t)q;
+        sp[2 * threadIdx.x + 1] = (uint8_t)(s_fi[q] * 4 + (a < 4 ? a : o));
+    }
+    __syncthreads();
     for (int J = threadIdx.x; J < NJ; J += BLOCK) {
         const int P0 = J / NP, P1 = J - P0 * NP;
-        const int c0 = s_fl[P0 >> 2], c1 = s_fl[P1 >> 2], o0 = P0 & 3, o1 = P1 & 3;
+        const int c0 = s_fl[P0 >> 2], c1 = s_fl[P1 >> 2];
         uint16_t* row = mvj + J * MVJ_ROW;
-        auto ahead = [&](int c, int d) {  // cell in direction d, or c itself when that leaves the grid
-            const int t = c + (d == 0 ? -W : d == 1 ? W : d == 2 ? 1 : -1);
-            return (t >= 0 && t < nc) ? t : c;
-        };
-        row[36] = (uint16_t)(ahead(c0, o0) * (BLOCK * 2));
-        row[37] = (uint16_t)(ahead(c1, o1) * (BLOCK * 2));
-        int np0[6], no0[6], np1[6], no1[6];
+        row[36] = (uint16_t)(ahead(c0, P0 & 3) * (BLOCK * 2));
+        row[37] = (uint16_t)(ahead(c1, P1 & 3) * (BLOCK * 2));
+        int q1[6], p1[6];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {  // _move_if_direction (mdp.py:1718-1727)
-            const int t0 = a < 4 ? ahead(c0, a) : c0, t1 = a < 4 ? ahead(c1, a) : c1;
-            np0[a] = (a < 4 && s_fi[t0] != 0xFF) ? t0 : c0;
-            np1[a] = (a < 4 && s_fi[t1] != 0xFF) ? t1 : c1;
-            no0[a] = a < 4 ? a : o0;
-            no1[a] = a < 4 ? a : o1;
-        }
+        for (int a = 0; a < 6; ++a) { q1[a] = sp[2 * (P1 * 6 + a)]; p1[a] = sp[2 * (P1 * 6 + a) + 1]; }
 #pragma unroll
-        for (int a0 = 0; a0 < 6; ++a0)
+        for (int a0 = 0; a0 < 6; ++a0) {
+            const int q0 = sp[2 * (P0 * 6 + a0)], p0 = sp[2 * (P0 * 6 + a0) + 1];
 #pragma unroll
             for (int a1 = 0; a1 < 6; ++a1) {
-                const bool collide = np0[a0] == np1[a1] || (np0[a0] == c1 && np1[a1] == c0);  // mdp.py:1673-1683
-                const int q0 = collide ? c0 : np0[a0], q1 = collide ? c1 : np1[a1];
-                const int Jn = (s_fi[q0] * 4 + no0[a0]) * NP + (s_fi[q1] * 4 + no1[a1]);
-                row[a0 * 6 + a1] = (uint16_t)(Jn * MVJ_ROW_BYTES);
+                // same target cell or swapped cells: nobody moves, orientations still turn (mdp.py:1673-1683, Q6)
+                const bool collide = q0 == q1[a1] || (q0 == c1 && q1[a1] == c0);
+                const int n0 = collide ? ((P0 & ~3) | (p0 & 3)) : p0, n1 = collide ? ((P1 & ~3) | (p1[a1] & 3)) : p1[a1];
+                row[a0 * 6 + a1] = (uint16_t)((n0 * NP + n1) * MVJ_ROW_BYTES);
             }
+        }
     }
 }
 
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             s_act[threadIdx.x] = (uint16_t)(M::LUT + (threadIdx.x / 6 == 5 ? 0 : LUT4_KEYS * 16));
             s_act[40 + threadIdx.x] = (uint16_t)(M::LUT + (threadIdx.x % 6 == 5 ? 0 : LUT4_KEYS * 16));
         }
-        build_joint_table(L, W, reinterpret_cast<uint16_t*>(s_dyn4), s_fl, s_fi);
+        build_joint_table(L, W, reinterpret_cast<uint16_t*>(s_dyn4), s_fl, s_fi, s_dyn4 + M::CELLS);  // (scratch: the cell words come later)
     }
     __syncthreads();
     if (!active) return;
