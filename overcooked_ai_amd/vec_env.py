@@ -238,7 +238,9 @@ class VecOvercookedEnv:
         return rewards_out, flags_out
 
     def rollout_random(self, n_steps, rewards_out=None, flags_out=None, events_out=None):
-        """n_steps fused random-policy transitions in one launch (Philox actions, see include/oc_amd.h).
+        """n_steps fused random-policy transitions in one launch (Philox actions, see include/oc_amd.h).  A launch
+        costs ~16 us outside its step loop (tables, state load / store, dispatch): 12 % of a 400-step launch at 65 536
+        envs, 3 % of a 2 000-step one — prefer few long launches.
         rewards_out: float32 [n_steps, n_envs, 4] or None; flags_out: uint8 [n_steps, n_envs] or None; events_out:
         int64 [n_steps, n_envs] event masks or None."""
         if events_out is not None:
