@@ -25,11 +25,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 N_ENVS_PER_GPU = 65536
 HORIZON = 400
-# env steps per oc_rollout_random launch: five whole episodes.  A launch pays ~21 us before its first step and after its
-# last (joint move table build, LUT staging, state load / store, the gap to the next launch): 14 % of a 400-step launch
-# (128 us), 3.7 % of a 2 000-step one (554 us) — measured 203.9 / 222.6 / 230.3 / 236.5 / 241.7 G env-steps/s at 400 / 800 /
-# 1 200 / 2 000 / 4 000 steps per launch.  2 000 keeps the per-launch outputs at 2.2 GB (PMC counters verified there).
-DEFAULT_FUSE = 5 * HORIZON
+# env steps per oc_rollout_random launch: ten whole episodes.  A launch pays ~16 us before its first step and after its
+# last (LUT staging, joint move table build, state load / store, the gap to the next launch): 12 % of a 400-step launch
+# (126 us), 1.5 % of a 4 000-step one (1.07 ms) — measured 203.9 / 222.6 / 230.3 / 236.5 / 241.7 / 243.2 G env-steps/s at
+# 400 / 800 / 1 200 / 2 000 / 4 000 / 8 000 steps per launch (before the last scheduling changes).  4 000 = 4.5 GB of
+# per-step outputs per launch; the PMC byte counters were verified up to 8 000.
+DEFAULT_FUSE = 10 * HORIZON
 
 # SURVEY.md §8d algorithmic bytes.  S = minimal state of cramped_room (2 players x 3 B + 14 non-floor cells
 # + 1 pot tick + 2 B timestep -> 24 B), outputs 17 B per env-step, actions generated in-kernel (0 B).
@@ -43,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--fuse", type=int, default=DEFAULT_FUSE, help="env steps fused per oc_rollout_random launch (default: five 400-step episodes)")
+    ap.add_argument("--fuse", type=int, default=DEFAULT_FUSE, help="env steps fused per oc_rollout_random launch (default: ten 400-step episodes)")
     ap.add_argument("--envs", type=int, default=N_ENVS_PER_GPU, help="envs per GPU")
     ap.add_argument("--layout", default="cramped_room")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
@@ -357,6 +358,8 @@ def main():
                 best, traffic = v["launches"], v["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
+    if traffic is not None and not 0.5 < traffic / bytes_per_launch < 2.0:
+        traffic = None  # profiles/traffic.json was collected for another launch length: not this launch's traffic
     issue = None
     try:  # SQ counters of the same kernel (tools/pmc_rollout.sh): what bounds it is instruction issue, not HBM
         with open(os.path.join(ROOT, "profiles", "sq_counters.json")) as f:

@@ -23,7 +23,7 @@ rm -rf $O/trace $O/pmc_fetch $O/pmc_write
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c3trace -o c3 -- python3 $R/bench.py --config 3 --steps 400 --warmup 400 > $O/bench_config3_trace.log 2>&1
 find /tmp/c3trace -name "*kernel_stats.csv" -exec cp {} $O/r02_config3_kernel_stats.csv \;
 cd $R
-STEPS=2000 bash tools/pmc_rollout.sh r02 > /dev/null 2>&1
+STEPS=4000 bash tools/pmc_rollout.sh r02 > /dev/null 2>&1
 cp gpurun_out/pmc_r02.txt gpurun_out/sq_counters_r02.json $O/ 2>/dev/null
 ls -la $O
 head -c 600 $O/bench_driver_cmd.json
