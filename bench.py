@@ -11,7 +11,11 @@ over all ranks (weak scaling: every rank owns 65 536 envs, disjoint Philox strea
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (see DESIGN.md §6 for every field).
+Prints ONE JSON line on rank 0 (see DESIGN.md §6 for every field).  After the timed region every rank replays one launch
+of the timed shape from reset and compares it with the C oracle (`parity_check`); at N = 1 rank 0 also collects the
+kernel's HBM traffic with two rocprofv3 --pmc child passes of the same launch shape (`roofline.traffic`, provenance in
+`roofline.traffic_source`) and times the oracle on the host cores (`cpu_baseline`).  Fields replayed from files under
+profiles/ instead of being measured in the run say so in a `source` / `how` key next to them.
 """
 import argparse
 import json
@@ -50,7 +54,6 @@ def parse():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json config index (1-based): 2 = headline (default); 3 = asymmetric_advantages + "
                          "lossless encoding every step; 4 = 5-layout mix padded to 9x5; 5 = 4096 generated 9x5 terrains")
-    ap.add_argument("--lane-per-env", action="store_true", help="force the one-lane-per-env rollout kernel")
     ap.add_argument("--lane-pair", action="store_true", help="force the two-lanes-per-env rollout kernel")
     ap.add_argument("--predicate-interact", action="store_true", help="lane-per-env kernel with the predicate-network interact (v2)")
     ap.add_argument("--rollout-v3", action="store_true", help="the previous table-driven rollout kernel (k_rollout3)")
@@ -61,19 +64,14 @@ def parse():
                     help="minimum length of the timed region: the --steps-step region is repeated back to back until it lasts this long")
     ap.add_argument("--stub", action="store_true",
                     help="CPU-only plumbing test (gloo, no kernels): exercises rank spawning and the reductions; never a measurement")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of one launch after the timed region")
+    ap.add_argument("--parity-steps", type=int, default=0,
+                    help="steps of the launch the parity check replays from reset (default: one whole --fuse launch at 1 GPU, "
+                         "1 200 steps per rank otherwise)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not collect roofline.traffic with rocprofv3 --pmc child passes of this same launch shape")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # internal: the process rocprofv3 wraps
     return ap.parse_args()
-
-
-def run_fused(env, n_steps, fuse, rew, fl):
-    """n_steps batched steps as ceil(n_steps / fuse) launches; returns number of launches."""
-    launches = 0
-    left = n_steps
-    while left > 0:
-        k = min(fuse, left)
-        env.rollout_random(k, rew[:k], fl[:k])
-        left -= k
-        launches += 1
-    return launches
 
 
 def usable_cores():
@@ -89,34 +87,33 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(layout, seconds):
+def cpu_baseline(wl, n_envs, seconds):
     """The C oracle (a scalar port of the reference's algorithm) on the host: a bounded sample of the same workload
-    (same layout, random policy, horizon 400 with auto-reset, outputs written every step), first on one core, then
-    with the independent envs spread over all cores (OpenMP).  `value` is the all-cores figure."""
+    (same layout table and env -> layout map, random policy, horizon 400 with auto-reset, outputs written every step),
+    first on one core, then with the independent envs spread over all cores (OpenMP).  `value` is the all-cores figure."""
     import numpy as np
 
     from oracle import oracle as O
-    from overcooked_ai_amd.layouts import spec_from_name
 
-    spec = spec_from_name(layout)
-    orc = O.Oracle(O.mdp_from_layout_dict(spec.to_layout_dict()))
-    n, T = 8192, 100
-    st = orc.reset(orc.new_state(n))
+    orc = O.Oracle([O.mdp_from_layout_dict(sp.to_layout_dict()) for sp in wl["specs"]])
+    n, T = min(8192, n_envs), 100
+    lid = None if wl["lid"] is None else np.ascontiguousarray(wl["lid"][:n])
+    st = orc.reset(orc.new_state(n), layout_id=lid)
     ep = np.zeros((n, 4), np.float32)
     tg = 0
 
     def timed(budget):
         nonlocal tg
-        orc.rollout_random(st, 10, horizon=HORIZON, options=1, seed=0, t0=tg, ep_returns=ep)  # warm
+        orc.rollout_random(st, 10, horizon=HORIZON, options=1, seed=0, t0=tg, ep_returns=ep, layout_id=lid)  # warm
         tg += 10
         t0 = time.perf_counter()
-        orc.rollout_random(st, T, horizon=HORIZON, options=1, seed=0, t0=tg, ep_returns=ep)
+        orc.rollout_random(st, T, horizon=HORIZON, options=1, seed=0, t0=tg, ep_returns=ep, layout_id=lid)
         tg += T
         probe = time.perf_counter() - t0
         reps = max(1, int(budget / max(probe, 1e-6)))
         t0 = time.perf_counter()
         for _ in range(reps):
-            orc.rollout_random(st, T, horizon=HORIZON, options=1, seed=0, t0=tg, ep_returns=ep)
+            orc.rollout_random(st, T, horizon=HORIZON, options=1, seed=0, t0=tg, ep_returns=ep, layout_id=lid)
             tg += T
         dt = time.perf_counter() - t0
         return reps * n * T / dt, reps * T, dt
@@ -128,22 +125,47 @@ def cpu_baseline(layout, seconds):
     O.set_threads(1)
     return {
         "value": allc, "unit": "env steps/s", "cores": cores, "kind": "port", "single_core": one,
-        "sample": "%d envs x %d steps of %s (C oracle, %d threads, %.1f s); single core: %d steps in %.1f s"
-                  % (n, steps_all, layout, cores, dt_all, steps1, dt1),
+        "sample": "%d envs x %d steps of the bench workload (C oracle, %d threads, %.1f s); single core: %d steps in %.1f s"
+                  % (n, steps_all, cores, dt_all, steps1, dt1),
     }
 
 
-# The reference's own rate (north_star: "next to the reference Python OvercookedEnv.step"): the Python reference cannot
-# travel to the GPU box (/root/reference does not exist there), so the figure measured in the build container
-# (SURVEY §8d-1 protocol: cramped_room, horizon 400, random joint actions, info_level 0) is carried in
-# the JSON with its provenance.
+def _reference_python():
+    """The reference's own rate (north_star: "next to the reference Python OvercookedEnv.step"): /root/reference does not
+    exist on the GPU box and its sources are never copied into this repo, so bench.py cannot time it in its own run.
+    What the line carries instead, with its provenance spelled out: the figure of tools/time_reference_python.py run ONCE on
+    an MI355X box of this pool from a git-ignored tarball (profiles/r03_reference_python_gpubox.json), else the build
+    container's figure."""
+    path = os.path.join(ROOT, "profiles", "r03_reference_python_gpubox.json")
+    try:
+        with open(path) as f:
+            j = json.load(f)
+        cr = j["cramped_room"]
+        return {
+            "value": cr["step_1core"]["steps_per_s"], "unit": "env steps/s", "cores": 1,
+            "all_cores": {"value": cr["step_allcores"]["steps_per_s"], "cores": cr["step_allcores"]["processes"],
+                          "note": "one env per process, multiprocessing.Pool"},
+            "with_lossless_encoding": {"value": cr["step_encode_1core"]["steps_per_s"], "cores": 1,
+                                       "all_cores": cr["step_encode_allcores"]["steps_per_s"]},
+            "same_run": False, "same_box": False,
+            "where": "an MI355X box of this pool (%s, %s usable cores, CPython %s, numpy %s) in a separate gpurun call, NOT this run"
+                     % (j.get("cpu_model"), j.get("usable_cores"), j.get("python"), j.get("numpy")),
+            "what": j.get("what", "") + ": cramped_room, horizon 400, np.random.RandomState joint actions, %s episodes per process "
+                                        "after 1 warm-up" % j.get("episodes_per_process"),
+            "source": "profiles/r03_reference_python_gpubox.json (tools/time_reference_python.py)",
+        }
+    except (OSError, ValueError, KeyError):
+        return REFERENCE_PYTHON
+
+
 REFERENCE_PYTHON = {
     "value": 16400.0, "unit": "env steps/s", "cores": 1,
     "all_cores": {"value": 74000.0, "cores": 8, "note": "one env per process, multiprocessing.Pool(8)"},
+    "same_run": False, "same_box": False,
     "where": "build container (8 vCPU Xeon 2.1 GHz, CPython 3.10.12, numpy 2.2.6), not the GPU box",
     "what": "reference OvercookedEnv.step (src/overcooked_ai_py/mdp/overcooked_env.py:244), cramped_room, horizon 400, "
             "np.random.RandomState joint actions, >= 50 episodes after 1 warm-up",
-    "source": "BASELINE.md §2 / SURVEY.md §8d-1",
+    "source": "BASELINE.md 2 / SURVEY.md 8d-1",
 }
 
 
@@ -163,18 +185,39 @@ def plan_repeats(steps, fuse, est_ms_per_step, min_seconds):
 
 
 class _StubEnv:
-    """CPU stand-in for VecOvercookedEnv used ONLY by `--stub` (tests of the rank-spawning / reduction plumbing on a
-    box without GPUs, gloo backend).  It steps nothing; the JSON it yields says data: "stub"."""
+    """CPU stand-in for VecOvercookedEnv used ONLY by `--stub` (tests of the rank-spawning / reduction / parity-check
+    plumbing on a box without GPUs, gloo backend): it steps the C oracle where the product steps the HIP kernels, so the
+    JSON it yields says data: "stub" and is never a measurement."""
 
-    n_planes = 3
+    def __init__(self, wl, n, rank):
+        import numpy as np
 
-    def __init__(self, n):
-        self.n_envs, self.t_global = n, 0
+        from oracle import oracle as O
+
+        self.n_envs, self.t_global, self.env_offset, self.lid = n, 0, rank * n, wl["lid"]
+        self.orc = O.Oracle([O.mdp_from_layout_dict(sp.to_layout_dict()) for sp in wl["specs"]])
+        self.n_planes = self.orc.n_planes
+        self.st = self.orc.reset(self.orc.new_state(n), layout_id=self.lid)
+        self.ep = np.zeros((n, 4), np.float32)
 
     def rollout_random(self, k, rew=None, fl=None):
+        import torch
+
+        r, f = self.orc.rollout_random(self.st, k, horizon=HORIZON, options=1, seed=0, env_offset=self.env_offset,
+                                       t0=self.t_global, layout_id=self.lid, ep_returns=self.ep)
         self.t_global += k
         if rew is not None:
-            rew[:k].fill_(1.0 / 16)
+            rew[:k].copy_(torch.from_numpy(r))
+            fl[:k].copy_(torch.from_numpy(f))
+
+    def get_packed_state(self):
+        return self.st
+
+    @property
+    def ep_returns(self):
+        import torch
+
+        return torch.from_numpy(self.ep)
 
 
 class _Timer:
@@ -249,6 +292,221 @@ def spawn_ranks(n):
     return rc
 
 
+def pin_to_gpu_numa(torch, local_rank):
+    """Keep this rank's host threads (launch loop, the oracle of the parity check) on the NUMA node its GPU hangs off:
+    PCI bus id of the HIP device -> /sys/bus/pci/devices/<id>/numa_node -> that node's cpulist, intersected with the
+    affinity the process already has.  Returns the node (None when the topology cannot be read: nothing is changed)."""
+    try:
+        props = torch.cuda.get_device_properties(local_rank)
+        bus = None
+        if hasattr(props, "pci_bus_id") and hasattr(props, "pci_device_id"):
+            bus = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id)
+        if bus is None or not os.path.exists("/sys/bus/pci/devices/%s/numa_node" % bus):
+            import ctypes
+
+            buf = ctypes.create_string_buffer(64)
+            hip = ctypes.CDLL("libamdhip64.so")
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(local_rank)) != 0:
+                return None
+            bus = buf.value.decode().lower()
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bus).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:
+        return None
+
+
+def src_hash():
+    from overcooked_ai_amd import build
+
+    return build.source_hash()
+
+
+def make_workload(args, rank):
+    """The batch a rank owns for --config 2 / 4 / 5 (BASELINE configs[1] / [3] / [4]): layout table, per-env layout ids
+    of ITS global env range, minimal-state bytes of SURVEY 8d, and a description."""
+    import numpy as np
+
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    n = args.envs
+    if args.config == 2:
+        table = LayoutTable([spec_from_name(args.layout)])
+        return {"table": table, "specs": table.specs, "lid": None,
+                "sbytes": S_CRAMPED if args.layout == "cramped_room" else 4 * ((table.n_planes * 16) // 4),
+                "workload": "%s x %d envs/GPU, in-kernel Philox random policy, horizon %d auto-reset, outputs every step"
+                            % (args.layout, n, HORIZON)}
+    if args.config == 4:
+        names = ["cramped_room", "asymmetric_advantages", "coordination_ring", "forced_coordination", "counter_circuit"]
+        table = LayoutTable([spec_from_name(nm) for nm in names], pad_to=(9, 5))
+        lid = ((np.arange(n) + rank * n) % 5).astype(np.uint16)
+        return {"table": table, "specs": table.specs, "lid": lid, "sbytes": 34,
+                "workload": "5 canonical layouts padded to 9x5 (global env e -> layout e %% 5) x %d envs/GPU, random policy, "
+                            "horizon %d auto-reset, outputs every step" % (n, HORIZON)}
+    from overcooked_ai_amd.layout_gen import reference_generated_layouts
+
+    K = 4096  # the reference LayoutGenerator's own terrains (np.random.seed(0)), recorded as package data
+    table = LayoutTable(reference_generated_layouts(K))
+    lid = ((np.arange(n) + rank * n) % K).astype(np.uint16)
+    return {"table": table, "specs": table.specs, "lid": lid, "sbytes": 36,
+            "workload": "%d LayoutGenerator 9x5 terrains (reference generator, seed 0; global env e -> terrain e %% %d) x %d "
+                        "envs/GPU, random policy, horizon %d auto-reset, outputs every step" % (K, K, n, HORIZON)}
+
+
+def parity_check(torch, wl, make_env, n, rank, steps, rew, fl, threads):
+    """Replay ONE launch of the timed shape from reset and compare every reward row, every flag byte, the final packed
+    states and the episode returns with the C oracle (the checker, not the thing measured), in 400-step chunks."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    t_start = time.perf_counter()
+    env = make_env()
+    env.rollout_random(steps, rew[:steps], fl[:steps])
+    threads = O.set_threads(max(1, threads))
+    orc = O.Oracle([O.mdp_from_layout_dict(sp.to_layout_dict()) for sp in wl["specs"]])
+    lid = wl["lid"]
+    st = orc.reset(orc.new_state(n), layout_id=lid)
+    ep = np.zeros((n, 4), np.float32)
+    bad_steps, restarts, chunk = 0, 0, 400
+    for c0 in range(0, steps, chunk):
+        k = min(chunk, steps - c0)
+        rew_o, fl_o = orc.rollout_random(st, k, horizon=HORIZON, options=1, seed=0, env_offset=rank * n, t0=c0,
+                                         layout_id=lid, ep_returns=ep)
+        rg, fg = rew[c0:c0 + k].cpu().numpy(), fl[c0:c0 + k].cpu().numpy()
+        bad_steps += int(((rg != rew_o).any(axis=2) | (fg != fl_o)).sum())
+        restarts += int(((fl_o & 4) != 0).sum())
+    bad_states = int((np.asarray(env.get_packed_state()) != st).any(axis=(0, 2)).sum())
+    bad_returns = int((env.ep_returns.cpu().numpy() != ep).any(axis=1).sum())
+    O.set_threads(1)
+    return {"envs": n, "steps": steps, "mismatches": bad_steps + bad_states + bad_returns,
+            "mismatching_env_steps": bad_steps, "mismatching_final_states": bad_states,
+            "mismatching_episode_returns": bad_returns, "restarts_covered": restarts,
+            "seconds": time.perf_counter() - t_start, "oracle_threads": threads,
+            "what": "one %d-step oc_rollout_random launch from reset (seed 0, global env offset %d): every reward quad and "
+                    "flag byte of every env-step, the final packed states and the episode returns, bit for bit against "
+                    "oracle/overcooked_oracle.c" % (steps, rank * n)}
+
+
+def pmc_child(args, torch, VecOvercookedEnv, dev):
+    """The process the --pmc passes wrap: the same batch, reset, then 3 launches of the timed shape and nothing else."""
+    wl = make_workload(args, 0)
+    n, fuse = args.envs, max(1, args.fuse)
+    env = VecOvercookedEnv(wl["table"], n, horizon=HORIZON, device=dev, auto_reset=True, seed=0, layout_id=wl["lid"])
+    rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
+    fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        env.rollout_random(fuse, rew, fl)
+    torch.cuda.synchronize(dev)
+
+
+def measure_traffic(args, kernel):
+    """roofline.traffic measured by THIS run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE — they do not fit one
+    pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots') over a child of this same command that runs 3 launches of the timed
+    shape.  KiB -> bytes; FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 B, same
+    guide, 'HBM').  Returns (bytes per launch or None, provenance dict)."""
+    import csv
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, {"how": "not collected", "why": "rocprofv3 not found"}
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", str(args.config), "--envs", str(args.envs),
+             "--fuse", str(args.fuse), "--layout", args.layout]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    got, launches = {}, 0
+    for counter, scale in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        d = tempfile.mkdtemp(prefix="oc_pmc_", dir="/tmp")
+        try:
+            p = subprocess.run([rocprof, "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "rocpd", "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f, newline="")):
+                    low = {k.lower(): v for k, v in row.items()}
+                    if kernel + "<" in low.get("kernel_name", "") and low.get("counter_name") == counter:
+                        vals.append(float(low["counter_value"]))
+            if not vals:
+                for f in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+                    db = sqlite3.connect(f)
+                    try:
+                        vals += [float(r[0]) for r in db.execute(
+                            "select counter_value from pmc_events where counter_name=? and name like ?", (counter, "%" + kernel + "<%"))]
+                    finally:
+                        db.close()
+            if not vals:
+                return None, {"how": "not collected", "why": "no %s rows for %s (rocprofv3 rc %d): %s"
+                                                              % (counter, kernel, p.returncode, (p.stderr or "")[-300:])}
+            got[counter] = sum(vals) / len(vals) * 1024.0 * scale
+            launches = len(vals)
+        except Exception as e:  # a profiler problem must never cost the measurement
+            return None, {"how": "not collected", "why": "%s pass failed: %r" % (counter, e)}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return got["FETCH_SIZE"] + got["WRITE_SIZE"], {
+        "how": "same run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate child passes of this command's launch "
+               "shape (%d launches each, mean per launch); KiB -> bytes, FETCH_SIZE x 2 (gfx950), WRITE_SIZE as reported"
+               % launches,
+        "fetch_bytes": got["FETCH_SIZE"], "write_bytes": got["WRITE_SIZE"], "kernel_source_sha": src_hash()}
+
+
+def traffic_from_file(kernel, n, fuse, layout, bytes_per_launch):
+    """Fallback provenance: the PMC figure tools/profile_round.sh stored for this launch shape — only when the kernel
+    sources are the ones that were profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            tj = json.load(f)
+    except (OSError, ValueError):
+        return None, {"how": "not collected", "why": "no profiles/traffic.json"}
+    if tj.get("_kernel_source_sha") != src_hash():
+        return None, {"how": "not collected", "why": "profiles/traffic.json was recorded for other kernel sources (sha %s)"
+                                                      % tj.get("_kernel_source_sha")}
+    best, traffic = 0, None
+    for k, v in tj.items():
+        if k.startswith(kernel + "<") and n == N_ENVS_PER_GPU and fuse == DEFAULT_FUSE and layout == "cramped_room" \
+                and v.get("launches", 0) > best:
+            best, traffic = v["launches"], v["hbm_bytes_per_launch"]
+    if traffic is None or not 0.5 < traffic / bytes_per_launch < 2.0:
+        return None, {"how": "not collected", "why": "profiles/traffic.json holds no entry for this launch shape"}
+    return traffic, {"how": "replayed from profiles/traffic.json (an earlier rocprofv3 --pmc run of the same kernel sources), NOT "
+                            "measured in this run", "kernel_source_sha": src_hash()}
+
+
+def issue_counters(kernel, n, layout):
+    """SQ counters of the headline kernel from profiles/sq_counters.json — a stored profile, labelled as such, and dropped
+    when the kernel sources have changed since it was taken."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "sq_counters.json")) as f:
+            sq = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if kernel != sq.get("kernel", "").split("<")[0] or n != N_ENVS_PER_GPU or layout != "cramped_room":
+        return None
+    if sq.get("kernel_source_sha") != src_hash():
+        return None
+    return {"valu_per_env_step": sq["valu_per_env_step"], "salu_per_env_step": sq["salu_per_env_step"],
+            "lds_per_env_step": sq["lds_per_env_step"], "valu_busy_frac": sq["valu_busy_frac"],
+            "wait_frac": sq["wait_any_frac"], "wave_clk_per_env_step": sq.get("wave_clk_per_env_step"),
+            "source": "replayed from profiles/sq_counters.json (rocprofv3 --pmc SQ_* passes of tools/pmc_rollout.sh on the same "
+                      "kernel sources, sha %s), NOT measured in this run" % sq.get("kernel_source_sha"),
+            "note": "one wavefront per SIMD at 65 536 envs: every instruction of the wavefront issues in turn (~4 clk "
+                    "each), so (VALU + SALU + LDS + VMEM per env-step) * 4 clk is the floor of a batched step "
+                    "whatever the bytes moved"}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -270,30 +528,51 @@ def main():
             raise SystemExit("--gpus %d but only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
     else:
         VecOvercookedEnv = None
+    if args.pmc_child:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        return pmc_child(args, torch, VecOvercookedEnv, dev)
 
     rank, local_rank, world = sharding.init_process_group("gloo" if args.stub else None)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if sharding._live():
+        import torch.distributed as dist
+
+        if dist.get_world_size() != args.gpus or (not args.stub and dist.get_backend() != "nccl"):
+            raise SystemExit("process group has %d ranks over %s; expected %d over nccl (RCCL)"
+                             % (dist.get_world_size(), dist.get_backend(), args.gpus))
     dev = torch.device("cpu") if args.stub else torch.device("cuda", local_rank)
+    numa = None
     if not args.stub:
         torch.cuda.set_device(dev)
+        if world > 1:
+            numa = pin_to_gpu_numa(torch, local_rank)
+    if args.config == 3:
+        return run_encode_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world)
+    return run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world, numa)
 
+
+def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world, numa):
+    """--config 2 (the headline: BASELINE configs[1]), 4 and 5 (configs[3] / [4] on one GPU's shard): oc_rollout_random
+    launches of `--fuse` steps under the timing protocol of the module docstring."""
     n = args.envs
-    if args.config != 2:
-        return run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world)
-    if args.stub:
-        env = _StubEnv(n)
-    else:
-        env = VecOvercookedEnv(args.layout, n, horizon=HORIZON, device=dev, auto_reset=True, seed=0,
-                               env_offset=rank * n)
-        env.lane_per_env = args.lane_per_env
+    wl = make_workload(args, rank)
+
+    def make_env():
+        if args.stub:
+            return _StubEnv(wl, n, rank)
+        env = VecOvercookedEnv(wl["table"], n, horizon=HORIZON, device=dev, auto_reset=True, seed=0, env_offset=rank * n,
+                               layout_id=wl["lid"])
         env.lane_pair = args.lane_pair
         env.predicate_interact = args.predicate_interact
         env.rollout_v3 = args.rollout_v3
+        return env
+
+    env = make_env()
     fuse = max(1, args.fuse)  # launch shape: independent of --steps (a 20-step --steps must not shrink the launches)
     rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
-    tm = _Timer(torch, dev)
 
     # warm-up: at least the W steps asked for, rounded up to whole launches of the timed shape (so every launch of the
     # kernel in a profile of this command is the same `fuse`-step launch), then 3 more that calibrate R
@@ -342,40 +621,39 @@ def main():
     value = float(world) * n * total_steps / wall_max
 
     # roofline of the dominant kernel (k_rollout4): algorithmic HBM bytes per launch / median launch duration
-    state_bytes = S_CRAMPED if args.layout == "cramped_room" else 4 * ((env.n_planes * 16) // 4)
+    state_bytes = wl["sbytes"]
     bytes_per_launch = n * (2 * state_bytes + OUT_BYTES * fuse)
     achieved = bytes_per_launch / (launch_med * 1e-3) / 1e9
     kernel = ("k_rollout" if args.predicate_interact else "k_rollout_pair" if args.lane_pair
               else "k_rollout3" if args.rollout_v3 else "k_rollout4")
-    traffic = None
-    try:  # PMC HBM bytes per launch measured by tools/profile_round.sh on this same launch shape (profiles/traffic.json)
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            tj = json.load(f)
-        best = 0
-        for k, v in tj.items():  # the template instance that ran the headline launches (most dispatches)
-            if k.startswith(kernel + "<") and n == N_ENVS_PER_GPU and fuse == DEFAULT_FUSE and args.layout == "cramped_room" \
-                    and v.get("launches", 0) > best:
-                best, traffic = v["launches"], v["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    if traffic is not None and not 0.5 < traffic / bytes_per_launch < 2.0:
-        traffic = None  # profiles/traffic.json was collected for another launch length: not this launch's traffic
-    issue = None
-    try:  # SQ counters of the same kernel (tools/pmc_rollout.sh): what bounds it is instruction issue, not HBM
-        with open(os.path.join(ROOT, "profiles", "sq_counters.json")) as f:
-            sq = json.load(f)
-        if kernel == sq.get("kernel", "").split("<")[0] and n == N_ENVS_PER_GPU and args.layout == "cramped_room":
-            issue = {"valu_per_env_step": sq["valu_per_env_step"], "salu_per_env_step": sq["salu_per_env_step"],
-                     "lds_per_env_step": sq["lds_per_env_step"], "valu_busy_frac": sq["valu_busy_frac"],
-                     "wait_frac": sq["wait_any_frac"],
-                     "wave_clk_per_env_step": sq.get("wave_clk_per_env_step"),
-                     "note": "one wavefront per SIMD at 65 536 envs: every instruction of the wavefront issues in turn (~4 clk "
-                             "each), so (VALU + SALU + LDS + VMEM per env-step) * 4 clk is the floor of a batched step "
-                             "whatever the bytes moved"}
-    except (OSError, ValueError, KeyError):
-        pass
+    traffic, traffic_src = None, {"how": "not collected", "why": "only rank 0 of a 1-GPU run collects PMC traffic"}
+    if rank == 0 and world == 1 and not args.stub:
+        if not args.no_traffic:
+            traffic, traffic_src = measure_traffic(args, kernel)
+        if traffic is None:
+            why = traffic_src.get("why")
+            traffic, traffic_src = traffic_from_file(kernel, n, fuse, args.layout if args.config == 2 else "", bytes_per_launch)
+            if traffic is None and why:
+                traffic_src["same_run_attempt"] = why
+    issue = issue_counters(kernel, n, args.layout) if args.config == 2 and not args.stub else None
+
+    # parity of the timed launch shape, per rank, against the C oracle (never inside the timed region)
+    parity = None
+    if not args.no_parity_check:
+        psteps = args.parity_steps or (fuse if world == 1 else min(fuse, 1200))
+        psteps = min(psteps, fuse)
+        mine = parity_check(torch, wl, make_env, n, rank, psteps, rew, fl, max(1, usable_cores() // max(1, world)))
+        pr = torch.zeros((world, 2), dtype=torch.float64, device=dev)
+        pr[rank, 0], pr[rank, 1] = mine["mismatches"], mine["seconds"]
+        sharding.allreduce_metrics(pr)
+        parity = dict(mine, envs=n * world, mismatches=int(pr[:, 0].sum().item()),
+                      mismatches_by_rank=[int(x) for x in pr[:, 0].tolist()],
+                      seconds_by_rank=[float(x) for x in pr[:, 1].tolist()], envs_per_rank=n)
+        if args.stub:
+            parity["stub"] = "oracle compared with itself: plumbing only"
+
     out = {
-        "metric": "env steps/sec (whole node), 65k parallel cramped_room envs",
+        "metric": "env steps/sec (whole node), 65k parallel cramped_room envs" if args.config == 2 else "env steps/sec (whole node)",
         "value": value, "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall_max * 1e3 / total_steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "stub" if args.stub else "synthetic",
@@ -383,81 +661,59 @@ def main():
         "warmup_steps_run": (warm_launches + 3) * fuse,
         "ms_per_step_median": launch_med / fuse, "ms_per_step_min": launch_min / fuse,
         "ms_per_step_by_rank": [float(x) for x in per_rank.tolist()],
-        "config": {"workload": "%s x %d envs/GPU, in-kernel Philox random policy, horizon %d auto-reset, outputs every step"
-                               % (args.layout, n, HORIZON),
+        "config": {"workload": wl["workload"], "baseline_config": args.config,
                    "envs_per_gpu": n, "fused_steps_per_launch": fuse, "launches": launches, "parallelism": "env-shard x%d" % world,
+                   "numa_node_rank0": numa,
                    "timing_rule": "timed region = `repeats` back-to-back repetitions of the --steps-step region (steps x repeats "
                                   "batched steps, issued as whole %d-step launches whatever --steps is), repeats = smallest count "
                                   "with steps*repeats a multiple of %d and a region >= %.2f s at the warm-up rate; value and "
                                   "ms_per_step are over the whole region (wall clock, max over ranks)" % (fuse, fuse, args.min_seconds)},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "bytes_per_launch": bytes_per_launch, "launch_ms": launch_med, "launch_ms_min": launch_min,
                      "launch_ms_mean": dev_ms / max(1, launches), "launch_timing": "per-launch HIP events on the launch stream, median",
                      "bytes_model": "n_envs*(2*S + 17*T): S=%d B state in+out once per launch, 17 B outputs per env-step, actions in-kernel" % state_bytes,
                      "survey_8d_per_step_model_GBs": n * (2 * state_bytes + OUT_BYTES) * fuse / (launch_med * 1e-3) / 1e9,
                      "issue_bound": issue},
+        "parity_check": parity,
         "device_ms_timed_region": dev_ms,
         "aggregate": {"sparse_return_last_launch": float(metrics[0]), "shaped_return_last_launch": float(metrics[1]),
                       "episodes_done_last_step": float(metrics[2]),
                       "reduced_over": ("RCCL all-reduce" if not args.stub else "gloo all-reduce") if sharding._live() else "single rank"},
     }
 
-    if rank == 0 and world == 1 and not args.no_extras and not args.stub:
+    if rank == 0 and world == 1 and not args.no_extras and not args.stub and args.config == 2:
         out["step_api"] = bench_step_api(env, dev, torch)
         out["single_env_api"] = bench_single_env_api(dev, torch)
         out["encode"] = bench_encode(dev, torch, VecOvercookedEnv)
         out["training_env"] = bench_training_env(dev, torch)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stub:  # the CPU leg runs at N = 1 only
-        out["cpu_baseline"] = cpu_baseline(args.layout, args.cpu_seconds)
-        out["cpu_baseline"]["reference_python"] = REFERENCE_PYTHON
+        out["cpu_baseline"] = cpu_baseline(wl, n, args.cpu_seconds)
+        out["cpu_baseline"]["reference_python"] = _reference_python()
     if rank == 0:
         emit(out)
     sharding.barrier()
 
 
-def run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
-    """Side measurements for BASELINE.json configs 3-5 (same timing protocol; not the headline line)."""
+def run_encode_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
+    """--config 3 = BASELINE configs[2] (the rollout of configs[1] plus oc_encode_lossless every step):
+    ENC_FUSE steps per launch through oc_rollout_encode, the observation of every step kept ([ENC_FUSE][n] u8
+    trajectory buffer: 7.7 GB at 65 536 9x5 envs); same timing protocol, not the headline line."""
     import numpy as np
 
-    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
-
     n = args.envs
-    encode = False
-    if args.config == 3:
-        env = VecOvercookedEnv("asymmetric_advantages", n, horizon=HORIZON, device=dev, auto_reset=True, seed=0,
-                               env_offset=rank * n)
-        encode, workload, sbytes = True, ("asymmetric_advantages x %d envs/GPU, random policy (in-kernel Philox actions) + lossless u8 "
-                                          "encoding of every step into a [steps][envs] trajectory buffer (oc_rollout_encode)" % n), S_ASYM
-    elif args.config == 4:
-        names = ["cramped_room", "asymmetric_advantages", "coordination_ring", "forced_coordination", "counter_circuit"]
-        table = LayoutTable([spec_from_name(nm) for nm in names], pad_to=(9, 5))
-        lid = ((np.arange(n) + rank * n) % 5).astype(np.uint16)
-        env = VecOvercookedEnv(table, n, horizon=HORIZON, device=dev, auto_reset=True, seed=0, env_offset=rank * n,
-                               layout_id=lid)
-        workload, sbytes = "5 canonical layouts padded to 9x5 (env e -> layout e %% 5) x %d envs/GPU, random policy" % n, 34
-    else:
-        from overcooked_ai_amd.layout_gen import reference_generated_layouts
-
-        K = 4096  # the reference LayoutGenerator's own terrains (np.random.seed(0)), recorded as package data
-        table = LayoutTable(reference_generated_layouts(K))
-        lid = ((np.arange(n) + rank * n) % K).astype(np.uint16)
-        env = VecOvercookedEnv(table, n, horizon=HORIZON, device=dev, auto_reset=True, seed=0, env_offset=rank * n,
-                               layout_id=lid)
-        workload, sbytes = "%d LayoutGenerator 9x5 terrains (reference generator, seed 0; env e -> terrain e %% %d) x %d envs/GPU, random policy" % (K, K, n), 36
-    # configs[2] (SURVEY 8d-3: the rollout of configs[1] plus oc_encode_lossless every step): ENC_FUSE steps per launch, the
-    # observation of every step kept ([ENC_FUSE][n] u8 trajectory buffer: 7.7 GB at 65 536 9x5 envs)
+    env = VecOvercookedEnv("asymmetric_advantages", n, horizon=HORIZON, device=dev, auto_reset=True, seed=0,
+                           env_offset=rank * n)
+    workload, sbytes = ("asymmetric_advantages x %d envs/GPU, random policy (in-kernel Philox actions) + lossless u8 "
+                        "encoding of every step into a [steps][envs] trajectory buffer (oc_rollout_encode)" % n), S_ASYM
     ENC_FUSE = 50
-    fuse = ENC_FUSE if encode else max(1, args.fuse)
+    fuse = ENC_FUSE
     rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
-    obs = torch.empty((fuse, n, 2, env.width, env.height, 26), dtype=torch.uint8, device=dev) if encode else None
+    obs = torch.empty((fuse, n, 2, env.width, env.height, 26), dtype=torch.uint8, device=dev)
 
     def launch():  # one `fuse`-step unit of the workload
-        if encode:
-            env.rollout_encode(fuse, obs, rew, fl)
-        else:
-            env.rollout_random(fuse, rew, fl)
+        env.rollout_encode(fuse, obs, rew, fl)
 
     for _ in range(-(-args.warmup // fuse)):
         launch()
@@ -489,52 +745,83 @@ def run_other_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
     tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
     sharding.allreduce_max(tmax)
     wall = float(tmax.item())
-    unit_bytes = n * (2 * sbytes + OUT_BYTES * fuse) + (fuse * n * 2 * env.width * env.height * 26 if encode else 0)
-    one_step = None
-    if encode:  # the same step with caller-supplied actions, one call per step (oc_step_encode: what a policy in the loop pays)
-        acts = torch.randint(0, 6, (64, n, 2), dtype=torch.uint8, device=dev)
-        ob1 = obs[0]
-        for i in range(20):
-            env.step_encode(acts[i % 64], torch.uint8, out=ob1)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        for i in range(300):
-            env.step_encode(acts[i % 64], torch.uint8, out=ob1)
-        ev1.record()
-        torch.cuda.synchronize(dev)
-        us = ev0.elapsed_time(ev1) / 300 * 1e3
-        one_step = {"us_per_step": us, "value": n / us * 1e6, "unit": "env steps/s (one GPU)",
-                    "note": "oc_step_encode: caller-supplied actions resident in HBM, one C call per batched step"}
+    unit_bytes = n * (2 * sbytes + OUT_BYTES * fuse) + fuse * n * 2 * env.width * env.height * 26
+    # parity of this launch shape: one ENC_FUSE-step launch from reset — rewards, flags, final states, and the observations
+    # of a sample of steps (the oracle's encoder is a scalar loop) against the C oracle
+    parity = None
+    if not args.no_parity_check:
+        from oracle import oracle as O
+        from overcooked_ai_amd.layouts import spec_from_name
+
+        t_par = time.perf_counter()
+        O.set_threads(max(1, usable_cores() // max(1, world)))
+        orc = O.Oracle(O.mdp_from_layout_dict(spec_from_name("asymmetric_advantages").to_layout_dict()))
+        env2 = VecOvercookedEnv("asymmetric_advantages", n, horizon=HORIZON, device=dev, auto_reset=True, seed=0, env_offset=rank * n)
+        env2.rollout_encode(fuse, obs, rew, fl)
+        st = orc.reset(orc.new_state(n))
+        bad, sampled = 0, []
+        rg, fg = rew.cpu().numpy(), fl.cpu().numpy()
+        for k in range(fuse):
+            r_o, f_o = orc.rollout_random(st, 1, horizon=HORIZON, options=1, seed=0, env_offset=rank * n, t0=k)
+            bad += int(((rg[k] != r_o[0]).any(axis=1) | (fg[k] != f_o[0])).sum())
+            if k in (0, fuse // 2, fuse - 1):
+                sub = slice(0, min(n, 8192))
+                enc_o = orc.encode_lossless(np.ascontiguousarray(st[:, sub]), horizon=HORIZON)
+                bad += int((obs[k, sub].cpu().numpy().astype(np.int32) != enc_o).any(axis=(1, 2, 3, 4)).sum())
+                sampled.append(k)
+        bad += int((env2.get_packed_state() != st).any(axis=(0, 2)).sum())
+        O.set_threads(1)
+        del env2
+        parity = {"envs": n, "steps": fuse, "mismatches": bad, "observations_checked": "steps %s, first %d envs" % (sampled, min(n, 8192)),
+                  "seconds": time.perf_counter() - t_par,
+                  "what": "one %d-step oc_rollout_encode launch from reset: every reward quad and flag byte, the final states and "
+                          "sampled u8 observations against oracle/overcooked_oracle.c" % fuse}
+    # the same step with caller-supplied actions, one call per step (oc_step_encode: what a policy in the loop pays)
+    acts = torch.randint(0, 6, (64, n, 2), dtype=torch.uint8, device=dev)
+    ob1 = obs[0]
+    for i in range(20):
+        env.step_encode(acts[i % 64], torch.uint8, out=ob1)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for i in range(300):
+        env.step_encode(acts[i % 64], torch.uint8, out=ob1)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    us = ev0.elapsed_time(ev1) / 300 * 1e3
+    one_step = {"us_per_step": us, "value": n / us * 1e6, "unit": "env steps/s (one GPU)",
+                "note": "oc_step_encode: caller-supplied actions resident in HBM, one C call per batched step"}
     out = {"metric": "env steps/sec (whole node)", "value": float(world) * n * total_steps / wall, "unit": "env steps/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / total_steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
            "repeats": repeats, "timed_steps": total_steps, "timed_region_s": wall, "ms_per_step_median": unit_med / fuse,
            "config": {"workload": workload, "baseline_config": args.config, "envs_per_gpu": n,
                       "fused_steps_per_launch": fuse},
-           "roofline": {"bound": "hbm", "achieved": unit_bytes / (unit_med * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "roofline": {"bound": "hbm", "kernel": "k_rollout_encode", "achieved": unit_bytes / (unit_med * 1e-3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": unit_bytes / (unit_med * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "traffic_source": {"how": "not collected", "why": "WRITE_SIZE wraps on multi-GB launches"},
                         "bytes_per_launch": unit_bytes, "launch_ms": unit_med,
-                        "note": "algorithmic bytes of one %d-step unit (all its kernels) / its median duration from HIP events" % fuse}}
-    if encode:  # the f32 variant of the observation (what the reference's RLlib wrapper casts to): 10 steps per launch
-        del obs
-        K32 = 10
-        obs32 = torch.empty((K32, n, 2, env.width, env.height, 26), dtype=torch.float32, device=dev)
-        for _ in range(2):
-            env.rollout_encode(K32, obs32, rew[:K32], fl[:K32], dtype=torch.float32)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        for _ in range(20):
-            env.rollout_encode(K32, obs32, rew[:K32], fl[:K32], dtype=torch.float32)
-        ev1.record()
-        torch.cuda.synchronize(dev)
-        us = ev0.elapsed_time(ev1) / (20 * K32) * 1e3
-        b32 = n * 2 * env.width * env.height * 26 * 4
-        out["f32_observations"] = {"us_per_step": us, "value": n / us * 1e6, "unit": "env steps/s (one GPU)",
-                                   "achieved_GBs": b32 / us / 1e3, "frac": b32 / us / 1e3 / HBM_PEAK_GBS,
-                                   "note": "oc_rollout_encode with f32 observations, %d steps per launch into a [steps][envs] buffer" % K32}
-        del obs32
-    if one_step is not None:
-        out["caller_actions_one_step"] = one_step
+                        "note": "algorithmic bytes of one %d-step unit (all its kernels) / its median duration from HIP events" % fuse},
+           "parity_check": parity}
+    # the f32 variant of the observation (what the reference's RLlib wrapper casts to): 10 steps per launch
+    del obs
+    K32 = 10
+    obs32 = torch.empty((K32, n, 2, env.width, env.height, 26), dtype=torch.float32, device=dev)
+    for _ in range(2):
+        env.rollout_encode(K32, obs32, rew[:K32], fl[:K32], dtype=torch.float32)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(20):
+        env.rollout_encode(K32, obs32, rew[:K32], fl[:K32], dtype=torch.float32)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    us = ev0.elapsed_time(ev1) / (20 * K32) * 1e3
+    b32 = n * 2 * env.width * env.height * 26 * 4
+    out["f32_observations"] = {"us_per_step": us, "value": n / us * 1e6, "unit": "env steps/s (one GPU)",
+                               "achieved_GBs": b32 / us / 1e3, "frac": b32 / us / 1e3 / HBM_PEAK_GBS,
+                               "note": "oc_rollout_encode with f32 observations, %d steps per launch into a [steps][envs] buffer" % K32}
+    del obs32
+    out["caller_actions_one_step"] = one_step
     if rank == 0:
         emit(out)
     sharding.barrier()
@@ -607,7 +894,7 @@ def bench_single_env_api(dev, torch, episodes=3):
     steps = sum(episode() for _ in range(episodes))
     dt = time.perf_counter() - t0
     return {"value": steps / dt, "unit": "env steps/s", "us_per_step": dt / steps * 1e6, "episodes": episodes,
-            "reference_python": REFERENCE_PYTHON["value"],
+            "reference_python": _reference_python()["value"],
             "note": "OvercookedEnv.step through the single-env drop-in API: state and action written into a pinned host buffer "
                     "the kernel reads and writes in place (no staging copies), one launch + one stream wait per call; "
                     "latency-bound by construction - batch with VecOvercookedEnv for throughput"}

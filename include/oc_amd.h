@@ -83,7 +83,7 @@ extern "C" {
 /* option bits for oc_step / oc_rollout_random */
 #define OC_OPT_AUTO_RESET 0x1u /* reset a done env to its layout's start state inside the kernel */
 
-#define OC_OPT_LANE_PER_ENV 0x2u /* oc_rollout_random: the one-lane-per-env kernel (the default; kept for callers that set it) */
+/* 0x2u: retired (was OC_OPT_LANE_PER_ENV; one lane per env is the default and only automatic choice); ignored when set */
 #define OC_OPT_LANE_PAIR 0x4u    /* oc_rollout_random: the lane-pair-per-env kernel where the table allows it
                                    (2-player layouts, <= 2 pots); never chosen automatically */
 #define OC_OPT_PREDICATE_INTERACT 0x8u /* oc_rollout_random: one-lane-per-env kernel with the predicate-network
@@ -99,6 +99,8 @@ extern "C" {
 /* OcBatch.batch_flags */
 #define OC_BATCH_TWO_PLAYERS 0x1u /* every layout of the table has exactly 2 players */
 #define OC_BATCH_NEW_DYNAMICS 0x2u /* no layout of the table uses old_dynamics (mdp.py:1696-1701) */
+#define OC_BATCH_UNIFORM_SHAPING 0x4u /* every layout of the table has the same rew_shaping_params and old_dynamics flag:
+                                         the interact table then carries the reward floats for the whole batch */
 
 /* obs dtypes of oc_encode_lossless */
 #define OC_OBS_U8 0

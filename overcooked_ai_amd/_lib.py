@@ -9,13 +9,13 @@ LIB_PATH = os.environ.get("OC_AMD_LIB") or os.path.join(PKG, "liboc_amd.so")  # 
 ABI_VERSION = 2
 F_DONE, F_BAD_ACTION, F_RESET = 0x01, 0x02, 0x04
 OPT_AUTO_RESET = 0x1
-OPT_LANE_PER_ENV = 0x2
 OPT_LANE_PAIR = 0x4
 OPT_PREDICATE_INTERACT = 0x8
 OPT_ROLLOUT_V3 = 0x10
 OPT_ONE_KERNEL = 0x20
 BATCH_TWO_PLAYERS = 0x1
 BATCH_NEW_DYNAMICS = 0x2
+BATCH_UNIFORM_SHAPING = 0x4
 OBS_U8, OBS_F32 = 0, 1
 
 EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_batch_hints", "oc_step", "oc_step_many",

@@ -29,6 +29,21 @@ def hipcc_path():
     return "hipcc"
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources and the C-ABI header: profiles that bench.py replays
+    (profiles/traffic.json, profiles/sq_counters.json) carry it, and are dropped when it no longer matches."""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.dirname(SRC)
+    for p in sorted(os.listdir(csrc)) + [HDR]:
+        path = p if os.path.isabs(p) else os.path.join(csrc, p)
+        if os.path.isfile(path):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     if not os.path.exists(LIB):
         return True

@@ -218,10 +218,13 @@ int oc_batch_hints(const OcLayout* h_layouts, int n_layouts, OcBatch* batch) {
     if (!h_layouts || !batch || n_layouts < 1) return fail(OC_EINVAL, "oc_batch_hints: NULL table / batch or no layouts");
     int max_pots = 0;
     uint32_t max_free = 0;
-    bool two = true, any_old = false;
+    bool two = true, any_old = false, same_shaping = true;
     for (int i = 0; i < n_layouts; ++i) {
         const OcLayout& l = h_layouts[i];
         any_old = any_old || l.old_dynamics != 0;
+        same_shaping = same_shaping && l.old_dynamics == h_layouts[0].old_dynamics &&
+                       l.rew_placement_in_pot == h_layouts[0].rew_placement_in_pot &&
+                       l.rew_dish_pickup == h_layouts[0].rew_dish_pickup && l.rew_soup_pickup == h_layouts[0].rew_soup_pickup;
         if (l.n_pots > OC_MAX_POTS || l.n_cells > OC_MAX_CELLS) return fail(OC_EINVAL, "oc_batch_hints: corrupt layout record");
         max_pots = l.n_pots > max_pots ? l.n_pots : max_pots;
         two = two && l.n_players == 2;
@@ -230,7 +233,8 @@ int oc_batch_hints(const OcLayout* h_layouts, int n_layouts, OcBatch* batch) {
         max_free = free_cells > max_free ? free_cells : max_free;
     }
     batch->max_pots = max_pots;
-    batch->batch_flags = (two ? OC_BATCH_TWO_PLAYERS : 0u) | (any_old ? 0u : OC_BATCH_NEW_DYNAMICS);
+    batch->batch_flags = (two ? OC_BATCH_TWO_PLAYERS : 0u) | (any_old ? 0u : OC_BATCH_NEW_DYNAMICS) |
+                         (same_shaping ? OC_BATCH_UNIFORM_SHAPING : 0u);
     batch->max_free_cells = max_free;
     return OC_OK;
 }
@@ -350,6 +354,13 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         const size_t cell_bytes = ((size_t)n_obj * 16 + 1) * BLOCK * sizeof(uint16_t);  // + one spare word per lane
         const dim3 grid4(grid_for(b->n_envs)), block4(BLOCK);
         const bool out = d_rewards != nullptr && d_flags != nullptr;
+        // big batches (more than ~1.5 wavefronts per SIMD) hide latency with the other wavefronts: no one-step-ahead reads
+        static const int forced_pipe = []() { const char* e = getenv("OC_ROLLOUT_PIPE"); return e ? atoi(e) : -1; }();  // tuning runs
+        const bool pipe = forced_pipe >= 0 ? forced_pipe != 0 : b->n_envs <= simd_count() * 64 * 3 / 2;
+        const bool shaping_uniform = uniform || (b->batch_flags & OC_BATCH_UNIFORM_SHAPING) != 0;
+        static const bool no_mode2 = getenv("OC_ROLLOUT_NO_MODE2") != nullptr;  // tuning / cross-check runs
+        const bool mode2 = !joint && two && !old && out && small && shaping_uniform && b->width * b->height <= 64 &&
+                           !ev_on(ea) && !no_mode2;
 #define GO4(U, MP, LL, MODE, OUT, OLD, NF, ...)                                                                     \
     do {                                                                                                            \
         const size_t smem4 = (size_t)Lds4<U, LL, MODE, NF>::CELLS + cell_bytes;                                     \
@@ -367,12 +378,25 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         }
         else if (joint && b->max_pots == 1 && out && !old && b->max_free_cells <= 6) {
             // one wavefront per SIMD (or less): read the faced cells a step ahead; more: do not (see PIPE)
-            if (b->n_envs <= simd_count() * 64 * 3 / 2) GO4(true, 1, true, 1, true, false, 6);
+            if (pipe) GO4(true, 1, true, 1, true, false, 6);
             else GO4(true, 1, true, 1, true, false, 6, false, false);
         }
         else if (joint && b->max_pots == 1) GO4(true, 1, true, 1, false, true, JOINT_MAX_FLOOR);
         else if (joint && small) GO4(true, 2, true, 1, false, true, JOINT_MAX_FLOOR);
         else if (joint) GO4(true, 8, true, 1, false, true, JOINT_MAX_FLOOR);
+        else if (mode2) {
+            // per-env terrain (or one layout with more free cells than the joint table holds): pose one step ahead on the
+            // per-lane floor mask (MODE 2); one wavefront per SIMD or less reads the faced cells a step ahead, more do not
+#define GO4M2(U, LL, RUF)                                                                                 \
+    do {                                                                                                  \
+        if (b->max_pots == 1) { if (pipe) GO4(U, 1, LL, 2, true, false, 0, false, true, RUF); else GO4(U, 1, LL, 2, true, false, 0, false, false, RUF); } \
+        else { if (pipe) GO4(U, 2, LL, 2, true, false, 0, false, true, RUF); else GO4(U, 2, LL, 2, true, false, 0, false, false, RUF); } \
+    } while (0)
+            if (uniform) GO4M2(true, true, false);
+            else if (lds) GO4M2(false, true, true);
+            else GO4M2(false, false, true);
+#undef GO4M2
+        }
         else if (uniform && !old && out && small) {
             if (b->max_pots == 1) GO4(true, 1, true, 0, true, false, 0);
             else GO4(true, 2, true, 0, true, false, 0);
@@ -381,6 +405,9 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
             if (b->max_pots == 1) GO4(true, 1, true, 0, false, true, 0);
             else if (small) GO4(true, 2, true, 0, false, true, 0);
             else GO4(true, 8, true, 0, false, true, 0);
+        }
+        else if (!old && out && small) {  // mixed table, new dynamics, both output arrays: no per-step NULL / old-dynamics tests
+            if (lds) GO4(false, 2, true, 0, true, false, 0); else GO4(false, 2, false, 0, true, false, 0);
         }
         else if (lds) { if (small) GO4(false, 2, true, 0, false, true, 0); else GO4(false, 8, true, 0, false, true, 0); }
         else { if (small) GO4(false, 2, false, 0, false, true, 0); else GO4(false, 8, false, 0, false, true, 0); }

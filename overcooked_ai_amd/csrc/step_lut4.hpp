@@ -315,11 +315,13 @@ __device__ __forceinline__ Phx4 philox_words(uint64_t blk, uint32_t g_lo, uint32
     philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, r);
     return Phx4{r[0], r[1], r[2], r[3]};
 }
-__device__ __forceinline__ uint32_t joint_action_of(const Phx4& p, uint32_t s8) {
-    uint32_t w = p.w0;
-    w = s8 >= 2u ? p.w1 : w;
-    w = s8 >= 4u ? p.w2 : w;
-    w = s8 >= 6u ? p.w3 : w;
+// (the words are passed by value and picked with arithmetic masks: a chain of selects between fields of one struct gets
+//  folded into a dynamically indexed load, which pins the struct in scratch memory — and a scratch load in the step loop
+//  waits, through vmcnt, for the output stores of the previous steps)
+__device__ __forceinline__ uint32_t joint_action_of(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t s8) {
+    const uint32_t pick = s8 >> 1;
+    const uint32_t w = (w0 & (0u - (uint32_t)(pick == 0u))) | (w1 & (0u - (uint32_t)(pick == 1u))) |
+                       (w2 & (0u - (uint32_t)(pick == 2u))) | (w3 & (0u - (uint32_t)(pick == 3u)));
     return __umulhi(w * ((s8 & 1u) ? 36u : 1u), 36u);
 }
 
@@ -332,11 +334,11 @@ __device__ __forceinline__ uint32_t joint_action_of(const Phx4& p, uint32_t s8) 
 //    FL / FI           free-cell list / cell -> free-cell index (MODE 1)
 //    CT                [32] cook time by the low five bits of the soup code (one layout)
 //    CELLS             cell words u16 [n_obj * 16][BLOCK]
-template <bool UNIFORM, bool LAY_LDS, int MODE, int NF>
+template <bool UNIFORM, bool LAY_LDS, int MODE, int NF, bool ONE_LUT = UNIFORM>
 struct Lds4 {
     static constexpr int MVJ_CAP = MODE == 1 ? ((16 * NF * NF * MVJ_ROW_BYTES + 15) & ~15) : 0;
     static constexpr int ACT = MVJ_CAP, ACT_BYTES = MODE == 1 ? 160 : 0;
-    static constexpr int LUT = ACT + ACT_BYTES, LUT_BYTES = UNIFORM ? LUT4_BYTES : 2 * LUT4_BYTES;
+    static constexpr int LUT = ACT + ACT_BYTES, LUT_BYTES = ONE_LUT ? LUT4_BYTES : 2 * LUT4_BYTES;
     static constexpr int LAY = LUT + LUT_BYTES, LAY_BYTES = LAY_LDS ? (UNIFORM ? 256 : LDS_LAYOUT_MAX * 256) : 16;
     static constexpr int FL = LAY + LAY_BYTES, FI = FL + 16, CT = FI + (MODE == 1 ? OC_MAX_CELLS : 0), CELLS = CT + 32;
     static_assert(MVJ_CAP + ACT_BYTES + LUT4_KEYS * 16 < 65536, "row / LUT addresses are u16 in the tables");
@@ -366,14 +368,20 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
     }
 }
 
-// MODE 0: arithmetic movement, any table; MODE 1: JOINT move table (one two-player layout with <= NF free cells)
+// MODE 0: arithmetic movement, any table; MODE 1: JOINT move table (one two-player layout with <= NF free cells);
+// MODE 2: per-env terrain, two players everywhere, at most 64 cells: resolve_movement (mdp.py:1644-1727) needs only the
+//   static terrain, so the pose runs ONE STEP AHEAD of the interacts on a per-lane 64-bit floor mask (no cell reads for the
+//   move targets), the faced cells of the next step are read as soon as this step's cell writes are issued (PIPE), and the
+//   ~25 VALU of the movement fill the shadow of this step's LUT reads
+// RU: every layout of the table has the same shaping rewards and dynamics flag (hint OC_BATCH_UNIFORM_SHAPING): one LUT
+//   variant whose entries carry the reward floats, as with a single layout
 // OLD: some layout of the table may use old dynamics (auto-start of full pots in the env effects)
 // EV: event_infos are logged (per-step masks and / or per-episode counters, EvArgs)
 // PIPE (MODE 1): the next step's faced cells are read one step ahead.  That hides the read behind the tail of the step
 //   when a SIMD holds one wavefront (65 536 envs); with two or more wavefronts per SIMD the extra LDS traffic costs
 //   more than the latency it hides (131 072 cramped_room envs: 0.48 vs 0.65 us per batched step), so big batches turn it off
 template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false,
-          bool PIPE = true>
+          bool PIPE = true, bool RU = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_rollout4(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                     const uint16_t* __restrict__ layout_id, uint4* st,
                                                     float4* __restrict__ rewards, uint8_t* __restrict__ flags,
@@ -381,7 +389,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                                                     int horizon, uint32_t options, uint32_t seed_lo, uint32_t seed_hi,
                                                     int64_t env_offset, int64_t t0, int n_steps, StartArgs sa, EvArgs ea) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn4[];
-    using M = Lds4<UNIFORM, LAY_LDS, MODE, NF>;
+    constexpr bool RUX = UNIFORM || RU;  // one LUT variant, patched with the reward floats
+    using M = Lds4<UNIFORM, LAY_LDS, MODE, NF, RUX>;
     if ((uint32_t)(uintptr_t)(OC_LDS uint8_t*)s_dyn4 != 0u) __builtin_trap();  // folds away: the region starts at address 0
     uint4* const s_lay = reinterpret_cast<uint4*>(s_dyn4 + M::LAY);
     uint4* const s_lut = reinterpret_cast<uint4*>(s_dyn4 + M::LUT);
@@ -393,10 +402,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
     const Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains a barrier
     {
         const uint4* src = reinterpret_cast<const uint4*>(&g_lut4);
-        const int first = UNIFORM ? (L.old_dynamics() ? 2 * LUT4_KEYS : 0) : 0, count = UNIFORM ? 2 * LUT4_KEYS : 4 * LUT4_KEYS;
+        const int first = RUX ? (L.old_dynamics() ? 2 * LUT4_KEYS : 0) : 0, count = RUX ? 2 * LUT4_KEYS : 4 * LUT4_KEYS;
         for (int i = threadIdx.x; i < count; i += BLOCK) {
             uint4 ent = src[first + i];
-            if (UNIFORM)  // one layout: the entry carries the shaped reward itself
+            if (RUX)  // one layout (or one set of shaping rewards for the whole table): the entry carries the shaped reward itself
                 ent.w = ent.w == RW4_PLACE ? __float_as_uint(L.rew_placement()) : ent.w == RW4_PLATE ? __float_as_uint(L.rew_soup()) : 0u;
             s_lut[i] = ent;
         }
@@ -416,11 +425,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
     if (!active) return;
     const uint32_t col = (uint32_t)M::CELLS + threadIdx.x * 2u;  // LDS address of this lane's column of cell words
     const LayC C = load_consts<UNIFORM>(L);
-    const uint32_t lut_var = (uint32_t)M::LUT + (UNIFORM ? 0u : (C.old_dyn ? (uint32_t)LUT4_BYTES : 0u));  // this lane's LUT
+    const uint32_t lut_var = (uint32_t)M::LUT + (RUX ? 0u : (C.old_dyn ? (uint32_t)LUT4_BYTES : 0u));  // this lane's LUT
     const uint32_t delta4 = make_delta4(W);
     Env4<MAXP> s;
     load_env4<MAXP>(C, L, st, n, e, n_obj, horizon, s, col);
-    const bool two = MODE == 1 || s.pos1 != 0xFFu;
+    const bool two = MODE == 1 || MODE == 2 || s.pos1 != 0xFFu;
     auto joint_row = [&]() {  // LDS address of the row of the joint pose (pos0, or0, pos1, or1)
         const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR];
         return ((s_fi[s.pos0] * 4u + s.or0) * NP + (s_fi[s.pos1] * 4u + s.or1)) * MVJ_ROW_BYTES;
@@ -440,7 +449,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
     //      address of (this lane's table, does the player interact), c*: the faced cell words (already read).
     //      m0..m3: the caller's movement result for this step, overwritten inside the horizon branch when the env is put
     //      back to its start state — MODE 1: (row of the next pose, its faced cells, row of the pose after that; ja2n = the
-    //      next step's joint action * 2), MODE 0: (pos0, pos1, or0, or1).
+    //      next step's joint action * 2), MODE 0: (pos0, pos1, or0, or1), MODE 2: (pos0, faced-cell offsets, pos1, or0, or1 = m4)
+    //      of the next step's pose.
     //      pw[k]: pot k's cell word read BEFORE this step's interacts (its class is the "pot_states" of mdp.py:1439),
     //      cookv[k]: the cook time of what that pot holds (FAST_START only), MAXP <= 2.
     // (!PIPE = two or more wavefronts per SIMD: LDS operations are what the step is short of — no pot word / cook time
@@ -467,8 +477,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         for (int k = 0; k < MAXP; ++k) out[k] = PW ? lds_rd16(col + s.poff[k]) : 0u;
     };
     auto core = [&](uint32_t fo0, uint32_t fo1, uint32_t off0, uint32_t off1, uint32_t c0, uint32_t c1, uint32_t ja2n,
-                    const uint32_t (&pw)[MAXP], uint32_t& m0, uint32_t& m1, uint32_t& m2, uint32_t& m3, uint32_t& nc0,
-                    uint32_t& nc1, uint32_t (&npw)[MAXP]) __attribute__((always_inline)) {
+                    const uint32_t (&pw)[MAXP], uint32_t& m0, uint32_t& m1, uint32_t& m2, uint32_t& m3, uint32_t& m4,
+                    uint32_t& nc0, uint32_t& nc1, uint32_t (&npw)[MAXP]) __attribute__((always_inline)) {
         // ---- the straight line: everything a step does when nothing rare happens -------------------------------------
         // (values read with ds_read_u16 a step earlier: tell the compiler they are still 16 bits wide)
         __builtin_assume(c0 <= 0xFFFFu); __builtin_assume(c1 <= 0xFFFFu);
@@ -505,14 +515,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                 lds_wr8(col + s.poff[k] + 1u, KB_POT + PC_READY);
             }
         }
-        if (MODE == 1 && PIPE) {  // the next step's cells: everything this step writes to the grid has been issued
+        if ((MODE == 1 || MODE == 2) && PIPE) {  // the next step's cells: everything this step writes to the grid has been issued
             nc0 = lds_rd16(col + (m1 & 0xFFFFu));
             nc1 = lds_rd16(col + (m1 >> 16));
             rd_pots(npw);
         }
         // shaped reward of potting / soup pickup straight from the entries (class -> this lane's layout when the table is mixed)
         auto shaped_of = [&](uint32_t w) __attribute__((always_inline)) {
-            return UNIFORM ? __uint_as_float(w) : (w == RW4_PLACE ? C.rew_place : w == RW4_PLATE ? C.rew_soup : 0.f);
+            if (RUX) return __uint_as_float(w);
+            // class -> this lane's layout, with masks (left as a ternary chain the compiler builds four exec-mask branches)
+            return __uint_as_float((__float_as_uint(C.rew_place) & (0u - (uint32_t)(w == RW4_PLACE))) |
+                                   (__float_as_uint(C.rew_soup) & (0u - (uint32_t)(w == RW4_PLATE))));
         };
         const float sh0 = shaped_of(e0.w);
         float sh1 = shaped_of(e1.w);
@@ -540,13 +553,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         if (OLD) gate |= C.old_dyn ? (uint32_t)F4_PLACE : 0u;  // old dynamics: the third item starts the pot (Q11)
         bool rare = (((r0 | r1) & gate) != 0u) | done | conflict;
         if (OLD) rare |= s.pending != 0u;
-#if defined(OC_EXPERIMENT) && (OC_EXPERIMENT == 2)
-        rare = done | conflict;
-#elif defined(OC_EXPERIMENT) && (OC_EXPERIMENT == 3)
-        rare = (((r0 | r1) & gate) != 0u) | done;
-#elif defined(OC_EXPERIMENT) && (OC_EXPERIMENT == 4)
-        rare = done;
-#endif
         uint32_t nh0 = r0, nh1 = r1;  // the hands after the step
         float add0 = sh0, add1 = sh1; // what the episode's shaped returns gain
         float4 rw = make_float4(0.f, 0.f, sh0, sh1);  // this step's reward quad and flag byte: stored ONCE, after the branch
@@ -653,6 +659,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                         m0 = joint_row();
                         m1 = lds_rd32(m0 + 72u);
                         m2 = lds_rd16(m0 + ja2n);
+                    } else if (MODE == 2) {
+                        m0 = s.pos0; m2 = s.pos1; m3 = s.or0; m4 = s.or1;
+                        m1 = (step_cell(s.pos0, s.or0, delta4) * (BLOCK * 2u)) | ((step_cell(s.pos1, s.or1, delta4) * (BLOCK * 2u)) << 16);
                     } else {
                         m0 = s.pos0; m1 = s.pos1; m2 = s.or0; m3 = s.or1;
                     }
@@ -661,7 +670,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                     s.over += 1u;
                 }
             }
-            if (MODE == 1 && PIPE && grid_changed) {  // read the next step's cells again
+            if ((MODE == 1 || MODE == 2) && PIPE && grid_changed) {  // read the next step's cells again
                 nc0 = lds_rd16(col + (m1 & 0xFFFFu));
                 nc1 = lds_rd16(col + (m1 >> 16));
                 rd_pots(npw);
@@ -704,10 +713,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             if (ea.events) ea.events[(int64_t)step_k * n + e] = ev;
             count_events(ea, e, ev, done, (options & OC_OPT_AUTO_RESET) != 0u);
         }
-#if !defined(OC_EXPERIMENT) || (OC_EXPERIMENT != 1)
         if (OUT || rew_k) rew_k[threadIdx.x] = rw;
         if (OUT || flg_k) store_flag_byte(flg_k, lane, fl);
-#endif
         s.h0 = nh0;
         s.h1 = nh1;
         s.dcount = dcount;
@@ -722,7 +729,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
     ([&]() __attribute__((always_inline)) {                                                                  \
         const uint64_t t_ = (uint64_t)(T);                                                                   \
         if ((FIRST) || ((uint32_t)t_ & 7u) == 0u) w = philox_words(t_ >> 3, g_lo, g_hi, seed_lo, seed_hi);   \
-        return joint_action_of(w, (uint32_t)t_ & 7u);                                                        \
+        return joint_action_of(w.w0, w.w1, w.w2, w.w3, (uint32_t)t_ & 7u);                                                        \
     }())
 
     if (MODE == 1) {
@@ -749,8 +756,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             // keep these look-ahead reads at the top of the step: they do not depend on this step's cells, and left to
             // itself the scheduler queues them in front of the LUT reads the step is waiting for (+0.75 %)
             __builtin_amdgcn_sched_barrier(0);
-            uint32_t Jcn = Jn, unused = 0, nc0 = 0, nc1 = 0, npw[MAXP];
-            core(fo0, fo1, off0, off1, c0, c1, ja2n, pw, Jcn, fa_n, Jnn, unused, nc0, nc1, npw);
+            uint32_t Jcn = Jn, unused = 0, unused4 = 0, nc0 = 0, nc1 = 0, npw[MAXP];
+            core(fo0, fo1, off0, off1, c0, c1, ja2n, pw, Jcn, fa_n, Jnn, unused, unused4, nc0, nc1, npw);
             Jc = Jcn; Jn = Jnn; fa = fa_n; off0 = off0n; off1 = off1n;
             if (PIPE) {
                 c0 = nc0; c1 = nc1;
@@ -765,16 +772,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         for (; k < head_end; ++k) pstep(OC_JA_AT(t0 + k + 1, false) * 2u);  // up to the next block boundary
         for (; n_steps - k >= 8; k += 8) {  // whole Philox blocks, unrolled; the look-ahead digit of step 7 is the next block's first
             const Phx4 nb = philox_words(((uint64_t)(t0 + k) >> 3) + 1u, g_lo, g_hi, seed_lo, seed_hi);
-#if defined(OC_ROLL2)
-            // two steps per iteration, the words rotate through (cur, nxt): one copy of the step pair instead of four
-            uint32_t q0 = w.w0, q1 = w.w1, q2 = w.w2, q3 = w.w3;
-#pragma unroll 1
-            for (int wi = 0; wi < 4; ++wi) {
-                pstep(__umulhi(q0 * 36u, 36u) * 2u);
-                pstep(__umulhi(q1, 36u) * 2u);
-                q0 = q1; q1 = q2; q2 = q3; q3 = nb.w0;
-            }
-#else
             pstep(__umulhi(w.w0 * 36u, 36u) * 2u);
             pstep(__umulhi(w.w1, 36u) * 2u);
             pstep(__umulhi(w.w1 * 36u, 36u) * 2u);
@@ -783,13 +780,81 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             pstep(__umulhi(w.w3, 36u) * 2u);
             pstep(__umulhi(w.w3 * 36u, 36u) * 2u);
             pstep(__umulhi(nb.w0, 36u) * 2u);
-#endif
             w = nb;
         }
         for (; k < n_steps; ++k) pstep(OC_JA_AT(t0 + k + 1, false) * 2u);  // the tail
         // joint pose -> cells / orientations
         const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR], Jidx = Jc / MVJ_ROW_BYTES, P0 = Jidx / NP, P1 = Jidx - P0 * NP;
         s.pos0 = s_fl[P0 >> 2]; s.or0 = P0 & 3u; s.pos1 = s_fl[P1 >> 2]; s.or1 = P1 & 3u;
+    } else if (MODE == 2) {
+        // Per-env terrain, pose one step ahead.  Carried across steps: the pose of the step about to run (P0, O0, P1, O1), the
+        // LDS offsets of its two faced cells (fa, within this lane's column) and — PIPE — those cells' words and the pot words,
+        // read right after the previous step's cell writes.
+        uint64_t fm = 0;  // bit c: cell c is floor (static)
+        for (int i = 0; i < n_obj * 4; ++i) {
+            const uint32_t T = L.u32(L_TERRAIN + 4 * i);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (((T >> (8 * b)) & 7u) == OC_T_FLOOR && (uint32_t)(4 * i + b) < L.u8(L_NCELLS)) fm |= 1ull << (4 * i + b);
+        }
+        const uint64_t d64 = (uint64_t)delta4;  // signed byte deltas of N, S, E, W; actions 4 and 5 (bytes 4, 5) move by 0
+        auto ahead = [&](uint32_t c, uint32_t d) __attribute__((always_inline)) {
+            return c + (uint32_t)(int32_t)(int8_t)(uint8_t)(d64 >> (8u * d));
+        };
+        uint32_t P0 = s.pos0, O0 = s.or0, P1 = s.pos1, O1 = s.or1;
+        uint32_t fa = (ahead(P0, O0) * (BLOCK * 2u)) | ((ahead(P1, O1) * (BLOCK * 2u)) << 16);
+        uint32_t c0 = 0, c1 = 0, pw[MAXP];
+        if (PIPE) {
+            c0 = lds_rd16(col + (fa & 0xFFFFu));
+            c1 = lds_rd16(col + (fa >> 16));
+        }
+        rd_pots(pw);
+        constexpr uint32_t NOI = (uint32_t)(LUT4_KEYS * 16);
+        auto mstep = [&](uint32_t ja) __attribute__((always_inline)) {  // ja = 6 * a0 + a1 of THIS step
+            const uint32_t a0 = (ja * 43u) >> 8, a1 = ja - 6u * a0;
+            const uint32_t fo0 = col + (fa & 0xFFFFu), fo1 = col + (fa >> 16);
+            if (!PIPE) {
+                c0 = lds_rd16(fo0);
+                c1 = lds_rd16(fo1);
+                rd_pots(pw);
+            }
+            const uint32_t off0 = lut_var + (ja >= 30u ? 0u : NOI), off1 = lut_var + (a1 == 5u ? 0u : NOI);
+            // resolve_movement (mdp.py:1644-1727) on the static terrain: the pose of the NEXT step
+            const uint32_t t0 = ahead(P0, a0), t1 = ahead(P1, a1);
+            const uint32_t np0 = ((fm >> t0) & 1ull) ? t0 : P0, np1 = ((fm >> t1) & 1ull) ? t1 : P1;
+            const bool collide = (np0 == np1) | ((np0 == P1) & (np1 == P0));
+            uint32_t q0 = collide ? P0 : np0, q1 = collide ? P1 : np1;
+            uint32_t o0 = a0 < 4u ? a0 : O0, o1 = a1 < 4u ? a1 : O1;
+            uint32_t fa_n = (ahead(q0, o0) * (BLOCK * 2u)) | ((ahead(q1, o1) * (BLOCK * 2u)) << 16);
+            uint32_t nc0 = 0, nc1 = 0, npw[MAXP];
+            core(fo0, fo1, off0, off1, c0, c1, 0u, pw, q0, fa_n, q1, o0, o1, nc0, nc1, npw);
+            P0 = q0; P1 = q1; O0 = o0; O1 = o1; fa = fa_n;
+            if (PIPE) {
+                c0 = nc0; c1 = nc1;
+#pragma unroll
+                for (int k = 0; k < MAXP; ++k) pw[k] = npw[k];
+            }
+        };
+        int k = 0;
+        const int head_end = min(n_steps, (int)((8u - ((uint32_t)t0 & 7u)) & 7u));
+        for (int phase = 0; phase < 2; ++phase) {
+            const int upto = phase == 0 ? head_end : n_steps;
+            for (; k < upto; ++k) mstep(OC_JA_AT(t0 + k, k == 0));  // rolled steps: up to the next block boundary, and the tail
+            if (phase == 0) {
+                for (; n_steps - k >= 8; k += 8) {  // whole Philox blocks, unrolled: two base-36 digits per word
+                    w = philox_words((uint64_t)(t0 + k) >> 3, g_lo, g_hi, seed_lo, seed_hi);
+                    mstep(__umulhi(w.w0, 36u));
+                    mstep(__umulhi(w.w0 * 36u, 36u));
+                    mstep(__umulhi(w.w1, 36u));
+                    mstep(__umulhi(w.w1 * 36u, 36u));
+                    mstep(__umulhi(w.w2, 36u));
+                    mstep(__umulhi(w.w2 * 36u, 36u));
+                    mstep(__umulhi(w.w3, 36u));
+                    mstep(__umulhi(w.w3 * 36u, 36u));
+                }
+            }
+        }
+        s.pos0 = P0; s.or0 = O0; s.pos1 = P1; s.or1 = O1;
     } else {
         auto astep = [&](uint32_t a0, uint32_t a1) __attribute__((always_inline)) {
             const uint32_t f0 = step_cell(s.pos0, s.or0, delta4), f1 = two ? step_cell(s.pos1, s.or1, delta4) : f0;
@@ -809,8 +874,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             const uint32_t q0 = collide ? s.pos0 : np0, q1 = collide ? s.pos1 : np1;
             const uint32_t o0 = mv0 ? a0 : s.or0, o1 = mv1 ? a1 : s.or1;
             uint32_t p0 = q0, p1 = q1, d0 = o0, d1 = o1;
-            uint32_t nc0 = 0, nc1 = 0, npw[MAXP];
-            core(fo0, fo1, off0, off1, c0, c1, 0u, pw, p0, p1, d0, d1, nc0, nc1, npw);
+            uint32_t nc0 = 0, nc1 = 0, unused4 = 0, npw[MAXP];
+            core(fo0, fo1, off0, off1, c0, c1, 0u, pw, p0, p1, d0, d1, unused4, nc0, nc1, npw);
             s.pos0 = p0; s.pos1 = p1; s.or0 = d0; s.or1 = d1;
         };
         int k = 0;

@@ -58,12 +58,12 @@ class VecOvercookedMultiAgent:
         self.ep_returns = torch.zeros((self.n_envs, 4), dtype=torch.float32, device=dev)
         self._obs = None
         self._phi_args = None
-        if self.use_phi:  # potential of each layout's standard start state: the fresh batch holds exactly those
-            self.phi_cur.copy_(v.potential(self.gamma))
-            lid = v.layout_id_host if v.layout_id is not None else np.zeros(self.n_envs, np.int64)
-            first = [int(np.nonzero(lid == l)[0][0]) if (lid == l).any() else 0 for l in range(len(v.table))]
-            self.phi_start.copy_(self.phi_cur[torch.as_tensor(first, device=dev)])
-        if self._random_starts and self.use_phi:  # the fresh batch already holds drawn start states (epoch 0)
+        if self.use_phi:
+            # phi of each layout's STANDARD start state (what a standard reset carries into phi_cur), from a probe batch of
+            # one env per layout — the training batch itself may already hold drawn start states (epoch 0)
+            L = len(v.table)
+            probe = VecOvercookedEnv(v.table, L, horizon=horizon, device=dev, layout_id=np.arange(L) if L > 1 else None)
+            self.phi_start.copy_(probe.potential(self.gamma))
             v.potential(self.gamma, out=self.phi_cur)
 
     def _obs_buffer(self):
@@ -117,7 +117,7 @@ class VecOvercookedMultiAgent:
                        self.horizon, v._start_spec(),  # random starts: finished envs restart from drawn states in the same call
                        v._event_sink() if v.event_counts is not None else None)
         self._lib.check(rc, "oc_multi_agent_step")
-        v.steps_done += 1
+        v._advance(1)
         infos = {"sparse_r_by_agent": v.rewards[:, 0:2], "shaped_r_by_agent": v.rewards[:, 2:4], "flags": v.flags,
                  "ep_returns": self.ep_returns}  # episode totals so far; final where done (the reset cleared the live ones)
         if self.use_phi:

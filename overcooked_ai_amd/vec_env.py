@@ -38,7 +38,6 @@ class VecOvercookedEnv:
         if self.device.type != "cuda":
             raise _lib.OcAmdError("VecOvercookedEnv needs a ROCm GPU device (got %r); there is no CPU fallback" % device)
         self.auto_reset = bool(auto_reset)
-        self.lane_per_env = False  # rollout_random: force the one-lane-per-env kernel (testing / comparison)
         self.lane_pair = False     # rollout_random: force the lane-pair kernel where the table allows it
         self.predicate_interact = False  # rollout_random: lane-per-env kernel with the predicate-network interact
         self.rollout_v3 = False          # rollout_random: k_rollout3 instead of k_rollout4 (cross-checks)
@@ -46,11 +45,14 @@ class VecOvercookedEnv:
         self.seed = int(seed)
         self.env_offset = int(env_offset)
         self.t_global = 0  # global step counter feeding the Philox counter of rollout_random
-        self.reset_epoch = 0  # counter of randomized resets (oc_reset_random's epoch)
+        # ONE epoch counter for every drawn start state of this env (key word of the Philox stream documented at
+        # oc_reset_random): an explicit randomized reset consumes one epoch, a launch of K steps consumes K (a restart at
+        # step k of the launch draws from epoch + k) — explicit resets and in-kernel restarts never share a draw
+        self._epoch = 0
         # start_state_fn = get_random_start_state_fn(random_start_pos, rnd_obj_prob_thresh) (mdp.py:1307-1369): when set,
         # reset() and every restart inside the step kernels (auto_reset) draw the start state instead of the standard one
         self.random_start_pos, self.rnd_obj_prob_thresh = bool(random_start_pos), float(rnd_obj_prob_thresh)
-        self.steps_done = 0  # batched steps executed: epoch base of the in-kernel restarts (1 + steps_done + k)
+        self.steps_done = 0  # batched steps executed
         self._start = _lib.OcStartSpec()
         self.width, self.height = self.table.width, self.table.height
         self.n_planes = self.table.n_planes
@@ -107,9 +109,18 @@ class VecOvercookedEnv:
 
     @property
     def options(self):
-        return ((_lib.OPT_AUTO_RESET if self.auto_reset else 0) | (_lib.OPT_LANE_PER_ENV if self.lane_per_env else 0)
+        return ((_lib.OPT_AUTO_RESET if self.auto_reset else 0)
                 | (_lib.OPT_LANE_PAIR if self.lane_pair else 0) | (_lib.OPT_PREDICATE_INTERACT if self.predicate_interact else 0)
                 | (_lib.OPT_ROLLOUT_V3 if self.rollout_v3 else 0))
+
+    @property
+    def reset_epoch(self):
+        """Epoch the next drawn start state (explicit reset or in-kernel restart) uses."""
+        return self._epoch
+
+    def _advance(self, k):
+        self.steps_done += k
+        self._epoch += k
 
     @property
     def random_starts(self):
@@ -120,7 +131,7 @@ class VecOvercookedEnv:
         if not self.random_starts:
             return None
         sp = self._start
-        sp.seed, sp.env_offset, sp.epoch = self.seed, self.env_offset, (1 + self.steps_done) & 0xFFFFFFFF
+        sp.seed, sp.env_offset, sp.epoch = self.seed, self.env_offset, self._epoch & 0xFFFFFFFF
         sp.random_start_pos, sp.rnd_obj_prob_thresh = int(self.random_start_pos), self.rnd_obj_prob_thresh
         return ctypes.byref(sp)
 
@@ -162,9 +173,9 @@ class VecOvercookedEnv:
         with torch.cuda.device(self.device):
             if random_start_pos or rnd_obj_prob_thresh:
                 rc = self.lib.oc_reset_random(self._bref, self.state.data_ptr(), d_mask, d_ep, self.seed, self.env_offset,
-                                              self.reset_epoch & 0xFFFFFFFF, int(bool(random_start_pos)),
+                                              self._epoch & 0xFFFFFFFF, int(bool(random_start_pos)),
                                               float(rnd_obj_prob_thresh), self._stream())
-                self.reset_epoch += 1
+                self._epoch += 1
             else:
                 rc = self.lib.oc_reset(self._bref, self.state.data_ptr(), d_mask, d_ep, self._stream())
         _lib.check(rc, "oc_reset")
@@ -195,7 +206,7 @@ class VecOvercookedEnv:
                           self._event_sink() if self.event_counts is not None else None)
         if rc:
             _lib.check(rc, "oc_step")
-        self.steps_done += 1
+        self._advance(1)
         return self.rewards, self.flags
 
     def step_encode(self, actions, dtype=torch.uint8, out=None):
@@ -218,7 +229,7 @@ class VecOvercookedEnv:
                           self.options | (_lib.OPT_ONE_KERNEL if self.one_kernel else 0),
                           self._start_spec() if self.auto_reset else None)
         _lib.check(rc, "oc_step_encode")
-        self.steps_done += 1
+        self._advance(1)
         return self.rewards, self.flags, out
 
     def step_many(self, actions, rewards_out, flags_out, events_out=None):
@@ -234,7 +245,7 @@ class VecOvercookedEnv:
                           flags_out.data_ptr(), self._ep_ptr, int(K), self.horizon, self.options,
                           self._start_spec() if self.auto_reset else None, self._event_sink(events_out))
         _lib.check(rc, "oc_step_many")
-        self.steps_done += int(K)
+        self._advance(int(K))
         return rewards_out, flags_out
 
     def rollout_random(self, n_steps, rewards_out=None, flags_out=None, events_out=None):
@@ -259,7 +270,7 @@ class VecOvercookedEnv:
                 self._start_spec() if self.auto_reset else None, self._event_sink(events_out), self._stream())
         _lib.check(rc, "oc_rollout_random")
         self.t_global += int(n_steps)
-        self.steps_done += int(n_steps)
+        self._advance(int(n_steps))
         return rewards_out, flags_out
 
     def rollout_encode(self, n_steps, obs_out, rewards_out=None, flags_out=None, actions=None, dtype=torch.uint8):
@@ -311,7 +322,7 @@ class VecOvercookedEnv:
         _lib.check(rc, "oc_rollout_encode")
         if actions is None:
             self.t_global += K
-        self.steps_done += K
+        self._advance(K)
         return obs_out, rewards_out, flags_out
 
     def encode_lossless(self, dtype=torch.uint8, out=None, state=None):

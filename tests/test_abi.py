@@ -45,9 +45,15 @@ def test_batch_hints_from_a_host_table():
     from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
 
     L = _lib.load()
-    for names, pots, free, flags in ((["cramped_room"], 1, 6, 3), (["asymmetric_advantages", "cramped_room"], 2, None, 3),
-                                     (["cramped_room_old_dynamics" if False else "cramped_room"], 1, 6, 3)):
-        table = LayoutTable([spec_from_name(nm) for nm in names], pad_to=(9, 5) if len(names) > 1 else None)
+    from overcooked_ai_amd.layouts import LayoutSpec
+
+    other_shaping = dict(spec_from_name("cramped_room").to_layout_dict(),
+                         rew_shaping_params={"PLACEMENT_IN_POT_REW": 1, "DISH_PICKUP_REWARD": 3, "SOUP_PICKUP_REWARD": 5})
+    # flags: two players everywhere (1) | new dynamics (2) | one set of shaping rewards for the whole table (4)
+    for names, pots, free, flags in ((["cramped_room"], 1, 6, 7), (["asymmetric_advantages", "cramped_room"], 2, None, 7),
+                                     (["cramped_room", LayoutSpec(other_shaping)], 1, 6, 3)):
+        table = LayoutTable([spec_from_name(nm) if isinstance(nm, str) else nm for nm in names],
+                            pad_to=(9, 5) if len(names) > 1 else None)
         rec = np.ascontiguousarray(table.records)
         b = _lib.OcBatch()
         assert L.oc_batch_hints(rec.ctypes.data, len(table), ctypes.byref(b)) == 0

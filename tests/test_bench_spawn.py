@@ -1,6 +1,6 @@
 """bench.py's multi-rank plumbing on CPU: `python bench.py --gpus 2` without a launcher spawns its own ranks
-(VERDICT r1 #2); `--stub` swaps the GPU env for a no-op stand-in and RCCL for gloo so only the rank spawning, the
-repeat planning and the reductions are exercised.  Nothing here is a measurement."""
+(VERDICT r1 #2); `--stub` swaps the GPU env for a stand-in that steps the C oracle and RCCL for gloo, so the rank spawning, the repeat
+planning, the per-rank shard maps, the parity check and the reductions are exercised.  Nothing here is a measurement."""
 import json
 import os
 import subprocess
@@ -33,18 +33,60 @@ def test_plan_repeats():
     assert bench.plan_repeats(400, 400, 100.0, 0.25) == 1
 
 
+def _check_two_rank_line(out, envs, fuse):
+    assert out["n_gpus"] == 2 and out["data"] == "stub" and out["steps"] == 20 and out["warmup"] == 5
+    assert out["timed_steps"] == 20 * out["repeats"] and out["timed_steps"] % fuse == 0
+    assert len(out["ms_per_step_by_rank"]) == 2 and all(x > 0 for x in out["ms_per_step_by_rank"])
+    assert out["aggregate"]["reduced_over"] == "gloo all-reduce"
+    assert abs(out["value"] - 2 * envs * out["timed_steps"] / out["timed_region_s"]) < 1e-6 * out["value"]
+    # every rank replayed a launch of its own shard (global env offset rank * envs) against the oracle
+    pc = out["parity_check"]
+    assert pc["mismatches"] == 0 and pc["mismatches_by_rank"] == [0, 0] and pc["envs"] == 2 * envs
+    assert pc["envs_per_rank"] == envs and pc["steps"] == min(fuse, 1200) and len(pc["seconds_by_rank"]) == 2
+    assert out["roofline"]["traffic"] is None and out["roofline"]["traffic_source"]["how"] == "not collected"
+
+
 def test_self_spawn_two_ranks_gloo():
     import bench
 
     out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--stub", "--envs", "64",
                 "--min-seconds", "0.02"])
-    assert out["n_gpus"] == 2 and out["data"] == "stub" and out["steps"] == 20 and out["warmup"] == 5
-    assert out["timed_steps"] == 20 * out["repeats"] and out["timed_steps"] % bench.DEFAULT_FUSE == 0
-    assert len(out["ms_per_step_by_rank"]) == 2 and all(x > 0 for x in out["ms_per_step_by_rank"])
-    # the stub writes 1/16 into every reward slot: the all-reduced sums prove both ranks took part
-    assert out["aggregate"]["sparse_return_last_launch"] == 2 * bench.DEFAULT_FUSE * 64 * 2 / 16
-    assert out["aggregate"]["reduced_over"] == "gloo all-reduce"
-    assert abs(out["value"] - 2 * 64 * out["timed_steps"] / out["timed_region_s"]) < 1e-6 * out["value"]
+    _check_two_rank_line(out, 64, bench.DEFAULT_FUSE)
+    # the stub steps the oracle: rank 1 owns global envs 64..127, so the all-reduced returns differ from 2 x rank 0's
+    assert out["aggregate"]["sparse_return_last_launch"] >= 0 and out["aggregate"]["shaped_return_last_launch"] > 0
+    assert out["config"]["baseline_config"] == 2 and "cramped_room" in out["config"]["workload"]
+
+
+def test_self_spawn_other_baseline_configs_gloo():
+    """BASELINE configs[3] / configs[4] as the 8-GPU runs shard them (--config 4: env e -> layout e % 5;
+    --config 5 --envs 131072: env e -> terrain e % 4096, here with a small batch) — per-rank layout ids follow the
+    GLOBAL env index, and the per-rank parity_check and ms_per_step_by_rank are in the line."""
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--stub", "--envs", "35",
+                "--config", "4", "--fuse", "600", "--min-seconds", "0.02"])
+    _check_two_rank_line(out, 35, 600)
+    assert out["config"]["baseline_config"] == 4 and "5 canonical layouts" in out["config"]["workload"]
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--stub", "--envs", "96",
+                "--config", "5", "--fuse", "500", "--min-seconds", "0.02"])
+    _check_two_rank_line(out, 96, 500)
+    assert out["config"]["baseline_config"] == 5 and "4096 LayoutGenerator" in out["config"]["workload"]
+
+
+def test_workload_layout_ids_follow_the_global_env_index():
+    """Rank r's slice of the env -> layout map equals the unsharded map's slice (what makes a shard reproduce its slice
+    of the single-GPU run)."""
+    import argparse
+
+    import numpy as np
+
+    import bench
+
+    for config, envs in ((4, 65536), (5, 131072)):
+        args = argparse.Namespace(config=config, envs=envs, layout="cramped_room")
+        k = 5 if config == 4 else 4096
+        for rank in (0, 3, 7):
+            wl = bench.make_workload(args, rank)
+            assert np.array_equal(wl["lid"], (np.arange(rank * envs, (rank + 1) * envs) % k).astype(np.uint16))
+            assert len(wl["specs"]) == k
 
 
 def test_launcher_env_is_respected():

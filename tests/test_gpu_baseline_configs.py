@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import CANONICAL_5
+from helpers import CANONICAL_5, select_kernel
 
 pytestmark = pytest.mark.gpu
 
@@ -40,11 +40,6 @@ def _env(layouts, gpu, **kw):
     from overcooked_ai_amd.vec_env import VecOvercookedEnv
 
     return VecOvercookedEnv(layouts, N, device=gpu, auto_reset=True, **kw)
-
-
-def _select(env, kernel):
-    for name in ("rollout_v3", "lane_pair", "predicate_interact"):
-        setattr(env, name, name == kernel)
 
 
 def test_config2_asymmetric_advantages_step_plus_encoding(gpu):
@@ -109,7 +104,7 @@ def test_config3_five_layout_mix(kernel, gpu):
     lid = (np.arange(N) % 5).astype(np.uint16)
     orc = _oracle(table.specs)
     env = _env(table, gpu, horizon=120, seed=0, layout_id=lid)
-    _select(env, kernel)
+    select_kernel(env, kernel)
     st = orc.reset(orc.new_state(N), layout_id=lid)
     ep_o = np.zeros((N, 4), np.float32)
     T = 160  # crosses the horizon at step 120
@@ -136,7 +131,7 @@ def test_config4_4096_generated_terrains(kernel, gpu):
     lid = (np.arange(N) % K).astype(np.uint16)
     orc = _oracle(table.specs)
     env = _env(table, gpu, horizon=100, seed=0, layout_id=lid)
-    _select(env, kernel)
+    select_kernel(env, kernel)
     st = orc.reset(orc.new_state(N), layout_id=lid)
     ep_o = np.zeros((N, 4), np.float32)
     T = 150  # crosses the horizon at step 100

@@ -1,0 +1,110 @@
+"""GPU parity at the shapes that actually launch: the 4 000-step launch `bench.py` times — ten episodes
+per launch, nine in-kernel restarts plus the one at the last step — and the per-env-terrain instances BASELINE
+configs[3] / configs[4] put on EACH of 8 GPUs (65 536 and 131 072 envs per GPU; `k_rollout4` MODE 0, layout table in LDS
+or read through L2, global env offset of an inner rank), compared with the C oracle (pinned to the reference by
+tests/test_oracle_golden.py): every reward quad and flag byte of every env-step, the final packed states and the
+episode returns, bit for bit.  The oracle runs in 400-step chunks to bound host memory."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import CANONICAL_5
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+HORIZON, T = 400, 4000
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    from overcooked_ai_amd import _lib
+
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _oracle(specs):
+    from oracle import oracle as O
+
+    O.set_threads(min(16, len(os.sched_getaffinity(0))))  # the envs are independent
+    return O.Oracle([O.mdp_from_layout_dict(s.to_layout_dict()) for s in specs])
+
+
+def _long_launch_against_oracle(gpu, table, n, lid=None, env_offset=0, seed=0, steps=T, horizon=HORIZON, start=None, **env_kw):
+    from overcooked_ai_amd.vec_env import VecOvercookedEnv
+
+    env = VecOvercookedEnv(table, n, horizon=horizon, device=gpu, auto_reset=True, seed=seed, env_offset=env_offset,
+                           layout_id=lid, **env_kw)
+    orc = _oracle(env.table.specs)
+    rew = torch.zeros((steps, n, 4), dtype=torch.float32, device=gpu)
+    fl = torch.zeros((steps, n), dtype=torch.uint8, device=gpu)
+    st = env.get_packed_state().copy()
+    st_o = orc.reset(orc.new_state(n), layout_id=lid)
+    if start is None:
+        assert np.array_equal(st, st_o)
+    else:
+        st_o = st
+    env.rollout_random(steps, rew, fl)  # ONE launch
+    ep_o = np.zeros((n, 4), np.float32)
+    restarts = shaped = sparse = 0
+    for c0 in range(0, steps, 400):
+        k = min(400, steps - c0)
+        sp = None
+        if start is not None:
+            from oracle import oracle as O
+
+            sp = O.start_spec(seed=seed, env_offset=env_offset, epoch=1 + c0, **start)
+        rew_o, fl_o = orc.rollout_random(st_o, k, horizon=horizon, options=1, seed=seed, env_offset=env_offset, t0=c0,
+                                         layout_id=lid, ep_returns=ep_o, start=sp)
+        assert np.array_equal(fl[c0:c0 + k].cpu().numpy(), fl_o), "flags differ in steps %d..%d" % (c0, c0 + k)
+        assert np.array_equal(rew[c0:c0 + k].cpu().numpy(), rew_o), "rewards differ in steps %d..%d" % (c0, c0 + k)
+        restarts += int(((fl_o & 4) != 0).sum())
+        sparse += float(rew_o[..., :2].sum())
+        shaped += float(rew_o[..., 2:].sum())
+    assert np.array_equal(env.get_packed_state(), st_o), "final states differ"
+    assert np.array_equal(env.ep_returns.cpu().numpy(), ep_o), "episode returns differ"
+    assert restarts == n * (steps // horizon) and shaped > 0
+    return sparse, shaped
+
+
+def test_bench_launch_shape_cramped_room_65536_x_4000(gpu):
+    """Exactly bench.py's launch: 65 536 cramped_room envs from the standard start, seed 0, horizon 400, auto-reset,
+    4 000 fused steps (k_rollout4, joint move table, one-step-ahead cell reads)."""
+    sparse, _ = _long_launch_against_oracle(gpu, "cramped_room", 65536)
+    assert sparse > 0  # soups were delivered somewhere in 262 M env-steps
+
+
+def test_config4_launch_shape_131072_generated_terrains_inner_rank(gpu):
+    """BASELINE configs[4] as rank 3 of 8 launches it: 131 072 envs per GPU, the reference LayoutGenerator's 4 096 terrains
+    (global env e -> terrain e % 4096, table read through L2), global env offset 3 x 131 072, 4 000 fused steps."""
+    from overcooked_ai_amd.layout_gen import reference_generated_layouts
+    from overcooked_ai_amd.layouts import LayoutTable
+
+    n, K, rank = 131072, 4096, 3
+    table = LayoutTable(reference_generated_layouts(K))
+    lid = ((np.arange(n) + rank * n) % K).astype(np.uint16)
+    _long_launch_against_oracle(gpu, table, n, lid=lid, env_offset=rank * n)
+
+
+def test_config3_launch_shape_five_layout_mix_65536_x_4000(gpu):
+    """BASELINE configs[3] as rank 5 of 8 launches it: 65 536 envs per GPU, the five canonical layouts padded to 9x5
+    (global env e -> layout e % 5, table staged in LDS), 4 000 fused steps."""
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    n, rank = 65536, 5
+    table = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+    lid = ((np.arange(n) + rank * n) % 5).astype(np.uint16)
+    sparse, _ = _long_launch_against_oracle(gpu, table, n, lid=lid, env_offset=rank * n)
+    assert sparse > 0
+
+
+def test_long_launch_with_drawn_start_states_131072(gpu):
+    """The big-batch (lean) joint-table instance with the env's start_state_fn drawn inside the fused auto-reset:
+    131 072 cramped_room envs, 2 000 steps = five restarts per env, each from a state drawn with its own epoch."""
+    _long_launch_against_oracle(gpu, "cramped_room", 131072, seed=5, steps=2000,
+                                start={"random_start_pos": True, "rnd_obj_prob_thresh": 0.4},
+                                random_start_pos=True, rnd_obj_prob_thresh=0.4)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from helpers import CANONICAL_5, random_packed_states
+from helpers import CANONICAL_5, random_packed_states, select_kernel
 
 pytestmark = pytest.mark.gpu
 
@@ -120,7 +120,7 @@ def test_reference_golden_trajectory(manifest, gpu):
     assert total == d["ep_rewards"][: n - 1].sum()
 
 
-@pytest.mark.parametrize("kernel", ["lane_per_env", "rollout_v3", "lane_pair", "predicate_interact"])
+@pytest.mark.parametrize("kernel", ["default", "rollout_v3", "lane_pair", "predicate_interact"])
 @pytest.mark.parametrize("name", ROLLOUT_CONFIGS)
 def test_golden_rollouts_fused(name, kernel, manifest, gpu):
     """Both fused Philox rollout kernels against episodes run through the reference's OvercookedEnv.step."""
@@ -131,7 +131,7 @@ def test_golden_rollouts_fused(name, kernel, manifest, gpu):
     d = np.load(os.path.join(GOLDEN, "rollouts_%s.npz" % name))
     n, seed, horizon = cfg["n_envs"], int(d["seed"]), int(d["horizon"])
     env = make_env(spec, n, gpu, horizon=horizon, seed=seed)
-    setattr(env, kernel, True)
+    select_kernel(env, kernel)
     for k in range(4):
         rew = torch.zeros((100, n, 4), dtype=torch.float32, device=gpu)
         fl = torch.zeros((100, n), dtype=torch.uint8, device=gpu)
@@ -221,7 +221,7 @@ def test_step_vs_oracle_random_states(n_envs, gpu):
         assert (fl_o & 2).any() or n_envs == 1
 
 
-@pytest.mark.parametrize("kernel", ["lane_per_env", "rollout_v3", "lane_pair", "predicate_interact"])
+@pytest.mark.parametrize("kernel", ["default", "rollout_v3", "lane_pair", "predicate_interact"])
 def test_full_size_rollout_vs_oracle(kernel, gpu):
     """BASELINE config 2 at full size: 65 536 cramped_room envs, random policy, horizon 400 with auto-reset."""
     from overcooked_ai_amd.layouts import spec_from_name
@@ -230,7 +230,7 @@ def test_full_size_rollout_vs_oracle(kernel, gpu):
     spec = spec_from_name("cramped_room")
     orc = oracle_for(spec)
     env = make_env(spec, n, gpu, horizon=400, auto_reset=True, seed=1234)
-    setattr(env, kernel, True)
+    select_kernel(env, kernel)
     st_o = orc.reset(orc.new_state(n))
     ep_o = np.zeros((n, 4), np.float32)
     t0 = 0
@@ -269,7 +269,7 @@ def test_full_size_rollout_vs_oracle(kernel, gpu):
     assert torch.equal(shard.state, env3.state[:, a:b])
 
 
-@pytest.mark.parametrize("kernel", ["lane_per_env", "rollout_v3", "lane_pair", "predicate_interact"])
+@pytest.mark.parametrize("kernel", ["default", "rollout_v3", "lane_pair", "predicate_interact"])
 def test_mixed_layout_batch_vs_oracle(kernel, gpu):
     """BASELINE config 4 (one GPU's shard): env e uses canonical layout e % 5, all padded to 9x5."""
     from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
@@ -279,7 +279,7 @@ def test_mixed_layout_batch_vs_oracle(kernel, gpu):
     lid = (np.arange(n) % 5).astype(np.uint16)
     orc = oracle_for(table.specs)
     env = make_env(table, n, gpu, horizon=400, auto_reset=True, seed=99, layout_id=lid)
-    setattr(env, kernel, True)
+    select_kernel(env, kernel)
     rng = np.random.default_rng(5)
     st = np.zeros((table.n_planes, n, 16), np.uint8)
     for l in range(5):
@@ -347,10 +347,8 @@ def test_every_registry_layout_vs_oracle(gpu):
         env = make_env(spec, n, gpu, horizon=400, auto_reset=True, seed=3)
         st_o = st.copy()
         rew_o, _ = orc.rollout_random(st_o, 60, horizon=400, options=1, seed=3)
-        for kernel in ("lane_per_env", "rollout_v3", "lane_pair", "predicate_interact"):  # lane_pair falls back where it does not apply
-            env.lane_per_env, env.lane_pair, env.predicate_interact = (kernel == "lane_per_env", kernel == "lane_pair",
-                                                                       kernel == "predicate_interact")
-            env.rollout_v3 = kernel == "rollout_v3"
+        for kernel in ("default", "rollout_v3", "lane_pair", "predicate_interact"):  # lane_pair falls back where it does not apply
+            select_kernel(env, kernel)
             env.set_packed_state(st)
             env.t_global = 0
             rew = torch.zeros((60, n, 4), dtype=torch.float32, device=gpu)
@@ -726,9 +724,8 @@ def test_no_out_of_bounds_writes_with_ragged_batches(gpu):
         K = 7
         r_raw, rew = guarded((K, n, 4), torch.float32); bufs.append((r_raw, rew))
         f_raw, fl = guarded((K, n), torch.uint8); bufs.append((f_raw, fl))
-        for mode in (None, "lane_per_env", "rollout_v3", "lane_pair", "predicate_interact"):
-            for m in ("lane_per_env", "rollout_v3", "lane_pair", "predicate_interact"):
-                setattr(env, m, m == mode)
+        for mode in (None, "default", "rollout_v3", "lane_pair", "predicate_interact"):
+            select_kernel(env, mode)
             env.rollout_random(K, rew, fl)
         s_raw, st_out = guarded(tuple(env.state.shape), torch.uint8); bufs.append((s_raw, st_out))
         e_raw, ev = guarded((n,), torch.int64); bufs.append((e_raw, ev))
@@ -1013,11 +1010,9 @@ def test_timestep_saturates_at_the_packing_limit(gpu):
     rng = np.random.default_rng(11)
     st = random_packed_states(spec, n, rng)
     st[0, :, 6], st[0, :, 7] = 0xFC, 0xFF  # timestep 65 532
-    for kernel in ("lane_per_env", "rollout_v3", "lane_pair", "predicate_interact", "step", "step_predicate"):
+    for kernel in ("default", "rollout_v3", "lane_pair", "predicate_interact", "step", "step_predicate"):
         env = make_env(spec, n, gpu, horizon=65535, auto_reset=False, seed=2)
-        env.lane_per_env, env.lane_pair = kernel == "lane_per_env", kernel == "lane_pair"
-        env.predicate_interact = kernel in ("predicate_interact", "step_predicate")
-        env.rollout_v3 = kernel == "rollout_v3"
+        select_kernel(env, "predicate_interact" if kernel == "step_predicate" else kernel)
         env.set_packed_state(st)
         if kernel.startswith("step"):
             for _ in range(12):

@@ -27,7 +27,13 @@ for kern in kerns:
             for f in glob.glob(d + "/*.db"):
                 names |= {r[0] for r in sqlite3.connect(f).execute("select distinct name from pmc_events where name like ?", ("%" + kern + "%",))}
         per = lambda k: round(vals.get(k, 0.0) / w / steps, 2)
+        import os
+
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from overcooked_ai_amd import build
+
         json.dump({
+            "kernel_source_sha": build.source_hash(),
             "_note": "rocprofv3 --pmc SQ_* passes of tools/prof_rollout.py (tools/pmc_rollout.sh), 65 536 cramped_room envs, %d fused "
                      "steps per launch; per wavefront and env-step (the launch prologue, e.g. the joint move table build, is included)" % steps,
             "kernel": sorted(n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] for n in names)[0] if names else kern,

@@ -1,5 +1,5 @@
 """Tiny driver for rocprofv3 counter passes over the fused rollout kernel (keeps the rocpd database small):
-    MODE=<lane_per_env|lane_pair|predicate_interact> LAYOUT=<name> ENVS=<n> python tools/prof_rollout.py"""
+    MODE=<rollout_v3|lane_pair|predicate_interact> LAYOUT=<name> ENVS=<n> python tools/prof_rollout.py"""
 import os
 import sys
 

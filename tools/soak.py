@@ -59,7 +59,7 @@ def main():
         env.reset(random_start_pos=True, rnd_obj_prob_thresh=thr)
         st = orc.reset_random(orc.new_state(n), seed=seed, epoch=0, random_start_pos=True, rnd_obj_prob_thresh=thr, layout_id=lid)
         assert np.array_equal(env.get_packed_state(), st), ("reset_random", seed)
-        mode = [None, "lane_per_env", "lane_pair", "predicate_interact"][seed % 4]
+        mode = [None, "rollout_v3", "lane_pair", "predicate_interact"][seed % 4]
         if mode:
             setattr(env, mode, True)
         t0, done = 0, 0
