@@ -149,6 +149,13 @@ inline int64_t simd_count() {
     return cached;
 }
 
+// dynamic LDS of a k_rollout4 instance: its tables + the cell words of a workgroup's 256 envs
+template <bool U, int MP, bool LL, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false, bool PIPE = true,
+          bool RU = false, int CW = 2>
+constexpr size_t lds4_bytes(size_t cell_rows) {
+    return (size_t)Lds4<U, LL, MODE, NF, U || RU, CW>::CELLS + cell_rows * BLOCK * CW;
+}
+
 #define DISPATCH_NOBJ(NOBJ_VALUE, ...)                                  \
     switch (NOBJ_VALUE) {                                               \
         case 1: { constexpr int NOBJ = 1; __VA_ARGS__; } break;         \
@@ -351,7 +358,7 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         const bool two = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0;
         const bool joint = uniform && two && b->max_free_cells >= 2 && b->max_free_cells <= (uint32_t)JOINT_MAX_FLOOR;
         const bool old = (b->batch_flags & OC_BATCH_NEW_DYNAMICS) == 0;  // some layout may use old dynamics
-        const size_t cell_bytes = ((size_t)n_obj * 16 + 1) * BLOCK * sizeof(uint16_t);  // + one spare word per lane
+        const size_t cell_rows = (size_t)n_obj * 16 + 1;  // + one spare word per lane
         const dim3 grid4(grid_for(b->n_envs)), block4(BLOCK);
         const bool out = d_rewards != nullptr && d_flags != nullptr;
         // big batches (more than ~1.5 wavefronts per SIMD) hide latency with the other wavefronts: no one-step-ahead reads
@@ -363,7 +370,7 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
                            !ev_on(ea) && !no_mode2;
 #define GO4(U, MP, LL, MODE, OUT, OLD, NF, ...)                                                                     \
     do {                                                                                                            \
-        const size_t smem4 = (size_t)Lds4<U, LL, MODE, NF>::CELLS + cell_bytes;                                     \
+        const size_t smem4 = lds4_bytes<U, MP, LL, MODE, OUT, OLD, NF, ##__VA_ARGS__>(cell_rows);                   \
         if (!want_lds(k_rollout4<U, MP, LL, MODE, OUT, OLD, NF, ##__VA_ARGS__>, smem4)) break;                      \
         hipLaunchKernelGGL((k_rollout4<U, MP, LL, MODE, OUT, OLD, NF, ##__VA_ARGS__>), grid4, block4, smem4, s, b->d_layouts, \
                            b->n_layouts, b->d_layout_id, (uint4*)d_state, (float4*)d_rewards, d_flags,              \
@@ -378,7 +385,10 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         }
         else if (joint && b->max_pots == 1 && out && !old && b->max_free_cells <= 6) {
             // one wavefront per SIMD (or less): read the faced cells a step ahead; more: do not (see PIPE)
-            if (pipe) GO4(true, 1, true, 1, true, false, 6);
+            // one wavefront per SIMD (or less) on a grid of at most 64 cells: 32-bit cell words (no re-masking of values
+            // carried across steps, no shared banks) and the faced cells read a step ahead; more wavefronts: neither
+            if (pipe && b->width * b->height <= 64) GO4(true, 1, true, 1, true, false, 6, false, true, false, 4);
+            else if (pipe) GO4(true, 1, true, 1, true, false, 6);
             else GO4(true, 1, true, 1, true, false, 6, false, false);
         }
         else if (joint && b->max_pots == 1) GO4(true, 1, true, 1, false, true, JOINT_MAX_FLOOR);

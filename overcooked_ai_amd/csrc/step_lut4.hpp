@@ -126,7 +126,23 @@ __device__ __forceinline__ uint4 lds_rd128(uint32_t a) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void lds_wr16(uint32_t a, uint32_t v) { *(OC_LDS uint16_t*)(uintptr_t)a = (uint16_t)v; }
+__device__ __forceinline__ void lds_wr32(uint32_t a, uint32_t v) { *(OC_LDS uint32_t*)(uintptr_t)a = v; }
 __device__ __forceinline__ void lds_wr8(uint32_t a, uint32_t v) { *(OC_LDS uint8_t*)(uintptr_t)a = (uint8_t)v; }
+
+// Cell words, [cell][lane] in LDS.  CW = 2: u16 = object code | key byte << 8.  CW = 4 (the instance that runs one wavefront
+// per SIMD on one small layout): u32 with the same two bytes in its UPPER half — the word an interact produces
+// ([flags][new hand][new object][new key byte]) is stored as it is, values carried across steps are full dwords (16-bit
+// loads carried through the loop are re-masked every step) and the lanes of a wavefront fall into distinct banks whatever
+// cells they touch (two lanes share a bank with u16 words).
+template <int CW> __device__ __forceinline__ uint32_t cw_rd(uint32_t a) { return CW == 2 ? lds_rd16(a) : lds_rd32(a); }
+template <int CW> __device__ __forceinline__ uint32_t cw_kb(uint32_t c) { return CW == 2 ? c >> 8 : c >> 24; }
+template <int CW> __device__ __forceinline__ uint32_t cw_obj(uint32_t c) { return CW == 2 ? (c & 0xFFu) : ((c >> 16) & 0xFFu); }
+template <int CW> __device__ __forceinline__ uint32_t cw_make(uint32_t obj, uint32_t kb) { return (obj | (kb << 8)) << (CW == 2 ? 0 : 16); }
+template <int CW> __device__ __forceinline__ void cw_wr(uint32_t a, uint32_t w) { if (CW == 2) lds_wr16(a, w); else lds_wr32(a, w); }
+template <int CW> __device__ __forceinline__ void cw_wr_kb(uint32_t a, uint32_t kb) { lds_wr8(a + (CW == 2 ? 1u : 3u), kb); }
+// the cell word an interact leaves behind, from its result [flags][new hand][new object][new key byte] (CW = 2: the upper
+// half, stored with ds_write_b16_d16_hi)
+template <int CW> __device__ __forceinline__ uint32_t cw_of_result(uint32_t r) { return CW == 2 ? r >> 16 : r; }
 
 __device__ __forceinline__ uint32_t key_byte_of(uint32_t terrain_type, uint32_t o) {
     const uint32_t cls = terrain_type == OC_T_COUNTER ? (o == 0u ? 0u : o == OC_O_DISH ? 1u : 2u) : 0u;
@@ -134,15 +150,17 @@ __device__ __forceinline__ uint32_t key_byte_of(uint32_t terrain_type, uint32_t 
 }
 
 // one player's INTERACT: `ent` = the LUT entry of (faced cell word, hand, does it interact); h carries the hand in byte 1
-__device__ __forceinline__ uint32_t interact4(const uint4 ent, uint32_t h, uint32_t c16) {
-    const uint32_t pool = __builtin_amdgcn_perm(c16, h, 0x05040401u) + ent.z;  // [hand][object][object + add][key byte]
+template <int CW>
+__device__ __forceinline__ uint32_t interact4(const uint4 ent, uint32_t h, uint32_t cw) {
+    const uint32_t pool = __builtin_amdgcn_perm(cw, h, CW == 2 ? 0x05040401u : 0x07060601u) + ent.z;  // [hand][object][object + add][key byte]
     return __builtin_amdgcn_perm(ent.y, pool, ent.x);                           // [flags][new hand][new object][new key byte]
 }
-__device__ __forceinline__ uint32_t lut4_addr(uint32_t off, uint32_t h, uint32_t c16) {
-    return (min((h >> 8) & 0xFFu, 4u) * 6u + (c16 >> 8)) * 16u + off;
+template <int CW>
+__device__ __forceinline__ uint32_t lut4_addr(uint32_t off, uint32_t h, uint32_t cw) {
+    return (min((h >> 8) & 0xFFu, 4u) * 6u + cw_kb<CW>(cw)) * 16u + off;
 }
 
-template <int MAXP>
+template <int MAXP, int CW>
 __device__ __forceinline__ void load_env4(const LayC& C, const Lay L, const uint4* __restrict__ st, int64_t n, int64_t e,
                                           int n_obj, int horizon, Env4<MAXP>& s, uint32_t col) {
     const uint4 h = st[e];
@@ -162,7 +180,7 @@ __device__ __forceinline__ void load_env4(const LayC& C, const Lay L, const uint
             for (int b = 0; b < 4; ++b) {
                 const uint32_t o = (ow[q] >> (8 * b)) & 0xFFu, type = (T >> (8 * b)) & 7u;
                 dishes += (type == OC_T_COUNTER && o == OC_O_DISH) ? 1u : 0u;
-                lds_wr16(col + (uint32_t)(16 * p + 4 * q + b) * (BLOCK * 2u), o | (key_byte_of(type, o) << 8));
+                cw_wr<CW>(col + (uint32_t)(16 * p + 4 * q + b) * (BLOCK * CW), cw_make<CW>(o, key_byte_of(type, o)));
             }
         }
     }
@@ -172,20 +190,20 @@ __device__ __forceinline__ void load_env4(const LayC& C, const Lay L, const uint
     for (int k = 0; k < MAXP; ++k) {
         s.rem[k] = REM_IDLE; s.tk[k] = 0; s.poff[k] = 0;
         if ((uint32_t)k < C.n_pots) {
-            s.poff[k] = L.pot_cell(k) * (BLOCK * 2u);
-            uint32_t o = lds_rd16(col + s.poff[k]) & 0xFFu;
+            s.poff[k] = L.pot_cell(k) * (BLOCK * CW);
+            uint32_t o = cw_obj<CW>(cw_rd<CW>(col + s.poff[k]));
             const uint32_t tkb = ((k < 4 ? h.z : h.w) >> (8 * (k & 3))) & 0xFFu;
             const uint32_t pc = pot_class(C, o, tkb);
             if (o == OC_O_SOUP) { s.exotic |= 1u << k; o = 0; }  // a soup object without ingredients behaves as an empty pot
             if (C.old_dyn && pc == PC_IDLE3) s.pending |= 1u << k;
             s.tk[k] = tkb;
             s.rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) : REM_IDLE;
-            lds_wr16(col + s.poff[k], o | ((KB_POT + pc) << 8));
+            cw_wr<CW>(col + s.poff[k], cw_make<CW>(o, KB_POT + pc));
         }
     }
 }
 
-template <int MAXP>
+template <int MAXP, int CW>
 __device__ __forceinline__ void store_env4(const LayC& C, const Lay L, uint4* __restrict__ st, int64_t n, int64_t e,
                                            int n_obj, int horizon, const Env4<MAXP>& s, uint32_t col) {
     uint4 h;
@@ -198,7 +216,7 @@ __device__ __forceinline__ void store_env4(const LayC& C, const Lay L, uint4* __
     for (int k = 0; k < MAXP; ++k) {
         pot_fix_cell[k] = 0xFFFFFFFFu; pot_fix_obj[k] = 0;
         if ((uint32_t)k < C.n_pots) {
-            const uint32_t cw = lds_rd16(col + s.poff[k]), o = cw & 0xFFu, pc = (cw >> 8) - KB_POT;
+            const uint32_t cw = cw_rd<CW>(col + s.poff[k]), o = cw_obj<CW>(cw), pc = cw_kb<CW>(cw) - KB_POT;
             uint32_t tkb = s.tk[k];
             const bool live = rem_live(s.rem[k]);
             if (live) {
@@ -220,7 +238,7 @@ __device__ __forceinline__ void store_env4(const LayC& C, const Lay L, uint4* __
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const uint32_t c = (uint32_t)(16 * p + 4 * q + b);
-                uint32_t o = lds_rd16(col + c * (BLOCK * 2u)) & 0xFFu;
+                uint32_t o = cw_obj<CW>(cw_rd<CW>(col + c * (BLOCK * CW)));
 #pragma unroll
                 for (int k = 0; k < MAXP; ++k) o = c == pot_fix_cell[k] ? pot_fix_obj[k] : o;
                 ow[q] |= o << (8 * b);
@@ -231,13 +249,13 @@ __device__ __forceinline__ void store_env4(const LayC& C, const Lay L, uint4* __
 }
 
 // restart at the horizon (OvercookedEnv.reset with the standard start state, env.py:288-319)
-template <int MAXP>
+template <int MAXP, int CW>
 __device__ __forceinline__ void env_reset4(const LayC& C, const Lay L, int n_obj, int horizon, Env4<MAXP>& s, uint32_t col) {
     s.pos0 = L.u8(L_START_POS); s.pos1 = L.u8(L_START_POS + 1);
     s.or0 = L.u8(L_START_OR); s.or1 = s.pos1 == 0xFFu ? 0u : L.u8(L_START_OR + 1);
     s.h0 = s.h1 = 0; s.dcount = 0; s.exotic = 0; s.pending = 0;
     s.tleft = (uint32_t)horizon - 1u; s.over = 0;
-    for (int c = 0; c < n_obj * 16; ++c) lds_wr16(col + (uint32_t)c * (BLOCK * 2u), ((L.terrain((uint32_t)c) & 7u) * 30u) << 8);
+    for (int c = 0; c < n_obj * 16; ++c) cw_wr<CW>(col + (uint32_t)c * (BLOCK * CW), cw_make<CW>(0u, (L.terrain((uint32_t)c) & 7u) * 30u));
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
         s.rem[k] = REM_IDLE; s.tk[k] = 0;
@@ -249,13 +267,22 @@ __device__ __forceinline__ void env_reset4(const LayC& C, const Lay L, int n_obj
 // cell among the layout's free cells (row-major), NP = 4 * #free cells; a row is 38 u16:
 //    [ja] for ja = 6 * a0 + a1: byte offset (J' * 76) of the joint pose after resolve_movement
 //    [36], [37]: LDS byte offsets (cell * 512) of the cells the two players face in pose J
+// With 32-bit cell words (CW = 4) the row is 37 u32: [ja] = J' * 148, [36] = both faced-cell offsets (cell * 1024), u16 each
+// (grids of at most 64 cells).
 // ------------------------------------------------------------------------------------------
-constexpr int MVJ_ROW = 38, MVJ_ROW_BYTES = MVJ_ROW * 2, JOINT_MAX_FLOOR = 7;
+constexpr int JOINT_MAX_FLOOR = 7;
+template <int CW> struct Mvj {
+    static constexpr int ROW_BYTES = CW == 2 ? 76 : 148;  // bytes of a row
+    static constexpr int FACES = CW == 2 ? 72 : 144;      // byte offset of the two faced-cell offsets (one u32) inside a row
+};
 
 // Built by every workgroup at launch (~2 us): the free cells are ranked by the first wavefront (ballot + prefix count),
 // the single-player moves SP[pose][action] = (cell, pose) after _move_if_direction by 168 lanes, and a joint row then
 // only combines two of them per entry (collision test + index arithmetic).  `sp` = 2 * 28 * 6 bytes of scratch LDS.
-__device__ __forceinline__ void build_joint_table(const Lay L, int W, uint16_t* mvj, uint8_t* s_fl, uint8_t* s_fi, uint8_t* sp) {
+// `mvj` = the table, `mvj_addr` = its LDS address (rows hold LDS addresses of rows).
+template <int CW>
+__device__ __forceinline__ void build_joint_table(const Lay L, int W, uint8_t* mvj, uint32_t mvj_addr, uint8_t* s_fl, uint8_t* s_fi,
+                                                  uint8_t* sp) {
     const int nc = (int)L.u8(L_NCELLS);
     if (threadIdx.x < 64) {  // free cells in row-major order: s_fi[cell] = rank (0xFF: not free / beyond the table), s_fl[rank] = cell
         int base = 0;
@@ -288,9 +315,10 @@ __device__ __forceinline__ void build_joint_table(const Lay L, int W, uint16_t* 
     for (int J = threadIdx.x; J < NJ; J += BLOCK) {
         const int P0 = J / NP, P1 = J - P0 * NP;
         const int c0 = s_fl[P0 >> 2], c1 = s_fl[P1 >> 2];
-        uint16_t* row = mvj + J * MVJ_ROW;
-        row[36] = (uint16_t)(ahead(c0, P0 & 3) * (BLOCK * 2));
-        row[37] = (uint16_t)(ahead(c1, P1 & 3) * (BLOCK * 2));
+        uint16_t* row16 = reinterpret_cast<uint16_t*>(mvj + J * Mvj<CW>::ROW_BYTES);
+        uint32_t* row32 = reinterpret_cast<uint32_t*>(mvj + J * Mvj<CW>::ROW_BYTES);
+        *reinterpret_cast<uint32_t*>(mvj + J * Mvj<CW>::ROW_BYTES + Mvj<CW>::FACES) =
+            (uint32_t)(ahead(c0, P0 & 3) * (BLOCK * CW)) | ((uint32_t)(ahead(c1, P1 & 3) * (BLOCK * CW)) << 16);
         int q1[6], p1[6];
 #pragma unroll
         for (int a = 0; a < 6; ++a) { q1[a] = sp[2 * (P1 * 6 + a)]; p1[a] = sp[2 * (P1 * 6 + a) + 1]; }
@@ -302,7 +330,8 @@ __device__ __forceinline__ void build_joint_table(const Lay L, int W, uint16_t* 
                 // same target cell or swapped cells: nobody moves, orientations still turn (mdp.py:1673-1683, Q6)
                 const bool collide = q0 == q1[a1] || (q0 == c1 && q1[a1] == c0);
                 const int n0 = collide ? ((P0 & ~3) | (p0 & 3)) : p0, n1 = collide ? ((P1 & ~3) | (p1[a1] & 3)) : p1[a1];
-                row[a0 * 6 + a1] = (uint16_t)((n0 * NP + n1) * MVJ_ROW_BYTES);
+                const uint32_t next_row = mvj_addr + (uint32_t)((n0 * NP + n1) * Mvj<CW>::ROW_BYTES);
+                if (CW == 2) row16[a0 * 6 + a1] = (uint16_t)next_row; else row32[a0 * 6 + a1] = next_row;
             }
         }
     }
@@ -327,21 +356,28 @@ __device__ __forceinline__ uint32_t joint_action_of(uint32_t w0, uint32_t w1, ui
 
 // LDS map of k_rollout4 — ONE dynamic region at compile-time offsets, starting at LDS address 0 (the kernel has no
 // static __shared__; checked at kernel start), so that table offsets are LDS addresses:
-//    [0, MVJ_CAP)      JOINT move table (MODE 1 only; capacity for NF free cells)
-//    ACT               [2][40] u16: LUT address of "this player does / does not interact" per joint action (MODE 1)
+//    MVJ               JOINT move table (MODE 1 only; capacity for NF free cells): first with CW = 2, after CT with CW = 4
+//    ACT               [2][40] u16 (u32 with CW = 4): LUT address of "this player does / does not interact" per joint action (MODE 1)
 //    LUT               interact table: one dynamics variant (one layout) or both
 //    LAY               staged layout records
 //    FL / FI           free-cell list / cell -> free-cell index (MODE 1)
 //    CT                [32] cook time by the low five bits of the soup code (one layout)
-//    CELLS             cell words u16 [n_obj * 16][BLOCK]
-template <bool UNIFORM, bool LAY_LDS, int MODE, int NF, bool ONE_LUT = UNIFORM>
+//    CELLS             cell words u16 / u32 [n_obj * 16 + 1][BLOCK]
+// With u16 table entries (CW = 2) the move table comes first, so that row addresses and the LUT addresses in ACT fit 16 bits;
+// with u32 entries (CW = 4, an 85 KB move table) the small tables come first instead, so that THEIR addresses stay below
+// 64 KiB and fold into the 16-bit offset field of the DS instructions.
+template <bool UNIFORM, bool LAY_LDS, int MODE, int NF, bool ONE_LUT = UNIFORM, int CW = 2>
 struct Lds4 {
-    static constexpr int MVJ_CAP = MODE == 1 ? ((16 * NF * NF * MVJ_ROW_BYTES + 15) & ~15) : 0;
-    static constexpr int ACT = MVJ_CAP, ACT_BYTES = MODE == 1 ? 160 : 0;
+    static constexpr int MVJ_CAP = MODE == 1 ? ((16 * NF * NF * Mvj<CW>::ROW_BYTES + 15) & ~15) : 0;
+    static constexpr bool TABLE_FIRST = CW == 2;
+    static constexpr int ACT = TABLE_FIRST ? MVJ_CAP : 0, ACT_P1 = 40 * CW, ACT_BYTES = MODE == 1 ? 2 * ACT_P1 : 0;  // [player][40] u16 / u32
     static constexpr int LUT = ACT + ACT_BYTES, LUT_BYTES = ONE_LUT ? LUT4_BYTES : 2 * LUT4_BYTES;
     static constexpr int LAY = LUT + LUT_BYTES, LAY_BYTES = LAY_LDS ? (UNIFORM ? 256 : LDS_LAYOUT_MAX * 256) : 16;
-    static constexpr int FL = LAY + LAY_BYTES, FI = FL + 16, CT = FI + (MODE == 1 ? OC_MAX_CELLS : 0), CELLS = CT + 32;
-    static_assert(MVJ_CAP + ACT_BYTES + LUT4_KEYS * 16 < 65536, "row / LUT addresses are u16 in the tables");
+    static constexpr int FL = LAY + LAY_BYTES, FI = FL + 16, CT = FI + (MODE == 1 ? OC_MAX_CELLS : 0);
+    static constexpr int MVJ = TABLE_FIRST ? 0 : CT + 32;  // LDS address of the move table
+    static constexpr int CELLS = TABLE_FIRST ? CT + 32 : MVJ + MVJ_CAP;
+    static_assert(CW == 4 || MVJ_CAP + ACT_BYTES + LUT4_KEYS * 16 < 65536, "row / LUT addresses are u16 in the tables");
+    static_assert(CW == 2 || CT + 32 < 65536, "the small tables' addresses must fit the DS offset field");
 };
 
 // flags[k][e] for the 64 envs of this wavefront: SGPR row pointer + lane offset, no 64-bit address arithmetic
@@ -349,11 +385,19 @@ __device__ __forceinline__ void store_flag_byte(uint8_t* row, uint32_t lane_off,
     asm volatile("global_store_byte %0, %1, %2" : : "v"(lane_off), "v"(v), "s"(row) : "memory");
 }
 
+// rewards[k][e]: the same addressing for the 16-byte quad (a C++ store through base + zero-extended offset becomes a 64-bit
+// VGPR address computation)
+__device__ __forceinline__ void store_quad(float4* row, uint32_t lane_off, float4 v) {
+    typedef float oc_f32x4 __attribute__((ext_vector_type(4)));
+    const oc_f32x4 q = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(lane_off), "v"(q), "s"(row) : "memory");
+}
+
 // a randomized start (get_random_start_state_fn, mdp.py:1307-1369) drawn by draw_start, in Env4 / key-byte form
-template <int MAXP>
+template <int MAXP, int CW>
 __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int n_obj, int horizon, Env4<MAXP>& s, uint32_t col,
                                                 const StartDraw& d) {
-    env_reset4<MAXP>(C, L, n_obj, horizon, s, col);
+    env_reset4<MAXP, CW>(C, L, n_obj, horizon, s, col);
     s.pos0 = d.pos0; s.pos1 = d.pos1;
     s.h0 = d.held[0] << 8; s.h1 = d.held[1] << 8;
 #pragma unroll
@@ -363,7 +407,7 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
             const uint32_t pc = pot_class(C, o, tkb);
             s.tk[k] = tkb;
             s.rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) : REM_IDLE;
-            lds_wr16(col + s.poff[k], o | ((KB_POT + pc) << 8));
+            cw_wr<CW>(col + s.poff[k], cw_make<CW>(o, KB_POT + pc));
         }
     }
 }
@@ -377,11 +421,12 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
 //   variant whose entries carry the reward floats, as with a single layout
 // OLD: some layout of the table may use old dynamics (auto-start of full pots in the env effects)
 // EV: event_infos are logged (per-step masks and / or per-episode counters, EvArgs)
-// PIPE (MODE 1): the next step's faced cells are read one step ahead.  That hides the read behind the tail of the step
+// CW: bytes of a cell word (2, or 4 for the one-wavefront-per-SIMD instance of small single layouts: see cw_rd)
+// PIPE (MODE 1, 2): the next step's faced cells are read one step ahead.  That hides the read behind the tail of the step
 //   when a SIMD holds one wavefront (65 536 envs); with two or more wavefronts per SIMD the extra LDS traffic costs
 //   more than the latency it hides (131 072 cramped_room envs: 0.48 vs 0.65 us per batched step), so big batches turn it off
 template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false,
-          bool PIPE = true, bool RU = false>
+          bool PIPE = true, bool RU = false, int CW = 2>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_rollout4(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                     const uint16_t* __restrict__ layout_id, uint4* st,
                                                     float4* __restrict__ rewards, uint8_t* __restrict__ flags,
@@ -390,11 +435,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                                                     int64_t env_offset, int64_t t0, int n_steps, StartArgs sa, EvArgs ea) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn4[];
     constexpr bool RUX = UNIFORM || RU;  // one LUT variant, patched with the reward floats
-    using M = Lds4<UNIFORM, LAY_LDS, MODE, NF, RUX>;
+    using M = Lds4<UNIFORM, LAY_LDS, MODE, NF, RUX, CW>;
+    static_assert(CW == 2 || CW == 4, "cell words are u16 or u32");
     if ((uint32_t)(uintptr_t)(OC_LDS uint8_t*)s_dyn4 != 0u) __builtin_trap();  // folds away: the region starts at address 0
     uint4* const s_lay = reinterpret_cast<uint4*>(s_dyn4 + M::LAY);
     uint4* const s_lut = reinterpret_cast<uint4*>(s_dyn4 + M::LUT);
-    uint16_t* const s_act = reinterpret_cast<uint16_t*>(s_dyn4 + M::ACT);  // [player][40]
     uint8_t* const s_fl = s_dyn4 + M::FL;
     uint8_t* const s_fi = s_dyn4 + M::FI;
     const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -416,23 +461,30 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
     }
     if (MODE == 1) {
         if (threadIdx.x < 36) {  // the LUT's LDS address is folded into the offsets
-            s_act[threadIdx.x] = (uint16_t)(M::LUT + (threadIdx.x / 6 == 5 ? 0 : LUT4_KEYS * 16));
-            s_act[40 + threadIdx.x] = (uint16_t)(M::LUT + (threadIdx.x % 6 == 5 ? 0 : LUT4_KEYS * 16));
+            const uint32_t a0 = (uint32_t)(M::LUT + (threadIdx.x / 6 == 5 ? 0 : LUT4_KEYS * 16));
+            const uint32_t a1 = (uint32_t)(M::LUT + (threadIdx.x % 6 == 5 ? 0 : LUT4_KEYS * 16));
+            if (CW == 2) {
+                reinterpret_cast<uint16_t*>(s_dyn4 + M::ACT)[threadIdx.x] = (uint16_t)a0;
+                reinterpret_cast<uint16_t*>(s_dyn4 + M::ACT + M::ACT_P1)[threadIdx.x] = (uint16_t)a1;
+            } else {
+                reinterpret_cast<uint32_t*>(s_dyn4 + M::ACT)[threadIdx.x] = a0;
+                reinterpret_cast<uint32_t*>(s_dyn4 + M::ACT + M::ACT_P1)[threadIdx.x] = a1;
+            }
         }
-        build_joint_table(L, W, reinterpret_cast<uint16_t*>(s_dyn4), s_fl, s_fi, s_dyn4 + M::CELLS);  // (scratch: the cell words come later)
+        build_joint_table<CW>(L, W, s_dyn4 + M::MVJ, (uint32_t)M::MVJ, s_fl, s_fi, s_dyn4 + M::CELLS);  // (scratch: the cell words come later)
     }
     __syncthreads();
     if (!active) return;
-    const uint32_t col = (uint32_t)M::CELLS + threadIdx.x * 2u;  // LDS address of this lane's column of cell words
+    const uint32_t col = (uint32_t)M::CELLS + threadIdx.x * (uint32_t)CW;  // LDS address of this lane's column of cell words
     const LayC C = load_consts<UNIFORM>(L);
     const uint32_t lut_var = (uint32_t)M::LUT + (RUX ? 0u : (C.old_dyn ? (uint32_t)LUT4_BYTES : 0u));  // this lane's LUT
     const uint32_t delta4 = make_delta4(W);
     Env4<MAXP> s;
-    load_env4<MAXP>(C, L, st, n, e, n_obj, horizon, s, col);
+    load_env4<MAXP, CW>(C, L, st, n, e, n_obj, horizon, s, col);
     const bool two = MODE == 1 || MODE == 2 || s.pos1 != 0xFFu;
     auto joint_row = [&]() {  // LDS address of the row of the joint pose (pos0, or0, pos1, or1)
         const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR];
-        return ((s_fi[s.pos0] * 4u + s.or0) * NP + (s_fi[s.pos1] * 4u + s.or1)) * MVJ_ROW_BYTES;
+        return (uint32_t)M::MVJ + ((s_fi[s.pos0] * 4u + s.or0) * NP + (s_fi[s.pos1] * 4u + s.or1)) * (uint32_t)Mvj<CW>::ROW_BYTES;
     };
     if (MODE == 1) s.J = joint_row();
     float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -471,30 +523,44 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
     }
     //      MODE 1 also prefetches the next step's faced cells (nc0, nc1) and pot words (npw) as soon as this step's cell
     //      writes are issued — m1 holds the next pose's faced-cell offsets on entry.
-    const uint32_t dummy = col + (uint32_t)n_obj * 16u * (BLOCK * 2u);  // a spare cell word per lane (one row past the grid)
+    const uint32_t dummy = col + (uint32_t)n_obj * 16u * (BLOCK * CW);  // a spare cell word per lane (one row past the grid)
     auto rd_pots = [&](uint32_t (&out)[MAXP]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < MAXP; ++k) out[k] = PW ? lds_rd16(col + s.poff[k]) : 0u;
+        for (int k = 0; k < MAXP; ++k) out[k] = PW ? cw_rd<CW>(col + s.poff[k]) : 0u;
     };
+    // Output rows of a whole unrolled block of 8 steps (OUT instances): per-lane byte offsets of the block's eight reward
+    // quads / flag bytes from the block's first row, computed once — the step then stores through (row of the block's
+    // first step) + offset[k] and the two row pointers advance once per block instead of every step (4 scalar
+    // instructions per step less).  Needs 8 rows within 4 GiB; larger batches stay in the rolled loop.
+    const bool blocked_rows = OUT && n < ((int64_t)1 << 24);
+    uint32_t rew_off[8], flg_off[8];
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8) {
+        rew_off[k8] = (threadIdx.x + (uint32_t)k8 * (uint32_t)n) * 16u;
+        flg_off[k8] = lane + (uint32_t)k8 * (uint32_t)n;
+    }
+    // k8: index of the step inside an unrolled block of 8 (stores through the block's row + offset), or -1 (rolled step)
     auto core = [&](uint32_t fo0, uint32_t fo1, uint32_t off0, uint32_t off1, uint32_t c0, uint32_t c1, uint32_t ja2n,
                     const uint32_t (&pw)[MAXP], uint32_t& m0, uint32_t& m1, uint32_t& m2, uint32_t& m3, uint32_t& m4,
-                    uint32_t& nc0, uint32_t& nc1, uint32_t (&npw)[MAXP]) __attribute__((always_inline)) {
+                    uint32_t& nf0, uint32_t& nf1, uint32_t& nc0, uint32_t& nc1, uint32_t (&npw)[MAXP], int k8)
+                    __attribute__((always_inline)) {
         // ---- the straight line: everything a step does when nothing rare happens -------------------------------------
-        // (values read with ds_read_u16 a step earlier: tell the compiler they are still 16 bits wide)
-        __builtin_assume(c0 <= 0xFFFFu); __builtin_assume(c1 <= 0xFFFFu);
-        __builtin_assume(off0 <= 0xFFFFu); __builtin_assume(off1 <= 0xFFFFu);
+        if (CW == 2) {  // (values read with ds_read_u16 a step earlier: tell the compiler they are still 16 bits wide)
+            __builtin_assume(c0 <= 0xFFFFu); __builtin_assume(c1 <= 0xFFFFu);
+            __builtin_assume(off0 <= 0xFFFFu); __builtin_assume(off1 <= 0xFFFFu);
 #pragma unroll
-        for (int k = 0; k < MAXP; ++k) __builtin_assume(pw[k] <= 0xFFFFu);
+            for (int k = 0; k < MAXP; ++k) __builtin_assume(pw[k] <= 0xFFFFu);
+        }
         uint32_t cookv = 0;
-        if (FAST_START) cookv = cook_time(pw[0]);  // cook time of what the pot holds, should somebody start it
+        if (FAST_START) cookv = cook_time(cw_obj<CW>(pw[0]));  // cook time of what the pot holds, should somebody start it
         // both players against the pre-step cells (resolve_interacts, mdp.py:1432-1579)
-        const uint4 e0 = lds_rd128(lut4_addr(off0, s.h0, c0));
-        uint4 e1 = lds_rd128(lut4_addr(off1, s.h1, c1));
-        const uint32_t r0 = interact4(e0, s.h0, c0);
-        uint32_t r1 = interact4(e1, s.h1, c1);
-        const uint32_t cw0 = r0 >> 16;  // player 0's faced cell afterwards
-        lds_wr16(fo0, cw0);
-        lds_wr16(fo1, r1 >> 16);
+        const uint4 e0 = lds_rd128(lut4_addr<CW>(off0, s.h0, c0));
+        uint4 e1 = lds_rd128(lut4_addr<CW>(off1, s.h1, c1));
+        const uint32_t r0 = interact4<CW>(e0, s.h0, c0);
+        uint32_t r1 = interact4<CW>(e1, s.h1, c1);
+        const uint32_t cw0 = cw_of_result<CW>(r0);  // player 0's faced cell afterwards
+        cw_wr<CW>(fo0, cw0);
+        cw_wr<CW>(fo1, cw_of_result<CW>(r1));
         const uint32_t h0_before = s.h0, h1_before = s.h1, dc_before = s.dcount;
         const uint32_t dc_mid = dc_before + (uint32_t)((int32_t)e0.y >> 24);  // loose dishes after player 0's interact
         uint32_t dcount = dc_mid + (uint32_t)((int32_t)e1.y >> 24);
@@ -510,14 +576,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             s.rem[k] -= 1u;
             ripe[k] = s.rem[k] == 0u;
             if (PIPE) {
-                if (MAXP <= 2 || (uint32_t)k < C.n_pots) lds_wr8(ripe[k] ? col + s.poff[k] + 1u : dummy, KB_POT + PC_READY);
+                if (MAXP <= 2 || (uint32_t)k < C.n_pots) cw_wr_kb<CW>(ripe[k] ? col + s.poff[k] : dummy, KB_POT + PC_READY);
             } else if (ripe[k]) {  // only the lanes concerned store
-                lds_wr8(col + s.poff[k] + 1u, KB_POT + PC_READY);
+                cw_wr_kb<CW>(col + s.poff[k], KB_POT + PC_READY);
             }
         }
+        if (MODE == 1 || MODE == 2) {  // LDS addresses of the next step's faced cells (its fo0 / fo1)
+            nf0 = col + (m1 & 0xFFFFu);
+            nf1 = col + (m1 >> 16);
+        }
         if ((MODE == 1 || MODE == 2) && PIPE) {  // the next step's cells: everything this step writes to the grid has been issued
-            nc0 = lds_rd16(col + (m1 & 0xFFFFu));
-            nc1 = lds_rd16(col + (m1 >> 16));
+            nc0 = cw_rd<CW>(nf0);
+            nc1 = cw_rd<CW>(nf1);
             rd_pots(npw);
         }
         // shaped reward of potting / soup pickup straight from the entries (class -> this lane's layout when the table is mixed)
@@ -543,7 +613,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             bool any_useful = false;
 #pragma unroll
             for (int k = 0; k < MAXP; ++k) {  // (unused slots read cell 0, whose key byte is no pot class unless it is pot 0)
-                const uint32_t kb = pw[k] >> 8;
+                const uint32_t kb = cw_kb<CW>(pw[k]);
                 any_useful |= (kb - (KB_POT + PC_IDLE1) <= (uint32_t)(PC_READY - PC_IDLE1)) & (kb != KB_POT + PC_IDLE3);
             }
             dish_ok &= any_useful;
@@ -560,10 +630,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         if (__builtin_expect(rare, 0)) {
             bool grid_changed = false;  // something below wrote to the grid after the prefetch
             if (conflict) {
-                e1 = lds_rd128(lut4_addr(off1, h1_before, cw0));
-                r1 = interact4(e1, h1_before, cw0);
+                e1 = lds_rd128(lut4_addr<CW>(off1, h1_before, cw0));
+                r1 = interact4<CW>(e1, h1_before, cw0);
                 nh1 = r1;
-                lds_wr16(fo1, r1 >> 16);
+                cw_wr<CW>(fo1, cw_of_result<CW>(r1));
                 dcount = dc_mid + (uint32_t)((int32_t)e1.y >> 24);
                 sh1 = shaped_of(e1.w);
                 add1 = sh1;
@@ -589,7 +659,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                         const bool fills = OLD && C.old_dyn && (rr & F4_PLACE) && (rr >> 24) == KB_POT + PC_IDLE3;
                         if ((begins | fills) && (MAXP == 1 || fo == pa)) { go = true; soup = (rr >> 16) & 0xFFu; }
                     }
-                    if (OLD && ((s.pending >> k) & 1u)) { go = true; soup = lds_rd16(pa) & 0xFFu; }
+                    if (OLD && ((s.pending >> k) & 1u)) { go = true; soup = cw_obj<CW>(cw_rd<CW>(pa)); }
                     // (the straight line may have loaded or not loaded the countdown from player 1's stale interact: redo)
                     uint32_t cook = 0;
                     if (go) cook = cook_time(soup);
@@ -597,10 +667,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                     ripe[k] = s.rem[k] == 0u;
                     if (go) {  // (cook == 0: ready at once, never ticks)
                         s.exotic &= ~(1u << k);
-                        lds_wr8(pa + 1u, (cook == 0u || ripe[k]) ? KB_POT + PC_READY : KB_POT + PC_COOKING);
+                        cw_wr_kb<CW>(pa, (cook == 0u || ripe[k]) ? KB_POT + PC_READY : KB_POT + PC_COOKING);
                         grid_changed = true;
                     } else if (ripe[k]) {
-                        lds_wr8(pa + 1u, KB_POT + PC_READY);
+                        cw_wr_kb<CW>(pa, KB_POT + PC_READY);
                         grid_changed = true;
                     }
                 }
@@ -616,13 +686,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                     if (MAXP > 1 && (uint32_t)k >= C.n_pots) break;
                     uint32_t kb;
                     if (PW) {
-                        kb = pw[k] >> 8;
+                        kb = cw_kb<CW>(pw[k]);
                     } else {  // the cells hold the classes after this step's interacts; a pot a player has just changed
                               // had the class of that player's faced cell word before (player 0's first)
                         const uint32_t pa = col + s.poff[k];
-                        kb = lds_rd16(pa) >> 8;
-                        kb = ((r1 & F4_POTBITS) && fo1 == pa) ? ((conflict ? cw0 : c1) >> 8) : kb;
-                        kb = ((r0 & F4_POTBITS) && fo0 == pa) ? (c0 >> 8) : kb;
+                        kb = cw_kb<CW>(cw_rd<CW>(pa));
+                        kb = ((r1 & F4_POTBITS) && fo1 == pa) ? cw_kb<CW>(conflict ? cw0 : c1) : kb;
+                        kb = ((r0 & F4_POTBITS) && fo0 == pa) ? cw_kb<CW>(c0) : kb;
                     }
                     useful_pots += (kb != KB_POT + PC_EMPTY && kb != KB_POT + PC_IDLE3) ? 1u : 0u;
                 }
@@ -643,11 +713,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                 fl = OC_F_DONE;
                 if (options & OC_OPT_AUTO_RESET) {
                     if (sa.enabled) {  // the batch's start_state_fn: drawn from (seed, global env, epoch of this step)
-                        env_reset4_draw<MAXP>(C, L, n_obj, horizon, s, col,
+                        env_reset4_draw<MAXP, CW>(C, L, n_obj, horizon, s, col,
                                               draw_start(L, g, sa.epoch + step_k, sa.seed_lo, sa.seed_hi, sa.random_start_pos, sa.thresh));
                         nh0 = s.h0; nh1 = s.h1;
                     } else {
-                        env_reset4<MAXP>(C, L, n_obj, horizon, s, col);
+                        env_reset4<MAXP, CW>(C, L, n_obj, horizon, s, col);
                         nh0 = nh1 = 0;
                     }
                     dcount = 0;
@@ -657,11 +727,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                     grid_changed = true;
                     if (MODE == 1) {  // redo the look-ahead from the start pose
                         m0 = joint_row();
-                        m1 = lds_rd32(m0 + 72u);
-                        m2 = lds_rd16(m0 + ja2n);
+                        m1 = lds_rd32(m0 + (uint32_t)Mvj<CW>::FACES);
+                        m2 = CW == 2 ? lds_rd16(m0 + ja2n) : lds_rd32(m0 + ja2n);
                     } else if (MODE == 2) {
                         m0 = s.pos0; m2 = s.pos1; m3 = s.or0; m4 = s.or1;
-                        m1 = (step_cell(s.pos0, s.or0, delta4) * (BLOCK * 2u)) | ((step_cell(s.pos1, s.or1, delta4) * (BLOCK * 2u)) << 16);
+                        m1 = (step_cell(s.pos0, s.or0, delta4) * (BLOCK * CW)) | ((step_cell(s.pos1, s.or1, delta4) * (BLOCK * CW)) << 16);
                     } else {
                         m0 = s.pos0; m1 = s.pos1; m2 = s.or0; m3 = s.or1;
                     }
@@ -670,9 +740,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                     s.over += 1u;
                 }
             }
+            if ((MODE == 1 || MODE == 2) && grid_changed) {  // (the restart may have changed the next pose)
+                nf0 = col + (m1 & 0xFFFFu);
+                nf1 = col + (m1 >> 16);
+            }
             if ((MODE == 1 || MODE == 2) && PIPE && grid_changed) {  // read the next step's cells again
-                nc0 = lds_rd16(col + (m1 & 0xFFFFu));
-                nc1 = lds_rd16(col + (m1 >> 16));
+                nc0 = cw_rd<CW>(nf0);
+                nc1 = cw_rd<CW>(nf1);
                 rd_pots(npw);
             }
         }
@@ -688,40 +762,49 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                     if (MAXP > 1 && (uint32_t)k >= C.n_pots) break;
                     uint32_t kb;
                     if (PW) {
-                        kb = pw[k] >> 8;
+                        kb = cw_kb<CW>(pw[k]);
                     } else {
                         const uint32_t pa = col + s.poff[k];
-                        kb = lds_rd16(pa) >> 8;
-                        kb = ((r1 & F4_POTBITS) && fo1 == pa) ? (cc1 >> 8) : kb;
-                        kb = ((r0 & F4_POTBITS) && fo0 == pa) ? (c0 >> 8) : kb;
+                        kb = cw_kb<CW>(cw_rd<CW>(pa));
+                        kb = ((r1 & F4_POTBITS) && fo1 == pa) ? cw_kb<CW>(cc1) : kb;
+                        kb = ((r0 & F4_POTBITS) && fo0 == pa) ? cw_kb<CW>(c0) : kb;
                     }
                     useful_pots += (kb != KB_POT + PC_EMPTY && kb != KB_POT + PC_IDLE3) ? 1u : 0u;
                     n_full += kb >= KB_POT + PC_IDLE3 ? 1u : 0u;
                 }
                 const bool du0 = two & (((hb1 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_before == 0u);
                 const bool du1 = two & (((hn0 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_mid == 0u);
-                const uint32_t t0_ = ((c0 >> 8) * 137u) >> 12, t1_ = ((cc1 >> 8) * 137u) >> 12;  // key byte / 30 = terrain type
+                const uint32_t t0_ = (cw_kb<CW>(c0) * 137u) >> 12, t1_ = (cw_kb<CW>(cc1) * 137u) >> 12;  // key byte / 30 = terrain type
                 const bool disp0 = (t0_ == OC_T_ONION_DISP) | (t0_ == OC_T_TOMATO_DISP) | (t0_ == OC_T_DISH_DISP);
                 const bool disp1 = (t1_ == OC_T_ONION_DISP) | (t1_ == OC_T_TOMATO_DISP) | (t1_ == OC_T_DISH_DISP);
-                ev = interact_events<0>(C, t0_, hb0, c0 & 0xFFu, ((r0 & F4_CHG) != 0u) & (t0_ == OC_T_COUNTER),
+                ev = interact_events<0>(C, t0_, hb0, cw_obj<CW>(c0), ((r0 & F4_CHG) != 0u) & (t0_ == OC_T_COUNTER),
                                         disp0 & (hb0 == 0u) & (hn0 != 0u), (r0 & F4_PLACE) != 0u, (r0 & F4_PLATE) != 0u,
                                         (r0 & F4_SERVE) != 0u, hb1, du0, n_full, two) |
-                     interact_events<1>(C, t1_, hb1, cc1 & 0xFFu, ((r1 & F4_CHG) != 0u) & (t1_ == OC_T_COUNTER),
+                     interact_events<1>(C, t1_, hb1, cw_obj<CW>(cc1), ((r1 & F4_CHG) != 0u) & (t1_ == OC_T_COUNTER),
                                         disp1 & (hb1 == 0u) & (hn1 != 0u), (r1 & F4_PLACE) != 0u, (r1 & F4_PLATE) != 0u,
                                         (r1 & F4_SERVE) != 0u, hn0, du1, n_full, two);
             }
             if (ea.events) ea.events[(int64_t)step_k * n + e] = ev;
             count_events(ea, e, ev, done, (options & OC_OPT_AUTO_RESET) != 0u);
         }
-        if (OUT || rew_k) rew_k[threadIdx.x] = rw;
-        if (OUT || flg_k) store_flag_byte(flg_k, lane, fl);
+        if (OUT && k8 >= 0) {  // a step of an unrolled block: the block's first row + this step's precomputed offset
+            store_quad(rew_k, rew_off[k8 & 7], rw);
+            store_flag_byte(flg_k, flg_off[k8 & 7], fl);
+        } else {
+            if (OUT || rew_k) rew_k[threadIdx.x] = rw;
+            if (OUT || flg_k) store_flag_byte(flg_k, lane, fl);
+            if (OUT || rew_k) rew_k += n;
+            if (OUT || flg_k) flg_k += n;
+        }
         s.h0 = nh0;
         s.h1 = nh1;
         s.dcount = dcount;
         ep.z += add0; ep.w += add1;
-        if (OUT || rew_k) rew_k += n;
-        if (OUT || flg_k) flg_k += n;
         step_k += 1u;
+    };
+    // after the eight steps of an unrolled block
+    auto advance_rows = [&]() __attribute__((always_inline)) {
+        if (OUT) { rew_k += 8 * n; flg_k += 8 * n; }
     };
 
     Phx4 w = {0, 0, 0, 0};  // the Philox block of the step being looked at
@@ -738,27 +821,29 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         //   Jc = row of the pose at step k, fa = its faced-cell offsets, off0/off1 = LUT addresses for step k's actions,
         //   Jn = row of the pose at step k + 1.
         uint32_t Jc = s.J;
-        uint32_t ja2 = OC_JA_AT(t0, true) * 2u;
-        uint32_t fa = lds_rd32(Jc + 72u), Jn = lds_rd16(Jc + ja2);
-        uint32_t off0 = lds_rd16((uint32_t)M::ACT + ja2), off1 = lds_rd16((uint32_t)M::ACT + 80u + ja2);
-        uint32_t c0 = lds_rd16(col + (fa & 0xFFFFu)), c1 = lds_rd16(col + (fa >> 16));  // the faced cells of step k
+        constexpr uint32_t JS = (uint32_t)CW;  // scale of a joint action as a table index: the tables' entries are u16 / u32
+        auto row_rd = [&](uint32_t a) __attribute__((always_inline)) { return CW == 2 ? lds_rd16(a) : lds_rd32(a); };
+        uint32_t ja2 = OC_JA_AT(t0, true) * JS;
+        uint32_t fa = lds_rd32(Jc + (uint32_t)Mvj<CW>::FACES), Jn = row_rd(Jc + ja2);
+        uint32_t off0 = row_rd((uint32_t)M::ACT + ja2), off1 = row_rd((uint32_t)(M::ACT + M::ACT_P1) + ja2);
+        uint32_t fo0 = col + (fa & 0xFFFFu), fo1 = col + (fa >> 16);  // LDS addresses of the faced cells of step k
+        uint32_t c0 = cw_rd<CW>(fo0), c1 = cw_rd<CW>(fo1);
         uint32_t pw[MAXP];
         rd_pots(pw);
-        auto pstep = [&](uint32_t ja2n) __attribute__((always_inline)) {  // ja2n: 2 * joint action of the NEXT step
-            const uint32_t fo0 = col + (fa & 0xFFFFu), fo1 = col + (fa >> 16);
+        auto pstep = [&](uint32_t ja2n, int k8) __attribute__((always_inline)) {  // ja2n: JS * joint action of the NEXT step
             if (!PIPE) {
-                c0 = lds_rd16(fo0);
-                c1 = lds_rd16(fo1);
+                c0 = cw_rd<CW>(fo0);
+                c1 = cw_rd<CW>(fo1);
                 rd_pots(pw);
             }
-            uint32_t fa_n = lds_rd32(Jn + 72u), Jnn = lds_rd16(Jn + ja2n);
-            const uint32_t off0n = lds_rd16((uint32_t)M::ACT + ja2n), off1n = lds_rd16((uint32_t)M::ACT + 80u + ja2n);
+            uint32_t fa_n = lds_rd32(Jn + (uint32_t)Mvj<CW>::FACES), Jnn = row_rd(Jn + ja2n);
+            const uint32_t off0n = row_rd((uint32_t)M::ACT + ja2n), off1n = row_rd((uint32_t)(M::ACT + M::ACT_P1) + ja2n);
             // keep these look-ahead reads at the top of the step: they do not depend on this step's cells, and left to
             // itself the scheduler queues them in front of the LUT reads the step is waiting for (+0.75 %)
             __builtin_amdgcn_sched_barrier(0);
-            uint32_t Jcn = Jn, unused = 0, unused4 = 0, nc0 = 0, nc1 = 0, npw[MAXP];
-            core(fo0, fo1, off0, off1, c0, c1, ja2n, pw, Jcn, fa_n, Jnn, unused, unused4, nc0, nc1, npw);
-            Jc = Jcn; Jn = Jnn; fa = fa_n; off0 = off0n; off1 = off1n;
+            uint32_t Jcn = Jn, unused = 0, unused4 = 0, nf0 = 0, nf1 = 0, nc0 = 0, nc1 = 0, npw[MAXP];
+            core(fo0, fo1, off0, off1, c0, c1, ja2n, pw, Jcn, fa_n, Jnn, unused, unused4, nf0, nf1, nc0, nc1, npw, k8);
+            Jc = Jcn; Jn = Jnn; off0 = off0n; off1 = off1n; fo0 = nf0; fo1 = nf1;
             if (PIPE) {
                 c0 = nc0; c1 = nc1;
 #pragma unroll
@@ -769,22 +854,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         const int head_end = min(n_steps, (int)((8u - ((uint32_t)t0 & 7u)) & 7u));
         // (the look-ahead call for the last head step loads the block the unrolled loop starts with; with no head, the
         //  prologue's ja_at(t0) did)
-        for (; k < head_end; ++k) pstep(OC_JA_AT(t0 + k + 1, false) * 2u);  // up to the next block boundary
-        for (; n_steps - k >= 8; k += 8) {  // whole Philox blocks, unrolled; the look-ahead digit of step 7 is the next block's first
+        for (; k < head_end; ++k) pstep(OC_JA_AT(t0 + k + 1, false) * JS, -1);  // up to the next block boundary
+        for (; blocked_rows && n_steps - k >= 8; k += 8) {  // whole Philox blocks, unrolled; the look-ahead digit of step 7 is the next block's first
             const Phx4 nb = philox_words(((uint64_t)(t0 + k) >> 3) + 1u, g_lo, g_hi, seed_lo, seed_hi);
-            pstep(__umulhi(w.w0 * 36u, 36u) * 2u);
-            pstep(__umulhi(w.w1, 36u) * 2u);
-            pstep(__umulhi(w.w1 * 36u, 36u) * 2u);
-            pstep(__umulhi(w.w2, 36u) * 2u);
-            pstep(__umulhi(w.w2 * 36u, 36u) * 2u);
-            pstep(__umulhi(w.w3, 36u) * 2u);
-            pstep(__umulhi(w.w3 * 36u, 36u) * 2u);
-            pstep(__umulhi(nb.w0, 36u) * 2u);
+            // JS * (top base-36 digit of x) = mulhi(x, 36 * JS) with the low bits cleared
+            auto jsd = [&](uint32_t x) __attribute__((always_inline)) { return __umulhi(x, 36u * JS) & ~(JS - 1u); };
+            pstep(jsd(w.w0 * 36u), 0);
+            pstep(jsd(w.w1), 1);
+            pstep(jsd(w.w1 * 36u), 2);
+            pstep(jsd(w.w2), 3);
+            pstep(jsd(w.w2 * 36u), 4);
+            pstep(jsd(w.w3), 5);
+            pstep(jsd(w.w3 * 36u), 6);
+            pstep(jsd(nb.w0), 7);
+            advance_rows();
             w = nb;
         }
-        for (; k < n_steps; ++k) pstep(OC_JA_AT(t0 + k + 1, false) * 2u);  // the tail
+        for (; k < n_steps; ++k) pstep(OC_JA_AT(t0 + k + 1, false) * JS, -1);  // the tail
         // joint pose -> cells / orientations
-        const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR], Jidx = Jc / MVJ_ROW_BYTES, P0 = Jidx / NP, P1 = Jidx - P0 * NP;
+        const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR], Jidx = (Jc - (uint32_t)M::MVJ) / (uint32_t)Mvj<CW>::ROW_BYTES, P0 = Jidx / NP, P1 = Jidx - P0 * NP;
         s.pos0 = s_fl[P0 >> 2]; s.or0 = P0 & 3u; s.pos1 = s_fl[P1 >> 2]; s.or1 = P1 & 3u;
     } else if (MODE == 2) {
         // Per-env terrain, pose one step ahead.  Carried across steps: the pose of the step about to run (P0, O0, P1, O1), the
@@ -802,33 +890,32 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             return c + (uint32_t)(int32_t)(int8_t)(uint8_t)(d64 >> (8u * d));
         };
         uint32_t P0 = s.pos0, O0 = s.or0, P1 = s.pos1, O1 = s.or1;
-        uint32_t fa = (ahead(P0, O0) * (BLOCK * 2u)) | ((ahead(P1, O1) * (BLOCK * 2u)) << 16);
+        uint32_t fo0 = col + ahead(P0, O0) * (BLOCK * CW), fo1 = col + ahead(P1, O1) * (BLOCK * CW);  // faced cells of the step about to run
         uint32_t c0 = 0, c1 = 0, pw[MAXP];
         if (PIPE) {
-            c0 = lds_rd16(col + (fa & 0xFFFFu));
-            c1 = lds_rd16(col + (fa >> 16));
+            c0 = cw_rd<CW>(fo0);
+            c1 = cw_rd<CW>(fo1);
         }
         rd_pots(pw);
         constexpr uint32_t NOI = (uint32_t)(LUT4_KEYS * 16);
-        auto mstep = [&](uint32_t ja) __attribute__((always_inline)) {  // ja = 6 * a0 + a1 of THIS step
+        auto mstep = [&](uint32_t ja, int k8) __attribute__((always_inline)) {  // ja = 6 * a0 + a1 of THIS step
             const uint32_t a0 = (ja * 43u) >> 8, a1 = ja - 6u * a0;
-            const uint32_t fo0 = col + (fa & 0xFFFFu), fo1 = col + (fa >> 16);
             if (!PIPE) {
-                c0 = lds_rd16(fo0);
-                c1 = lds_rd16(fo1);
+                c0 = cw_rd<CW>(fo0);
+                c1 = cw_rd<CW>(fo1);
                 rd_pots(pw);
             }
             const uint32_t off0 = lut_var + (ja >= 30u ? 0u : NOI), off1 = lut_var + (a1 == 5u ? 0u : NOI);
             // resolve_movement (mdp.py:1644-1727) on the static terrain: the pose of the NEXT step
-            const uint32_t t0 = ahead(P0, a0), t1 = ahead(P1, a1);
-            const uint32_t np0 = ((fm >> t0) & 1ull) ? t0 : P0, np1 = ((fm >> t1) & 1ull) ? t1 : P1;
+            const uint32_t t0_ = ahead(P0, a0), t1_ = ahead(P1, a1);
+            const uint32_t np0 = ((fm >> t0_) & 1ull) ? t0_ : P0, np1 = ((fm >> t1_) & 1ull) ? t1_ : P1;
             const bool collide = (np0 == np1) | ((np0 == P1) & (np1 == P0));
             uint32_t q0 = collide ? P0 : np0, q1 = collide ? P1 : np1;
             uint32_t o0 = a0 < 4u ? a0 : O0, o1 = a1 < 4u ? a1 : O1;
-            uint32_t fa_n = (ahead(q0, o0) * (BLOCK * 2u)) | ((ahead(q1, o1) * (BLOCK * 2u)) << 16);
-            uint32_t nc0 = 0, nc1 = 0, npw[MAXP];
-            core(fo0, fo1, off0, off1, c0, c1, 0u, pw, q0, fa_n, q1, o0, o1, nc0, nc1, npw);
-            P0 = q0; P1 = q1; O0 = o0; O1 = o1; fa = fa_n;
+            uint32_t fa_n = (ahead(q0, o0) * (BLOCK * CW)) | ((ahead(q1, o1) * (BLOCK * CW)) << 16);
+            uint32_t nf0 = 0, nf1 = 0, nc0 = 0, nc1 = 0, npw[MAXP];
+            core(fo0, fo1, off0, off1, c0, c1, 0u, pw, q0, fa_n, q1, o0, o1, nf0, nf1, nc0, nc1, npw, k8);
+            P0 = q0; P1 = q1; O0 = o0; O1 = o1; fo0 = nf0; fo1 = nf1;
             if (PIPE) {
                 c0 = nc0; c1 = nc1;
 #pragma unroll
@@ -839,18 +926,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         const int head_end = min(n_steps, (int)((8u - ((uint32_t)t0 & 7u)) & 7u));
         for (int phase = 0; phase < 2; ++phase) {
             const int upto = phase == 0 ? head_end : n_steps;
-            for (; k < upto; ++k) mstep(OC_JA_AT(t0 + k, k == 0));  // rolled steps: up to the next block boundary, and the tail
+            for (; k < upto; ++k) mstep(OC_JA_AT(t0 + k, k == 0), -1);  // rolled steps: up to the next block boundary, and the tail
             if (phase == 0) {
-                for (; n_steps - k >= 8; k += 8) {  // whole Philox blocks, unrolled: two base-36 digits per word
+                for (; blocked_rows && n_steps - k >= 8; k += 8) {  // whole Philox blocks, unrolled: two base-36 digits per word
                     w = philox_words((uint64_t)(t0 + k) >> 3, g_lo, g_hi, seed_lo, seed_hi);
-                    mstep(__umulhi(w.w0, 36u));
-                    mstep(__umulhi(w.w0 * 36u, 36u));
-                    mstep(__umulhi(w.w1, 36u));
-                    mstep(__umulhi(w.w1 * 36u, 36u));
-                    mstep(__umulhi(w.w2, 36u));
-                    mstep(__umulhi(w.w2 * 36u, 36u));
-                    mstep(__umulhi(w.w3, 36u));
-                    mstep(__umulhi(w.w3 * 36u, 36u));
+                    mstep(__umulhi(w.w0, 36u), 0);
+                    mstep(__umulhi(w.w0 * 36u, 36u), 1);
+                    mstep(__umulhi(w.w1, 36u), 2);
+                    mstep(__umulhi(w.w1 * 36u, 36u), 3);
+                    mstep(__umulhi(w.w2, 36u), 4);
+                    mstep(__umulhi(w.w2 * 36u, 36u), 5);
+                    mstep(__umulhi(w.w3, 36u), 6);
+                    mstep(__umulhi(w.w3 * 36u, 36u), 7);
+                    advance_rows();
                 }
             }
         }
@@ -860,22 +948,22 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             const uint32_t f0 = step_cell(s.pos0, s.or0, delta4), f1 = two ? step_cell(s.pos1, s.or1, delta4) : f0;
             const uint32_t m0 = a0 < 4u ? step_cell(s.pos0, a0, delta4) : s.pos0;
             const uint32_t m1 = (two & (a1 < 4u)) ? step_cell(s.pos1, a1, delta4) : (two ? s.pos1 : s.pos0);
-            const uint32_t fo0 = col + f0 * (BLOCK * 2u), fo1 = col + f1 * (BLOCK * 2u);
+            const uint32_t fo0 = col + f0 * (BLOCK * CW), fo1 = col + f1 * (BLOCK * CW);
             const uint32_t off0 = lut_var + (a0 == OC_A_INTERACT ? 0u : (uint32_t)(LUT4_KEYS * 16));
             const uint32_t off1 = lut_var + ((two & (a1 == OC_A_INTERACT)) ? 0u : (uint32_t)(LUT4_KEYS * 16));
-            const uint32_t c0 = lds_rd16(fo0), c1 = lds_rd16(fo1);
-            const uint32_t cm0 = lds_rd16(col + m0 * (BLOCK * 2u)), cm1 = lds_rd16(col + m1 * (BLOCK * 2u));
+            const uint32_t c0 = cw_rd<CW>(fo0), c1 = cw_rd<CW>(fo1);
+            const uint32_t cm0 = cw_rd<CW>(col + m0 * (BLOCK * CW)), cm1 = cw_rd<CW>(col + m1 * (BLOCK * CW));
             uint32_t pw[MAXP];
             rd_pots(pw);
             // resolve_movement (mdp.py:1644-1727): decided on the pre-step terrain, applied after the interacts
             const bool mv0 = a0 < 4u, mv1 = two & (a1 < 4u);
-            const uint32_t np0 = (mv0 & ((cm0 >> 8) < 30u)) ? m0 : s.pos0, np1 = (mv1 & ((cm1 >> 8) < 30u)) ? m1 : s.pos1;
+            const uint32_t np0 = (mv0 & (cw_kb<CW>(cm0) < 30u)) ? m0 : s.pos0, np1 = (mv1 & (cw_kb<CW>(cm1) < 30u)) ? m1 : s.pos1;
             const bool collide = two & ((np0 == np1) | ((np0 == s.pos1) & (np1 == s.pos0)));
             const uint32_t q0 = collide ? s.pos0 : np0, q1 = collide ? s.pos1 : np1;
             const uint32_t o0 = mv0 ? a0 : s.or0, o1 = mv1 ? a1 : s.or1;
             uint32_t p0 = q0, p1 = q1, d0 = o0, d1 = o1;
-            uint32_t nc0 = 0, nc1 = 0, unused4 = 0, npw[MAXP];
-            core(fo0, fo1, off0, off1, c0, c1, 0u, pw, p0, p1, d0, d1, unused4, nc0, nc1, npw);
+            uint32_t nc0 = 0, nc1 = 0, nf0 = 0, nf1 = 0, unused4 = 0, npw[MAXP];
+            core(fo0, fo1, off0, off1, c0, c1, 0u, pw, p0, p1, d0, d1, unused4, nf0, nf1, nc0, nc1, npw, -1);
             s.pos0 = p0; s.pos1 = p1; s.or0 = d0; s.or1 = d1;
         };
         int k = 0;
@@ -907,6 +995,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         }
     }
 #undef OC_JA_AT
-    store_env4<MAXP>(C, L, st, n, e, n_obj, horizon, s, col);
+    store_env4<MAXP, CW>(C, L, st, n, e, n_obj, horizon, s, col);
     if (ep_returns) ep_returns[e] = ep;
 }

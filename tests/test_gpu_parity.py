@@ -605,8 +605,10 @@ def test_reset_random_matches_oracle(gpu):
     before = env.get_packed_state()
     mask = (np.arange(n) % 3 == 0)
     env.ep_returns.fill_(1.0)
+    epoch = env.reset_epoch  # 37: the launch consumed one epoch per step (explicit resets and in-kernel restarts share ONE counter)
+    assert epoch == 37
     env.reset(mask=torch.from_numpy(mask), random_start_pos=True, rnd_obj_prob_thresh=0.5)
-    want = oracle_for(table.specs).reset_random(before.copy(), seed=5, epoch=0, random_start_pos=True, rnd_obj_prob_thresh=0.5,
+    want = oracle_for(table.specs).reset_random(before.copy(), seed=5, epoch=epoch, random_start_pos=True, rnd_obj_prob_thresh=0.5,
                                                 layout_id=lid, mask=mask.astype(np.uint8))
     assert np.array_equal(env.get_packed_state(), want)
     ep = env.ep_returns.cpu().numpy()
