@@ -768,7 +768,79 @@ def gen_generated_layouts(k=4096):
     print("generated layouts", k, "distinct", len({"|".join(g) for g in grids}), os.path.getsize(path), "bytes")
 
 
+def gen_state_queries():
+    """The reference's host-side state queries agents and planners call on the mdp (get_pot_states,
+    get_counter_objects_dict, get_empty_counter_locations, the get_*_pots family, soup_ready_at_location,
+    soup_to_be_cooked_at_location; mdp.py:1809-1907) on states sampled from the transition fixtures."""
+    out = {}
+    for name, lname, ov in CONFIGS:
+        if name not in ("cramped_room", "asymmetric_advantages", "counter_circuit", "mdp_test", "cramped_room_tomato"):
+            continue
+        spec, mdp = make_ref_mdp(lname, ov)
+        activate(mdp)
+        d = np.load(os.path.join(GOLDEN, "transitions_%s.npz" % name))
+        from overcooked_ai_amd.state import unpack_states
+        idx = list(range(0, d["state_in"].shape[1], d["state_in"].shape[1] // 60))[:60]
+        dicts = unpack_states(spec, np.ascontiguousarray(d["state_in"][:, idx]), as_dict=True)
+        cases = []
+        for sd in dicts:
+            st = R.OvercookedState.from_dict(sd)
+            ps = mdp.get_pot_states(st)
+            rec = {"state": sd, "pot_states": {k: [list(p) for p in v] for k, v in dict(ps).items() if v},
+                   "counter_objects": {k: [list(p) for p in v] for k, v in mdp.get_counter_objects_dict(st).items()},
+                   "empty_counters": [list(p) for p in mdp.get_empty_counter_locations(st)],
+                   "empty_pots": [list(p) for p in mdp.get_empty_pots(ps)], "ready_pots": [list(p) for p in mdp.get_ready_pots(ps)],
+                   "cooking_pots": [list(p) for p in mdp.get_cooking_pots(ps)],
+                   "full_not_cooking": [list(p) for p in mdp.get_full_but_not_cooking_pots(ps)],
+                   "full_pots": [list(p) for p in mdp.get_full_pots(ps)],
+                   "partially_full": sorted(list(p) for p in mdp.get_partially_full_pots(ps)),
+                   "soup_ready": [bool(mdp.soup_ready_at_location(st, p)) for p in mdp.get_pot_locations()],
+                   "soup_to_cook": [bool(mdp.soup_to_be_cooked_at_location(st, p)) for p in mdp.get_pot_locations()],
+                   "adjacent": [[[list(pos), t] for pos, t in mdp.get_adjacent_features(pl)] for pl in st.players]}
+            cases.append(rec)
+        out[name] = {"layout": spec.to_layout_dict(), "cases": cases}
+    with open(os.path.join(GOLDEN, "state_queries.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("state queries", {k: len(v["cases"]) for k, v in out.items()})
+
+
+def gen_agent_pair_rollouts():
+    """Episodes the REFERENCE's own agents play in the reference's own env: AgentPair(RandomAgent(all_actions=True),
+    RandomAgent(all_actions=True)).joint_action + OvercookedEnv.run_agents (agents/agent.py:137, 223;
+    overcooked_env.py:425-470), np.random seeded — the trajectory (states, joint actions with their action_probs infos,
+    rewards, dones) and the episode summary that the mirror env must reproduce when it replays the same actions."""
+    from overcooked_ai_py.agents.agent import AgentPair, RandomAgent
+    out = {}
+    for lname, horizon, seed in (("cramped_room", 120, 5), ("counter_circuit", 90, 6)):
+        spec, mdp = make_ref_mdp(lname, {})
+        activate(mdp)
+        env = R.OvercookedEnv.from_mdp(mdp, horizon=horizon, info_level=0)
+        env._mp = object()
+        np.random.seed(seed)
+        pair = AgentPair(RandomAgent(all_actions=True), RandomAgent(all_actions=True))
+        traj, t_elapsed, total_sparse, total_shaped = env.run_agents(pair, include_final_state=True)
+        steps = []
+        for (s_t, a_t, r_t, done, info) in traj[:-1]:
+            steps.append({"state": s_t.to_dict(), "action": [R.Action.ACTION_TO_INDEX[a] for a in a_t], "reward": float(r_t),
+                          "done": bool(done), "agent_infos": [{k: np.asarray(v).tolist() for k, v in ai.items()} for ai in info["agent_infos"]],
+                          "sparse_r_by_agent": [float(x) for x in info["sparse_r_by_agent"]],
+                          "shaped_r_by_agent": [float(x) for x in info["shaped_r_by_agent"]]})
+        ep = traj[-2][4]["episode"]
+        out[lname] = {"layout": spec.to_layout_dict(), "horizon": horizon, "seed": seed, "steps": steps,
+                      "final_state": traj[-1][0].to_dict(), "t_elapsed": int(t_elapsed), "total_sparse": float(total_sparse),
+                      "total_shaped": float(total_shaped), "ep_length": int(ep["ep_length"]),
+                      "ep_game_stats": {k: ([list(map(int, x)) for x in v] if isinstance(v, list) else np.asarray(v).tolist())
+                                        for k, v in ep["ep_game_stats"].items()}}
+    with open(os.path.join(GOLDEN, "agent_pair_rollouts.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("agent pair rollouts", {k: len(v["steps"]) for k, v in out.items()})
+
+
 def main():
+    if "--queries-only" in sys.argv:
+        gen_state_queries()
+        gen_agent_pair_rollouts()
+        return
     if "--generated-layouts-only" in sys.argv:
         gen_generated_layouts()
         return
@@ -816,6 +888,8 @@ def main():
     gen_potential()
     gen_multi_agent()
     gen_generated_layouts()
+    gen_state_queries()
+    gen_agent_pair_rollouts()
     with open(os.path.join(GOLDEN, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
     print("done")

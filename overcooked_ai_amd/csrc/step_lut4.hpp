@@ -344,6 +344,22 @@ __device__ __forceinline__ Phx4 philox_words(uint64_t blk, uint32_t g_lo, uint32
     philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, r);
     return Phx4{r[0], r[1], r[2], r[3]};
 }
+// The same block computed a few rounds at a time (the unrolled step loop spreads the next block's ten rounds over the
+// shadows of its steps' look-ups instead of paying for them in one lump)
+struct PhxInc {
+    uint32_t c0, c1, c2, c3, k0, k1;
+    __device__ __forceinline__ void start(uint64_t blk, uint32_t g_lo, uint32_t g_hi, uint32_t seed_lo, uint32_t seed_hi) {
+        c0 = (uint32_t)blk; c1 = g_lo; c2 = g_hi; c3 = (uint32_t)(blk >> 32); k0 = seed_lo; k1 = seed_hi;
+    }
+    __device__ __forceinline__ void round() {  // one round of philox4x32_10 (common.hpp)
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    __device__ __forceinline__ Phx4 words() const { return Phx4{c0, c1, c2, c3}; }
+};
 // (the words are passed by value and picked with arithmetic masks: a chain of selects between fields of one struct gets
 //  folded into a dynamically indexed load, which pins the struct in scratch memory — and a scratch load in the step loop
 //  waits, through vmcnt, for the output stores of the previous steps)
@@ -385,12 +401,13 @@ __device__ __forceinline__ void store_flag_byte(uint8_t* row, uint32_t lane_off,
     asm volatile("global_store_byte %0, %1, %2" : : "v"(lane_off), "v"(v), "s"(row) : "memory");
 }
 
-// rewards[k][e]: the same addressing for the 16-byte quad (a C++ store through base + zero-extended offset becomes a 64-bit
-// VGPR address computation)
+// rewards[k][e] through the same addressing, as a plain C++ store (the compiler must see it: a store of more than 8 bytes
+// needs wait states before its data registers may be rewritten, which it inserts only for stores it knows).  The empty asm
+// keeps the zero-extension of the offset next to the store — hoisted out of the loop it becomes a 64-bit VGPR pair and the
+// store a 64-bit VGPR address computation instead of  global_store_dwordx4 v_off, v[data], s[row].
 __device__ __forceinline__ void store_quad(float4* row, uint32_t lane_off, float4 v) {
-    typedef float oc_f32x4 __attribute__((ext_vector_type(4)));
-    const oc_f32x4 q = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(lane_off), "v"(q), "s"(row) : "memory");
+    asm volatile("" : "+v"(lane_off));
+    *reinterpret_cast<float4*>(reinterpret_cast<uint8_t*>(row) + lane_off) = v;
 }
 
 // a randomized start (get_random_start_state_fn, mdp.py:1307-1369) drawn by draw_start, in Env4 / key-byte form
@@ -539,23 +556,41 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         rew_off[k8] = (threadIdx.x + (uint32_t)k8 * (uint32_t)n) * 16u;
         flg_off[k8] = lane + (uint32_t)k8 * (uint32_t)n;
     }
-    // k8: index of the step inside an unrolled block of 8 (stores through the block's row + offset), or -1 (rolled step)
-    auto core = [&](uint32_t fo0, uint32_t fo1, uint32_t off0, uint32_t off1, uint32_t c0, uint32_t c1, uint32_t ja2n,
-                    const uint32_t (&pw)[MAXP], uint32_t& m0, uint32_t& m1, uint32_t& m2, uint32_t& m3, uint32_t& m4,
-                    uint32_t& nf0, uint32_t& nf1, uint32_t& nc0, uint32_t& nc1, uint32_t (&npw)[MAXP], int k8)
-                    __attribute__((always_inline)) {
-        // ---- the straight line: everything a step does when nothing rare happens -------------------------------------
+    // The look-ups of a step: both players' LUT entries against the pre-step cells (resolve_interacts, mdp.py:1432-1579)
+    // and — FAST_START — the cook time of what the pot holds, should somebody start it.  Issued first; whatever the
+    // caller has that does not depend on them runs while they are in flight.
+    struct Looked { uint4 e0, e1; uint32_t cookv; };
+    auto look_up = [&](uint32_t off0, uint32_t off1, uint32_t c0, uint32_t c1, const uint32_t (&pw)[MAXP]) __attribute__((always_inline)) {
         if (CW == 2) {  // (values read with ds_read_u16 a step earlier: tell the compiler they are still 16 bits wide)
             __builtin_assume(c0 <= 0xFFFFu); __builtin_assume(c1 <= 0xFFFFu);
             __builtin_assume(off0 <= 0xFFFFu); __builtin_assume(off1 <= 0xFFFFu);
 #pragma unroll
             for (int k = 0; k < MAXP; ++k) __builtin_assume(pw[k] <= 0xFFFFu);
         }
-        uint32_t cookv = 0;
-        if (FAST_START) cookv = cook_time(cw_obj<CW>(pw[0]));  // cook time of what the pot holds, should somebody start it
-        // both players against the pre-step cells (resolve_interacts, mdp.py:1432-1579)
-        const uint4 e0 = lds_rd128(lut4_addr<CW>(off0, s.h0, c0));
-        uint4 e1 = lds_rd128(lut4_addr<CW>(off1, s.h1, c1));
+        Looked q;
+        q.e0 = lds_rd128(lut4_addr<CW>(off0, s.h0, c0));
+        q.e1 = lds_rd128(lut4_addr<CW>(off1, s.h1, c1));
+        q.cookv = FAST_START ? cook_time(cw_obj<CW>(pw[0])) : 0u;
+        return q;
+    };
+    // Outputs of a step whose stores (and episode-return additions) are put off to the next step of the same unrolled block,
+    // where they run while that step's look-ups are in flight.
+    struct Pend { float4 rw; uint32_t fl; float add0, add1; };
+    auto flush = [&](const Pend& p, int k8) __attribute__((always_inline)) {
+        store_quad(rew_k, rew_off[k8 & 7], p.rw);
+        store_flag_byte(flg_k, flg_off[k8 & 7], p.fl);
+        ep.z += p.add0; ep.w += p.add1;
+    };
+    // k8: index of the step inside an unrolled block of 8 (stores through the block's row + offset), or -1 (rolled step);
+    // defer: where to leave the step's outputs instead of storing them (flush() follows), or nullptr
+    auto core = [&](uint32_t fo0, uint32_t fo1, uint32_t off0, uint32_t off1, uint32_t c0, uint32_t c1, uint32_t ja2n,
+                    const uint32_t (&pw)[MAXP], uint32_t& m0, uint32_t& m1, uint32_t& m2, uint32_t& m3, uint32_t& m4,
+                    uint32_t& nf0, uint32_t& nf1, uint32_t& nc0, uint32_t& nc1, uint32_t (&npw)[MAXP], int k8,
+                    const Looked& looked, Pend* defer = nullptr) __attribute__((always_inline)) {
+        // ---- the straight line: everything a step does when nothing rare happens -------------------------------------
+        const uint32_t cookv = looked.cookv;
+        const uint4 e0 = looked.e0;
+        uint4 e1 = looked.e1;
         const uint32_t r0 = interact4<CW>(e0, s.h0, c0);
         uint32_t r1 = interact4<CW>(e1, s.h1, c1);
         const uint32_t cw0 = cw_of_result<CW>(r0);  // player 0's faced cell afterwards
@@ -702,8 +737,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                 float4 r;
                 r.z = (((r0 & F4_TAKE_DISH) != 0u) & du0) ? C.rew_dish : 0.f;
                 r.w = (((r1 & F4_TAKE_DISH) != 0u) & du1) ? C.rew_dish : 0.f;
-                r.x = (r0 & F4_SERVE) ? L.value(recipe_idx(hb0) & 15u) : 0.f;  // deliver_soup (mdp.py:1631-1642)
-                r.y = (r1 & F4_SERVE) ? L.value(recipe_idx(hb1) & 15u) : 0.f;
+                r.x = r.y = 0.f;
+                if ((r0 | r1) & F4_SERVE) {  // deliver_soup (mdp.py:1631-1642): the recipe value look-ups only where somebody serves
+                    r.x = (r0 & F4_SERVE) ? L.value(recipe_idx(hb0) & 15u) : 0.f;
+                    r.y = (r1 & F4_SERVE) ? L.value(recipe_idx(hb1) & 15u) : 0.f;
+                }
                 ep.x += r.x; ep.y += r.y; ep.z += r.z; ep.w += r.w;
                 rw = make_float4(r.x, r.y, r.z + sh0, r.w + sh1);
             } else {
@@ -787,7 +825,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             if (ea.events) ea.events[(int64_t)step_k * n + e] = ev;
             count_events(ea, e, ev, done, (options & OC_OPT_AUTO_RESET) != 0u);
         }
-        if (OUT && k8 >= 0) {  // a step of an unrolled block: the block's first row + this step's precomputed offset
+        const bool deferred = OUT && k8 >= 0 && defer != nullptr;
+        if (deferred) {  // stored by the next step of the block, in the shadow of its look-ups
+            defer->rw = rw; defer->fl = fl; defer->add0 = add0; defer->add1 = add1;
+        } else if (OUT && k8 >= 0) {  // a step of an unrolled block: the block's first row + this step's precomputed offset
             store_quad(rew_k, rew_off[k8 & 7], rw);
             store_flag_byte(flg_k, flg_off[k8 & 7], fl);
         } else {
@@ -799,7 +840,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         s.h0 = nh0;
         s.h1 = nh1;
         s.dcount = dcount;
-        ep.z += add0; ep.w += add1;
+        if (!deferred) { ep.z += add0; ep.w += add1; }
         step_k += 1u;
     };
     // after the eight steps of an unrolled block
@@ -823,26 +864,41 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         uint32_t Jc = s.J;
         constexpr uint32_t JS = (uint32_t)CW;  // scale of a joint action as a table index: the tables' entries are u16 / u32
         auto row_rd = [&](uint32_t a) __attribute__((always_inline)) { return CW == 2 ? lds_rd16(a) : lds_rd32(a); };
-        uint32_t ja2 = OC_JA_AT(t0, true) * JS;
-        uint32_t fa = lds_rd32(Jc + (uint32_t)Mvj<CW>::FACES), Jn = row_rd(Jc + ja2);
-        uint32_t off0 = row_rd((uint32_t)M::ACT + ja2), off1 = row_rd((uint32_t)(M::ACT + M::ACT_P1) + ja2);
+        // JS * (top base-36 digit of x) = mulhi(x, 36 * JS) with the low bits cleared
+        auto jsd = [&](uint32_t x) __attribute__((always_inline)) { return __umulhi(x, 36u * JS) & ~(JS - 1u); };
+        const uint32_t ja0 = OC_JA_AT(t0, true) * JS;
+        uint32_t fa = lds_rd32(Jc + (uint32_t)Mvj<CW>::FACES), Jn = row_rd(Jc + ja0);
+        uint32_t off0 = row_rd((uint32_t)M::ACT + ja0), off1 = row_rd((uint32_t)(M::ACT + M::ACT_P1) + ja0);
         uint32_t fo0 = col + (fa & 0xFFFFu), fo1 = col + (fa >> 16);  // LDS addresses of the faced cells of step k
         uint32_t c0 = cw_rd<CW>(fo0), c1 = cw_rd<CW>(fo1);
         uint32_t pw[MAXP];
         rd_pots(pw);
-        auto pstep = [&](uint32_t ja2n, int k8) __attribute__((always_inline)) {  // ja2n: JS * joint action of the NEXT step
+        Pend pend = {zero4, 0u, 0.f, 0.f};
+        PhxInc inc = {0, 0, 0, 0, 0, 0};
+        // One step.  On entry: Jc / Jn = rows of the poses of this step and the next, fo* = this step's faced cells, off* = the
+        // LUT addresses for this step's actions, c* / pw = the cell words (PIPE).  xn = Philox word holding the NEXT step's
+        // joint action (second digit when mul36), rounds = how many Philox rounds of the block after this one to run here.
+        // Three regions, kept apart by scheduling barriers: the step's look-ups are issued; then everything that does not
+        // depend on them (the previous step's output stores, a slice of the next Philox block, the next action and the
+        // table reads it feeds) runs while they are in flight; then the interacts themselves.
+        auto pstep = [&](uint32_t xn, bool mul36, int k8, int rounds) __attribute__((always_inline)) {
             if (!PIPE) {
                 c0 = cw_rd<CW>(fo0);
                 c1 = cw_rd<CW>(fo1);
                 rd_pots(pw);
             }
+            const Looked looked = look_up(off0, off1, c0, c1, pw);
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);  // (two or more wavefronts per SIMD hide each other's latency: no hand-made shadow)
+            if (PIPE && OUT && k8 >= 1) flush(pend, k8 - 1);
+#pragma unroll
+            for (int r = 0; r < rounds; ++r) inc.round();
+            const uint32_t ja2n = jsd(mul36 ? xn * 36u : xn);
             uint32_t fa_n = lds_rd32(Jn + (uint32_t)Mvj<CW>::FACES), Jnn = row_rd(Jn + ja2n);
             const uint32_t off0n = row_rd((uint32_t)M::ACT + ja2n), off1n = row_rd((uint32_t)(M::ACT + M::ACT_P1) + ja2n);
-            // keep these look-ahead reads at the top of the step: they do not depend on this step's cells, and left to
-            // itself the scheduler queues them in front of the LUT reads the step is waiting for (+0.75 %)
-            __builtin_amdgcn_sched_barrier(0);
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);
             uint32_t Jcn = Jn, unused = 0, unused4 = 0, nf0 = 0, nf1 = 0, nc0 = 0, nc1 = 0, npw[MAXP];
-            core(fo0, fo1, off0, off1, c0, c1, ja2n, pw, Jcn, fa_n, Jnn, unused, unused4, nf0, nf1, nc0, nc1, npw, k8);
+            core(fo0, fo1, off0, off1, c0, c1, ja2n, pw, Jcn, fa_n, Jnn, unused, unused4, nf0, nf1, nc0, nc1, npw, k8, looked,
+                 (PIPE && k8 >= 0 && k8 < 7) ? &pend : nullptr);
             Jc = Jcn; Jn = Jnn; off0 = off0n; off1 = off1n; fo0 = nf0; fo1 = nf1;
             if (PIPE) {
                 c0 = nc0; c1 = nc1;
@@ -850,27 +906,32 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                 for (int k = 0; k < MAXP; ++k) pw[k] = npw[k];
             }
         };
+        // the Philox word of global step t (w = the block it lies in) and whether t's action is the word's second digit
+        auto word_of = [&](int64_t t) __attribute__((always_inline)) {
+            const uint64_t t_ = (uint64_t)t;
+            if (((uint32_t)t_ & 7u) == 0u) w = philox_words(t_ >> 3, g_lo, g_hi, seed_lo, seed_hi);
+            const uint32_t pick = ((uint32_t)t_ & 7u) >> 1;
+            return (w.w0 & (0u - (uint32_t)(pick == 0u))) | (w.w1 & (0u - (uint32_t)(pick == 1u))) |
+                   (w.w2 & (0u - (uint32_t)(pick == 2u))) | (w.w3 & (0u - (uint32_t)(pick == 3u)));
+        };
         int k = 0;
         const int head_end = min(n_steps, (int)((8u - ((uint32_t)t0 & 7u)) & 7u));
-        // (the look-ahead call for the last head step loads the block the unrolled loop starts with; with no head, the
-        //  prologue's ja_at(t0) did)
-        for (; k < head_end; ++k) pstep(OC_JA_AT(t0 + k + 1, false) * JS, -1);  // up to the next block boundary
-        for (; blocked_rows && n_steps - k >= 8; k += 8) {  // whole Philox blocks, unrolled; the look-ahead digit of step 7 is the next block's first
-            const Phx4 nb = philox_words(((uint64_t)(t0 + k) >> 3) + 1u, g_lo, g_hi, seed_lo, seed_hi);
-            // JS * (top base-36 digit of x) = mulhi(x, 36 * JS) with the low bits cleared
-            auto jsd = [&](uint32_t x) __attribute__((always_inline)) { return __umulhi(x, 36u * JS) & ~(JS - 1u); };
-            pstep(jsd(w.w0 * 36u), 0);
-            pstep(jsd(w.w1), 1);
-            pstep(jsd(w.w1 * 36u), 2);
-            pstep(jsd(w.w2), 3);
-            pstep(jsd(w.w2 * 36u), 4);
-            pstep(jsd(w.w3), 5);
-            pstep(jsd(w.w3 * 36u), 6);
-            pstep(jsd(nb.w0), 7);
+        // rolled steps up to the next block boundary (the last one loads the block the unrolled loop starts in)
+        for (; k < head_end; ++k) { const uint32_t xn = word_of(t0 + k + 1); pstep(xn, ((t0 + k + 1) & 1) != 0, -1, 0); }
+        for (; blocked_rows && n_steps - k >= 8; k += 8) {  // whole Philox blocks, unrolled; w = the block of these 8 steps
+            inc.start(((uint64_t)(t0 + k) >> 3) + 1u, g_lo, g_hi, seed_lo, seed_hi);  // the next block: ten rounds over steps 0..6
+            pstep(w.w0, true, 0, 2);
+            pstep(w.w1, false, 1, 2);
+            pstep(w.w1, true, 2, 2);
+            pstep(w.w2, false, 3, 1);
+            pstep(w.w2, true, 4, 1);
+            pstep(w.w3, false, 5, 1);
+            pstep(w.w3, true, 6, 1);
+            w = inc.words();
+            pstep(w.w0, false, 7, 0);  // the look-ahead digit of step 7 is the next block's first
             advance_rows();
-            w = nb;
         }
-        for (; k < n_steps; ++k) pstep(OC_JA_AT(t0 + k + 1, false) * JS, -1);  // the tail
+        for (; k < n_steps; ++k) { const uint32_t xn = word_of(t0 + k + 1); pstep(xn, ((t0 + k + 1) & 1) != 0, -1, 0); }  // the tail
         // joint pose -> cells / orientations
         const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR], Jidx = (Jc - (uint32_t)M::MVJ) / (uint32_t)Mvj<CW>::ROW_BYTES, P0 = Jidx / NP, P1 = Jidx - P0 * NP;
         s.pos0 = s_fl[P0 >> 2]; s.or0 = P0 & 3u; s.pos1 = s_fl[P1 >> 2]; s.or1 = P1 & 3u;
@@ -906,6 +967,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                 rd_pots(pw);
             }
             const uint32_t off0 = lut_var + (ja >= 30u ? 0u : NOI), off1 = lut_var + (a1 == 5u ? 0u : NOI);
+            const Looked looked = look_up(off0, off1, c0, c1, pw);
             // resolve_movement (mdp.py:1644-1727) on the static terrain: the pose of the NEXT step
             const uint32_t t0_ = ahead(P0, a0), t1_ = ahead(P1, a1);
             const uint32_t np0 = ((fm >> t0_) & 1ull) ? t0_ : P0, np1 = ((fm >> t1_) & 1ull) ? t1_ : P1;
@@ -914,7 +976,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             uint32_t o0 = a0 < 4u ? a0 : O0, o1 = a1 < 4u ? a1 : O1;
             uint32_t fa_n = (ahead(q0, o0) * (BLOCK * CW)) | ((ahead(q1, o1) * (BLOCK * CW)) << 16);
             uint32_t nf0 = 0, nf1 = 0, nc0 = 0, nc1 = 0, npw[MAXP];
-            core(fo0, fo1, off0, off1, c0, c1, 0u, pw, q0, fa_n, q1, o0, o1, nf0, nf1, nc0, nc1, npw, k8);
+            core(fo0, fo1, off0, off1, c0, c1, 0u, pw, q0, fa_n, q1, o0, o1, nf0, nf1, nc0, nc1, npw, k8, looked);
             P0 = q0; P1 = q1; O0 = o0; O1 = o1; fo0 = nf0; fo1 = nf1;
             if (PIPE) {
                 c0 = nc0; c1 = nc1;
@@ -963,7 +1025,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             const uint32_t o0 = mv0 ? a0 : s.or0, o1 = mv1 ? a1 : s.or1;
             uint32_t p0 = q0, p1 = q1, d0 = o0, d1 = o1;
             uint32_t nc0 = 0, nc1 = 0, nf0 = 0, nf1 = 0, unused4 = 0, npw[MAXP];
-            core(fo0, fo1, off0, off1, c0, c1, 0u, pw, p0, p1, d0, d1, unused4, nf0, nf1, nc0, nc1, npw, -1);
+            core(fo0, fo1, off0, off1, c0, c1, 0u, pw, p0, p1, d0, d1, unused4, nf0, nf1, nc0, nc1, npw, -1, look_up(off0, off1, c0, c1, pw));
             s.pos0 = p0; s.pos1 = p1; s.or0 = d0; s.or1 = d1;
         };
         int k = 0;

@@ -12,14 +12,35 @@ from .mdp import EVENT_TYPES, OvercookedGridworld
 
 DEFAULT_ENV_PARAMS = {"horizon": 400}
 MAX_HORIZON = 1e10
+MAX_TIMESTEP = 65535  # the packed state's timestep is a u16 (include/oc_amd.h)
+DEFAULT_TRAJ_KEYS = ["ep_states", "ep_actions", "ep_rewards", "ep_dones", "ep_infos", "ep_returns", "ep_lengths",
+                     "mdp_params", "env_params", "metadatas"]  # get_rollouts' trajectory dict (env.py:27-38)
+
+
+class _UnsupportedPlanner:
+    """What `OvercookedEnv.mlam` returns: the reference builds a MediumLevelActionManager there (joint motion planning
+    and medium-level action enumeration, planning/planners.py:453-1400), which lies outside the accelerated path.  The
+    object carries the parts that ARE available — `motion_planner` (planner.MotionPlanner) and `params` — so that
+    `featurize_state(state, env.mlam)`-style calls work, and names what is missing when anything else is asked of it."""
+
+    def __init__(self, motion_planner, params):
+        self.motion_planner, self.params = motion_planner, params
+
+    def __getattr__(self, name):
+        raise NotImplementedError(
+            "OvercookedEnv.mlam.%s: the MediumLevelActionManager / JointMotionPlanner of the reference "
+            "(overcooked_ai_py/planning/planners.py:453-1400) is not part of overcooked_ai_amd; available here: "
+            ".motion_planner (single-agent MotionPlanner: get_plan, min_cost_to_feature, ...) and .params.  Agents that "
+            "need medium-level actions (GreedyHumanModel, agents/agent.py:298) must be given the reference's planner." % name)
 
 
 class OvercookedEnv:
     """The reference's OvercookedEnv surface (overcooked_env.py:33-405) over the HIP transition.
 
     One difference in range: the packed state carries the timestep as a u16, so an episode can run for at most
-    65 535 steps (the reference's default horizon, 1e10, means "never done" there and "done at the packing limit"
-    here: step() raises ValueError at timestep 65 536; the batched kernels saturate the stored timestep instead)."""
+    65 535 steps.  The reference's default horizon (MAX_HORIZON = 1e10: "never done") is accepted, but step() raises
+    ValueError once the state's timestep has reached 65 535 instead of silently freezing it there (the kernels saturate
+    the stored timestep); give a horizon <= 65 535 for episodes that end."""
 
     _CTOR_KEYS = ("start_state_fn", "horizon", "info_level", "num_mdp")  # what env_params / copy() carry over
 
@@ -31,6 +52,7 @@ class OvercookedEnv:
         self.mdp_generator_fn, self.mlam_params = mdp_generator_fn, mlam_params
         self.start_state_fn, self.horizon, self.info_level, self.num_mdp = start_state_fn, horizon, info_level, num_mdp
         self.variable_mdp = num_mdp > 1
+        self._mp = self._mlam = None
         self.reset(outside_info=initial_info)
 
     @staticmethod
@@ -46,10 +68,32 @@ class OvercookedEnv:
         """A fresh env (reset to a start state) over the same generator and parameters (env.py:236-242)."""
         return OvercookedEnv(self.mdp_generator_fn, **self.env_params)
 
+    # ---------------------------------------------------------------- planners (env.py:92-115)
+    @property
+    def mp(self):
+        """Single-agent motion planner of the current mdp (lazily built, dropped when reset() regenerates the mdp)."""
+        if self._mp is None:
+            from .planner import MotionPlanner
+
+            self._mp = MotionPlanner(self.mdp, (self.mlam_params or {}).get("counter_goals") or ())
+        return self._mp
+
+    @property
+    def mlam(self):
+        if self._mlam is None:
+            self._mlam = _UnsupportedPlanner(self.mp, self.mlam_params)
+        return self._mlam
+
+    def __repr__(self):
+        return self.mdp.state_string(self.state)
+
     # ---------------------------------------------------------------- stepping (API of env.py:244-325)
     def step(self, joint_action, joint_agent_action_info=None, display_phi=False):
         """One joint action -> (next_state, summed sparse reward, done, env_info); refuses to step a finished env."""
         assert not self.is_done()
+        if self.state.timestep >= MAX_TIMESTEP:
+            raise ValueError("timestep %d: the packed state counts steps in 16 bits; use a horizon <= %d"
+                             % (self.state.timestep, MAX_TIMESTEP))
         agent_infos = joint_agent_action_info if joint_agent_action_info is not None else [{}, {}]
         next_state, mdp_infos = self.mdp.get_state_transition(self.state, joint_action, display_phi)
         self._update_game_stats(mdp_infos)  # events are stamped with the pre-step timestep (env.py:385)
@@ -72,6 +116,7 @@ class OvercookedEnv:
         """New episode (env.py:288-319): optionally a new mdp from the generator, a start state, empty game_stats."""
         if regen_mdp:
             self.mdp = self.mdp_generator_fn(outside_info)
+            self._mp = self._mlam = None
         start = self.start_state_fn or self.mdp.get_standard_start_state
         self.state = start()
         n = self.mdp.num_players
@@ -132,7 +177,65 @@ class OvercookedEnv:
             done = self.is_done()
             if done:
                 break
-        return self.state, done
+        successor_state = self.state
+        self.reset(False)  # like the reference: the env is left at a start state of the same mdp
+        return successor_state, done
+
+    def run_agents(self, agent_pair, include_final_state=False, display=False, dir=None, display_phi=False,
+                   display_until=np.inf):
+        """One episode driven by an agent pair (anything with `joint_action(state) -> ((a0, info0), (a1, info1))`, e.g. the
+        reference's AgentPair, agents/agent.py:137): -> (trajectory, timesteps, total sparse, total shaped) with
+        trajectory an object array of (state, joint action, reward, done, info) rows (+ a closing row holding the final
+        state when include_final_state), exactly like env.py:425-483."""
+        assert self.state.timestep == 0, "Did not reset environment before running agents"
+        rows, done = [], False
+        while not done:
+            s_t = self.state
+            a_t, a_info_t = zip(*agent_pair.joint_action(s_t))
+            assert all(a in Action.ALL_ACTIONS for a in a_t) and all(type(i) is dict for i in a_info_t)
+            s_next, r_t, done, info = self.step(a_t, a_info_t, display_phi)
+            rows.append((s_t, a_t, r_t, done, info))
+            if display and self.state.timestep < display_until:
+                print(self)
+        assert len(rows) == self.state.timestep, "%d vs %d" % (len(rows), self.state.timestep)
+        if include_final_state:
+            rows.append((s_next, (None, None), 0, True, None))
+        trajectory = np.empty((len(rows), 5), dtype=object)
+        for i, row in enumerate(rows):
+            for j, item in enumerate(row):
+                trajectory[i, j] = item
+        return (trajectory, self.state.timestep, sum(self.game_stats["cumulative_sparse_rewards_by_agent"]),
+                sum(self.game_stats["cumulative_shaped_rewards_by_agent"]))
+
+    def get_rollouts(self, agent_pair, num_games, display=False, dir=None, final_state=False, display_phi=False,
+                     display_until=np.inf, metadata_fn=None, metadata_info_fn=None, info=True):
+        """`num_games` episodes of `agent_pair` in the codebase's standard trajectories format (env.py:485-580): a dict of
+        per-episode lists / arrays under DEFAULT_TRAJ_KEYS."""
+        out = {k: [] for k in DEFAULT_TRAJ_KEYS}
+        for _ in range(num_games):
+            if hasattr(agent_pair, "set_mdp"):
+                agent_pair.set_mdp(self.mdp)
+            rollout = self.run_agents(agent_pair, include_final_state=final_state, display=display, dir=dir,
+                                      display_phi=display_phi, display_until=display_until)
+            traj, length, sparse_total, _ = rollout
+            for key, col in zip(DEFAULT_TRAJ_KEYS[:5], traj.T):
+                out[key].append(col)
+            out["ep_returns"].append(sparse_total)
+            out["ep_lengths"].append(length)
+            out["mdp_params"].append(self.mdp.mdp_params)
+            out["env_params"].append(self.env_params)
+            out["metadatas"].append(metadata_fn(rollout) if metadata_fn else {})
+            self.reset(regen_mdp=False)
+            if hasattr(agent_pair, "reset"):
+                agent_pair.reset()
+        out = {k: np.array(v, dtype=object) if k in DEFAULT_TRAJ_KEYS[:5] else np.array(v) if k in ("ep_returns", "ep_lengths") else v
+               for k, v in out.items()}
+        if out["metadatas"]:  # list of dicts -> dict of lists, like the reference's merge
+            keys = out["metadatas"][0].keys()
+            out["metadatas"] = {k: [m[k] for m in out["metadatas"]] for k in keys}
+        else:
+            out["metadatas"] = {}
+        return out
 
 
 class _Discrete:

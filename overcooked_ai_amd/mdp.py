@@ -88,6 +88,7 @@ class _SingleEnvPort:
         self.stream = torch.cuda.Stream(device=env.device)
         self.stream_ptr = ctypes.c_void_p(self.stream.cuda_stream)
         self.device = env.device
+        self.dev_index = env._dev_index
         self.torch = torch
         self.num_players = mdp.num_players
 
@@ -99,7 +100,11 @@ class _SingleEnvPort:
         mv[self.o_act] = a0
         mv[self.o_act + 1] = a1
         p = self.ptrs
-        rc = self.lib.oc_step(self.bref, p[0], p[1], p[2], p[3], p[4], None, p[5], 65535, 0, None, None, self.stream_ptr)
+        if self.torch.cuda.current_device() == self.dev_index:
+            rc = self.lib.oc_step(self.bref, p[0], p[1], p[2], p[3], p[4], None, p[5], 65535, 0, None, None, self.stream_ptr)
+        else:  # the launch must happen with this env's device current (its stream and buffers live there)
+            with self.torch.cuda.device(self.device):
+                rc = self.lib.oc_step(self.bref, p[0], p[1], p[2], p[3], p[4], None, p[5], 65535, 0, None, None, self.stream_ptr)
         if rc:
             from . import _lib
             _lib.check(rc, "oc_step")
@@ -424,6 +429,127 @@ class OvercookedGridworld:
     @property
     def num_pots(self):
         return len(self.get_pot_locations())
+
+    def get_valid_player_positions_and_orientations(self):
+        return [(pos, d) for pos in self.get_valid_player_positions() for d in Direction.ALL_DIRECTIONS]
+
+    def get_adjacent_features(self, player):
+        """[(cell next to the player, its terrain character)] for the four directions (mdp.py:1773-1781)."""
+        x, y = player.position
+        return [((x + dx, y + dy), self.get_terrain_type_at_pos((x + dx, y + dy))) for dx, dy in Direction.ALL_DIRECTIONS]
+
+    # ---------------------------------------------------------------- state queries agents use (mdp.py:1809-1907)
+    # Host-side views of one OvercookedState: what the reference's planners and scripted agents (agents/agent.py) ask the mdp.
+    def get_pot_states(self, state):
+        """{"empty": [...], "1_items" / "2_items" / "3_items": idle pots by fill, "cooking": [...], "ready": [...]} — pot
+        positions in get_pot_locations() order; a missing key reads as [] (mdp.py:1809-1838)."""
+        from collections import defaultdict
+
+        out = defaultdict(list)
+        for pos in self.get_pot_locations():
+            soup = state.objects.get(pos)
+            if soup is None:
+                key = "empty"
+            else:
+                assert soup.name == "soup", "soup at %s is not a soup but a %s" % (pos, soup.name)
+                key = "ready" if soup.is_ready else "cooking" if soup.is_cooking else "%d_items" % len(soup.ingredients)
+            out[key].append(pos)
+        return out
+
+    def get_counter_objects_dict(self, state, counter_subset=None):
+        """{object name: [positions]} of what lies on counters (all of them, or `counter_subset`), in the order of the
+        state's objects dict (mdp.py:1840-1852)."""
+        from collections import defaultdict
+
+        where = self.terrain_pos_dict["X"] if counter_subset is None else counter_subset
+        out = defaultdict(list)
+        for obj in state.objects.values():
+            if obj.position in where:
+                out[obj.name].append(obj.position)
+        return out
+
+    def get_empty_counter_locations(self, state):
+        return [pos for pos in self.get_counter_locations() if not state.has_object(pos)]
+
+    def get_empty_pots(self, pot_states):
+        return pot_states["empty"]
+
+    def get_ready_pots(self, pot_states):
+        return pot_states["ready"]
+
+    def get_cooking_pots(self, pot_states):
+        return pot_states["cooking"]
+
+    def get_full_but_not_cooking_pots(self, pot_states):
+        return pot_states["%d_items" % self.spec.num_items_for_soup]
+
+    def get_full_pots(self, pot_states):
+        return self.get_cooking_pots(pot_states) + self.get_ready_pots(pot_states) + self.get_full_but_not_cooking_pots(pot_states)
+
+    def get_partially_full_pots(self, pot_states):
+        # (a set union in the reference, mdp.py:1882-1890: the order of its result is the interpreter's set order)
+        return list(set().union(*[pot_states["%d_items" % i] for i in range(1, self.spec.num_items_for_soup)]))
+
+    def get_non_empty_pots(self, pot_states):
+        return self.get_full_pots(pot_states) + self.get_partially_full_pots(pot_states)
+
+    def soup_ready_at_location(self, state, pos):
+        if not state.has_object(pos):
+            return False
+        obj = state.get_object(pos)
+        assert obj.name == "soup", "Object in pot was not soup"
+        return obj.is_ready
+
+    def soup_to_be_cooked_at_location(self, state, pos):
+        if not state.has_object(pos):
+            return False
+        obj = state.get_object(pos)
+        return obj.name == "soup" and not obj.is_cooking and not obj.is_ready and len(obj.ingredients) > 0
+
+    def state_string(self, state):
+        """Text picture of a state, one row of the grid per line: the terrain character of every cell; a player as its
+        orientation arrow + player index (+ a letter for what it holds: o / t / d, or the soup's ingredients); a loose
+        object by its letter; a pot as its content, e.g. "ooo" idle, "oo5" cooking at tick 5, "ooo+" ready.  (Same
+        information as the reference's state_string, mdp.py:3253-3312; the exact glyphs are this package's.)"""
+        arrows = {Direction.NORTH: "^", Direction.SOUTH: "v", Direction.EAST: ">", Direction.WEST: "<"}
+
+        def obj_txt(obj):
+            if obj.name != "soup":
+                return obj.name[0]
+            txt = "".join(i[0] for i in obj.ingredients)
+            return txt + ("+" if obj.is_ready else str(obj.cooking_tick) if obj.is_cooking else "")
+
+        players = {p.position: (i, p) for i, p in enumerate(state.players)}
+        lines = []
+        for y, row in enumerate(self.terrain_mtx):
+            cells = []
+            for x, ch in enumerate(row):
+                if (x, y) in players:
+                    i, p = players[(x, y)]
+                    txt = arrows[tuple(p.orientation)] + str(i) + (obj_txt(p.held_object) if p.has_object() else "")
+                elif state.has_object((x, y)):
+                    txt = ch + "{" + obj_txt(state.get_object((x, y))) + "}"
+                else:
+                    txt = ch
+                cells.append(txt.ljust(6))
+            lines.append("".join(cells).rstrip())
+        orders = ", ".join("+".join(o["ingredients"]) if isinstance(o, dict) else str(o) for o in (state.bonus_orders or []))
+        return "\n".join(lines) + ("\nbonus orders: " + orders if orders else "") + "\n"
+
+    # ---------------------------------------------------------------- copying / pickling
+    # The device plumbing (cached batched envs, the pinned-buffer port with its stream and ctypes pointers) is per process
+    # and rebuilt on first use: copies and pickles carry the layout only.
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_envs"], d["_single"] = {}, None
+        return d
+
+    def __deepcopy__(self, memo):
+        new = OvercookedGridworld.__new__(OvercookedGridworld)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k == "_envs" else None if k == "_single" else copy.deepcopy(v, memo)
+        return new
 
 
 def _num(v):

@@ -110,3 +110,118 @@ def pack_plan_tables(specs, counter_goals="none"):
         parts.append(raw)
         pos += len(raw)
     return np.frombuffer(b"".join(parts), dtype=np.uint8).copy(), np.asarray(offs, dtype=np.uint32)
+
+
+class MotionPlanner:
+    """Host-side stand-in for the reference's single-agent `MotionPlanner` (planning/planners.py:46-450) over the BFS
+    tables above: what `OvercookedEnv.mp` hands to code written against the reference (featurize_state's
+    `min_cost_to_feature`, potential_function's distances, scripted agents that walk a `get_plan`).  Costs and goal rules
+    are the reference's: a plan ends standing next to the feature, facing it, and pays one more action for the INTERACT.
+    Positions are (x, y) tuples and orientations Direction tuples, as in the reference."""
+
+    def __init__(self, mdp, counter_goals=()):
+        from .actions import Action, Direction
+
+        self._A, self._D = Action, Direction
+        self.mdp = mdp
+        spec = mdp.spec if hasattr(mdp, "spec") else mdp
+        self.spec = spec
+        self.counter_goals = [tuple(c) for c in counter_goals]
+        self._W = spec.width
+        self._dist, self._floor = state_distances(spec)
+        self._fidx = {c: i for i, c in enumerate(self._floor)}
+        self._dirs = [tuple(d) for d in Direction.ALL_DIRECTIONS]
+        goal_cells = {t: spec.cells_of(t) for t in "OTPDS"}
+        feats = [p for t in "OTPDS" for p in goal_cells[t]] + list(spec.cells_of("X"))
+        # every terrain feature has its list of goals (stand on a free neighbour, face the feature) — reference planners.py:425-450
+        self.motion_goals_for_pos = {tuple(p): self._goals_of(tuple(p)) for p in feats}
+        self._valid_goal_states = set()
+        for t in "OTPDS":
+            for p in goal_cells[t]:
+                self._valid_goal_states.update(self.motion_goals_for_pos[tuple(p)])
+        for p in self.counter_goals:
+            self._valid_goal_states.update(self.motion_goals_for_pos.get(p, []))
+
+    def _goals_of(self, pos):
+        x, y = pos
+        out = []
+        for d, (dx, dy) in enumerate(DIRS):
+            c = (y + dy) * self._W + (x + dx)
+            if 0 <= x + dx < self._W and 0 <= y + dy < self.spec.height and c in self._fidx:
+                out.append(((x + dx, y + dy), self._dirs[OPPOSITE[d]]))
+        return out
+
+    def _state(self, pos_and_or):
+        (x, y), o = pos_and_or
+        return 4 * self._fidx[y * self._W + x] + self._dirs.index(tuple(o))
+
+    def is_valid_motion_goal(self, goal_pos_and_or):
+        return (tuple(goal_pos_and_or[0]), tuple(goal_pos_and_or[1])) in self._valid_goal_states
+
+    def is_valid_motion_start_goal_pair(self, start_pos_and_or, goal_pos_and_or):
+        if not self.is_valid_motion_goal(goal_pos_and_or):
+            return False
+        try:
+            return self._dist[self._state(start_pos_and_or), self._state(goal_pos_and_or)] >= 0
+        except (KeyError, ValueError):
+            return False
+
+    def get_gridworld_distance(self, start_pos_and_or, goal_pos_and_or):
+        """Actions from start to goal, the closing INTERACT not counted."""
+        assert self.is_valid_motion_start_goal_pair(start_pos_and_or, goal_pos_and_or), \
+            "Goal position and orientation were not a valid motion goal"
+        return int(self._dist[self._state(start_pos_and_or), self._state(goal_pos_and_or)])
+
+    def get_plan(self, start_pos_and_or, goal_pos_and_or):
+        """(action_plan ending in INTERACT, [(pos, orientation) after every action], number of actions): one shortest
+        plan, found by walking down the distance table (the reference's planner may pick a different shortest path)."""
+        n = self.get_gridworld_distance(start_pos_and_or, goal_pos_and_or)
+        goal = self._state(goal_pos_and_or)
+        (x, y), o = start_pos_and_or
+        o = tuple(o)
+        actions, path = [], []
+        for left in range(n, 0, -1):
+            for d, (dx, dy) in enumerate(DIRS):
+                c = (y + dy) * self._W + (x + dx)
+                nx, ny = (x + dx, y + dy) if c in self._fidx and 0 <= x + dx < self._W else (x, y)
+                s = 4 * self._fidx[ny * self._W + nx] + d
+                if self._dist[s, goal] == left - 1:
+                    x, y, o = nx, ny, self._dirs[d]
+                    actions.append(self._dirs[d])
+                    path.append(((x, y), o))
+                    break
+            else:  # the table says a shorter state exists among the four successors
+                raise AssertionError("inconsistent distance table")
+        actions.append(self._A.INTERACT)
+        path.append(((x, y), o))
+        return actions, path, len(actions)
+
+    def min_cost_to_feature(self, start_pos_and_or, feature_pos_list, with_argmin=False, debug=False):
+        """Fewest actions (INTERACT included) from a (position, orientation) to any of the features; inf when none is
+        reachable.  Ties keep the first feature of the list, like the reference's strict '<'."""
+        best, arg = np.inf, None
+        s = self._state(start_pos_and_or)
+        for pos in feature_pos_list:
+            for g in self.motion_goals_for_pos.get(tuple(pos), []):
+                if g not in self._valid_goal_states:
+                    continue
+                d = self._dist[s, self._state(g)]
+                if 0 <= d < best:
+                    best, arg = int(d), tuple(pos)
+        cost = best + 1
+        return (cost, arg) if with_argmin else cost
+
+    def min_cost_between_features(self, pos_list1, pos_list2, manhattan_if_fail=False):
+        """Fewest actions from (any goal of) a feature of the first list to interacting with a feature of the second."""
+        best, manhattan = np.inf, np.inf
+        for p1 in pos_list1:
+            for p2 in pos_list2:
+                for g1 in self.motion_goals_for_pos.get(tuple(p1), []):
+                    for g2 in self.motion_goals_for_pos.get(tuple(p2), []):
+                        if self.is_valid_motion_start_goal_pair(g1, g2):
+                            best = min(best, self.get_gridworld_distance(g1, g2))
+                        elif manhattan_if_fail:
+                            manhattan = min(manhattan, abs(g1[0][0] - g2[0][0]) + abs(g1[0][1] - g2[0][1]))
+        if manhattan_if_fail and best == np.inf:
+            best = manhattan
+        return best + 1
