@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define OC_ABI_VERSION 2
+#define OC_ABI_VERSION 3
 
 #define OC_MAX_CELLS 128
 #define OC_MAX_POTS 8
@@ -146,7 +146,9 @@ typedef struct OcLayout {
  */
 typedef struct OcBatch {
     const OcLayout* d_layouts;   /* [n_layouts] compiled layouts in HBM */
-    const uint16_t* d_layout_id; /* [n_envs] layout index per env, or NULL when n_layouts == 1 */
+    const uint16_t* d_layout_id; /* [n_envs] layout index per env, or NULL when n_layouts == 1.  WRITTEN by the step kernels
+                                    (and oc_regen_layouts) when an OcStartSpec with regen_count > 0 moves restarted envs
+                                    to other layouts: keep it in writable device memory then */
     int64_t n_envs;
     int32_t n_layouts;
     int32_t width, height;       /* grid shape shared by every layout of the table */
@@ -173,15 +175,25 @@ int oc_batch_hints(const OcLayout* h_layouts, int n_layouts, OcBatch* batch);
  * oc_reset_random for global env g = env_offset + e and
  *      epoch of a restart at step k of the call = epoch + k      (k = 0 for single-step entry points),
  * so a caller that passes epoch = 1 + (steps executed so far) never reuses the draws of its initial
- * oc_reset_random(epoch 0).  Supported by the table-driven kernels (oc_step without d_events, oc_step_many,
- * oc_rollout_random without OC_OPT_ROLLOUT_V3 / LANE_PAIR / PREDICATE_INTERACT, oc_multi_agent_step).
+ * oc_reset_random(epoch 0).  Supported by the table-driven kernels (oc_step and oc_step_many without
+ * OC_OPT_PREDICATE_INTERACT — with or without event logging —, oc_rollout_random without OC_OPT_ROLLOUT_V3 / LANE_PAIR /
+ * PREDICATE_INTERACT, oc_step_encode, oc_rollout_encode, oc_multi_agent_step); the others return OC_EINVAL.
  */
 typedef struct OcStartSpec {
     uint64_t seed;
-    int64_t env_offset;          /* global index of local env 0 (oc_rollout_random: must equal its env_offset argument) */
+    int64_t env_offset;          /* global index of local env 0 (oc_rollout_random / oc_rollout_encode: must equal their
+                                    env_offset argument) */
     uint32_t epoch;
     int32_t random_start_pos;    /* 0 / 1 */
     double rnd_obj_prob_thresh;  /* 0 .. 1 */
+    /* Per-episode layout re-draw = OvercookedEnv.reset(regen_mdp=True) over an mdp_generator_fn that yields a different
+     * layout every time (env.py:288-302; LayoutGenerator, layout_generator.py:110-160 — BASELINE configs[4]): with
+     * regen_count > 0 an env that restarts first moves to layout
+     *      regen_first + mulhi32(word 0 of block 15 of the reset stream of oc_reset_random, regen_count)
+     * (same epoch as its start-state draws), the new id is stored in OcBatch.d_layout_id[e], and the start state (standard,
+     * or drawn per the two fields above) is that of the NEW layout.  regen_first + regen_count <= n_layouts; 0 = off. */
+    uint32_t regen_first;
+    uint32_t regen_count;
 } OcStartSpec;
 
 /*
@@ -221,7 +233,8 @@ int oc_state_planes(int width, int height);
  *   d_events       [n_envs] u64 event_infos of this step (EVENT_TYPES, mdp.py:1027-1058): bit 2*k + p is
  *                  event_infos[EVENT_TYPES[k]][p]; or NULL (shorthand for an OcEventSink with only d_events)
  *   events         per-episode event counters / masks (OcEventSink), or NULL
- *   horizon        done when timestep >= horizon (1..65535)
+ *   horizon        done when timestep >= horizon (1..65535; the stored timestep is a u16 that saturates at 65535 — the
+ *                  Python OvercookedEnv keeps the reference's default horizon of 1e10 but raises at that limit)
  */
 int oc_step(const OcBatch* batch, const void* d_state_in, void* d_state_out, const uint8_t* d_actions,
             float* d_rewards, uint8_t* d_flags, float* d_ep_returns, uint64_t* d_events, int horizon,
@@ -375,6 +388,16 @@ int oc_multi_agent_step(const OcBatch* batch, void* d_state, const uint8_t* d_ac
 int oc_reset_random(const OcBatch* batch, void* d_state, const uint8_t* d_mask, float* d_ep_returns, uint64_t seed,
                     int64_t env_offset, uint32_t epoch, int random_start_pos, double rnd_obj_prob_thresh,
                     void* stream);
+
+/*
+ * oc_regen_layouts — new layout ids for the envs an explicit reset is about to restart (regen_mdp=True semantics for
+ * oc_reset / oc_reset_random: call this first, then the reset with the same mask).  Env e is selected when d_mask is NULL
+ * or (d_mask[e] & mask_bits) != 0 — mask_bits = OC_F_RESET selects from a flags array the envs a step has just restarted;
+ * its new id is the draw documented at OcStartSpec for (start->seed, start->env_offset + e, start->epoch).
+ *   d_layout_id  [n_envs], writable; start->regen_count > 0 required
+ */
+int oc_regen_layouts(const OcBatch* batch, uint16_t* d_layout_id, const uint8_t* d_mask, uint8_t mask_bits,
+                     const OcStartSpec* start, void* stream);
 
 /*
  * oc_potential — phi(s), the potential used for potential-based reward shaping.

@@ -166,13 +166,27 @@ def mdp_from_layout_dict(layout, **overrides):
 
 class OracleStartSpec(ctypes.Structure):
     _fields_ = [("seed", ctypes.c_uint64), ("env_offset", ctypes.c_int64), ("epoch", ctypes.c_uint32),
-                ("random_start_pos", ctypes.c_int32), ("rnd_obj_prob_thresh", ctypes.c_double)]
+                ("random_start_pos", ctypes.c_int32), ("rnd_obj_prob_thresh", ctypes.c_double),
+                ("regen_first", ctypes.c_uint32), ("regen_count", ctypes.c_uint32)]
 
 
-def start_spec(seed=0, env_offset=0, epoch=0, random_start_pos=False, rnd_obj_prob_thresh=0.0):
-    """start_state_fn of a batch for Oracle.step / rollout_random (restarts at the horizon draw from it)."""
+def start_spec(seed=0, env_offset=0, epoch=0, random_start_pos=False, rnd_obj_prob_thresh=0.0, regen=None):
+    """start_state_fn of a batch for Oracle.step / rollout_random (restarts at the horizon draw from it).  regen =
+    (first, count): a restarting env first moves to a layout drawn from that range (regen_mdp=True, env.py:288-302) — the
+    layout_id array handed to step / rollout_random must then be a uint16 numpy array: it is updated in place."""
+    first, count = regen if regen else (0, 0)
     return OracleStartSpec(int(seed), int(env_offset), int(epoch) & 0xFFFFFFFF, int(bool(random_start_pos)),
-                           float(rnd_obj_prob_thresh))
+                           float(rnd_obj_prob_thresh), int(first), int(count))
+
+
+def regen_layouts(layout_id, spec, mask=None, mask_bits=0xFF):
+    """oc_regen_layouts on the host: new ids (in place, uint16 array) for the selected envs."""
+    assert layout_id.dtype == np.uint16 and layout_id.flags["C_CONTIGUOUS"]
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    rc = lib().oracle_regen_layouts(_ptr(layout_id, ctypes.c_uint16), _ptr(m, ctypes.c_uint8), ctypes.c_uint8(mask_bits),
+                                    ctypes.c_int64(layout_id.shape[0]), ctypes.byref(spec))
+    assert rc == 0
+    return layout_id
 
 
 class Oracle:

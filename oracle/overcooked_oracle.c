@@ -547,14 +547,28 @@ typedef struct OracleStartSpec {
     uint32_t epoch;
     int32_t random_start_pos;
     double rnd_obj_prob_thresh;
+    /* regen_count > 0: OvercookedEnv.reset(regen_mdp=True) over a generator that yields another layout every episode
+     * (env.py:288-302): a restarting env first moves to layout regen_first + draw % regen_count (include/oc_amd.h) */
+    uint32_t regen_first, regen_count;
 } OracleStartSpec;
+
+void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+static uint32_t draw_layout_id(const OracleStartSpec* ss, uint64_t g, uint32_t epoch) {
+    uint32_t ctr[4] = {epoch, (uint32_t)g, (uint32_t)(g >> 32), 15u};
+    uint32_t key[2] = {(uint32_t)ss->seed, (uint32_t)(ss->seed >> 32) ^ 0x52535421u}, r[4];
+    oracle_philox4x32_10(ctr, key, r);
+    return ss->regen_first + (uint32_t)(((uint64_t)r[0] * ss->regen_count) >> 32);
+}
 
 static void random_start_state(const OracleMdp* m, State* s, uint64_t seed, uint64_t g, uint32_t epoch,
                                int random_start_pos, uint64_t thresh);
 
-static void env_step_one(const OracleMdp* m, State* s, const int* ja, float* rew4, uint8_t* flag, float* ep4,
+/* mdps / lid: the layout table and this env's (writable) layout id, for restarts that re-draw the layout; *mp is the env's
+ * current mdp and follows such a move */
+static void env_step_one(const OracleMdp** mp, State* s, const int* ja, float* rew4, uint8_t* flag, float* ep4,
                          int horizon, uint32_t options, uint64_t* events, const OracleStartSpec* ss, uint64_t g,
-                         uint32_t epoch) {
+                         uint32_t epoch, const OracleMdp* mdps, uint16_t* lid) {
+    const OracleMdp* m = *mp;
     double sparse[2], shaped[2];
     uint8_t f = 0;
     uint64_t ev = 0;
@@ -577,6 +591,10 @@ static void env_step_one(const OracleMdp* m, State* s, const int* ja, float* rew
     if (s->timestep >= horizon) { /* is_done, env.py:321-325 */
         f |= F_DONE;
         if (options & OPT_AUTO_RESET) { /* OvercookedEnv.reset, env.py:288-319: start_state_fn() or the standard state */
+            if (ss && ss->regen_count && lid) { /* regen_mdp: the next episode's layout (env.py:293-302) */
+                *lid = (uint16_t)draw_layout_id(ss, g, epoch);
+                m = *mp = &mdps[*lid];
+            }
             if (ss)
                 random_start_state(m, s, ss->seed, g, epoch, ss->random_start_pos,
                                    (uint64_t)(ss->rnd_obj_prob_thresh * 4294967296.0));
@@ -589,7 +607,7 @@ static void env_step_one(const OracleMdp* m, State* s, const int* ja, float* rew
     if (flag) *flag = f;
 }
 
-int oracle_step(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, const uint8_t* state_in,
+int oracle_step(const OracleMdp* mdps, int n_mdps, uint16_t* layout_id, const uint8_t* state_in,
                 uint8_t* state_out, const uint8_t* actions, float* rewards, uint8_t* flags, float* ep_returns,
                 uint64_t* events, int64_t n_envs, int horizon, uint32_t options, const OracleStartSpec* ss) {
     (void)n_mdps;
@@ -598,10 +616,20 @@ int oracle_step(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, co
         State s;
         unpack_state(m, state_in, n_envs, e, &s);
         int ja[2] = {actions[2 * e], actions[2 * e + 1]};
-        env_step_one(m, &s, ja, rewards ? rewards + 4 * e : 0, flags ? flags + e : 0, ep_returns ? ep_returns + 4 * e : 0,
+        env_step_one(&m, &s, ja, rewards ? rewards + 4 * e : 0, flags ? flags + e : 0, ep_returns ? ep_returns + 4 * e : 0,
                      horizon, options, events ? events + e : 0, ss, ss ? (uint64_t)(ss->env_offset + e) : 0,
-                     ss ? ss->epoch : 0);
+                     ss ? ss->epoch : 0, mdps, layout_id ? layout_id + e : 0);
         pack_state(m, &s, state_out, n_envs, e);
+    }
+    return 0;
+}
+
+/* oc_regen_layouts: new layout ids for the envs an explicit reset is about to restart */
+int oracle_regen_layouts(uint16_t* layout_id, const uint8_t* mask, uint8_t mask_bits, int64_t n_envs, const OracleStartSpec* ss) {
+    if (!layout_id || !ss || !ss->regen_count) return -1;
+    for (int64_t e = 0; e < n_envs; ++e) {
+        if (mask && !(mask[e] & mask_bits)) continue;
+        layout_id[e] = (uint16_t)draw_layout_id(ss, (uint64_t)(ss->env_offset + e), ss->epoch);
     }
     return 0;
 }
@@ -676,7 +704,7 @@ int oracle_set_threads(int n) { /* returns the number of threads that will be us
     return g_threads;
 }
 
-int oracle_rollout_random(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, uint8_t* state, float* rewards,
+int oracle_rollout_random(const OracleMdp* mdps, int n_mdps, uint16_t* layout_id, uint8_t* state, float* rewards,
                           uint8_t* flags, float* ep_returns, int64_t n_envs, int horizon, uint32_t options,
                           uint64_t seed, int64_t env_offset, int64_t t0, int n_steps, const OracleStartSpec* ss) {
     (void)n_mdps;
@@ -693,9 +721,10 @@ int oracle_rollout_random(const OracleMdp* mdps, int n_mdps, const uint16_t* lay
         for (int k = 0; k < n_steps; ++k) {
             int ja[2];
             draw_actions(seed, g, (uint64_t)(t0 + k), &ja[0], &ja[1]);
-            env_step_one(m, &s, ja, rewards ? rewards + 4 * ((int64_t)k * n_envs + e) : 0,
+            env_step_one(&m, &s, ja, rewards ? rewards + 4 * ((int64_t)k * n_envs + e) : 0,
                          flags ? flags + ((int64_t)k * n_envs + e) : 0, ep_returns ? ep_returns + 4 * e : 0, horizon,
-                         options, 0, ss, g, ss ? ss->epoch + (uint32_t)k : 0); /* restart at step k: epoch + k */
+                         options, 0, ss, g, ss ? ss->epoch + (uint32_t)k : 0, /* restart at step k: epoch + k */
+                         mdps, layout_id ? layout_id + e : 0);
         }
         pack_state(m, &s, state, n_envs, e);
     }

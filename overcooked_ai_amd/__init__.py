@@ -20,7 +20,7 @@ def __getattr__(name):  # lazy: these import torch
     if name in ("OvercookedEnv", "Overcooked", "DEFAULT_ENV_PARAMS", "MAX_HORIZON"):
         from . import env
         return getattr(env, name)
-    if name == "VecOvercookedMultiAgent":
+    if name in ("VecOvercookedMultiAgent", "OvercookedMultiAgent"):
         from . import multi_agent
         return getattr(multi_agent, name)
     raise AttributeError(name)

@@ -6,7 +6,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OC_AMD_LIB") or os.path.join(PKG, "liboc_amd.so")  # OC_AMD_LIB: developer override
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 F_DONE, F_BAD_ACTION, F_RESET = 0x01, 0x02, 0x04
 OPT_AUTO_RESET = 0x1
 OPT_LANE_PAIR = 0x4
@@ -20,7 +20,7 @@ OBS_U8, OBS_F32 = 0, 1
 
 EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_batch_hints", "oc_step", "oc_step_many",
            "oc_rollout_random", "oc_encode_lossless", "oc_step_encode", "oc_rollout_encode", "oc_featurize", "oc_potential",
-           "oc_phi_table_size", "oc_reset", "oc_reset_random", "oc_shape_rewards", "oc_multi_agent_step")
+           "oc_phi_table_size", "oc_reset", "oc_reset_random", "oc_regen_layouts", "oc_shape_rewards", "oc_multi_agent_step")
 
 
 class OcBatch(ctypes.Structure):
@@ -44,6 +44,8 @@ class OcStartSpec(ctypes.Structure):
         ("epoch", ctypes.c_uint32),
         ("random_start_pos", ctypes.c_int32),
         ("rnd_obj_prob_thresh", ctypes.c_double),
+        ("regen_first", ctypes.c_uint32),
+        ("regen_count", ctypes.c_uint32),
     ]
 
 
@@ -110,6 +112,8 @@ def load():
     L.oc_reset_random.argtypes = [bp, vp, vp, vp, u64, i64, u32, i32, ctypes.c_double, vp]
     L.oc_reset.restype = i32
     L.oc_reset.argtypes = [bp, vp, vp, vp, vp]
+    L.oc_regen_layouts.restype = i32
+    L.oc_regen_layouts.argtypes = [bp, vp, vp, ctypes.c_uint8, sp, vp]
     if L.oc_abi_version() != ABI_VERSION:
         raise OcAmdError("liboc_amd.so ABI version %d != expected %d; rebuild" % (L.oc_abi_version(), ABI_VERSION))
     if L.oc_layout_size() != 256:

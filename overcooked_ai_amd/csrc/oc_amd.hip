@@ -108,11 +108,20 @@ inline size_t enc_uniform_budget(size_t env_bytes) {
     return want < cap ? want : cap;
 }
 
-// OcStartSpec -> kernel argument; false when the spec is malformed
-bool start_args(const OcStartSpec* sp, StartArgs* sa) {
+// OcStartSpec -> kernel argument; false when the spec is malformed (a message is left in g_err)
+bool start_args(const OcStartSpec* sp, StartArgs* sa, const OcBatch* b = nullptr) {
     memset(sa, 0, sizeof(*sa));
     if (!sp) return true;
     if (!(sp->rnd_obj_prob_thresh >= 0.0 && sp->rnd_obj_prob_thresh <= 1.0)) return false;
+    if (sp->regen_count) {  // per-episode layout re-draw: the ids must exist, be writable and in range
+        if (!b || (uint64_t)sp->regen_first + sp->regen_count > (uint64_t)(b ? b->n_layouts : 0)) return false;
+        if (b->n_layouts > 1) {
+            if (!b->d_layout_id) return false;
+            sa->regen_first = sp->regen_first;
+            sa->regen_count = sp->regen_count;
+            sa->layout_ids = const_cast<uint16_t*>(b->d_layout_id);
+        }  // (one layout: nothing to draw)
+    }
     sa->enabled = 1;
     sa->seed_lo = (uint32_t)sp->seed;
     sa->seed_hi = (uint32_t)(sp->seed >> 32);
@@ -252,7 +261,7 @@ int oc_step(const OcBatch* b, const void* d_state_in, void* d_state_out, const u
     int n_obj = 0;
     if (int rc = check_batch(b, &n_obj)) return rc;
     StartArgs sa;
-    if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_step: start.rnd_obj_prob_thresh must be in [0, 1]");
+    if (!start_args(start, &sa, b)) return fail(OC_EINVAL, "oc_step: start.rnd_obj_prob_thresh must be in [0, 1] and its regen range within the table");
     const EvArgs ea = ev_args(events, d_events);
     if (options & OC_OPT_PREDICATE_INTERACT) {
         if (start) return fail(OC_EINVAL, "oc_step: drawn start states need the table-driven kernel (no PREDICATE_INTERACT)");
@@ -277,7 +286,7 @@ int oc_step_many(const OcBatch* b, void* d_state, const uint8_t* d_actions, floa
                  const OcEventSink* events, void* stream) {
     if (n_steps < 0) return fail(OC_EINVAL, "oc_step_many: n_steps < 0");
     StartArgs sa;
-    if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_step_many: start.rnd_obj_prob_thresh must be in [0, 1]");
+    if (!start_args(start, &sa, b)) return fail(OC_EINVAL, "oc_step_many: start.rnd_obj_prob_thresh must be in [0, 1] and its regen range within the table");
     const EvArgs ea = ev_args(events, nullptr);
     if ((start || ev_on(ea)) && (options & OC_OPT_PREDICATE_INTERACT))
         return fail(OC_EINVAL, "oc_step_many: drawn start states / event logging need the table-driven kernel");
@@ -311,7 +320,7 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
     int n_obj = 0;
     if (int rc = check_batch(b, &n_obj)) return rc;
     StartArgs sa;
-    if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_rollout_random: start.rnd_obj_prob_thresh must be in [0, 1]");
+    if (!start_args(start, &sa, b)) return fail(OC_EINVAL, "oc_rollout_random: start.rnd_obj_prob_thresh must be in [0, 1] and its regen range within the table");
     const EvArgs ea = ev_args(events, nullptr);
     if ((start || ev_on(ea)) && (options & (OC_OPT_ROLLOUT_V3 | OC_OPT_LANE_PAIR | OC_OPT_PREDICATE_INTERACT)))
         return fail(OC_EINVAL, "oc_rollout_random: drawn start states / event logging need the default kernel (k_rollout4)");
@@ -547,7 +556,7 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
                         void* stream) {
     if (!d_done) return fail(OC_EINVAL, "oc_multi_agent_step: d_done is required (it is the reset mask)");
     StartArgs sa;
-    if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_multi_agent_step: start.rnd_obj_prob_thresh must be in [0, 1]");
+    if (!start_args(start, &sa, b)) return fail(OC_EINVAL, "oc_multi_agent_step: start.rnd_obj_prob_thresh must be in [0, 1] and its regen range within the table");
     const EvArgs ea = ev_args(events, nullptr, 1u);
     {
         int n_obj = 0;
@@ -620,6 +629,9 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
             return fail(OC_ELAUNCH, "oc_multi_agent_step: copy of the episode returns failed");
     }
     if (start) {  // finished envs restart from drawn states; d_phi_cur = the potential of what every env starts the next step from
+        if (start->regen_count && b->n_layouts > 1) {  // ... on layouts drawn for their new episodes
+            if (int rc = oc_regen_layouts(b, const_cast<uint16_t*>(b->d_layout_id), d_done, 0xFF, start, stream)) return rc;
+        }
         if (int rc = oc_reset_random(b, d_state, d_done, d_ep_returns, start->seed, start->env_offset, start->epoch,
                                      start->random_start_pos, start->rnd_obj_prob_thresh, stream))
             return rc;
@@ -631,6 +643,24 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
     }
     if (d_obs) return oc_encode_lossless(b, d_state, d_obs, obs_dtype, horizon, stream);
     return OC_OK;
+}
+
+int oc_regen_layouts(const OcBatch* b, uint16_t* d_layout_id, const uint8_t* d_mask, uint8_t mask_bits, const OcStartSpec* start,
+                     void* stream) {
+    int n_obj = 0;
+    if (int rc = check_batch(b, &n_obj)) return rc;
+    if (!d_layout_id || !start || !start->regen_count) return fail(OC_EINVAL, "oc_regen_layouts: needs d_layout_id and a start spec with regen_count > 0");
+    if ((uint64_t)start->regen_first + start->regen_count > (uint64_t)b->n_layouts)
+        return fail(OC_EINVAL, "oc_regen_layouts: regen_first + regen_count exceeds the layout table");
+    if (b->n_envs == 0) return OC_OK;
+    StartArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.enabled = 1; sa.seed_lo = (uint32_t)start->seed; sa.seed_hi = (uint32_t)(start->seed >> 32); sa.epoch = start->epoch;
+    sa.env_offset = start->env_offset; sa.regen_first = start->regen_first; sa.regen_count = start->regen_count;
+    sa.layout_ids = d_layout_id;
+    hipLaunchKernelGGL(k_regen_layouts, dim3(grid_for(b->n_envs)), dim3(BLOCK), 0, (hipStream_t)stream, d_layout_id, d_mask,
+                       mask_bits, b->n_envs, sa);
+    return check_launch("oc_regen_layouts");
 }
 
 int oc_reset_random(const OcBatch* b, void* d_state, const uint8_t* d_mask, float* d_ep_returns, uint64_t seed,
@@ -722,7 +752,7 @@ int oc_step_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions, fl
     if (((uintptr_t)d_obs & 15u) != 0) return fail(OC_EINVAL, "oc_step_encode: d_obs must be 16-byte aligned");
     if (horizon < 1 || horizon > 65535) return fail(OC_EINVAL, "oc_step_encode: horizon must be in 1..65535");
     StartArgs sa;
-    if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_step_encode: start.rnd_obj_prob_thresh must be in [0, 1]");
+    if (!start_args(start, &sa, b)) return fail(OC_EINVAL, "oc_step_encode: start.rnd_obj_prob_thresh must be in [0, 1] and its regen range within the table");
     if (b->n_envs == 0) return OC_OK;
     if (!start && !(options & ~(uint32_t)(OC_OPT_AUTO_RESET | OC_OPT_ONE_KERNEL)))  // one kernel where that applies
         return oc_rollout_encode(b, d_state, d_actions, d_rewards, d_flags, d_ep_returns, d_obs, obs_dtype, 0, horizon, options,
@@ -740,7 +770,7 @@ int oc_rollout_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions,
     int n_obj = 0;
     if (int rc = check_batch(b, &n_obj)) return rc;
     StartArgs sa;
-    if (!start_args(start, &sa)) return fail(OC_EINVAL, "oc_rollout_encode: start.rnd_obj_prob_thresh must be in [0, 1]");
+    if (!start_args(start, &sa, b)) return fail(OC_EINVAL, "oc_rollout_encode: start.rnd_obj_prob_thresh must be in [0, 1] and its regen range within the table");
     if (!d_state || !d_obs) return fail(OC_EINVAL, "oc_rollout_encode: NULL state / observation pointer");
     if (obs_dtype != OC_OBS_U8 && obs_dtype != OC_OBS_F32) return fail(OC_EINVAL, "oc_rollout_encode: bad obs_dtype");
     if (((uintptr_t)d_obs & 15u) != 0 || obs_step_stride < 0 || (obs_step_stride & 15) != 0)
@@ -750,6 +780,8 @@ int oc_rollout_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions,
     if (options & ~(uint32_t)(OC_OPT_AUTO_RESET | OC_OPT_ONE_KERNEL))
         return fail(OC_EINVAL, "oc_rollout_encode: options other than OC_OPT_AUTO_RESET / OC_OPT_ONE_KERNEL");
     if (d_actions && (!d_rewards || !d_flags)) return fail(OC_EINVAL, "oc_rollout_encode: caller actions need the rewards and flags arrays");
+    if (start && start->env_offset != env_offset)  // (both paths below: the one-step fallback would refuse it, the single kernel must too)
+        return fail(OC_EINVAL, "oc_rollout_encode: start.env_offset differs from env_offset");
     if (b->n_envs == 0 || n_steps == 0) return OC_OK;
     hipStream_t s = (hipStream_t)stream;
     // one layout, u8 observations, at most two pots: the whole trajectory in one launch (k_rollout_encode).  The LDS of

@@ -52,7 +52,18 @@ struct StartArgs {
     int64_t env_offset;
     uint64_t thresh;  // floor(rnd_obj_prob_thresh * 2^32)
     int32_t random_start_pos;
+    uint32_t regen_first, regen_count;  // regen_count > 0: a restarted env moves to layout regen_first + draw % regen_count
+    uint16_t* layout_ids;               // the batch's layout ids, writable (regen_count > 0)
 };
+
+// The layout of an env's NEXT episode (OvercookedEnv.reset(regen_mdp=True) with a generator that returns a different mdp
+// every time, env.py:288-302; layout_generator.py:110-160): block 15 of the reset stream documented above, word 0.
+constexpr uint32_t REGEN_BLOCK = 15u;
+__device__ __forceinline__ uint32_t draw_layout(const StartArgs& sa, uint64_t g, uint32_t epoch) {
+    uint32_t r[4];
+    philox4x32_10(epoch, (uint32_t)g, (uint32_t)(g >> 32), REGEN_BLOCK, sa.seed_lo, sa.seed_hi ^ 0x52535421u, r);
+    return sa.regen_first + __umulhi(r[0], sa.regen_count);
+}
 
 // Where the event_infos of a launch go (include/oc_amd.h, OcEventSink), by value in kernel arguments.
 struct EvArgs {
@@ -160,4 +171,14 @@ __global__ __launch_bounds__(BLOCK) void k_reset_random(const OcLayout* __restri
         st[(int64_t)(1 + p) * n + e] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     if (ep_returns) ep_returns[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// k_regen_layouts: new layout ids for the selected envs (explicit resets with regen_mdp semantics; the caller then resets
+// those envs' states with oc_reset / oc_reset_random under the same mask)
+__global__ __launch_bounds__(BLOCK) void k_regen_layouts(uint16_t* layout_id, const uint8_t* __restrict__ mask, uint8_t mask_bits,
+                                                         int64_t n, StartArgs sa) {
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= n) return;
+    if (mask && !(mask[e] & mask_bits)) return;
+    layout_id[e] = (uint16_t)draw_layout(sa, (uint64_t)(sa.env_offset + e), sa.epoch);
 }

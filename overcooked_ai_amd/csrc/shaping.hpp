@@ -59,13 +59,13 @@ __global__ __launch_bounds__(BLOCK) void k_train_step(const OcLayout* __restrict
     const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool active = e < n;
     for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
-    const Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains the barrier
+    Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains the barrier
     if (!active) return;
     uint16_t* cells = s_cells3 + threadIdx.x;
-    const LayC C = load_consts<UNIFORM>(L);
+    LayC C = load_consts<UNIFORM>(L);
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut) + (C.old_dyn ? LUT_ENTRIES * 8 : 0);
     const uint32_t delta4 = make_delta4(W);
-    const uint32_t lid = layout_id ? layout_id[e] : 0u;
+    uint32_t lid = layout_id ? layout_id[e] : 0u;
     Env3<MAXP> s;
     load_env3<MAXP>(C, L, st, n, e, n_obj, s, cells);
     const uint32_t a01 = reinterpret_cast<const uint16_t*>(actions)[e];
@@ -103,6 +103,8 @@ __global__ __launch_bounds__(BLOCK) void k_train_step(const OcLayout* __restrict
     if (ep_out) ep_out[e] = ep;
     if (is_done) {  // the next episode: the standard start state, or one drawn from the batch's start_state_fn
         if (sa.enabled) {
+            // (... on a layout drawn for the new episode when the spec says so; phi_cur below is then that layout's)
+            regen_layout<UNIFORM, LAY_LDS>(sa, (uint64_t)(sa.env_offset + e), sa.epoch, e, s_lay, g_layouts, L, C, &lid);
             env_reset3_draw<MAXP>(C, L, n_obj, s, cells, draw_start(L, (uint64_t)(sa.env_offset + e), sa.epoch, sa.seed_lo,
                                                                     sa.seed_hi, sa.random_start_pos, sa.thresh));
             if (phi_tables) {  // phi(s) of the next step is the potential of THAT state

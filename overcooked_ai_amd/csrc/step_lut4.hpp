@@ -461,7 +461,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
     uint8_t* const s_fi = s_dyn4 + M::FI;
     const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool active = e < n;
-    const Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains a barrier
+    Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains a barrier
     {
         const uint4* src = reinterpret_cast<const uint4*>(&g_lut4);
         const int first = RUX ? (L.old_dynamics() ? 2 * LUT4_KEYS : 0) : 0, count = RUX ? 2 * LUT4_KEYS : 4 * LUT4_KEYS;
@@ -493,12 +493,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
     __syncthreads();
     if (!active) return;
     const uint32_t col = (uint32_t)M::CELLS + threadIdx.x * (uint32_t)CW;  // LDS address of this lane's column of cell words
-    const LayC C = load_consts<UNIFORM>(L);
-    const uint32_t lut_var = (uint32_t)M::LUT + (RUX ? 0u : (C.old_dyn ? (uint32_t)LUT4_BYTES : 0u));  // this lane's LUT
+    // (L, C, lut_var, two and MODE 2's floor mask change when a restart moves the env to another layout: StartArgs.regen_count)
+    LayC C = load_consts<UNIFORM>(L);
+    uint32_t lut_var = (uint32_t)M::LUT + (RUX ? 0u : (C.old_dyn ? (uint32_t)LUT4_BYTES : 0u));  // this lane's LUT
     const uint32_t delta4 = make_delta4(W);
     Env4<MAXP> s;
     load_env4<MAXP, CW>(C, L, st, n, e, n_obj, horizon, s, col);
-    const bool two = MODE == 1 || MODE == 2 || s.pos1 != 0xFFu;
+    bool two = MODE == 1 || MODE == 2 || s.pos1 != 0xFFu;
+    uint64_t fm = 0;  // MODE 2: bit c = cell c is floor (static per layout)
+    auto floor_mask_of = [&](const Lay Lx) __attribute__((always_inline)) {
+        uint64_t m = 0;
+        for (int i = 0; i < n_obj * 4; ++i) {
+            const uint32_t T = Lx.u32(L_TERRAIN + 4 * i);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (((T >> (8 * b)) & 7u) == OC_T_FLOOR && (uint32_t)(4 * i + b) < Lx.u8(L_NCELLS)) m |= 1ull << (4 * i + b);
+        }
+        return m;
+    };
+    if (MODE == 2) fm = floor_mask_of(L);
     auto joint_row = [&]() {  // LDS address of the row of the joint pose (pos0, or0, pos1, or1)
         const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR];
         return (uint32_t)M::MVJ + ((s_fi[s.pos0] * 4u + s.or0) * NP + (s_fi[s.pos1] * 4u + s.or1)) * (uint32_t)Mvj<CW>::ROW_BYTES;
@@ -751,6 +764,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                 fl = OC_F_DONE;
                 if (options & OC_OPT_AUTO_RESET) {
                     if (sa.enabled) {  // the batch's start_state_fn: drawn from (seed, global env, epoch of this step)
+                        if (!UNIFORM && sa.regen_count) {  // ... on a layout drawn for the new episode (regen_mdp, env.py:288-302)
+                            const uint32_t lid = draw_layout(sa, g, sa.epoch + step_k);
+                            sa.layout_ids[e] = (uint16_t)lid;
+                            L = LAY_LDS ? Lay{reinterpret_cast<const uint8_t*>(s_lay) + lid * 256u}
+                                        : Lay{reinterpret_cast<const uint8_t*>(g_layouts) + (size_t)lid * 256u};
+                            C = load_consts<UNIFORM>(L);
+                            lut_var = (uint32_t)M::LUT + (RUX ? 0u : (C.old_dyn ? (uint32_t)LUT4_BYTES : 0u));
+#pragma unroll
+                            for (int k = 0; k < MAXP; ++k) s.poff[k] = (uint32_t)k < C.n_pots ? L.pot_cell(k) * (BLOCK * CW) : 0u;
+                            if (MODE == 0) two = L.n_players() == 2u;
+                            if (MODE == 2) fm = floor_mask_of(L);
+                        }
                         env_reset4_draw<MAXP, CW>(C, L, n_obj, horizon, s, col,
                                               draw_start(L, g, sa.epoch + step_k, sa.seed_lo, sa.seed_hi, sa.random_start_pos, sa.thresh));
                         nh0 = s.h0; nh1 = s.h1;
@@ -939,13 +964,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         // Per-env terrain, pose one step ahead.  Carried across steps: the pose of the step about to run (P0, O0, P1, O1), the
         // LDS offsets of its two faced cells (fa, within this lane's column) and — PIPE — those cells' words and the pot words,
         // read right after the previous step's cell writes.
-        uint64_t fm = 0;  // bit c: cell c is floor (static)
-        for (int i = 0; i < n_obj * 4; ++i) {
-            const uint32_t T = L.u32(L_TERRAIN + 4 * i);
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                if (((T >> (8 * b)) & 7u) == OC_T_FLOOR && (uint32_t)(4 * i + b) < L.u8(L_NCELLS)) fm |= 1ull << (4 * i + b);
-        }
         const uint64_t d64 = (uint64_t)delta4;  // signed byte deltas of N, S, E, W; actions 4 and 5 (bytes 4, 5) move by 0
         auto ahead = [&](uint32_t c, uint32_t d) __attribute__((always_inline)) {
             return c + (uint32_t)(int32_t)(int8_t)(uint8_t)(d64 >> (8u * d));

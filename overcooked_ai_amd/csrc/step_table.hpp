@@ -414,15 +414,18 @@ __device__ __forceinline__ void env_reset3_draw(const LayC& C, const Lay L, int 
 
 // sa / g / epoch: the start_state_fn of the batch (disabled: the standard start state), this env's global index and the
 // epoch of a restart at this step
-template <int MAXP>
-__device__ __forceinline__ uint32_t finish_step3(const LayC& C, const Lay L, int n_obj, uint16_t* cells, Env3<MAXP>& s,
+// before_restart(): called right before the env is put back to a start state — the caller's hook for moving the env to
+// another layout first (regen_layout below): C and L are read again after it.
+template <int MAXP, typename F>
+__device__ __forceinline__ uint32_t finish_step3(const LayC& C, const Lay& L, int n_obj, uint16_t* cells, Env3<MAXP>& s,
                                                  int horizon, uint32_t options, const float4& r, float4& ep,
-                                                 const StartArgs& sa, uint64_t g, uint32_t epoch) {
+                                                 const StartArgs& sa, uint64_t g, uint32_t epoch, F&& before_restart) {
     ep.x += r.x; ep.y += r.y; ep.z += r.z; ep.w += r.w;
     uint32_t fl = 0;
     if (__builtin_expect((int)s.t >= horizon, 0)) {  // once per episode: keep the restart out of the straight-line path
         fl |= OC_F_DONE;
         if (options & OC_OPT_AUTO_RESET) {
+            before_restart();
             if (sa.enabled)
                 env_reset3_draw<MAXP>(C, L, n_obj, s, cells, draw_start(L, g, epoch, sa.seed_lo, sa.seed_hi, sa.random_start_pos, sa.thresh));
             else
@@ -432,6 +435,27 @@ __device__ __forceinline__ uint32_t finish_step3(const LayC& C, const Lay L, int
         }
     }
     return fl;
+}
+
+template <int MAXP>
+__device__ __forceinline__ uint32_t finish_step3(const LayC& C, const Lay& L, int n_obj, uint16_t* cells, Env3<MAXP>& s,
+                                                 int horizon, uint32_t options, const float4& r, float4& ep,
+                                                 const StartArgs& sa, uint64_t g, uint32_t epoch) {
+    return finish_step3<MAXP>(C, L, n_obj, cells, s, horizon, options, r, ep, sa, g, epoch, []() {});
+}
+
+// A restart with StartArgs.regen_count > 0 (OvercookedEnv.reset(regen_mdp=True) over a generator of layouts, env.py:288-302):
+// draw the env's next layout, record it, and switch this lane's layout pointer and constants to it.  False: nothing changed.
+template <bool UNIFORM, bool LAY_LDS>
+__device__ __forceinline__ bool regen_layout(const StartArgs& sa, uint64_t g, uint32_t epoch, int64_t e, const uint4* s_lay,
+                                             const OcLayout* g_layouts, Lay& L, LayC& C, uint32_t* lid) {
+    if (UNIFORM || !sa.regen_count) return false;
+    *lid = draw_layout(sa, g, epoch);
+    sa.layout_ids[e] = (uint16_t)*lid;
+    L = LAY_LDS ? Lay{reinterpret_cast<const uint8_t*>(s_lay) + *lid * 256u}
+                : Lay{reinterpret_cast<const uint8_t*>(g_layouts) + (size_t)*lid * 256u};
+    C = load_consts<UNIFORM>(L);
+    return true;
 }
 
 // stage the interact table (both variants, 3 840 bytes) in LDS; returns this lane's variant
@@ -575,16 +599,16 @@ __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_
     const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool active = e < n;
     for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
-    const Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains the barrier
+    Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains the barrier
     if (!active) return;
     uint16_t* cells = s_cells3 + threadIdx.x;
-    const LayC C = load_consts<UNIFORM>(L);
+    LayC C = load_consts<UNIFORM>(L);  // (L, C, lut and the floor mask follow the env to another layout at a restart with regen_count)
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut) + (C.old_dyn ? LUT_ENTRIES * 8 : 0);
     const uint32_t delta4 = make_delta4(W);
     Env3<MAXP> s;
     load_env3<MAXP>(C, L, st_in, n, e, n_obj, s, cells);
     const uint64_t g = (uint64_t)(sa.env_offset + e);
-    const uint64_t floor_mask = FAST ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull;
+    uint64_t floor_mask = FAST ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull;
     float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     // n_steps transitions with the caller's actions [n_steps][n][2] (oc_step: one; oc_step_many: K in one launch, the
     // env staying on chip in between).  The next step's actions are fetched while the current step runs.
@@ -614,7 +638,13 @@ __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_
         } else {
             uint64_t ev = 0;
             env_step3<MAXP, FAST ? 2 : 0, EVENTS>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask, nullptr, &ev);
-            fl = finish_step3<MAXP>(C, L, n_obj, cells, s, horizon, options, r, ep, sa, g, sa.epoch + (uint32_t)k);
+            fl = finish_step3<MAXP>(C, L, n_obj, cells, s, horizon, options, r, ep, sa, g, sa.epoch + (uint32_t)k, [&]() {
+                uint32_t lid;
+                if (regen_layout<UNIFORM, LAY_LDS>(sa, g, sa.epoch + (uint32_t)k, e, s_lay, g_layouts, L, C, &lid)) {
+                    lut = reinterpret_cast<const uint8_t*>(s_lut) + (C.old_dyn ? LUT_ENTRIES * 8 : 0);
+                    if (FAST) floor_mask = make_floor_mask(L, (int)L.u8(L_NCELLS));
+                }
+            });
             if (EVENTS) {
                 if (ea.events) ea.events[(int64_t)k * n + e] = ev;
                 count_events(ea, e, ev, (fl & OC_F_DONE) != 0u, (fl & OC_F_RESET) != 0u);

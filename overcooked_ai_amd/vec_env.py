@@ -27,7 +27,7 @@ def as_layout_table(layouts, pad_to=None):
 class VecOvercookedEnv:
     def __init__(self, layouts, n_envs, horizon=400, device="cuda", layout_id=None, auto_reset=False, seed=0,
                  env_offset=0, pad_to=None, track_returns=True, random_start_pos=False, rnd_obj_prob_thresh=0.0,
-                 track_events=False):
+                 track_events=False, regen_layout=False):
         self.lib = _lib.load()
         self.table = as_layout_table(layouts, pad_to)
         self.n_envs = int(n_envs)
@@ -53,6 +53,16 @@ class VecOvercookedEnv:
         # reset() and every restart inside the step kernels (auto_reset) draw the start state instead of the standard one
         self.random_start_pos, self.rnd_obj_prob_thresh = bool(random_start_pos), float(rnd_obj_prob_thresh)
         self.steps_done = 0  # batched steps executed
+        # regen_layout: every new episode of an env runs on a layout drawn from the table (True: any of its layouts; (first,
+        # count): that range) — OvercookedEnv.reset(regen_mdp=True) over a layout generator (env.py:288-302), inside the
+        # fused auto-reset; the current ids are in self.layout_id (device) / layout_ids()
+        self.regen = None
+        if regen_layout:
+            self.regen = (0, len(self.table)) if regen_layout is True else (int(regen_layout[0]), int(regen_layout[1]))
+            if not (0 <= self.regen[0] and self.regen[1] >= 1 and self.regen[0] + self.regen[1] <= len(self.table)):
+                raise ValueError("regen_layout range %r outside the table of %d layouts" % (self.regen, len(self.table)))
+            if len(self.table) > 1 and layout_id is None:
+                raise ValueError("regen_layout needs layout_id (the layouts of the first episodes)")
         self._start = _lib.OcStartSpec()
         self.width, self.height = self.table.width, self.table.height
         self.n_planes = self.table.n_planes
@@ -95,7 +105,9 @@ class VecOvercookedEnv:
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._state_ptr, self._rewards_ptr, self._flags_ptr = self.state.data_ptr(), self.rewards.data_ptr(), self.flags.data_ptr()
         self._ep_ptr = self.ep_returns.data_ptr() if self.ep_returns is not None else None
+        self._constructed = False  # (the first reset keeps the layouts the caller assigned)
         self.reset()
+        self._constructed = True
 
     # ------------------------------------------------------------------ helpers
     def _check(self, t, dtype, numel, what):
@@ -126,11 +138,18 @@ class VecOvercookedEnv:
     def random_starts(self):
         return self.random_start_pos or self.rnd_obj_prob_thresh > 0.0
 
+    def layout_ids(self):
+        """Current layout index of every env (numpy uint16 [n_envs]); changes at restarts when regen_layout is on."""
+        if self.layout_id is None:
+            return np.zeros((self.n_envs,), np.uint16)
+        return self.layout_id.cpu().numpy().view(np.uint16).copy()
+
     def _start_spec(self):
         """OcStartSpec* for the next launch (None = restarts from the standard start state)."""
-        if not self.random_starts:
+        if not self.random_starts and self.regen is None:
             return None
         sp = self._start
+        sp.regen_first, sp.regen_count = self.regen if self.regen is not None else (0, 0)
         sp.seed, sp.env_offset, sp.epoch = self.seed, self.env_offset, self._epoch & 0xFFFFFFFF
         sp.random_start_pos, sp.rnd_obj_prob_thresh = int(self.random_start_pos), self.rnd_obj_prob_thresh
         return ctypes.byref(sp)
@@ -171,6 +190,15 @@ class VecOvercookedEnv:
             d_mask = mask.data_ptr()
         d_ep = self.ep_returns.data_ptr() if self.ep_returns is not None else None
         with torch.cuda.device(self.device):
+            if self.regen is not None and self.layout_id is not None and getattr(self, "_constructed", False):
+                # regen_mdp=True semantics for an explicit reset: the selected envs move to freshly drawn layouts first
+                sp = self._start
+                sp.seed, sp.env_offset, sp.epoch = self.seed, self.env_offset, self._epoch & 0xFFFFFFFF
+                sp.regen_first, sp.regen_count = self.regen
+                _lib.check(self.lib.oc_regen_layouts(self._bref, self.layout_id.data_ptr(), d_mask, 0xFF, ctypes.byref(sp),
+                                                     self._stream()), "oc_regen_layouts")
+                if not (random_start_pos or rnd_obj_prob_thresh):
+                    self._epoch += 1  # (the layout draw used this epoch; a drawn start state below shares it)
             if random_start_pos or rnd_obj_prob_thresh:
                 rc = self.lib.oc_reset_random(self._bref, self.state.data_ptr(), d_mask, d_ep, self.seed, self.env_offset,
                                               self._epoch & 0xFFFFFFFF, int(bool(random_start_pos)),
@@ -389,13 +417,19 @@ class VecOvercookedEnv:
     def get_packed_state(self):
         return self.state.cpu().numpy()
 
+    def _refresh_layout_ids(self):
+        if self.regen is not None and self.layout_id is not None:  # restarts may have moved envs to other layouts
+            self.layout_id_host = self.layout_ids()
+
     def set_states(self, states):
         assert len(states) == self.n_envs
+        self._refresh_layout_ids()
         out = np.zeros((self.n_planes, self.n_envs, 16), np.uint8)
         for e, s in enumerate(states):
             out[:, e:e + 1] = pack_states(self.spec_of(e), [s], self.n_planes)
         self.set_packed_state(out)
 
     def get_states(self, as_dict=False):
+        self._refresh_layout_ids()
         packed = self.get_packed_state()
         return [unpack_states(self.spec_of(e), packed[:, e:e + 1], as_dict=as_dict)[0] for e in range(self.n_envs)]

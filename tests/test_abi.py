@@ -23,7 +23,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
     for s in syms:
         assert getattr(L, s) is not None
-    assert L.oc_abi_version() == 2
+    assert L.oc_abi_version() == 3
     assert L.oc_layout_size() == 256
     assert L.oc_state_planes(5, 4) == 3 and L.oc_state_planes(9, 5) == 4 and L.oc_state_planes(14, 9) == 9
 
@@ -61,7 +61,8 @@ def test_batch_hints_from_a_host_table():
         assert b.max_pots == pots == table.max_pots and b.batch_flags == flags and b.max_free_cells == want_free
         if free is not None:
             assert b.max_free_cells == free
-    assert ctypes.sizeof(_lib.OcStartSpec) == 32 and _lib.OcStartSpec.rnd_obj_prob_thresh.offset == 24
+    assert ctypes.sizeof(_lib.OcStartSpec) == 40 and _lib.OcStartSpec.rnd_obj_prob_thresh.offset == 24
+    assert _lib.OcStartSpec.regen_first.offset == 32 and _lib.OcStartSpec.regen_count.offset == 36
     assert L.oc_batch_hints(None, 1, None) == -1
 
 

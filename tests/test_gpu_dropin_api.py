@@ -329,3 +329,133 @@ def test_vec_multi_agent_event_counters():
         assert np.array_equal(np.stack([got & 0xFFFF, (got >> 16) & 0xFFFF], -1), counts) and counts.sum() > 0
         gd = env.venv.event_counts_done.cpu().numpy().astype(np.int64)
         assert np.array_equal(np.stack([gd & 0xFFFF, (gd >> 16) & 0xFFFF], -1), done_counts) and done_counts.sum() > 0
+
+
+class _ReplayAgentPair:
+    """Stands where the reference's AgentPair(RandomAgent, RandomAgent) stood when the fixture was recorded
+    (agents/agent.py:137, 223): `joint_action(state)` hands back that episode's recorded (action, info) pairs."""
+
+    def __init__(self, steps):
+        self.steps, self.t, self.mdp, self.resets = steps, 0, None, 0
+
+    def joint_action(self, state):
+        from overcooked_ai_amd import Action
+
+        st = self.steps[self.t]
+        self.t += 1
+        return tuple((Action.INDEX_TO_ACTION[a], {k: np.asarray(v) for k, v in info.items()})
+                     for a, info in zip(st["action"], st["agent_infos"]))
+
+    def set_mdp(self, mdp):
+        self.mdp = mdp
+
+    def reset(self):
+        self.t, self.resets = 0, self.resets + 1
+
+
+def test_run_agents_replays_the_reference_agent_pair_episodes():
+    """Episodes the reference's own AgentPair(RandomAgent(all_actions=True) x 2) played through the reference's
+    OvercookedEnv.run_agents (recorded by oracle/gen_golden.py gen_agent_pair_rollouts): the mirror env's run_agents, fed
+    the same joint actions through the agent-pair interface, yields the same trajectory rows, totals, episode summary —
+    and get_rollouts the codebase's trajectory dict of it."""
+    from overcooked_ai_amd import OvercookedEnv, OvercookedGridworld
+    from overcooked_ai_amd import state as S
+    from overcooked_ai_amd.env import DEFAULT_TRAJ_KEYS
+    from overcooked_ai_amd.layouts import LayoutSpec
+
+    with open(os.path.join(GOLDEN, "agent_pair_rollouts.json")) as f:
+        fixtures = json.load(f)
+    for name, fx in fixtures.items():
+        mdp = OvercookedGridworld.from_spec(LayoutSpec(fx["layout"]))
+        env = OvercookedEnv.from_mdp(mdp, horizon=fx["horizon"], info_level=0)
+        pair = _ReplayAgentPair(fx["steps"])
+        traj, t_elapsed, total_sparse, total_shaped = env.run_agents(pair, include_final_state=True)
+        assert traj.shape == (len(fx["steps"]) + 1, 5) and t_elapsed == fx["t_elapsed"]
+        assert total_sparse == fx["total_sparse"] and total_shaped == fx["total_shaped"]
+        for row, st in zip(traj[:-1], fx["steps"]):
+            s_t, a_t, r_t, done, info = row
+            assert S.canonical_state_dict(s_t) == S.canonical_state_dict(st["state"])
+            assert r_t == st["reward"] and done == st["done"]
+            assert info["sparse_r_by_agent"] == st["sparse_r_by_agent"] and info["shaped_r_by_agent"] == st["shaped_r_by_agent"]
+            assert [ai["action_probs"].tolist() for ai in info["agent_infos"]] == [ai["action_probs"] for ai in st["agent_infos"]]
+        assert S.canonical_state_dict(traj[-1][0]) == S.canonical_state_dict(fx["final_state"]) and traj[-1][1] == (None, None)
+        ep = traj[-2][4]["episode"]
+        assert ep["ep_length"] == fx["ep_length"]
+        for key, want in fx["ep_game_stats"].items():
+            got = ep["ep_game_stats"][key]
+            assert (got.tolist() if hasattr(got, "tolist") else [list(x) for x in got]) == want, (name, key)
+        # the same through get_rollouts (two games of the same recorded actions: the env restarts from the standard state)
+        env.reset(regen_mdp=False)
+        pair.reset()
+        out = env.get_rollouts(pair, 2, info=False)
+        assert sorted(out) == sorted(DEFAULT_TRAJ_KEYS) and pair.mdp is mdp and pair.resets == 3
+        assert out["ep_returns"].tolist() == [fx["total_sparse"]] * 2 and out["ep_lengths"].tolist() == [fx["ep_length"]] * 2
+        assert out["ep_states"].shape == (2, fx["ep_length"]) and out["ep_rewards"][1].tolist() == [s["reward"] for s in fx["steps"]]
+        assert out["mdp_params"][0]["layout_name"] == mdp.layout_name and out["env_params"][0]["horizon"] == fx["horizon"]
+
+
+def test_env_planner_properties_and_limits():
+    """OvercookedEnv.mp is the MotionPlanner of the current mdp (rebuilt when reset regenerates the mdp); .mlam carries it
+    and names what it cannot do; execute_plan leaves the env at a start state like the reference's; a step at the
+    packing limit of the timestep raises instead of freezing it."""
+    from overcooked_ai_amd import Action, Direction, OvercookedEnv, OvercookedGridworld
+
+    mdp = OvercookedGridworld.from_layout_name("cramped_room")
+    env = OvercookedEnv.from_mdp(mdp, horizon=400, info_level=0)
+    mp = env.mp
+    assert env.mlam.motion_planner is mp and env.mp is mp
+    start = mdp.get_standard_start_state()
+    cost, where = mp.min_cost_to_feature(start.players[0].pos_and_or, mdp.get_pot_locations(), with_argmin=True)
+    assert where == (2, 0) and cost == 3  # the reference planner's figure for the start pose: 2 motion actions + the interact
+    with pytest.raises(NotImplementedError):
+        env.mlam.joint_ml_actions(start)
+    env.reset(regen_mdp=True)
+    assert env.mp is not mp
+    end, done = env.execute_plan(start, [(Direction.NORTH, Action.STAY)] * 3)
+    assert end.timestep == 3 and not done and env.state.timestep == 0
+    assert "^0" in repr(env) or "0" in repr(env)
+    late = start.deepcopy()
+    late.timestep = 65535
+    env2 = OvercookedEnv.from_mdp(mdp, info_level=0)  # the reference's default horizon
+    env2.state = late
+    with pytest.raises(ValueError, match="16 bits"):
+        env2.step((Action.STAY, Action.STAY))
+
+
+def test_overcooked_multi_agent_matches_reference_episodes():
+    """The RLlib environment class (human_aware_rl/rllib/rllib.py:112-438) replayed against episodes recorded from the
+    reference: agent roles (same np.random stream), per-agent observations (lossless / featurize_state), rewards
+    sparse + factor * (phi' - phi | shaped) as exact Python floats, dones, annealed factors."""
+    from overcooked_ai_amd import OvercookedEnv, OvercookedGridworld, OvercookedMultiAgent
+    from overcooked_ai_amd.layouts import LayoutSpec
+
+    for name, case, obs, obs_len in _multi_agent_fixture():
+        mdp = OvercookedGridworld.from_spec(LayoutSpec(dict(case["layout"])))
+        base_env = OvercookedEnv.from_mdp(mdp, horizon=case["horizon"], info_level=0)
+        np.random.seed(2024)
+        env = OvercookedMultiAgent(base_env, **{k: (list(map(tuple, v)) if isinstance(v, list) else v)
+                                                for k, v in case["kwargs"].items()})
+        row, total = 0, 0
+        for ep in case["episodes"]:
+            ob = env.reset()
+            agents = list(env.curr_agents)
+            assert agents == ep["agents"], name
+            for j, a in enumerate(agents):
+                assert ob[a].dtype == np.float32 and np.array_equal(ob[a].ravel(), obs[row, j, :obs_len[row, j]])
+            row += 1
+            for st in ep["steps"]:
+                ob, rew, dones, infos = env.step({agents[0]: st["actions"][0], agents[1]: st["actions"][1]})
+                total += 1
+                assert [rew[a] for a in agents] == st["rewards"], (name, total)
+                assert dones["__all__"] == st["done"] and env.reward_shaping_factor == st["factor"] and env.bc_factor == st["bc_factor"]
+                assert infos[agents[0]].get("phi_s") == st["phi_s"] and infos[agents[0]].get("phi_s_prime") == st["phi_s_prime"]
+                for j, a in enumerate(agents):
+                    assert np.array_equal(ob[a].ravel(), obs[row, j, :obs_len[row, j]]), (name, total, a)
+                row += 1
+                if total % 7 == 0:
+                    env.anneal_reward_shaping_factor(total)
+                    env.anneal_bc_factor(total)
+            assert infos[agents[0]]["episode"]["ep_shaped_r"] == ep["ep_shaped_r"]
+    cfg = dict(OvercookedMultiAgent.DEFAULT_CONFIG)
+    env = OvercookedMultiAgent.from_config(cfg)
+    assert sorted(env.reset()) == ["ppo_0", "ppo_1"] and env.base_env.horizon == 400

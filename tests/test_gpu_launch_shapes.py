@@ -108,3 +108,78 @@ def test_long_launch_with_drawn_start_states_131072(gpu):
     _long_launch_against_oracle(gpu, "cramped_room", 131072, seed=5, steps=2000,
                                 start={"random_start_pos": True, "rnd_obj_prob_thresh": 0.4},
                                 random_start_pos=True, rnd_obj_prob_thresh=0.4)
+
+
+@pytest.mark.parametrize("table_kind", ["generated_4096", "canonical_5"])
+def test_layout_redrawn_every_episode_inside_the_fused_auto_reset(table_kind, gpu):
+    """regen_layout (OvercookedEnv.reset(regen_mdp=True) over a layout generator, env.py:288-302 — the reference meaning of
+    BASELINE configs[4]): every restart inside oc_rollout_random / oc_step / oc_step_many moves the env to a layout drawn from
+    the table, then starts the episode there.  Layout ids, states, rewards and flags against the oracle's restatement across
+    more than three episode boundaries, on the 4 096-terrain table (read through L2) and the 5-layout table (in LDS), with
+    standard and with drawn start states; then an explicit reset with the same semantics."""
+    from oracle import oracle as O
+    from overcooked_ai_amd.layout_gen import reference_generated_layouts
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+    from overcooked_ai_amd.vec_env import VecOvercookedEnv
+
+    if table_kind == "generated_4096":
+        table = LayoutTable(reference_generated_layouts(4096))
+    else:
+        table = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+    K, n, horizon, seed, off = len(table), 70000 if table_kind == "generated_4096" else 30000, 23, 17, 5000
+    orc = _oracle(table.specs)
+    for start_kw in ({}, {"random_start_pos": True, "rnd_obj_prob_thresh": 0.3}):
+        lid = ((np.arange(n) * 7 + 3) % K).astype(np.uint16)
+        lid_o = lid.copy()
+        env = VecOvercookedEnv(table, n, horizon=horizon, device=gpu, auto_reset=True, seed=seed, env_offset=off, layout_id=lid,
+                               regen_layout=True, **start_kw)
+        st = env.get_packed_state().copy()
+        if not start_kw:
+            assert np.array_equal(st, orc.reset(orc.new_state(n), layout_id=lid_o))
+        ep_o = np.zeros((n, 4), np.float32)
+        steps = 0
+        for T in (31, 40):  # the fused rollout: three boundaries (steps 23, 46, 69)
+            rew = torch.zeros((T, n, 4), dtype=torch.float32, device=gpu)
+            fl = torch.zeros((T, n), dtype=torch.uint8, device=gpu)
+            env.rollout_random(T, rew, fl)
+            sp = O.start_spec(seed, off, 1 + steps, regen=(0, K), **start_kw)
+            rew_o, fl_o = orc.rollout_random(st, T, horizon=horizon, options=1, seed=seed, env_offset=off, t0=steps,
+                                             layout_id=lid_o, ep_returns=ep_o, start=sp)
+            steps += T
+            assert np.array_equal(env.layout_ids(), lid_o), "layout ids differ after %d steps" % steps
+            assert np.array_equal(fl.cpu().numpy(), fl_o) and np.array_equal(rew.cpu().numpy(), rew_o)
+            assert np.array_equal(env.get_packed_state(), st) and np.array_equal(env.ep_returns.cpu().numpy(), ep_o)
+        assert (lid_o != lid).mean() > 0.9 and len(np.unique(lid_o)) > min(K, 1000) * 0.9
+        rng = np.random.default_rng(4)
+        for t in range(horizon + 2):  # the step API, one call per step, across a fourth boundary
+            acts = rng.integers(0, 6, size=(n, 2)).astype(np.uint8)
+            r, f = env.step(torch.from_numpy(acts).to(gpu))
+            sp = O.start_spec(seed, off, 1 + steps, regen=(0, K), **start_kw)
+            st, r_o, f_o = orc.step(st, acts, horizon=horizon, options=1, layout_id=lid_o, ep_returns=ep_o, start=sp)
+            steps += 1
+            assert np.array_equal(f.cpu().numpy(), f_o) and np.array_equal(r.cpu().numpy(), r_o), t
+        assert np.array_equal(env.layout_ids(), lid_o) and np.array_equal(env.get_packed_state(), st)
+        Ks = horizon + 4  # K steps in one launch (oc_step_many), a fifth boundary
+        acts_k = rng.integers(0, 6, size=(Ks, n, 2)).astype(np.uint8)
+        rew_k = torch.zeros((Ks, n, 4), dtype=torch.float32, device=gpu)
+        fl_k = torch.zeros((Ks, n), dtype=torch.uint8, device=gpu)
+        env.step_many(torch.from_numpy(acts_k).to(gpu), rew_k, fl_k)
+        for k in range(Ks):
+            sp = O.start_spec(seed, off, 1 + steps + k, regen=(0, K), **start_kw)
+            st, r_o, f_o = orc.step(st, acts_k[k], horizon=horizon, options=1, layout_id=lid_o, ep_returns=ep_o, start=sp)
+            assert np.array_equal(rew_k[k].cpu().numpy(), r_o) and np.array_equal(fl_k[k].cpu().numpy(), f_o), k
+        steps += Ks
+        assert np.array_equal(env.layout_ids(), lid_o) and np.array_equal(env.get_packed_state(), st)
+        # an explicit reset of a third of the envs: new layouts first, then their start states
+        mask = (np.arange(n) % 3 == 1)
+        epoch = env.reset_epoch
+        env.reset(mask=torch.from_numpy(mask))
+        O.regen_layouts(lid_o, O.start_spec(seed, off, epoch, regen=(0, K)), mask=mask.astype(np.uint8))
+        if start_kw:
+            st = orc.reset_random(st, seed=seed, env_offset=off, epoch=epoch, layout_id=lid_o, mask=mask.astype(np.uint8), **start_kw)
+        else:
+            st = orc.reset(st, layout_id=lid_o, mask=mask.astype(np.uint8))
+        assert np.array_equal(env.layout_ids(), lid_o) and np.array_equal(env.get_packed_state(), st)
+        # the object view follows the moved layouts
+        some = env.get_states()[:5]
+        assert [s.timestep for s in some] == [int(st[0, e, 6]) for e in range(5)]

@@ -259,3 +259,92 @@ def test_reference_generated_layouts_package_data():
     table = LayoutTable(specs[:100])
     assert table.records.shape == (100, 256) and table.max_pots >= 1
     assert all(s.delivery_value((3, 0)) == 20 and s.recipe_time((3, 0)) == 20 for s in specs[:50])
+
+
+# ------------------------------------------------------------------ drop-in query surface (host side, no GPU)
+def _state_queries():
+    import json
+
+    with open(os.path.join(GOLDEN, "state_queries.json")) as f:
+        return json.load(f)
+
+
+def test_state_queries_match_the_reference():
+    """get_pot_states / get_counter_objects_dict / get_empty_counter_locations / the get_*_pots family /
+    soup_ready_at_location / soup_to_be_cooked_at_location / get_adjacent_features (mdp.py:1773-1907) on 300 states
+    recorded from the reference (oracle/gen_golden.py gen_state_queries)."""
+    from overcooked_ai_amd.layouts import LayoutSpec
+    from overcooked_ai_amd.mdp import OvercookedGridworld
+    from overcooked_ai_amd.state import OvercookedState
+
+    tup = lambda ps: [tuple(p) for p in ps]
+    n = 0
+    for name, rec in _state_queries().items():
+        mdp = OvercookedGridworld.from_spec(LayoutSpec(rec["layout"]))
+        for case in rec["cases"]:
+            st = OvercookedState.from_dict(case["state"])
+            ps = mdp.get_pot_states(st)
+            assert {k: v for k, v in dict(ps).items() if v} == {k: tup(v) for k, v in case["pot_states"].items()}, name
+            assert dict(mdp.get_counter_objects_dict(st)) == {k: tup(v) for k, v in case["counter_objects"].items()}
+            assert mdp.get_empty_counter_locations(st) == tup(case["empty_counters"])
+            assert mdp.get_empty_pots(ps) == tup(case["empty_pots"]) and mdp.get_ready_pots(ps) == tup(case["ready_pots"])
+            assert mdp.get_cooking_pots(ps) == tup(case["cooking_pots"])
+            assert mdp.get_full_but_not_cooking_pots(ps) == tup(case["full_not_cooking"])
+            assert mdp.get_full_pots(ps) == tup(case["full_pots"])
+            assert sorted(mdp.get_partially_full_pots(ps)) == sorted(tup(case["partially_full"]))
+            assert sorted(mdp.get_non_empty_pots(ps)) == sorted(tup(case["full_pots"]) + tup(case["partially_full"]))
+            pots = mdp.get_pot_locations()
+            assert [mdp.soup_ready_at_location(st, p) for p in pots] == case["soup_ready"]
+            assert [mdp.soup_to_be_cooked_at_location(st, p) for p in pots] == case["soup_to_cook"]
+            assert [[[list(pos), t] for pos, t in mdp.get_adjacent_features(pl)] for pl in st.players] == case["adjacent"]
+            txt = mdp.state_string(st)
+            assert txt.count("\n") >= mdp.height and all(str(i) in txt for i in range(len(st.players)))
+            n += 1
+    assert n == 300
+
+
+def test_motion_planner_facade_and_mlam_error():
+    """planner.MotionPlanner (what OvercookedEnv.mp returns): its costs equal the tables the kernels use, plans have the
+    length the cost says and end on the goal; OvercookedEnv.mlam's stand-in names what is unsupported."""
+    from overcooked_ai_amd.actions import Action, Direction
+    from overcooked_ai_amd.env import _UnsupportedPlanner
+    from overcooked_ai_amd.layouts import spec_from_name
+    from overcooked_ai_amd.planner import UNREACHABLE, MotionPlanner, feature_costs
+
+    for name in ("cramped_room", "forced_coordination", "counter_circuit"):
+        spec = spec_from_name(name)
+        mp = MotionPlanner(spec)
+        fi, cost = feature_costs(spec, "none")
+        W = spec.width
+        feats = [p for t in "OTPDS" for p in spec.cells_of(t)]
+        for (x, y) in spec.cells_of(" "):
+            for o, d in enumerate(Direction.ALL_DIRECTIONS):
+                for f in feats:
+                    c = int(cost[4 * fi[y * W + x] + o, f[1] * W + f[0]])
+                    got = mp.min_cost_to_feature(((x, y), d), [f])
+                    assert got == (np.inf if c == UNREACHABLE else c + 1), (name, x, y, o, f)
+        start = (spec.cells_of(" ")[0], Direction.NORTH)
+        for f in feats:
+            for goal in mp.motion_goals_for_pos[tuple(f)]:
+                if mp.is_valid_motion_start_goal_pair(start, goal):
+                    plan, path, n = mp.get_plan(start, goal)
+                    assert n == len(plan) == len(path) == mp.get_gridworld_distance(start, goal) + 1
+                    assert plan[-1] == Action.INTERACT and path[-1] == goal
+        assert mp.min_cost_between_features(spec.cells_of("P"), spec.cells_of("S")) >= 1
+    m = _UnsupportedPlanner(mp, {"counter_goals": []})
+    assert m.motion_planner is mp
+    with pytest.raises(NotImplementedError, match="MediumLevelActionManager"):
+        m.get_medium_level_actions
+
+
+def test_gridworld_copies_and_pickles_without_device_state():
+    import copy
+    import pickle
+
+    from overcooked_ai_amd.mdp import OvercookedGridworld
+
+    mdp = OvercookedGridworld.from_layout_name("asymmetric_advantages")
+    mdp._envs[3], mdp._single = object(), object()  # stand-ins for the per-process device plumbing
+    for other in (copy.deepcopy(mdp), pickle.loads(pickle.dumps(mdp))):
+        assert other == mdp and other._envs == {} and other._single is None and other.terrain_mtx == mdp.terrain_mtx
+    assert mdp._single is not None  # the original keeps its own
