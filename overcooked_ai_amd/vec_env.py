@@ -108,6 +108,7 @@ class VecOvercookedEnv:
         self._constructed = False  # (the first reset keeps the layouts the caller assigned)
         self.reset()
         self._constructed = True
+        self._epoch = max(self._epoch, 1)  # epoch 0 belongs to the first states, drawn or not: launches count from 1
 
     # ------------------------------------------------------------------ helpers
     def _check(self, t, dtype, numel, what):

@@ -596,7 +596,7 @@ def test_reset_random_matches_oracle(gpu):
             want = orc.reset_random(orc.new_state(n), seed=21, env_offset=700, epoch=epoch, random_start_pos=pos,
                                     rnd_obj_prob_thresh=t)
             assert np.array_equal(env.get_packed_state(), want), (spec.layout_name, pos, t)
-        assert env.reset_epoch == 4
+        assert env.reset_epoch == 5  # epoch 0 belongs to the constructor's reset, then one per explicit reset
     table = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
     n = 4097
     lid = (np.arange(n) % 5).astype(np.uint16)
@@ -605,8 +605,8 @@ def test_reset_random_matches_oracle(gpu):
     before = env.get_packed_state()
     mask = (np.arange(n) % 3 == 0)
     env.ep_returns.fill_(1.0)
-    epoch = env.reset_epoch  # 37: the launch consumed one epoch per step (explicit resets and in-kernel restarts share ONE counter)
-    assert epoch == 37
+    epoch = env.reset_epoch  # the launch consumed one epoch per step (explicit resets and in-kernel restarts share ONE counter)
+    assert epoch == 1 + 37
     env.reset(mask=torch.from_numpy(mask), random_start_pos=True, rnd_obj_prob_thresh=0.5)
     want = oracle_for(table.specs).reset_random(before.copy(), seed=5, epoch=epoch, random_start_pos=True, rnd_obj_prob_thresh=0.5,
                                                 layout_id=lid, mask=mask.astype(np.uint8))

@@ -56,8 +56,9 @@ def main():
         env = VecOvercookedEnv(table, n, horizon=horizon, device=dev, layout_id=lid, auto_reset=True, seed=seed)
         orc = O.Oracle([O.mdp_from_layout_dict(s.to_layout_dict()) for s in specs])
         thr = float(rng.choice([0.0, 0.3, 0.8]))
+        epoch = env.reset_epoch
         env.reset(random_start_pos=True, rnd_obj_prob_thresh=thr)
-        st = orc.reset_random(orc.new_state(n), seed=seed, epoch=0, random_start_pos=True, rnd_obj_prob_thresh=thr, layout_id=lid)
+        st = orc.reset_random(orc.new_state(n), seed=seed, epoch=epoch, random_start_pos=True, rnd_obj_prob_thresh=thr, layout_id=lid)
         assert np.array_equal(env.get_packed_state(), st), ("reset_random", seed)
         mode = [None, "rollout_v3", "lane_pair", "predicate_interact"][seed % 4]
         if mode:
