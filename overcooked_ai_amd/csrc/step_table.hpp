@@ -643,6 +643,8 @@ __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_
                 if (regen_layout<UNIFORM, LAY_LDS>(sa, g, sa.epoch + (uint32_t)k, e, s_lay, g_layouts, L, C, &lid)) {
                     lut = reinterpret_cast<const uint8_t*>(s_lut) + (C.old_dyn ? LUT_ENTRIES * 8 : 0);
                     if (FAST) floor_mask = make_floor_mask(L, (int)L.u8(L_NCELLS));
+                    // the cell words carry the terrain in their upper byte: the new layout's (the restart clears the objects)
+                    for (int c = 0; c < n_obj * 16; ++c) cells[c * BLOCK] = (uint16_t)(L.terrain((uint32_t)c) << 8);
                 }
             });
             if (EVENTS) {

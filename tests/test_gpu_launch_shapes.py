@@ -149,7 +149,7 @@ def test_layout_redrawn_every_episode_inside_the_fused_auto_reset(table_kind, gp
             assert np.array_equal(env.layout_ids(), lid_o), "layout ids differ after %d steps" % steps
             assert np.array_equal(fl.cpu().numpy(), fl_o) and np.array_equal(rew.cpu().numpy(), rew_o)
             assert np.array_equal(env.get_packed_state(), st) and np.array_equal(env.ep_returns.cpu().numpy(), ep_o)
-        assert (lid_o != lid).mean() > 0.9 and len(np.unique(lid_o)) > min(K, 1000) * 0.9
+        assert (lid_o != lid).mean() > 0.75 and len(np.unique(lid_o)) > min(K, 1000) * 0.9  # (5 layouts: one restart in five redraws its own)
         rng = np.random.default_rng(4)
         for t in range(horizon + 2):  # the step API, one call per step, across a fourth boundary
             acts = rng.integers(0, 6, size=(n, 2)).astype(np.uint8)
