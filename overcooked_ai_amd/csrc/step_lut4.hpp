@@ -912,15 +912,30 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
                 c1 = cw_rd<CW>(fo1);
                 rd_pots(pw);
             }
+            // the next step's joint action and the table reads it feeds: the next pose's faced cells, the pose after it, who interacts
+            uint32_t ja2n = 0, fa_n = 0, Jnn = 0, off0n = 0, off1n = 0;
+            auto next_tables = [&]() __attribute__((always_inline)) {
+                ja2n = jsd(mul36 ? xn * 36u : xn);
+                fa_n = lds_rd32(Jn + (uint32_t)Mvj<CW>::FACES);
+                Jnn = row_rd(Jn + ja2n);
+                off0n = row_rd((uint32_t)M::ACT + ja2n);
+                off1n = row_rd((uint32_t)(M::ACT + M::ACT_P1) + ja2n);
+            };
+            if (!PIPE) {  // two or more wavefronts per SIMD hide each other's latency: no hand-made shadow, the look-ahead reads first
+                next_tables();
+                __builtin_amdgcn_sched_barrier(0);  // (left to itself the scheduler queues them behind the LUT reads the step waits for)
+            }
             const Looked looked = look_up(off0, off1, c0, c1, pw);
-            if (PIPE) __builtin_amdgcn_sched_barrier(0);  // (two or more wavefronts per SIMD hide each other's latency: no hand-made shadow)
-            if (PIPE && OUT && k8 >= 1) flush(pend, k8 - 1);
+            if (PIPE) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (OUT && k8 >= 1) flush(pend, k8 - 1);
+            }
 #pragma unroll
             for (int r = 0; r < rounds; ++r) inc.round();
-            const uint32_t ja2n = jsd(mul36 ? xn * 36u : xn);
-            uint32_t fa_n = lds_rd32(Jn + (uint32_t)Mvj<CW>::FACES), Jnn = row_rd(Jn + ja2n);
-            const uint32_t off0n = row_rd((uint32_t)M::ACT + ja2n), off1n = row_rd((uint32_t)(M::ACT + M::ACT_P1) + ja2n);
-            if (PIPE) __builtin_amdgcn_sched_barrier(0);
+            if (PIPE) {
+                next_tables();
+                __builtin_amdgcn_sched_barrier(0);
+            }
             uint32_t Jcn = Jn, unused = 0, unused4 = 0, nf0 = 0, nf1 = 0, nc0 = 0, nc1 = 0, npw[MAXP];
             core(fo0, fo1, off0, off1, c0, c1, ja2n, pw, Jcn, fa_n, Jnn, unused, unused4, nf0, nf1, nc0, nc1, npw, k8, looked,
                  (PIPE && k8 >= 0 && k8 < 7) ? &pend : nullptr);

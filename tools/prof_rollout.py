@@ -1,5 +1,6 @@
 """Tiny driver for rocprofv3 counter passes over the fused rollout kernel (keeps the rocpd database small):
-    MODE=<rollout_v3|lane_pair|predicate_interact> LAYOUT=<name> ENVS=<n> python tools/prof_rollout.py"""
+    MODE=<rollout_v3|lane_pair|predicate_interact> LAYOUT=<name> ENVS=<n> STEPS=<fused steps> python tools/prof_rollout.py
+    CONFIG=4 | CONFIG=5: the 5-layout mix / the 4 096 generated terrains of BASELINE configs[3] / [4] instead of one layout"""
 import os
 import sys
 
@@ -10,7 +11,16 @@ from overcooked_ai_amd.vec_env import VecOvercookedEnv  # noqa: E402
 
 dev = torch.device("cuda:0")
 n = int(os.environ.get("ENVS", "65536"))
-env = VecOvercookedEnv(os.environ.get("LAYOUT", "cramped_room"), n, horizon=400, device=dev, auto_reset=True, seed=0)
+cfg = os.environ.get("CONFIG", "")
+if cfg in ("4", "5"):
+    import argparse
+
+    import bench
+
+    wl = bench.make_workload(argparse.Namespace(config=int(cfg), envs=n, layout="cramped_room"), 0)
+    env = VecOvercookedEnv(wl["table"], n, horizon=400, device=dev, auto_reset=True, seed=0, layout_id=wl["lid"])
+else:
+    env = VecOvercookedEnv(os.environ.get("LAYOUT", "cramped_room"), n, horizon=400, device=dev, auto_reset=True, seed=0)
 mode = os.environ.get("MODE", "")
 if mode:
     setattr(env, mode, True)
