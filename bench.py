@@ -533,7 +533,29 @@ def main():
         torch.cuda.set_device(dev)
         return pmc_child(args, torch, VecOvercookedEnv, dev)
 
-    rank, local_rank, world = sharding.init_process_group("gloo" if args.stub else None)
+    # RCCL prints its version banner to C stdio's stdout when the first communicator comes up: bring the process group up
+    # (and run one collective) with fd 1 pointed at stderr, so that stdout carries the ONE JSON line and nothing else
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        rank, local_rank, world = sharding.init_process_group("gloo" if args.stub else None)
+        if sharding._live():
+            if not args.stub:
+                torch.cuda.set_device(local_rank)
+            warm = torch.zeros((1,), device="cpu" if args.stub else torch.device("cuda", local_rank))
+            sharding.allreduce_metrics(warm)
+            if not args.stub:
+                torch.cuda.synchronize()
+        import ctypes
+
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+    finally:
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if sharding._live():
