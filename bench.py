@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--min-seconds", type=float, default=0.25,
                     help="minimum length of the timed region: the --steps-step region is repeated back to back until it lasts this long")
+    ap.add_argument("--terrains", type=int, default=4096,
+                    help="--config 5: size of the LayoutGenerator terrain table (first 4 096 = the grids recorded from the "
+                         "reference; more are generated on this host by the draw-exact restatement, up to 65 536)")
     ap.add_argument("--stub", action="store_true",
                     help="CPU-only plumbing test (gloo, no kernels): exercises rank spawning and the reductions; never a measurement")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of one launch after the timed region")
@@ -351,10 +354,12 @@ def make_workload(args, rank):
         return {"table": table, "specs": table.specs, "lid": lid, "sbytes": 34,
                 "workload": "5 canonical layouts padded to 9x5 (global env e -> layout e %% 5) x %d envs/GPU, random policy, "
                             "horizon %d auto-reset, outputs every step" % (n, HORIZON)}
-    from overcooked_ai_amd.layout_gen import reference_generated_layouts
+    from overcooked_ai_amd.layout_gen import generate_reference_layouts, reference_generated_layouts
 
-    K = 4096  # the reference LayoutGenerator's own terrains (np.random.seed(0)), recorded as package data
-    table = LayoutTable(reference_generated_layouts(K))
+    # the reference LayoutGenerator's own terrains (np.random.seed(0)): recorded as package data up to 4 096, generated here
+    # by its draw-exact restatement (layout_gen.generate_reference_layouts) beyond
+    K = int(getattr(args, "terrains", 4096))
+    table = LayoutTable(reference_generated_layouts(K) if K <= 4096 else generate_reference_layouts(K, seed=0))
     lid = ((np.arange(n) + rank * n) % K).astype(np.uint16)
     return {"table": table, "specs": table.specs, "lid": lid, "sbytes": 36,
             "workload": "%d LayoutGenerator 9x5 terrains (reference generator, seed 0; global env e -> terrain e %% %d) x %d "

@@ -348,3 +348,26 @@ def test_gridworld_copies_and_pickles_without_device_state():
     for other in (copy.deepcopy(mdp), pickle.loads(pickle.dumps(mdp))):
         assert other == mdp and other._envs == {} and other._single is None and other.terrain_mtx == mdp.terrain_mtx
     assert mdp._single is not None  # the original keeps its own
+
+
+def test_reference_layout_generator_draws_are_reproduced():
+    """layout_gen.generate_reference_layouts restates the reference's LayoutGenerator draw for draw (same numpy legacy-stream
+    calls, layout_generator.py:277-420, 493-520): RandomState(0) here yields exactly the 4 096 grids recorded from the
+    reference after np.random.seed(0) (package data), so any number of further — unique — terrains can be generated without
+    the reference.  (Other shapes / feature sets were checked against the live reference in the build container.)"""
+    import gzip
+
+    from overcooked_ai_amd.layout_gen import generate_reference_layouts, reference_generated_layouts
+
+    path = os.path.join(os.path.dirname(L.__file__), "data", "ref_generated_9x5_seed0.json.gz")
+    with gzip.open(path, "rt") as f:
+        recorded = json.load(f)["grids"]
+    mine = generate_reference_layouts(len(recorded) + 50, seed=0)
+    assert [s.to_layout_dict()["grid"].split("\n") for s in mine[:len(recorded)]] == [list(g) for g in recorded]
+    shipped = reference_generated_layouts(8)
+    assert [s.to_layout_dict()["grid"] for s in shipped] == [s.to_layout_dict()["grid"] for s in mine[:8]]
+    assert shipped[0].recipe_value((3, 0)) == mine[0].recipe_value((3, 0)) == 20
+    # beyond the recorded set: valid, new grids; another seed: another sequence
+    tail = {s.to_layout_dict()["grid"] for s in mine[len(recorded):]}
+    assert len(tail) >= 49 and all(s.width == 9 and s.height == 5 and s.num_players == 2 for s in mine[-50:])
+    assert generate_reference_layouts(3, seed=1)[0].to_layout_dict()["grid"] != mine[0].to_layout_dict()["grid"]
