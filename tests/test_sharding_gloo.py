@@ -1,6 +1,11 @@
 """Multi-GPU path on CPU: world_size-2 gloo process group.  The envs shard as contiguous ranges with no
-data-path collective; each rank steps its shard (here with the CPU oracle standing in for the GPU) using its
-global env offset for the Philox streams, and only the aggregate metrics are all-reduced."""
+data-path collective; each rank steps its shard using its global env offset for the Philox streams, and only the
+aggregate metrics are all-reduced.
+
+What this does and does not show: there is no GPU here, so every rank steps the C ORACLE, not the HIP path — the test
+covers the partition arithmetic, the env_offset / layout-id conventions and the collectives.  That a HIP shard equals its
+slice of the unsharded batch is shown on one GPU (the sharding property checked in tests/test_gpu_parity.py's full-size rollout test and the
+inner-rank launch shapes of tests/test_gpu_launch_shapes.py); a multi-GPU run has not been measured on hardware."""
 import os
 import socket
 import sys
