@@ -717,6 +717,9 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stub:  # the CPU leg runs at N = 1 only
         out["cpu_baseline"] = cpu_baseline(wl, n, args.cpu_seconds)
         out["cpu_baseline"]["reference_python"] = _reference_python()
+    out["process_note"] = ("the timed region (%.2f s) is a small part of this process: warm-up, the side measurements, the "
+                           "parity check, the PMC child passes and the CPU baseline run before / after it with the GPU mostly "
+                           "idle, so a coarse utilisation sampler over the whole process reads close to zero" % wall_max)
     if rank == 0:
         emit(out)
     sharding.barrier()

@@ -99,6 +99,8 @@ extern "C" {
 /* OcBatch.batch_flags */
 #define OC_BATCH_TWO_PLAYERS 0x1u /* every layout of the table has exactly 2 players */
 #define OC_BATCH_NEW_DYNAMICS 0x2u /* no layout of the table uses old_dynamics (mdp.py:1696-1701) */
+#define OC_BATCH_NO_SHARED_FACES 0x8u /* in no layout of the table does a non-floor cell touch two floor cells: two players can
+                                         never face the same cell (cramped_room), so the interact order needs no replay */
 #define OC_BATCH_UNIFORM_SHAPING 0x4u /* every layout of the table has the same rew_shaping_params and old_dynamics flag:
                                          the interact table then carries the reward floats for the whole batch */
 

@@ -16,6 +16,7 @@ OPT_ONE_KERNEL = 0x20
 BATCH_TWO_PLAYERS = 0x1
 BATCH_NEW_DYNAMICS = 0x2
 BATCH_UNIFORM_SHAPING = 0x4
+BATCH_NO_SHARED_FACES = 0x8
 OBS_U8, OBS_F32 = 0, 1
 
 EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_batch_hints", "oc_step", "oc_step_many",

@@ -160,7 +160,7 @@ inline int64_t simd_count() {
 
 // dynamic LDS of a k_rollout4 instance: its tables + the cell words of a workgroup's 256 envs
 template <bool U, int MP, bool LL, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false, bool PIPE = true,
-          bool RU = false, int CW = 2>
+          bool RU = false, int CW = 2, bool NOCONF = false>
 constexpr size_t lds4_bytes(size_t cell_rows) {
     return (size_t)Lds4<U, LL, MODE, NF, U || RU, CW>::CELLS + cell_rows * BLOCK * CW;
 }
@@ -234,7 +234,7 @@ int oc_batch_hints(const OcLayout* h_layouts, int n_layouts, OcBatch* batch) {
     if (!h_layouts || !batch || n_layouts < 1) return fail(OC_EINVAL, "oc_batch_hints: NULL table / batch or no layouts");
     int max_pots = 0;
     uint32_t max_free = 0;
-    bool two = true, any_old = false, same_shaping = true;
+    bool two = true, any_old = false, same_shaping = true, shared_faces = false;
     for (int i = 0; i < n_layouts; ++i) {
         const OcLayout& l = h_layouts[i];
         any_old = any_old || l.old_dynamics != 0;
@@ -246,11 +246,23 @@ int oc_batch_hints(const OcLayout* h_layouts, int n_layouts, OcBatch* batch) {
         two = two && l.n_players == 2;
         uint32_t free_cells = 0;
         for (int c = 0; c < l.n_cells; ++c) free_cells += (l.terrain[c] & 7) == OC_T_FLOOR ? 1u : 0u;
+        for (int c = 0; c < l.n_cells && l.width; ++c) {  // does some non-floor cell touch two floor cells (two players could face it)?
+            if ((l.terrain[c] & 7) == OC_T_FLOOR) continue;
+            const int x = c % l.width, y = c / l.width;
+            int touching = 0;
+            const int nb[4][2] = {{x, y - 1}, {x, y + 1}, {x + 1, y}, {x - 1, y}};
+            for (int k = 0; k < 4; ++k) {
+                const int nx = nb[k][0], ny = nb[k][1];
+                if (nx < 0 || ny < 0 || nx >= l.width || ny >= l.height) continue;
+                touching += (l.terrain[ny * l.width + nx] & 7) == OC_T_FLOOR ? 1 : 0;
+            }
+            shared_faces = shared_faces || touching >= 2;
+        }
         max_free = free_cells > max_free ? free_cells : max_free;
     }
     batch->max_pots = max_pots;
     batch->batch_flags = (two ? OC_BATCH_TWO_PLAYERS : 0u) | (any_old ? 0u : OC_BATCH_NEW_DYNAMICS) |
-                         (same_shaping ? OC_BATCH_UNIFORM_SHAPING : 0u);
+                         (same_shaping ? OC_BATCH_UNIFORM_SHAPING : 0u) | (shared_faces ? 0u : OC_BATCH_NO_SHARED_FACES);
     batch->max_free_cells = max_free;
     return OC_OK;
 }
@@ -396,7 +408,9 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
             // one wavefront per SIMD (or less): read the faced cells a step ahead; more: do not (see PIPE)
             // one wavefront per SIMD (or less) on a grid of at most 64 cells: 32-bit cell words (no re-masking of values
             // carried across steps, no shared banks) and the faced cells read a step ahead; more wavefronts: neither
-            if (pipe && b->width * b->height <= 64) GO4(true, 1, true, 1, true, false, 6, false, true, false, 4);
+            const bool noconf = (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0;
+            if (pipe && b->width * b->height <= 64 && noconf) GO4(true, 1, true, 1, true, false, 6, false, true, false, 4, true);
+            else if (pipe && b->width * b->height <= 64) GO4(true, 1, true, 1, true, false, 6, false, true, false, 4);
             else if (pipe) GO4(true, 1, true, 1, true, false, 6);
             else GO4(true, 1, true, 1, true, false, 6, false, false);
         }

@@ -438,12 +438,14 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
 //   variant whose entries carry the reward floats, as with a single layout
 // OLD: some layout of the table may use old dynamics (auto-start of full pots in the env effects)
 // EV: event_infos are logged (per-step masks and / or per-episode counters, EvArgs)
+// NOCONF: no non-floor cell of the layout touches two floor cells (hint OC_BATCH_NO_SHARED_FACES; cramped_room): the two players
+//   can never face the same cell, so player 1 never has to redo its interact on a cell player 0 has just changed
 // CW: bytes of a cell word (2, or 4 for the one-wavefront-per-SIMD instance of small single layouts: see cw_rd)
 // PIPE (MODE 1, 2): the next step's faced cells are read one step ahead.  That hides the read behind the tail of the step
 //   when a SIMD holds one wavefront (65 536 envs); with two or more wavefronts per SIMD the extra LDS traffic costs
 //   more than the latency it hides (131 072 cramped_room envs: 0.48 vs 0.65 us per batched step), so big batches turn it off
 template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false,
-          bool PIPE = true, bool RU = false, int CW = 2>
+          bool PIPE = true, bool RU = false, int CW = 2, bool NOCONF = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_rollout4(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                     const uint16_t* __restrict__ layout_id, uint4* st,
                                                     float4* __restrict__ rewards, uint8_t* __restrict__ flags,
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         //    line does not do them
         // A dish taken from the dispenser can only be "useful" when some pot is (pot_states before the interacts) and no
         // dish lies on a counter — before, or after player 0's own pick-up.
-        const bool conflict = (fo0 == fo1) & ((r0 & F4_CHG) != 0u);
+        const bool conflict = NOCONF ? false : (fo0 == fo1) & ((r0 & F4_CHG) != 0u);
         bool dish_ok = min(dc_before, dc_mid) == 0u;
         if (PW) {
             bool any_useful = false;
