@@ -1,6 +1,6 @@
 // common.hpp — constants, the OcLayout accessor, per-env working registers, Philox, layout staging
 // Part of liboc_amd.so: included by oc_amd.hip inside its anonymous namespace, in this order:
-//   common, step_predicate, step_table, rollout_pair, reset, encode, featurize, potential, shaping.
+//   common, reset, step_predicate, step_table, step_one, step_lut4, rollout_pair, encode, rollout_encode, featurize, potential, shaping.
 #pragma once
 
 constexpr int BLOCK = 256;

@@ -1,6 +1,6 @@
 // encode.hpp — lossless_state_encoding: k_encode, k_encode_uniform
 // Part of liboc_amd.so: included by oc_amd.hip inside its anonymous namespace, in this order:
-//   common, step_predicate, step_table, rollout_pair, reset, encode, featurize, potential, shaping.
+//   common, reset, step_predicate, step_table, step_one, step_lut4, rollout_pair, encode, rollout_encode, featurize, potential, shaping.
 #pragma once
 
 // ------------------------------------------------------------------------------------------

@@ -36,6 +36,7 @@ namespace {
 #include "reset.hpp"
 #include "step_predicate.hpp"
 #include "step_table.hpp"
+#include "step_one.hpp"
 #include "step_lut4.hpp"
 #include "rollout_pair.hpp"
 #include "encode.hpp"
@@ -192,6 +193,20 @@ void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_st
     const size_t smem = (size_t)n_obj * 8 * BLOCK * sizeof(uint32_t);
     const dim3 grid(grid_for(b->n_envs)), block(BLOCK);
     if (!(options & OC_OPT_PREDICATE_INTERACT)) {
+        // one step, in place, no event logging, at most 64 cells: the transition on the wire format itself (step_one.hpp)
+        static const bool no_lean = getenv("OC_STEP_NO_LEAN") != nullptr;  // developer knob: k_step3 for every oc_step
+        if (!EVENTS && n_steps == 1 && d_state_in == d_state_out && n_obj <= STEP1_MAX_PLANES && !no_lean) {
+            const size_t smem1 = (size_t)n_obj * BLOCK * sizeof(uint4);
+#define GO1(U, MP, LL)                                                                                                \
+    hipLaunchKernelGGL((k_step1<U, MP, LL>), grid, block, smem1, s, b->d_layouts, b->n_layouts, b->d_layout_id,      \
+                       (uint4*)d_state_out, d_actions, (float4*)d_rewards, d_flags, (float4*)d_ep_returns, b->n_envs, \
+                       b->width, n_obj, horizon, options, sa)
+            if (uniform) { if (b->max_pots == 1) GO1(true, 1, true); else if (small) GO1(true, 2, true); else GO1(true, 8, true); }
+            else if (lds) { if (small) GO1(false, 2, true); else GO1(false, 8, true); }
+            else { if (small) GO1(false, 2, false); else GO1(false, 8, false); }
+#undef GO1
+            return;
+        }
 #define GO3(U, MP, LL, F)                                                                                            \
     do {                                                                                                             \
         if (!want_lds(k_step3<U, MP, LL, F, EVENTS>, smem)) break;                                                   \

@@ -1,6 +1,6 @@
 // potential.hpp — potential_function: k_potential, k_potential2
 // Part of liboc_amd.so: included by oc_amd.hip inside its anonymous namespace, in this order:
-//   common, step_predicate, step_table, rollout_pair, reset, encode, featurize, potential, shaping.
+//   common, reset, step_predicate, step_table, step_one, step_lut4, rollout_pair, encode, rollout_encode, featurize, potential, shaping.
 #pragma once
 
 // ------------------------------------------------------------------------------------------

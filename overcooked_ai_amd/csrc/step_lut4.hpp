@@ -669,6 +669,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             dish_ok &= any_useful;
         }
         uint32_t gate = dish_ok ? (uint32_t)(F4_SERVE | F4_TAKE_DISH) : (uint32_t)F4_SERVE;
+#ifdef OC_WHATIF_NODISH
+        gate = F4_SERVE;
+#endif
+#ifdef OC_WHATIF_NOSERVE
+        gate = dish_ok ? (uint32_t)F4_TAKE_DISH : 0u;
+#endif
         if (!FAST_START || zero_cook) gate |= F4_START;
         if (OLD) gate |= C.old_dyn ? (uint32_t)F4_PLACE : 0u;  // old dynamics: the third item starts the pot (Q11)
         bool rare = (((r0 | r1) & gate) != 0u) | done | conflict;

@@ -1,6 +1,6 @@
 // step_predicate.hpp — get_state_transition with the predicate-network interact (emits event_infos): k_step, k_rollout
 // Part of liboc_amd.so: included by oc_amd.hip inside its anonymous namespace, in this order:
-//   common, step_predicate, step_table, rollout_pair, reset, encode, featurize, potential, shaping.
+//   common, reset, step_predicate, step_table, step_one, step_lut4, rollout_pair, encode, rollout_encode, featurize, potential, shaping.
 #pragma once
 
 // EVENT_TYPES bit helpers (mdp.py:1027-1058): bit 2*k + player

@@ -14,6 +14,8 @@ from . import _lib
 from .layouts import LayoutSpec, LayoutTable, spec_from_name
 from .state import pack_states, unpack_states
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # (device index) -> hipStream_t as an int
+
 
 def as_layout_table(layouts, pad_to=None):
     if isinstance(layouts, LayoutTable):
@@ -118,6 +120,10 @@ class VecOvercookedEnv:
             raise ValueError("%s must be a contiguous %s tensor with %d elements on %s" % (what, dtype, numel, self.state.device))
 
     def _stream(self):
+        """Raw handle of torch's current stream on this env's device (torch.cuda.current_stream() builds a Stream object
+        per call: 2.7 us of the 8 us a one-step call used to cost on the host; the raw getter is 0.06 us)."""
+        if _raw_stream is not None:
+            return _raw_stream(self._dev_index)
         return torch.cuda.current_stream(self.device).cuda_stream
 
     @property
@@ -212,9 +218,9 @@ class VecOvercookedEnv:
     def _launch(self, fn, *args):
         """Call a C-ABI entry point with this env's device current (skips the context switch when it already is)."""
         if torch.cuda.current_device() == self._dev_index:
-            return fn(*args, torch.cuda.current_stream().cuda_stream)
+            return fn(*args, self._stream())
         with torch.cuda.device(self.device):
-            return fn(*args, torch.cuda.current_stream().cuda_stream)
+            return fn(*args, self._stream())
 
     def step(self, actions, state_out=None, events_out=None):
         """actions: uint8 tensor [n_envs, 2] of action indices (Action.INDEX_TO_ACTION order).

@@ -219,6 +219,14 @@ def test_step_vs_oracle_random_states(n_envs, gpu):
         assert np.array_equal(u8(rew), rew_o) and np.array_equal(u8(flags), fl_o)
         assert np.array_equal(u8(env.ep_returns), ep_o)
         assert (fl_o & 2).any() or n_envs == 1
+        # the same step in place without event logging = k_step1 (the transition on the wire format itself), and through
+        # OC_STEP's out-of-place form = k_step3
+        lean = make_env(spec, n_envs, gpu, horizon=horizon, auto_reset=True)
+        lean.set_packed_state(st)
+        lean.ep_returns.copy_(torch.from_numpy(ep0))
+        rew2, flags2 = lean.step(torch.from_numpy(acts).to(gpu))
+        assert np.array_equal(lean.get_packed_state(), out_o), name
+        assert np.array_equal(u8(rew2), rew_o) and np.array_equal(u8(flags2), fl_o) and np.array_equal(u8(lean.ep_returns), ep_o)
 
 
 @pytest.mark.parametrize("kernel", ["default", "rollout_v3", "lane_pair", "predicate_interact"])
