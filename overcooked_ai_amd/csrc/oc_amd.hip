@@ -616,7 +616,22 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
                            d_phi_next, d_phi_cur, d_phi_start, reward_shaping_factor, d_shaped, d_done, b->n_envs,    \
                            b->width, b->height, n_obj, horizon, sa, ea);                                              \
     } while (0)
-                if (uniform && fast && b->max_pots == 1) GOT(true, 1, true, true);
+                static const bool no_lean = getenv("OC_STEP_NO_LEAN") != nullptr;  // developer knob: k_train_step always
+                if (!ev_on(ea) && n_obj <= STEP1_MAX_PLANES && !no_lean) {  // the transition on the wire format itself (step_one.hpp)
+                    const size_t smem1 = (size_t)n_obj * BLOCK * sizeof(uint4);
+#define GOT1(U, MP, LL)                                                                                                \
+    hipLaunchKernelGGL((k_train_step1<U, MP, LL>), grid, block, smem1, (hipStream_t)stream, b->d_layouts, b->n_layouts, \
+                       b->d_layout_id, (uint4*)d_state, d_actions, (float4*)d_rewards, d_flags, (float4*)d_ep_returns,  \
+                       (float4*)d_ep_returns_out, d_plan_blob, d_plan_off, d_phi_tables, d_phi_next, d_phi_cur,         \
+                       d_phi_start, reward_shaping_factor, d_shaped, d_done, b->n_envs, b->width, b->height, n_obj,     \
+                       horizon, sa)
+                    if (uniform && b->max_pots == 1) GOT1(true, 1, true);
+                    else if (uniform) GOT1(true, 2, true);
+                    else if (lds) GOT1(false, 2, true);
+                    else GOT1(false, 2, false);
+#undef GOT1
+                }
+                else if (uniform && fast && b->max_pots == 1) GOT(true, 1, true, true);
                 else if (uniform && fast) GOT(true, 2, true, true);
                 else if (uniform) GOT(true, 2, true, false);
                 else if (lds) GOT(false, 2, true, false);

@@ -23,74 +23,77 @@
 // ==========================================================================================
 constexpr int STEP1_MAX_PLANES = 4;
 
-template <bool UNIFORM, int MAXP, bool LAY_LDS>
-__global__ __launch_bounds__(BLOCK) void k_step1(const OcLayout* __restrict__ g_layouts, int n_layouts,
-                                                 const uint16_t* __restrict__ layout_id, uint4* st,
-                                                 const uint8_t* __restrict__ actions, float4* __restrict__ rewards,
-                                                 uint8_t* __restrict__ flags, float4* ep_returns, int64_t n, int W,
-                                                 int n_obj, int horizon, uint32_t options, StartArgs sa) {
-    extern __shared__ __attribute__((aligned(16))) uint4 s_rows1[];  // [n_obj][BLOCK]: the object planes, one 16-byte row per lane
-    __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];
-    __shared__ uint2 s_lut[2 * LUT_ENTRIES];
-    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const bool active = e < n;
-    const int64_t el = active ? e : n - 1;  // (the lanes past the batch load valid addresses and leave after the barrier)
-    // ---- one round trip: everything the step reads
-    const uint4 h = st[el];
-    const uint32_t a01 = reinterpret_cast<const uint16_t*>(actions)[el];
-    float4 ep = ep_returns ? ep_returns[el] : make_float4(0.f, 0.f, 0.f, 0.f);
-    uint4 v[STEP1_MAX_PLANES];
+// what a one-step kernel reads: requested together, before the first wait
+struct OneIn {
+    uint4 h;                       // header plane
+    uint4 v[STEP1_MAX_PLANES];     // object planes (zeros past n_obj)
+    uint32_t a01;                  // both actions
+    float4 ep;                     // episode returns so far
+};
+__device__ __forceinline__ OneIn one_load(const uint4* st, const uint8_t* __restrict__ actions, const float4* ep_returns,
+                                          int64_t n, int64_t el, int n_obj) {
+    OneIn in;
+    in.h = st[el];
+    in.a01 = reinterpret_cast<const uint16_t*>(actions)[el];
+    in.ep = ep_returns ? ep_returns[el] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int p = 0; p < STEP1_MAX_PLANES; ++p) v[p] = p < n_obj ? st[(int64_t)(1 + p) * n + el] : make_uint4(0u, 0u, 0u, 0u);
-    for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
-    Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains the barrier
-    if (!active) return;
-#pragma unroll
-    for (int p = 0; p < STEP1_MAX_PLANES; ++p)
-        if (p < n_obj) s_rows1[p * BLOCK + threadIdx.x] = v[p];  // read back by this lane only: no barrier
-    const uint8_t* row = reinterpret_cast<const uint8_t*>(s_rows1 + threadIdx.x);
-    auto obj_at = [&](uint32_t c) __attribute__((always_inline)) { return (uint32_t)row[(c >> 4) * (uint32_t)(BLOCK * 16) + (c & 15u)]; };
-    // the faced cell word of interact3: object byte | terrain byte << 8
-    auto cell16 = [&](uint32_t c) __attribute__((always_inline)) { return obj_at(c) | (L.terrain(c) << 8); };
-    LayC C = load_consts<UNIFORM>(L);
-    const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut) + (C.old_dyn ? LUT_ENTRIES * 8 : 0);
-    const uint32_t delta4 = make_delta4(W);
+    for (int p = 0; p < STEP1_MAX_PLANES; ++p) in.v[p] = p < n_obj ? st[(int64_t)(1 + p) * n + el] : make_uint4(0u, 0u, 0u, 0u);
+    return in;
+}
 
+// object byte of cell c in this lane's planes parked in LDS ([plane][BLOCK] rows of 16 bytes)
+__device__ __forceinline__ uint32_t one_obj(const uint8_t* row, uint32_t c) {
+    return (uint32_t)row[(c >> 4) * (uint32_t)(BLOCK * 16) + (c & 15u)];
+}
+
+// one env in flight: the registers of env_step3 plus what the step changed on the grid
+template <int MAXP>
+struct One {
     Env3<MAXP> s;
+    uint32_t ps_in[MAXP];  // pot objects as loaded
+    uint32_t f0, f1;       // faced cells
+    uint32_t o0, o1;       // their object bytes after the interacts
+    bool w0, w1;           // ... to be written back (counter pick-ups / drops)
+};
+
+template <int MAXP>
+__device__ __forceinline__ void one_decode(const LayC& C, const Lay L, const uint4 h, const uint8_t* row, One<MAXP>& q) {
+    Env3<MAXP>& s = q.s;
     s.pos0 = h.x & 0xFFu; s.or0 = (h.x >> 8) & 0xFFu; s.held0 = (h.x >> 16) & 0xFFu; s.pos1 = h.x >> 24;
     s.or1 = h.y & 0xFFu; s.held1 = (h.y >> 8) & 0xFFu; s.t = h.y >> 16;
     s.dcount = 0;
-    uint32_t ps_in[MAXP];
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
         s.ps[k] = 0; s.tk[k] = 0; s.pc[k] = PC_EMPTY;
         if ((uint32_t)k < C.n_pots) {
-            s.ps[k] = obj_at(L.pot_cell(k));
+            s.ps[k] = one_obj(row, L.pot_cell(k));
             s.tk[k] = ((k < 4 ? h.z : h.w) >> (8 * (k & 3))) & 0xFFu;
             s.pc[k] = pot_class(C, s.ps[k], s.tk[k]);
         }
-        ps_in[k] = s.ps[k];
+        q.ps_in[k] = s.ps[k];
     }
+    q.f0 = q.f1 = q.o0 = q.o1 = 0;
+    q.w0 = q.w1 = false;
+}
 
-    const uint32_t a0 = a01 & 0xFFu, a1 = a01 >> 8;
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t fl = 0;
-    if (__builtin_expect(a0 > 5u || a1 > 5u, 0)) {  // get_state_transition raises ValueError (mdp.py:1394-1398): the env stays as it is
-        rewards[e] = r;
-        flags[e] = (uint8_t)OC_F_BAD_ACTION;
-        return;
-    }
+// get_state_transition (mdp.py:1375-1430) for legal actions a0, a1: the sequencing of step3_main (both interacts against
+// the pre-step pots / cells, player 1 again when player 0 changed what it faces), movement on the layout's terrain bytes,
+// step3_env.  r = (sparse0, sparse1, shaped0, shaped1).
+template <int MAXP>
+__device__ __forceinline__ void one_transition(const LayC& C, const Lay L, const uint8_t* lut, uint32_t delta4, uint32_t a0,
+                                               uint32_t a1, const uint4 (&v)[STEP1_MAX_PLANES], int n_obj,
+                                               const uint8_t* row, One<MAXP>& q, float4& r) {
+    Env3<MAXP>& s = q.s;
     const bool two = s.pos1 != 0xFFu;
     const bool mv0 = a0 < 4u, mv1 = two & (a1 < 4u);
     // the faced cells (pre-move pose, mdp.py:1452-1454) and the move targets
     const uint32_t f0 = step_cell(s.pos0, s.or0, delta4), f1 = two ? step_cell(s.pos1, s.or1, delta4) : f0;
     const uint32_t m0 = mv0 ? step_cell(s.pos0, a0, delta4) : s.pos0;
     const uint32_t m1 = mv1 ? step_cell(s.pos1, a1, delta4) : (two ? s.pos1 : s.pos0);
-    const uint32_t c_f0 = cell16(f0), c_f1 = cell16(f1);
+    const uint32_t c_f0 = one_obj(row, f0) | (L.terrain(f0) << 8), c_f1 = one_obj(row, f1) | (L.terrain(f1) << 8);  // interact3's cell words
     const uint32_t t_m0 = L.terrain(m0) & 7u, t_m1 = L.terrain(m1) & 7u;
 
-    // ---- resolve_interacts (mdp.py:1432-1579): both players against the pre-step pots / cells, player 1 again when
-    //      player 0 changed what it faces
+    // ---- resolve_interacts (mdp.py:1432-1579)
     uint32_t useful_pots = 0;  // pot_states before any interact (mdp.py:1439): ready / cooking / 1..2 idle items
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) useful_pots += ((s.pc[k] != PC_EMPTY) & (s.pc[k] != PC_IDLE3)) ? 1u : 0u;
@@ -124,6 +127,10 @@ __global__ __launch_bounds__(BLOCK) void k_step1(const OcLayout* __restrict__ g_
     s.held1 = r1.new_h;
     apply_pot3<MAXP>(s, r1);
     const bool swap1 = (r1.flags & LF_SWAP) != 0u;
+    // (counter cells: the faced cell after a pick-up / drop; player 1's result stands when both changed the same cell)
+    q.f0 = f0; q.f1 = f1; q.o0 = r0.cell_obj; q.o1 = r1.cell_obj;
+    q.w0 = swap0 & !(same_cell & swap1);
+    q.w1 = swap1;
     // deliver_soup (mdp.py:1631-1642): the recipe-value look-ups behind a wave-uniform branch
     float sp0 = 0.f, sp1 = 0.f;
     const bool serve0 = (r0.flags & LF_SERVE) != 0u, serve1 = (r1.flags & LF_SERVE) != 0u;
@@ -142,49 +149,39 @@ __global__ __launch_bounds__(BLOCK) void k_step1(const OcLayout* __restrict__ g_
     s.pos0 = collide ? s.pos0 : np0;
     s.pos1 = collide ? s.pos1 : np1;
     step3_env<MAXP>(C, s);  // step_environment_effects (mdp.py:1691-1703)
+}
 
-    // ---- OvercookedEnv.step bookkeeping (env.py:266-267, 321-325)
-    ep.x += r.x; ep.y += r.y; ep.z += r.z; ep.w += r.w;
+// the env's next episode: the layout's standard start state, or one drawn by the batch's start_state_fn
+// (get_random_start_state_fn, mdp.py:1307-1353) — players, hands, pots; nothing lies on the counters
+template <int MAXP>
+__device__ __forceinline__ void one_restart(const LayC& C, const Lay L, const StartArgs& sa, uint64_t g, Env3<MAXP>& s) {
+    s.pos0 = L.u8(L_START_POS); s.pos1 = L.u8(L_START_POS + 1);
+    s.or0 = L.u8(L_START_OR); s.or1 = s.pos1 == 0xFFu ? 0u : L.u8(L_START_OR + 1);
+    s.held0 = s.held1 = 0; s.t = 0; s.dcount = 0;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) { s.ps[k] = 0; s.tk[k] = 0; s.pc[k] = PC_EMPTY; }
+    if (sa.enabled) {
+        const StartDraw d = draw_start(L, g, sa.epoch, sa.seed_lo, sa.seed_hi, sa.random_start_pos, sa.thresh);
+        s.pos0 = d.pos0; s.pos1 = d.pos1; s.held0 = d.held[0]; s.held1 = d.held[1];
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            if ((uint32_t)k < C.n_pots) {
+                s.ps[k] = d.pot_obj[k];
+                s.tk[k] = (d.ticks[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            }
+        }
+    }
+}
+
+// write-back: the header always; the planes from scratch for a restarted env, else only the object bytes that changed
+template <int MAXP>
+__device__ __forceinline__ void one_store(const LayC& C, const Lay L, uint4* st, int64_t n, int64_t e, int n_obj,
+                                          const One<MAXP>& q, bool restarted) {
+    const Env3<MAXP>& s = q.s;
     uint8_t* gbytes = reinterpret_cast<uint8_t*>(st);
     auto store_obj = [&](uint32_t c, uint32_t o) __attribute__((always_inline)) {
         gbytes[((int64_t)(1 + (c >> 4)) * n + e) * 16 + (c & 15u)] = (uint8_t)o;
     };
-    bool restarted = false;
-    if (__builtin_expect((int)s.t >= horizon, 0)) {  // once per episode
-        fl |= OC_F_DONE;
-        if (options & OC_OPT_AUTO_RESET) {
-            const uint64_t g = (uint64_t)(sa.env_offset + e);
-            uint32_t lid;
-            regen_layout<UNIFORM, LAY_LDS>(sa, g, sa.epoch, e, s_lay, g_layouts, L, C, &lid);  // (regen_mdp: the next episode's layout)
-            s.pos0 = L.u8(L_START_POS); s.pos1 = L.u8(L_START_POS + 1);
-            s.or0 = L.u8(L_START_OR); s.or1 = s.pos1 == 0xFFu ? 0u : L.u8(L_START_OR + 1);
-            s.held0 = s.held1 = 0; s.t = 0;
-#pragma unroll
-            for (int k = 0; k < MAXP; ++k) { s.ps[k] = 0; s.tk[k] = 0; }
-            if (sa.enabled) {  // the batch's start_state_fn (get_random_start_state_fn, mdp.py:1307-1353)
-                const StartDraw d = draw_start(L, g, sa.epoch, sa.seed_lo, sa.seed_hi, sa.random_start_pos, sa.thresh);
-                s.pos0 = d.pos0; s.pos1 = d.pos1; s.held0 = d.held[0]; s.held1 = d.held[1];
-#pragma unroll
-                for (int k = 0; k < MAXP; ++k) {
-                    if ((uint32_t)k < C.n_pots) {
-                        s.ps[k] = d.pot_obj[k];
-                        s.tk[k] = (d.ticks[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                    }
-                }
-            }
-            ep = make_float4(0.f, 0.f, 0.f, 0.f);
-            fl |= OC_F_RESET;
-            restarted = true;
-            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-            for (int p = 0; p < STEP1_MAX_PLANES; ++p)
-                if (p < n_obj) st[(int64_t)(1 + p) * n + e] = z;
-#pragma unroll
-            for (int k = 0; k < MAXP; ++k)
-                if ((uint32_t)k < C.n_pots && s.ps[k] != 0u) store_obj(L.pot_cell(k), s.ps[k]);  // (same lane, after the zeros)
-        }
-    }
-    // ---- the header, and the object bytes this step changed
     uint4 ho;
     ho.x = s.pos0 | (s.or0 << 8) | (s.held0 << 16) | (s.pos1 << 24);
     ho.y = s.or1 | (s.held1 << 8) | (min(s.t, 0xFFFFu) << 16);  // the wire format's u16 timestep saturates
@@ -197,14 +194,72 @@ __global__ __launch_bounds__(BLOCK) void k_step1(const OcLayout* __restrict__ g_
         }
     }
     st[e] = ho;
-    if (!restarted) {
-        // (counter cells: the faced cell after a pick-up / drop; player 1's result stands when both changed the same cell)
-        if (swap0 & !(same_cell & swap1)) store_obj(f0, r0.cell_obj);
-        if (swap1) store_obj(f1, r1.cell_obj);
+    if (restarted) {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int p = 0; p < STEP1_MAX_PLANES; ++p)
+            if (p < n_obj) st[(int64_t)(1 + p) * n + e] = z;
 #pragma unroll
         for (int k = 0; k < MAXP; ++k)
-            if ((uint32_t)k < C.n_pots && s.ps[k] != ps_in[k]) store_obj(L.pot_cell(k), s.ps[k]);
+            if ((uint32_t)k < C.n_pots && s.ps[k] != 0u) store_obj(L.pot_cell(k), s.ps[k]);  // (same lane, after the zeros)
+    } else {
+        if (q.w0) store_obj(q.f0, q.o0);
+        if (q.w1) store_obj(q.f1, q.o1);
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k)
+            if ((uint32_t)k < C.n_pots && s.ps[k] != q.ps_in[k]) store_obj(L.pot_cell(k), s.ps[k]);
     }
+}
+
+template <bool UNIFORM, int MAXP, bool LAY_LDS>
+__global__ __launch_bounds__(BLOCK) void k_step1(const OcLayout* __restrict__ g_layouts, int n_layouts,
+                                                 const uint16_t* __restrict__ layout_id, uint4* st,
+                                                 const uint8_t* __restrict__ actions, float4* __restrict__ rewards,
+                                                 uint8_t* __restrict__ flags, float4* ep_returns, int64_t n, int W,
+                                                 int n_obj, int horizon, uint32_t options, StartArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) uint4 s_rows1[];  // [n_obj][BLOCK]: the object planes, one 16-byte row per lane
+    __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];
+    __shared__ uint2 s_lut[2 * LUT_ENTRIES];
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = e < n;
+    const int64_t el = active ? e : n - 1;  // (the lanes past the batch load valid addresses and leave after the barrier)
+    const OneIn in = one_load(st, actions, ep_returns, n, el, n_obj);  // ---- one round trip: everything the step reads
+    for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
+    Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains the barrier
+    if (!active) return;
+#pragma unroll
+    for (int p = 0; p < STEP1_MAX_PLANES; ++p)
+        if (p < n_obj) s_rows1[p * BLOCK + threadIdx.x] = in.v[p];  // read back by this lane only: no barrier
+    const uint8_t* row = reinterpret_cast<const uint8_t*>(s_rows1 + threadIdx.x);
+    LayC C = load_consts<UNIFORM>(L);
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut) + (C.old_dyn ? LUT_ENTRIES * 8 : 0);
+    One<MAXP> q;
+    one_decode<MAXP>(C, L, in.h, row, q);
+    const uint32_t a0 = in.a01 & 0xFFu, a1 = in.a01 >> 8;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f), ep = in.ep;
+    if (__builtin_expect(a0 > 5u || a1 > 5u, 0)) {  // get_state_transition raises ValueError (mdp.py:1394-1398): the env stays as it is
+        rewards[e] = r;
+        flags[e] = (uint8_t)OC_F_BAD_ACTION;
+        return;
+    }
+    one_transition<MAXP>(C, L, lut, make_delta4(W), a0, a1, in.v, n_obj, row, q, r);
+    // ---- OvercookedEnv.step bookkeeping (env.py:266-267, 321-325)
+    ep.x += r.x; ep.y += r.y; ep.z += r.z; ep.w += r.w;
+    uint32_t fl = 0;
+    bool restarted = false;
+    if (__builtin_expect((int)q.s.t >= horizon, 0)) {  // once per episode
+        fl |= OC_F_DONE;
+        if (options & OC_OPT_AUTO_RESET) {
+            const uint64_t g = (uint64_t)(sa.env_offset + e);
+            uint32_t lid;
+            regen_layout<UNIFORM, LAY_LDS>(sa, g, sa.epoch, e, s_lay, g_layouts, L, C, &lid);  // (regen_mdp: the next episode's layout)
+            one_restart<MAXP>(C, L, sa, g, q.s);
+            ep = make_float4(0.f, 0.f, 0.f, 0.f);
+            fl |= OC_F_RESET;
+            restarted = true;
+        }
+    }
+    one_store<MAXP>(C, L, st, n, e, n_obj, q, restarted);
     rewards[e] = r;
     flags[e] = (uint8_t)fl;
     if (ep_returns) ep_returns[e] = ep;
