@@ -237,6 +237,9 @@ int oc_state_planes(int width, int height);
  *   events         per-episode event counters / masks (OcEventSink), or NULL
  *   horizon        done when timestep >= horizon (1..65535; the stored timestep is a u16 that saturates at 65535 — the
  *                  Python OvercookedEnv keeps the reference's default horizon of 1e10 but raises at that limit)
+ * In place (d_state_out == d_state_in) without event logging, on grids of at most 64 cells, the step runs on the wire format
+ * itself (k_step1: header + changed object bytes written back, <= 4.3 us per batched step of 65 536 envs, launch-bound); other
+ * forms unpack the env (k_step3, 5.7-7.0 us).  Same results.
  */
 int oc_step(const OcBatch* batch, const void* d_state_in, void* d_state_out, const uint8_t* d_actions,
             float* d_rewards, uint8_t* d_flags, float* d_ep_returns, uint64_t* d_events, int horizon,

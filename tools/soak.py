@@ -93,9 +93,16 @@ def main():
             assert np.array_equal(env.get_packed_state(), st2) and np.array_equal(r.cpu().numpy(), r2) and np.array_equal(f.cpu().numpy(), f2), ("step", seed)
             assert np.array_equal(ev.cpu().numpy().view(np.uint64), orc.last_events), ("events", seed)
             st = st2
-            t0 += 0
-            done += 1
-            total += n * (k + 1)
+            # the same call in place without event logging = k_step1 (the transition on the wire format), an illegal action now and then
+            acts = rng.integers(0, 6, size=(n, 2)).astype(np.uint8)
+            acts[rng.integers(0, n, 2), rng.integers(0, 2, 2)] = 6 + int(rng.integers(0, 200))
+            sp = spec_now()
+            r, f = env.step(torch.from_numpy(acts).to(dev))
+            st, r2, f2 = orc.step(st, acts, horizon=horizon, options=1, layout_id=lid, start=sp)
+            assert np.array_equal(env.get_packed_state(), st) and np.array_equal(r.cpu().numpy(), r2) and np.array_equal(f.cpu().numpy(), f2), ("lean step", seed)
+            assert lid is None or np.array_equal(env.layout_ids(), lid), ("layout ids after the lean step", seed, done)
+            done += 2
+            total += n * (k + 2)
         # K caller-supplied-action transitions in one launch (oc_step_many), illegal actions included
         K = int(rng.integers(2, 40))
         a = rng.integers(0, 6, size=(K, n, 2)).astype(np.uint8)
