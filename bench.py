@@ -976,7 +976,31 @@ def bench_training_env(dev, torch, iters=300):
         torch.cuda.synchronize(dev)
         wall = time.perf_counter() - t0
         out[name] = {"value": n * iters / wall, "unit": "env steps/s", "us_per_batched_step": wall / iters * 1e6}
-    out["note"] = "per batched step: one oc_multi_agent_step call = k_train_step (step + phi + shaped rewards + restart, fused) + k_encode"
+        if name == "obs_u8":  # the same chain (k_train_step1 -> k_encode) replayed from a HIP graph of 16 captured steps
+            try:
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    env.step(acts[0])
+                torch.cuda.current_stream(dev).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for i in range(16):
+                        env.step(acts[i])
+                for _ in range(3):
+                    g.replay()
+                torch.cuda.synchronize(dev)
+                reps = max(1, iters // 16)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    g.replay()
+                torch.cuda.synchronize(dev)
+                wall_g = time.perf_counter() - t0
+                out[name]["graph_replay_us_per_batched_step"] = wall_g / (16 * reps) * 1e6
+            except Exception as exc:
+                out[name]["graph_replay_error"] = repr(exc)[:200]
+    out["note"] = ("per batched step: one oc_multi_agent_step call = k_train_step1 (step + phi + shaped rewards + restart, fused, on the "
+                   "wire format) + k_encode; graph_replay: 16 such calls captured in one HIP graph")
     return out
 
 

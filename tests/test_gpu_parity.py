@@ -657,6 +657,38 @@ def test_hip_graph_capture_of_step_and_encode(gpu):
     assert torch.equal(env.state, ref.state) and torch.equal(obs, obs_ref) and torch.equal(env.ep_returns, ref.ep_returns)
 
 
+def test_hip_graph_capture_of_the_training_step(gpu):
+    """oc_multi_agent_step (k_train_step1 + k_encode: step, phi, shaped rewards, restart, observation) enqueues on the
+    caller's stream without synchronising: captured in a HIP graph and replayed with new actions it gives what the eager
+    calls give — the (actions -> step -> observation) chain of a policy loop without per-kernel launches."""
+    from overcooked_ai_amd.multi_agent import VecOvercookedMultiAgent
+
+    n = 3000
+    kw = dict(horizon=40, reward_shaping_factor=0.7, use_phi=True, obs_dtype=torch.uint8, device=gpu)
+    env = VecOvercookedMultiAgent("cramped_room", n, **kw)
+    ref = VecOvercookedMultiAgent("cramped_room", n, **kw)
+    acts = torch.zeros((n, 2), dtype=torch.uint8, device=gpu)
+    side = torch.cuda.Stream(device=gpu)
+    side.wait_stream(torch.cuda.current_stream(gpu))
+    with torch.cuda.stream(side):
+        env.step(acts)  # (builds the potential tables outside the capture)
+    torch.cuda.current_stream(gpu).wait_stream(side)
+    ref.step(acts)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        obs, shaped, done, infos = env.step(acts)
+    graph.replay()  # (capturing recorded the call without running it)
+    ref.step(acts)
+    gen = torch.Generator(device=gpu).manual_seed(5)
+    for k in range(55):  # crosses the horizon: finished envs restart inside the captured call
+        acts.copy_(torch.randint(0, 6, (n, 2), dtype=torch.uint8, device=gpu, generator=gen))
+        graph.replay()
+        obs_r, shaped_r, done_r, infos_r = ref.step(acts)
+        assert torch.equal(shaped, shaped_r) and torch.equal(done, done_r) and torch.equal(obs, obs_r), k
+        assert torch.equal(infos["phi_s_prime"], infos_r["phi_s_prime"]), k
+    assert torch.equal(env.venv.state, ref.venv.state) and done_r.sum() >= 0
+
+
 def test_fused_training_step_equals_the_kernel_sequence(gpu):
     """oc_multi_agent_step runs k_train_step (one kernel) for two-player tables with <= 2 pots and the sequence
     oc_step -> oc_potential -> oc_shape_rewards -> copy -> oc_reset otherwise; both must produce identical states,
