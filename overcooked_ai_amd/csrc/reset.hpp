@@ -40,10 +40,15 @@ constexpr uint32_t RESET_KEY_TWEAK = 0x52535421u;  // "RST!"
 
 // What a randomized start consists of; players face NORTH, nothing lies on the counters, timestep 0.
 struct StartDraw {
-    uint32_t pos0, pos1;          // cells (pos1 = 0xFF on one-player layouts)
-    uint32_t held[2];             // object codes
-    uint32_t ticks[2];            // header bytes 8..15: cooking_tick + 1 per pot slot
-    uint8_t pot_obj[OC_MAX_POTS]; // soup code per pot slot (0 = empty)
+    uint32_t pos0, pos1;      // cells (pos1 = 0xFF on one-player layouts)
+    uint32_t held0, held1;    // object codes
+    uint32_t ticks0, ticks1;  // header bytes 8..15: cooking_tick + 1 per pot slot
+    uint32_t pots0, pots1;    // soup code per pot slot, one byte each (0 = empty)
+    // (plain words, no arrays: a dynamically indexed member array becomes a stack object — scratch in the step kernels, LDS
+    //  plus a read of the dispatch packet in host memory, ~10 us per launch, in k_reset_random; tools/launch_floor.hip)
+    __device__ __forceinline__ uint32_t held(uint32_t i) const { return i ? held1 : held0; }
+    __device__ __forceinline__ uint32_t tick(uint32_t k) const { return ((k < 4u ? ticks0 : ticks1) >> (8u * (k & 3u))) & 0xFFu; }
+    __device__ __forceinline__ uint32_t pot_obj(uint32_t k) const { return ((k < 4u ? pots0 : pots1) >> (8u * (k & 3u))) & 0xFFu; }
 };
 
 // Launch-time description of the start_state_fn (include/oc_amd.h, OcStartSpec), by value in kernel arguments.
@@ -120,10 +125,10 @@ __device__ __forceinline__ StartDraw draw_start(const Lay L, uint64_t g, uint32_
             ++seen;
         }
     }
-    d.held[0] = d.held[1] = 0u;
-    d.ticks[0] = d.ticks[1] = 0u;
+    d.held0 = d.held1 = 0u;
+    d.ticks0 = d.ticks1 = 0u;
+    d.pots0 = d.pots1 = 0u;
     const uint32_t n_pots = L.n_pots();
-    for (uint32_t k = 0; k < (uint32_t)OC_MAX_POTS; ++k) d.pot_obj[k] = 0;
     auto soup_code = [](uint32_t n_on, uint32_t n_to) {  // onions first, then tomatoes (SoupState.get_soup, mdp.py:664-693)
         return OC_O_SOUP | ((n_on + n_to) << 3) | (((1u << n_to) - 1u) << n_on);
     };
@@ -132,15 +137,17 @@ __device__ __forceinline__ StartDraw draw_start(const Lay L, uint64_t g, uint32_
             philox4x32_10(epoch, g_lo, g_hi, 1u + i, seed_lo, k1, r);
             if ((uint64_t)r[0] < thresh) {
                 const uint32_t n_on = 1u + __umulhi(r[2], 3u), n_to = __umulhi(r[3], 4u - n_on);
-                d.held[i] = r[1] < 858993459u ? (uint32_t)OC_O_DISH : r[1] < 3435973836u ? (uint32_t)OC_O_ONION : soup_code(n_on, n_to);
+                const uint32_t h = r[1] < 858993459u ? (uint32_t)OC_O_DISH : r[1] < 3435973836u ? (uint32_t)OC_O_ONION : soup_code(n_on, n_to);
+                if (i) d.held1 = h; else d.held0 = h;
             }
         }
         for (uint32_t k = 0; k < n_pots; ++k) {
             philox4x32_10(epoch, g_lo, g_hi, 3u + k, seed_lo, k1, r);
             if ((uint64_t)r[0] < thresh) {
                 const uint32_t n_on = 1u + __umulhi(r[1], 3u), n_to = __umulhi(r[2], 4u - n_on);
-                d.pot_obj[k] = (uint8_t)soup_code(n_on, n_to);
-                if ((uint64_t)r[3] < thresh) d.ticks[k >> 2] |= 1u << (8u * (k & 3u));  // cooking_tick 0 -> stored 1
+                const uint32_t sh = 8u * (k & 3u), code = (soup_code(n_on, n_to) & 0xFFu) << sh;
+                const uint32_t tick = ((uint64_t)r[3] < thresh) ? 1u << sh : 0u;  // cooking_tick 0 -> stored 1
+                if (k < 4u) { d.pots0 |= code; d.ticks0 |= tick; } else { d.pots1 |= code; d.ticks1 |= tick; }
             }
         }
     }
@@ -161,14 +168,15 @@ __global__ __launch_bounds__(BLOCK) void k_reset_random(const OcLayout* __restri
     const Lay L{reinterpret_cast<const uint8_t*>(g_layouts) + (size_t)lid * 256u};
     const StartDraw d = draw_start(L, (uint64_t)(env_offset + e), epoch, seed_lo, seed_hi, random_start_pos, thresh);
     const uint32_t np = L.n_players(), n_pots = L.n_pots();
-    st[e] = make_uint4(d.pos0 | (d.held[0] << 16) | (d.pos1 << 24), np == 2u ? (d.held[1] << 8) : 0u, d.ticks[0], d.ticks[1]);
+    st[e] = make_uint4(d.pos0 | (d.held0 << 16) | (d.pos1 << 24), np == 2u ? (d.held1 << 8) : 0u, d.ticks0, d.ticks1);
     for (int p = 0; p < n_obj; ++p) {
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        uint32_t w0 = 0u, w1 = 0u, w2 = 0u, w3 = 0u;
         for (uint32_t k = 0; k < n_pots; ++k) {
-            const uint32_t c = L.pot_cell((int)k);
-            if ((int)(c >> 4) == p) w[(c >> 2) & 3u] |= (uint32_t)d.pot_obj[k] << (8u * (c & 3u));
+            const uint32_t c = L.pot_cell((int)k), q = (c >> 2) & 3u;
+            const uint32_t v = (int)(c >> 4) == p ? d.pot_obj(k) << (8u * (c & 3u)) : 0u;
+            w0 |= q == 0u ? v : 0u; w1 |= q == 1u ? v : 0u; w2 |= q == 2u ? v : 0u; w3 |= q == 3u ? v : 0u;
         }
-        st[(int64_t)(1 + p) * n + e] = make_uint4(w[0], w[1], w[2], w[3]);
+        st[(int64_t)(1 + p) * n + e] = make_uint4(w0, w1, w2, w3);
     }
     if (ep_returns) ep_returns[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 }

@@ -416,11 +416,11 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
                                                 const StartDraw& d) {
     env_reset4<MAXP, CW>(C, L, n_obj, horizon, s, col);
     s.pos0 = d.pos0; s.pos1 = d.pos1;
-    s.h0 = d.held[0] << 8; s.h1 = d.held[1] << 8;
+    s.h0 = d.held0 << 8; s.h1 = d.held1 << 8;
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
         if ((uint32_t)k < C.n_pots) {
-            const uint32_t o = d.pot_obj[k], tkb = (d.ticks[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            const uint32_t o = d.pot_obj((uint32_t)k), tkb = d.tick((uint32_t)k);
             const uint32_t pc = pot_class(C, o, tkb);
             s.tk[k] = tkb;
             s.rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) : REM_IDLE;
@@ -669,12 +669,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             dish_ok &= any_useful;
         }
         uint32_t gate = dish_ok ? (uint32_t)(F4_SERVE | F4_TAKE_DISH) : (uint32_t)F4_SERVE;
-#ifdef OC_WHATIF_NODISH
-        gate = F4_SERVE;
-#endif
-#ifdef OC_WHATIF_NOSERVE
-        gate = dish_ok ? (uint32_t)F4_TAKE_DISH : 0u;
-#endif
         if (!FAST_START || zero_cook) gate |= F4_START;
         if (OLD) gate |= C.old_dyn ? (uint32_t)F4_PLACE : 0u;  // old dynamics: the third item starts the pot (Q11)
         bool rare = (((r0 | r1) & gate) != 0u) | done | conflict;

@@ -162,12 +162,12 @@ __device__ __forceinline__ void one_restart(const LayC& C, const Lay L, const St
     for (int k = 0; k < MAXP; ++k) { s.ps[k] = 0; s.tk[k] = 0; s.pc[k] = PC_EMPTY; }
     if (sa.enabled) {
         const StartDraw d = draw_start(L, g, sa.epoch, sa.seed_lo, sa.seed_hi, sa.random_start_pos, sa.thresh);
-        s.pos0 = d.pos0; s.pos1 = d.pos1; s.held0 = d.held[0]; s.held1 = d.held[1];
+        s.pos0 = d.pos0; s.pos1 = d.pos1; s.held0 = d.held0; s.held1 = d.held1;
 #pragma unroll
         for (int k = 0; k < MAXP; ++k) {
             if ((uint32_t)k < C.n_pots) {
-                s.ps[k] = d.pot_obj[k];
-                s.tk[k] = (d.ticks[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                s.ps[k] = d.pot_obj((uint32_t)k);
+                s.tk[k] = d.tick((uint32_t)k);
             }
         }
     }

@@ -401,12 +401,12 @@ __device__ __forceinline__ void env_reset3_draw(const LayC& C, const Lay L, int 
                                                 const StartDraw& d) {
     env_reset3<MAXP>(L, n_obj, s, cells);
     s.pos0 = d.pos0; s.pos1 = d.pos1;
-    s.held0 = d.held[0]; s.held1 = d.held[1];
+    s.held0 = d.held0; s.held1 = d.held1;
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
         if ((uint32_t)k < C.n_pots) {
-            s.ps[k] = d.pot_obj[k];
-            s.tk[k] = (d.ticks[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            s.ps[k] = d.pot_obj((uint32_t)k);
+            s.tk[k] = d.tick((uint32_t)k);
             s.pc[k] = pot_class(C, s.ps[k], s.tk[k]);
         }
     }
