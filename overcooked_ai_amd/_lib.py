@@ -70,6 +70,11 @@ def load():
         raise OcAmdError(
             "liboc_amd.so not found at %s — build it with `python -m overcooked_ai_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # torch first: the library's libamdhip64 dependency must resolve to the HIP runtime torch has loaded (its wheel bundles one),
+    # or the process ends up with two runtimes and the second one finds "no ROCm-capable device" (seen when
+    # __graft_entry__.build() loaded the library before smoke() imported torch)
+    import torch  # noqa: F401
+
     try:
         L = ctypes.CDLL(LIB_PATH)
     except OSError as e:
