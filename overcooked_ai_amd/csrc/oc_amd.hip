@@ -437,8 +437,8 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
             // per-lane floor mask (MODE 2); one wavefront per SIMD or less reads the faced cells a step ahead, more do not
 #define GO4M2(U, LL, RUF)                                                                                 \
     do {                                                                                                  \
-        if (b->max_pots == 1) { if (pipe) GO4(U, 1, LL, 2, true, false, 0, false, true, RUF); else GO4(U, 1, LL, 2, true, false, 0, false, false, RUF); } \
-        else { if (pipe) GO4(U, 2, LL, 2, true, false, 0, false, true, RUF); else GO4(U, 2, LL, 2, true, false, 0, false, false, RUF); } \
+        if (b->max_pots == 1) { if (pipe) GO4(U, 1, LL, 2, true, false, 0, false, true, RUF, 4); else GO4(U, 1, LL, 2, true, false, 0, false, false, RUF); } \
+        else { if (pipe) GO4(U, 2, LL, 2, true, false, 0, false, true, RUF, 4); else GO4(U, 2, LL, 2, true, false, 0, false, false, RUF); } \
     } while (0)
             if (uniform) GO4M2(true, true, false);
             else if (lds) GO4M2(false, true, true);

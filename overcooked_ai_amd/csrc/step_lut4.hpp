@@ -981,9 +981,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         // Per-env terrain, pose one step ahead.  Carried across steps: the pose of the step about to run (P0, O0, P1, O1), the
         // LDS offsets of its two faced cells (fa, within this lane's column) and — PIPE — those cells' words and the pot words,
         // read right after the previous step's cell writes.
-        const uint64_t d64 = (uint64_t)delta4;  // signed byte deltas of N, S, E, W; actions 4 and 5 (bytes 4, 5) move by 0
+        // signed byte deltas of N, S, E, W; actions 4 and 5 (bytes 4, 5 of the pair {0, delta4}) move by 0: one v_perm_b32
+        // picks the byte, the add sign-extends it
         auto ahead = [&](uint32_t c, uint32_t d) __attribute__((always_inline)) {
-            return c + (uint32_t)(int32_t)(int8_t)(uint8_t)(d64 >> (8u * d));
+            return c + (uint32_t)(int32_t)(int8_t)(uint8_t)__builtin_amdgcn_perm(0u, delta4, d);
         };
         uint32_t P0 = s.pos0, O0 = s.or0, P1 = s.pos1, O1 = s.or1;
         uint32_t fo0 = col + ahead(P0, O0) * (BLOCK * CW), fo1 = col + ahead(P1, O1) * (BLOCK * CW);  // faced cells of the step about to run
@@ -994,14 +995,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         }
         rd_pots(pw);
         constexpr uint32_t NOI = (uint32_t)(LUT4_KEYS * 16);
-        auto mstep = [&](uint32_t ja, int k8) __attribute__((always_inline)) {  // ja = 6 * a0 + a1 of THIS step
-            const uint32_t a0 = (ja * 43u) >> 8, a1 = ja - 6u * a0;
+        auto mstep = [&](uint32_t a0, uint32_t a1, int k8) __attribute__((always_inline)) {  // the two actions of THIS step
             if (!PIPE) {
                 c0 = cw_rd<CW>(fo0);
                 c1 = cw_rd<CW>(fo1);
                 rd_pots(pw);
             }
-            const uint32_t off0 = lut_var + (ja >= 30u ? 0u : NOI), off1 = lut_var + (a1 == 5u ? 0u : NOI);
+            const uint32_t off0 = lut_var + (a0 == 5u ? 0u : NOI), off1 = lut_var + (a1 == 5u ? 0u : NOI);
             const Looked looked = look_up(off0, off1, c0, c1, pw);
             // resolve_movement (mdp.py:1644-1727) on the static terrain: the pose of the NEXT step
             const uint32_t t0_ = ahead(P0, a0), t1_ = ahead(P1, a1);
@@ -1023,18 +1023,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         const int head_end = min(n_steps, (int)((8u - ((uint32_t)t0 & 7u)) & 7u));
         for (int phase = 0; phase < 2; ++phase) {
             const int upto = phase == 0 ? head_end : n_steps;
-            for (; k < upto; ++k) mstep(OC_JA_AT(t0 + k, k == 0), -1);  // rolled steps: up to the next block boundary, and the tail
+            for (; k < upto; ++k) {  // rolled steps: up to the next block boundary, and the tail
+                const uint32_t ja = OC_JA_AT(t0 + k, k == 0), a0 = (ja * 43u) >> 8;
+                mstep(a0, ja - 6u * a0, -1);
+            }
             if (phase == 0) {
-                for (; blocked_rows && n_steps - k >= 8; k += 8) {  // whole Philox blocks, unrolled: two base-36 digits per word
+                // whole Philox blocks, unrolled: a word x holds two steps; the actions are the base-6 digits of x (and of 36 x):
+                // player 0 = mulhi(x, 6), player 1 = mulhi(6 x, 6) — the joint action mulhi(x, 36) = 6 a0 + a1 taken apart
+                auto xstep = [&](uint32_t x, int k8) __attribute__((always_inline)) { mstep(__umulhi(x, 6u), __umulhi(x * 6u, 6u), k8); };
+                for (; blocked_rows && n_steps - k >= 8; k += 8) {
                     w = philox_words((uint64_t)(t0 + k) >> 3, g_lo, g_hi, seed_lo, seed_hi);
-                    mstep(__umulhi(w.w0, 36u), 0);
-                    mstep(__umulhi(w.w0 * 36u, 36u), 1);
-                    mstep(__umulhi(w.w1, 36u), 2);
-                    mstep(__umulhi(w.w1 * 36u, 36u), 3);
-                    mstep(__umulhi(w.w2, 36u), 4);
-                    mstep(__umulhi(w.w2 * 36u, 36u), 5);
-                    mstep(__umulhi(w.w3, 36u), 6);
-                    mstep(__umulhi(w.w3 * 36u, 36u), 7);
+                    xstep(w.w0, 0); xstep(w.w0 * 36u, 1);
+                    xstep(w.w1, 2); xstep(w.w1 * 36u, 3);
+                    xstep(w.w2, 4); xstep(w.w2 * 36u, 5);
+                    xstep(w.w3, 6); xstep(w.w3 * 36u, 7);
                     advance_rows();
                 }
             }
