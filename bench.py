@@ -4,8 +4,14 @@
 Workload (BASELINE.json configs[1] / SURVEY.md §8d-2): 65 536 parallel cramped_room envs PER GPU, uniform random
 policy drawn in-kernel with Philox, horizon 400 with auto-reset to the standard start state, outputs written
 every step (4 x f32 rewards + 1 flag byte per env-step).  A "step" is one batched transition of all envs of a
-GPU.  The timed region launches oc_rollout_random with --fuse steps per launch; `value` is whole-job env-steps/s
+GPU.  The timed region launches oc_rollout_random with --fuse transitions per launch; `value` is whole-job env-steps/s
 over all ranks (weak scaling: every rank owns 65 536 envs, disjoint Philox streams via env_offset).
+
+What `--steps K` counts (round 4): one bench STEP is one pass of the hot path over the batch long enough for a clock
+outside this process to see it: LAUNCHES_PER_STEP (400) back-to-back 4 000-transition launches = 1.6 M batched
+transitions of all 65 536 envs of a GPU = 4 000 episodes per env (about a third of a second).  Exactly K such steps are
+timed after W warm-up steps; `ms_per_step` is per bench step, `ms_per_batched_transition` per batched env transition
+(the figure earlier rounds called ms_per_step), and `ms_per_step_each` lists the K steps one by one.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -35,6 +41,11 @@ HORIZON = 400
 # 400 / 800 / 1 200 / 2 000 / 4 000 / 8 000 steps per launch (before the last scheduling changes).  4 000 = 4.5 GB of
 # per-step outputs per launch; the PMC byte counters were verified up to 8 000.
 DEFAULT_FUSE = 10 * HORIZON
+# launches per bench step (see the module docstring): 400 x 4 000 transitions = 0.34 s at 300 G env-steps/s, so the
+# driver's `--steps 20` is a ~7 s timed region its utilisation sampler and its own clock can see
+LAUNCHES_PER_STEP = 400
+ENC_FUSE = 50                 # --config 3: transitions (+ observations) per oc_rollout_encode launch
+ENC_LAUNCHES_PER_STEP = 200   # ... 200 x 50 = 10 000 transitions + observations per bench step (~0.3 s)
 
 # SURVEY.md §8d algorithmic bytes.  S = minimal state of cramped_room (2 players x 3 B + 14 non-floor cells
 # + 1 pot tick + 2 B timestep -> 24 B), outputs 17 B per env-step, actions generated in-kernel (0 B).
@@ -46,8 +57,11 @@ S_ASYM = 44
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=20, help="bench steps timed (one step = --launches-per-step launches)")
+    ap.add_argument("--warmup", type=int, default=2, help="bench steps run before the timed region")
+    ap.add_argument("--launches-per-step", type=int, default=0,
+                    help="launches per bench step (default: %d rollout launches of --fuse transitions; %d oc_rollout_encode "
+                         "launches of %d transitions for --config 3)" % (LAUNCHES_PER_STEP, ENC_LAUNCHES_PER_STEP, ENC_FUSE))
     ap.add_argument("--fuse", type=int, default=DEFAULT_FUSE, help="env steps fused per oc_rollout_random launch (default: ten 400-step episodes)")
     ap.add_argument("--envs", type=int, default=N_ENVS_PER_GPU, help="envs per GPU")
     ap.add_argument("--layout", default="cramped_room")
@@ -60,11 +74,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the step-API and encode side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--min-seconds", type=float, default=0.25,
-                    help="minimum length of the timed region: the --steps-step region is repeated back to back until it lasts this long")
+    ap.add_argument("--leg-seconds", type=float, default=1.2,
+                    help="length of the timed region of each `configs` side leg (BASELINE configs[2..4]) of the default line")
     ap.add_argument("--terrains", type=int, default=4096,
                     help="--config 5: size of the LayoutGenerator terrain table (first 4 096 = the grids recorded from the "
                          "reference; more are generated on this host by the draw-exact restatement, up to 65 536)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N from ONE process: ShardedVecOvercookedEnv drives one shard per visible GPU on its own "
+                         "stream (no ranks, no process group); the default for N > 1 stays one process per GPU")
     ap.add_argument("--stub", action="store_true",
                     help="CPU-only plumbing test (gloo, no kernels): exercises rank spawning and the reductions; never a measurement")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of one launch after the timed region")
@@ -133,12 +150,51 @@ def cpu_baseline(wl, n_envs, seconds):
     }
 
 
-def _reference_python():
-    """The reference's own rate (north_star: "next to the reference Python OvercookedEnv.step"): /root/reference does not
-    exist on the GPU box and its sources are never copied into this repo, so bench.py cannot time it in its own run.
-    What the line carries instead, with its provenance spelled out: the figure of tools/time_reference_python.py run ONCE on
-    an MI355X box of this pool from a git-ignored tarball (profiles/r03_reference_python_gpubox.json), else the build
-    container's figure."""
+def reference_python(args=None):
+    """The reference's own rate (north_star: "next to the reference Python OvercookedEnv.step timed on the same box's host
+    cores").  /root/reference does not exist on the GPU box and its sources are never copied into this repo; what travels
+    is oracle/_ref/src — the reference's hot-path modules byte-compiled by oracle/build_ref.py in the build container
+    (build output, git-ignored, like liboc_amd.so).  When it is there, tools/time_reference_python.py times it IN THIS RUN
+    on this box (1 core and all usable cores, with and without the lossless encoding): same_run / same_box true.
+    Otherwise the stored figure of an earlier box is replayed and labelled as such."""
+    import subprocess
+
+    src = os.path.join(ROOT, "oracle", "_ref", "src")
+    if os.path.exists(os.path.join(src, "overcooked_ai_py", "mdp", "overcooked_env.pyc")):
+        try:
+            env = dict(os.environ, OVERCOOKED_REFERENCE_SRC=src, LAYOUTS="cramped_room", EPISODES="25", PYTHONDONTWRITEBYTECODE="1")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            t0 = time.perf_counter()
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "time_reference_python.py")], env=env, cwd=ROOT,
+                               capture_output=True, text=True, timeout=240)
+            j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+            cr = j["cramped_room"]
+            return {
+                "value": cr["step_1core"]["steps_per_s"], "unit": "env steps/s", "cores": 1,
+                "all_cores": {"value": cr["step_allcores"]["steps_per_s"], "cores": cr["step_allcores"]["processes"],
+                              "note": "one env per process, multiprocessing.Pool"},
+                "with_lossless_encoding": {"value": cr["step_encode_1core"]["steps_per_s"], "cores": 1,
+                                           "all_cores": cr["step_encode_allcores"]["steps_per_s"]},
+                "same_run": True, "same_box": True, "seconds": time.perf_counter() - t0,
+                "where": "this box, this run (%s, %s usable cores, CPython %s, numpy %s)"
+                         % (j.get("cpu_model"), j.get("usable_cores"), j.get("python"), j.get("numpy")),
+                "what": j.get("what", "") + ": cramped_room, horizon 400, np.random.RandomState joint actions, %s episodes per "
+                                            "process after 1 warm-up (%d steps on one core)"
+                                            % (j.get("episodes_per_process"), cr["step_1core"]["steps"]),
+                "source": "tools/time_reference_python.py on oracle/_ref/src: the reference's own modules (overcooked_env.py, "
+                          "overcooked_mdp.py, actions.py, ...) byte-compiled from /root/reference by oracle/build_ref.py",
+            }
+        except Exception as exc:  # (byte code of another CPython, a missing module: fall back, say why)
+            stored = _reference_python_stored()
+            stored["same_run_attempt"] = repr(exc)[:300]
+            return stored
+    return _reference_python_stored()
+
+
+def _reference_python_stored():
+    """Fallback: the figure of tools/time_reference_python.py run once on an MI355X box of this pool in round 3
+    (profiles/r03_reference_python_gpubox.json), else the build container's figure — NOT this run."""
     path = os.path.join(ROOT, "profiles", "r03_reference_python_gpubox.json")
     try:
         with open(path) as f:
@@ -158,7 +214,7 @@ def _reference_python():
             "source": "profiles/r03_reference_python_gpubox.json (tools/time_reference_python.py)",
         }
     except (OSError, ValueError, KeyError):
-        return REFERENCE_PYTHON
+        return dict(REFERENCE_PYTHON)
 
 
 REFERENCE_PYTHON = {
@@ -172,19 +228,34 @@ REFERENCE_PYTHON = {
 }
 
 
-def lcm(a, b):
-    import math
+def timed_launches(torch, dev, sharding, launch, n_launches):
+    """The timed region: barrier + synchronize, `n_launches` back-to-back calls of `launch()` with a HIP event before each
+    (and one after the last) on the launch stream, synchronize + barrier.  Returns (wall seconds of this rank, per-launch
+    milliseconds in issue order)."""
+    tm = _Timer(torch, dev, reserve=n_launches + 1)
+    tm.sync()
+    sharding.barrier()
+    tm.sync()
+    t0 = time.perf_counter()
+    for _ in range(n_launches):
+        tm.mark()
+        launch()
+    tm.mark()
+    tm.sync()
+    sharding.barrier()
+    tm.sync()
+    return time.perf_counter() - t0, tm.launch_ms()
 
-    return a * b // math.gcd(a, b)
 
-
-def plan_repeats(steps, fuse, est_ms_per_step, min_seconds):
-    """The timed region is R back-to-back repetitions of the --steps-step region, launched as whole `fuse`-step
-    launches: R is the smallest count that (a) makes steps * R a multiple of `fuse` and (b) lasts >= min_seconds at the
-    rate estimated during warm-up."""
-    unit = lcm(steps, fuse) // steps  # repetitions per whole number of launches
-    need = max(1, int(-(-min_seconds * 1.05e3 // max(est_ms_per_step * steps, 1e-9))))  # 5 % margin over the estimate
-    return -(-need // unit) * unit
+def launches_for(torch, dev, launch, seconds, lo=3):
+    """How many launches fill `seconds` (side legs: a bounded region, not a step count): 3 calibration launches."""
+    cal = _Timer(torch, dev)
+    for _ in range(3):
+        cal.mark()
+        launch()
+    cal.mark()
+    cal.sync()
+    return max(lo, int(seconds * 1e3 / max(min(cal.launch_ms()[1:]), 1e-6)))
 
 
 class _StubEnv:
@@ -405,7 +476,7 @@ def pmc_child(args, torch, VecOvercookedEnv, dev):
     """The process the --pmc passes wrap: the same batch, reset, then 3 launches of the timed shape and nothing else."""
     wl = make_workload(args, 0)
     n, fuse = args.envs, max(1, args.fuse)
-    env = VecOvercookedEnv(wl["table"], n, horizon=HORIZON, device=dev, auto_reset=True, seed=0, layout_id=wl["lid"])
+    env = rollout_workload_env(args, wl, n, 0, dev, VecOvercookedEnv)()
     rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
     for _ in range(3):
@@ -429,7 +500,10 @@ def measure_traffic(args, kernel):
     if not os.path.exists(rocprof):
         return None, {"how": "not collected", "why": "rocprofv3 not found"}
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", str(args.config), "--envs", str(args.envs),
-             "--fuse", str(args.fuse), "--layout", args.layout]
+             "--fuse", str(args.fuse), "--layout", args.layout, "--terrains", str(args.terrains)]
+    for flag, on in (("--lane-pair", args.lane_pair), ("--predicate-interact", args.predicate_interact), ("--rollout-v3", args.rollout_v3)):
+        if on:
+            child.append(flag)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["TMPDIR"] = "/tmp"
     got, launches = {}, 0
@@ -514,6 +588,8 @@ def issue_counters(kernel, n, layout):
 
 def main():
     args = parse()
+    if args.single_process:
+        return run_single_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
     quiet_stdout_unless_rank0()
@@ -580,72 +656,123 @@ def main():
     return run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world, numa)
 
 
-def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world, numa):
-    """--config 2 (the headline: BASELINE configs[1]), 4 and 5 (configs[3] / [4] on one GPU's shard): oc_rollout_random
-    launches of `--fuse` steps under the timing protocol of the module docstring."""
-    n = args.envs
-    wl = make_workload(args, rank)
+def run_single_process(args):
+    """`--gpus N --single-process`: the product-level sharded env (overcooked_ai_amd.sharded_env) instead of N ranks —
+    one process, one VecOvercookedEnv + HIP stream per GPU, every launch fanned out to all shards without a host
+    synchronisation in between; same step definition, same JSON keys; the aggregate metrics are summed on the host."""
+    import argparse as _ap
 
+    import numpy as np
+    import torch
+
+    from overcooked_ai_amd import build
+    from overcooked_ai_amd.sharded_env import ShardedVecOvercookedEnv
+
+    build.build_extension()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    N = args.gpus
+    devices = ["cuda:%d" % (i % torch.cuda.device_count()) for i in range(N)]  # (more shards than GPUs: several per device)
+    n, fuse = args.envs, max(1, args.fuse)
+    lps = args.launches_per_step or LAUNCHES_PER_STEP
+    # the global batch = the N per-rank workloads side by side (global env e -> layout e % K)
+    wls = [make_workload(_ap.Namespace(config=args.config if args.config != 3 else 2, envs=n, layout=args.layout,
+                                       terrains=args.terrains), r) for r in range(N)]
+    lid = None if wls[0]["lid"] is None else np.concatenate([w["lid"] for w in wls])
+    env = ShardedVecOvercookedEnv(wls[0]["table"], N * n, devices=devices, layout_id=lid, horizon=HORIZON, auto_reset=True, seed=0)
+    rews, fls = env.alloc_outputs(fuse)
+
+    def launch():
+        env.rollout_random(fuse, rews, fls)
+
+    for _ in range(max(1, args.warmup * lps)):
+        launch()
+    env.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps * lps):
+        launch()
+    env.synchronize()
+    wall = time.perf_counter() - t0
+    transitions = args.steps * lps * fuse
+    agg = env.aggregate(rews, fls)
+    parity = None
+    if not args.no_parity_check:
+        from oracle import oracle as O
+
+        psteps = min(fuse, args.parity_steps or 400)
+        chk = ShardedVecOvercookedEnv(wls[0]["table"], N * n, devices=devices, layout_id=lid, horizon=HORIZON, auto_reset=True, seed=0)
+        chk.rollout_random(psteps, [r[:psteps] for r in rews], [f[:psteps] for f in fls])
+        O.set_threads(usable_cores())
+        orc = O.Oracle([O.mdp_from_layout_dict(sp.to_layout_dict()) for sp in wls[0]["specs"]])
+        st = orc.reset(orc.new_state(N * n), layout_id=lid)
+        ep = np.zeros((N * n, 4), np.float32)
+        rew_o, fl_o = orc.rollout_random(st, psteps, horizon=HORIZON, options=1, seed=0, layout_id=lid, ep_returns=ep)
+        O.set_threads(1)
+        bad = int(((chk.gather([r[:psteps] for r in rews], 1) != rew_o).any(axis=2) | (chk.gather([f[:psteps] for f in fls], 1) != fl_o)).sum())
+        bad += int((chk.get_packed_state() != st).any(axis=(0, 2)).sum()) + int((chk.ep_returns() != ep).any(axis=1).sum())
+        parity = {"envs": N * n, "steps": psteps, "mismatches": bad,
+                  "what": "one %d-step launch per shard from reset: rewards, flags, final states and episode returns of all "
+                          "%d envs against oracle/overcooked_oracle.c" % (psteps, N * n)}
+    emit({"metric": "env steps/sec (whole node), 65k parallel cramped_room envs" if args.config == 2 else "env steps/sec (whole node)",
+          "value": float(N) * n * transitions / wall, "unit": "env steps/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+          "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+          "data": "synthetic", "timed_region_s": wall, "timed_transitions_per_env": transitions,
+          "ms_per_batched_transition": wall * 1e3 / transitions,
+          "config": {"workload": wls[0]["workload"], "baseline_config": args.config, "envs_per_gpu": n,
+                     "fused_transitions_per_launch": fuse, "launches_per_step": lps,
+                     "parallelism": "single process, ShardedVecOvercookedEnv, %d shards on %s" % (N, sorted(set(devices)))},
+          "roofline": None, "parity_check": parity, "aggregate": dict(agg, reduced_over="host sum over shards")})
+
+
+def rollout_workload_env(args, wl, n, rank, dev, VecOvercookedEnv):
     def make_env():
         if args.stub:
             return _StubEnv(wl, n, rank)
         env = VecOvercookedEnv(wl["table"], n, horizon=HORIZON, device=dev, auto_reset=True, seed=0, env_offset=rank * n,
                                layout_id=wl["lid"])
-        env.lane_pair = args.lane_pair
-        env.predicate_interact = args.predicate_interact
-        env.rollout_v3 = args.rollout_v3
+        env.lane_pair = getattr(args, "lane_pair", False)
+        env.predicate_interact = getattr(args, "predicate_interact", False)
+        env.rollout_v3 = getattr(args, "rollout_v3", False)
         return env
+    return make_env
 
+
+def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world, numa):
+    """--config 2 (the headline: BASELINE configs[1]), 4 and 5 (configs[3] / [4] on one GPU's shard): K bench steps of
+    `--launches-per-step` oc_rollout_random launches of `--fuse` transitions each (module docstring)."""
+    n = args.envs
+    wl = make_workload(args, rank)
+    make_env = rollout_workload_env(args, wl, n, rank, dev, VecOvercookedEnv)
     env = make_env()
-    fuse = max(1, args.fuse)  # launch shape: independent of --steps (a 20-step --steps must not shrink the launches)
+    fuse = max(1, args.fuse)
+    lps = args.launches_per_step or LAUNCHES_PER_STEP
     rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
 
-    # warm-up: at least the W steps asked for, rounded up to whole launches of the timed shape (so every launch of the
-    # kernel in a profile of this command is the same `fuse`-step launch), then 3 more that calibrate R
-    warm_launches = max(1, -(-args.warmup // fuse))
-    for _ in range(warm_launches):
+    def launch():
         env.rollout_random(fuse, rew, fl)
-    cal = _Timer(torch, dev)
-    for _ in range(3):
-        cal.mark()
-        env.rollout_random(fuse, rew, fl)
-    cal.mark()
-    cal.sync()
-    est = torch.tensor([min(cal.launch_ms()[1:]) / fuse], dtype=torch.float64, device=dev)
-    sharding.allreduce_max(est)  # every rank must pick the same R
-    repeats = plan_repeats(args.steps, fuse, float(est.item()), args.min_seconds)
-    total_steps = args.steps * repeats
-    launches = total_steps // fuse
-    tm = _Timer(torch, dev, reserve=launches + 1)
 
-    tm.sync()
-    sharding.barrier()
-    tm.sync()
-    t0 = time.perf_counter()
-    for _ in range(launches):
-        tm.mark()
-        env.rollout_random(fuse, rew, fl)
-    tm.mark()
-    tm.sync()
-    sharding.barrier()
-    tm.sync()
-    wall = time.perf_counter() - t0
-    per_launch = sorted(tm.launch_ms())
+    for _ in range(max(1, args.warmup * lps)):  # W bench steps, untimed (at least one launch)
+        launch()
+    launches = args.steps * lps
+    wall, per_launch_ms = timed_launches(torch, dev, sharding, launch, launches)
+    step_each = [sum(per_launch_ms[i * lps:(i + 1) * lps]) for i in range(args.steps)]
+    per_launch = sorted(per_launch_ms)
     dev_ms = sum(per_launch)
     launch_med, launch_min = per_launch[len(per_launch) // 2], per_launch[0]
     tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
     sharding.allreduce_max(tmax)
     wall_max = float(tmax.item())
+    transitions = launches * fuse  # batched transitions of every env in the timed region
     per_rank = torch.zeros((world,), dtype=torch.float64, device=dev)
-    per_rank[rank] = wall * 1e3 / total_steps
+    per_rank[rank] = wall * 1e3 / args.steps
     sharding.allreduce_metrics(per_rank)  # disjoint slots: the sum is a gather
     # aggregate-return metric: the only collective, outside the hot path (RCCL all-reduce of 3 scalars)
     metrics = torch.stack([rew[..., 0:2].sum().to(torch.float64), rew[..., 2:4].sum().to(torch.float64),
                            (fl[-1] & 1).sum().to(torch.float64)])
     sharding.allreduce_metrics(metrics)
 
-    value = float(world) * n * total_steps / wall_max
+    value = float(world) * n * transitions / wall_max
 
     # roofline of the dominant kernel (k_rollout4): algorithmic HBM bytes per launch / median launch duration
     state_bytes = wl["sbytes"]
@@ -682,19 +809,22 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
     out = {
         "metric": "env steps/sec (whole node), 65k parallel cramped_room envs" if args.config == 2 else "env steps/sec (whole node)",
         "value": value, "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": wall_max * 1e3 / total_steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": wall_max * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "stub" if args.stub else "synthetic",
-        "repeats": repeats, "timed_steps": total_steps, "timed_region_s": wall_max,
-        "warmup_steps_run": (warm_launches + 3) * fuse,
-        "ms_per_step_median": launch_med / fuse, "ms_per_step_min": launch_min / fuse,
-        "ms_per_step_by_rank": [float(x) for x in per_rank.tolist()],
+        "timed_region_s": wall_max, "timed_launches": launches, "timed_transitions_per_env": transitions,
+        "timed_env_steps": float(world) * n * transitions,
+        "ms_per_batched_transition": wall_max * 1e3 / transitions,
+        "ms_per_batched_transition_median": launch_med / fuse, "ms_per_batched_transition_min": launch_min / fuse,
+        "ms_per_step_each": step_each, "ms_per_step_by_rank": [float(x) for x in per_rank.tolist()],
+        "warmup_launches_run": max(1, args.warmup * lps),
         "config": {"workload": wl["workload"], "baseline_config": args.config,
-                   "envs_per_gpu": n, "fused_steps_per_launch": fuse, "launches": launches, "parallelism": "env-shard x%d" % world,
-                   "numa_node_rank0": numa,
-                   "timing_rule": "timed region = `repeats` back-to-back repetitions of the --steps-step region (steps x repeats "
-                                  "batched steps, issued as whole %d-step launches whatever --steps is), repeats = smallest count "
-                                  "with steps*repeats a multiple of %d and a region >= %.2f s at the warm-up rate; value and "
-                                  "ms_per_step are over the whole region (wall clock, max over ranks)" % (fuse, fuse, args.min_seconds)},
+                   "envs_per_gpu": n, "fused_transitions_per_launch": fuse, "launches_per_step": lps, "launches": launches,
+                   "parallelism": "env-shard x%d" % world, "numa_node_rank0": numa,
+                   "step_definition": "one bench step = %d back-to-back oc_rollout_random launches of %d transitions = %d "
+                                      "batched transitions of all %d envs of a GPU (%d episodes per env); exactly --steps of "
+                                      "them are timed after --warmup untimed ones; value = n_gpus x envs x transitions / wall "
+                                      "clock (max over ranks); ms_per_step_each = the steps one by one (HIP events, rank 0)"
+                                      % (lps, fuse, lps * fuse, n, lps * fuse // HORIZON)},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "bytes_per_launch": bytes_per_launch, "launch_ms": launch_med, "launch_ms_min": launch_min,
@@ -709,34 +839,85 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
                       "reduced_over": ("RCCL all-reduce" if not args.stub else "gloo all-reduce") if sharding._live() else "single rank"},
     }
 
-    if rank == 0 and world == 1 and not args.no_extras and not args.stub and args.config == 2:
+    side = rank == 0 and world == 1 and not args.no_extras and not args.stub and args.config == 2
+    if side:
         out["step_api"] = bench_step_api(env, dev, torch)
+    del env, rew, fl
+    if side:
         out["single_env_api"] = bench_single_env_api(dev, torch)
         out["encode"] = bench_encode(dev, torch, VecOvercookedEnv)
         out["training_env"] = bench_training_env(dev, torch)
+        # the other BASELINE configs, each with its own roofline and parity check, in this same line
+        out["configs"] = side_legs(args, torch, VecOvercookedEnv, sharding, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stub:  # the CPU leg runs at N = 1 only
-        out["cpu_baseline"] = cpu_baseline(wl, n, args.cpu_seconds)
-        out["cpu_baseline"]["reference_python"] = _reference_python()
-    out["process_note"] = ("the timed region (%.2f s) is a small part of this process: warm-up, the side measurements, the "
-                           "parity check, the PMC child passes and the CPU baseline run before / after it with the GPU mostly "
-                           "idle, so a coarse utilisation sampler over the whole process reads close to zero" % wall_max)
+        wl_cpu = make_workload(args, rank)
+        out["cpu_baseline"] = cpu_baseline(wl_cpu, n, args.cpu_seconds)
+        out["cpu_baseline"]["reference_python"] = reference_python(args)
+        if "single_env_api" in out:
+            out["single_env_api"]["reference_python"] = out["cpu_baseline"]["reference_python"]["value"]
     if rank == 0:
         emit(out)
     sharding.barrier()
 
 
-def run_encode_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
-    """--config 3 = BASELINE configs[2] (the rollout of configs[1] plus oc_encode_lossless every step):
-    ENC_FUSE steps per launch through oc_rollout_encode, the observation of every step kept ([ENC_FUSE][n] u8
-    trajectory buffer: 7.7 GB at 65 536 9x5 envs); same timing protocol, not the headline line."""
+def side_legs(args, torch, VecOvercookedEnv, sharding, dev):
+    """BASELINE configs[2], [3], [4] on this GPU — what `--config 3 / 4 / 5` print, bounded to --leg-seconds each: value,
+    median launch duration (HIP events), roofline, parity check against the C oracle (config 3: the observation of every
+    step of one launch; configs 4 / 5: 1 200 steps from reset across two restarts).  Config 5 runs the shape ONE rank of
+    the 8-GPU config launches: 131 072 envs."""
+    legs = {}
+    try:
+        legs["3"] = encode_measure(torch, VecOvercookedEnv, sharding, dev, 0, 1, N_ENVS_PER_GPU, seconds=args.leg_seconds,
+                                   parity=not args.no_parity_check, extras=False)
+    except Exception as exc:  # a side leg must never cost the headline line
+        legs["3"] = {"error": repr(exc)[:300]}
+    for cfg, envs in ((4, N_ENVS_PER_GPU), (5, 2 * N_ENVS_PER_GPU)):
+        try:
+            a = argparse.Namespace(config=cfg, envs=envs, layout="cramped_room", terrains=4096, stub=False)
+            wl = make_workload(a, 0)
+            make_env = rollout_workload_env(a, wl, envs, 0, dev, VecOvercookedEnv)
+            env = make_env()
+            fuse = DEFAULT_FUSE
+            rew = torch.zeros((fuse, envs, 4), dtype=torch.float32, device=dev)
+            fl = torch.zeros((fuse, envs), dtype=torch.uint8, device=dev)
+
+            def launch():
+                env.rollout_random(fuse, rew, fl)
+
+            launch()
+            k = launches_for(torch, dev, launch, args.leg_seconds)
+            wall, ms = timed_launches(torch, dev, sharding, launch, k)
+            ms = sorted(ms)
+            med = ms[len(ms) // 2]
+            bpl = envs * (2 * wl["sbytes"] + OUT_BYTES * fuse)
+            leg = {"value": envs * fuse * k / wall, "unit": "env steps/s (one GPU)", "envs": envs, "launches": k,
+                   "timed_region_s": wall, "launch_ms": med, "launch_ms_min": ms[0], "workload": wl["workload"],
+                   "roofline": {"bound": "hbm", "kernel": "k_rollout4", "achieved": bpl / (med * 1e-3) / 1e9,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bpl / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "bytes_per_launch": bpl, "traffic": None,
+                                "traffic_source": {"how": "not collected", "why": "side leg; `bench.py --config %d` collects it" % cfg},
+                                "bytes_model": "n_envs*(2*S + 17*T), S=%d B (SURVEY 8d)" % wl["sbytes"]}}
+            if not args.no_parity_check:
+                leg["parity_check"] = parity_check(torch, wl, make_env, envs, 0, 1200, rew, fl, usable_cores())
+            legs[str(cfg)] = leg
+            del env, rew, fl
+        except Exception as exc:
+            legs[str(cfg)] = {"error": repr(exc)[:300]}
+    return legs
+
+
+def encode_measure(torch, VecOvercookedEnv, sharding, dev, rank, world, n, launches=0, warm_launches=2, seconds=0.0,
+                   parity=True, extras=True):
+    """BASELINE configs[2] (the rollout of configs[1] plus oc_encode_lossless every step) on this rank's
+    shard: ENC_FUSE transitions per oc_rollout_encode launch, the observation of every step kept ([ENC_FUSE][n] u8
+    trajectory buffer: 7.7 GB at 65 536 9x5 envs).  `launches` fixed (the --config 3 line) or as many as fill `seconds`
+    (the side leg of the default line)."""
     import numpy as np
 
-    n = args.envs
     env = VecOvercookedEnv("asymmetric_advantages", n, horizon=HORIZON, device=dev, auto_reset=True, seed=0,
                            env_offset=rank * n)
     workload, sbytes = ("asymmetric_advantages x %d envs/GPU, random policy (in-kernel Philox actions) + lossless u8 "
                         "encoding of every step into a [steps][envs] trajectory buffer (oc_rollout_encode)" % n), S_ASYM
-    ENC_FUSE = 50
     fuse = ENC_FUSE
     rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
@@ -745,113 +926,110 @@ def run_encode_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world)
     def launch():  # one `fuse`-step unit of the workload
         env.rollout_encode(fuse, obs, rew, fl)
 
-    for _ in range(-(-args.warmup // fuse)):
+    for _ in range(max(1, warm_launches)):
         launch()
-    cal = _Timer(torch, dev)
-    for _ in range(4):
-        cal.mark()
-        launch()
-    cal.mark()
-    cal.sync()
-    est = torch.tensor([min(cal.launch_ms()[1:]) / fuse], dtype=torch.float64, device=dev)
-    sharding.allreduce_max(est)
-    repeats = plan_repeats(args.steps, fuse, float(est.item()), args.min_seconds)
-    total_steps = args.steps * repeats
-    tm = _Timer(torch, dev, reserve=total_steps // fuse + 1)
-    tm.sync()
-    sharding.barrier()
-    tm.sync()
-    t0 = time.perf_counter()
-    for _ in range(total_steps // fuse):
-        tm.mark()
-        launch()
-    tm.mark()
-    tm.sync()
-    sharding.barrier()
-    tm.sync()
-    wall = time.perf_counter() - t0
-    per_launch = sorted(tm.launch_ms())
+    if not launches:
+        launches = launches_for(torch, dev, launch, seconds)
+    wall, per_launch_ms = timed_launches(torch, dev, sharding, launch, launches)
+    per_launch = sorted(per_launch_ms)
     unit_med = per_launch[len(per_launch) // 2]
     tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
     sharding.allreduce_max(tmax)
     wall = float(tmax.item())
     unit_bytes = n * (2 * sbytes + OUT_BYTES * fuse) + fuse * n * 2 * env.width * env.height * 26
-    # parity of this launch shape: one ENC_FUSE-step launch from reset — rewards, flags, final states, and the observations
-    # of a sample of steps (the oracle's encoder is a scalar loop) against the C oracle
-    parity = None
-    if not args.no_parity_check:
+    # parity of this launch shape: one ENC_FUSE-step launch from reset — every reward quad and flag byte, the final states,
+    # and the u8 observation of EVERY step of every env (the oracle's encoder threaded over the host cores; compared on
+    # the GPU) against the C oracle
+    pc = None
+    if parity:
         from oracle import oracle as O
         from overcooked_ai_amd.layouts import spec_from_name
 
         t_par = time.perf_counter()
-        O.set_threads(max(1, usable_cores() // max(1, world)))
+        threads = O.set_threads(max(1, usable_cores() // max(1, world)))
         orc = O.Oracle(O.mdp_from_layout_dict(spec_from_name("asymmetric_advantages").to_layout_dict()))
         env2 = VecOvercookedEnv("asymmetric_advantages", n, horizon=HORIZON, device=dev, auto_reset=True, seed=0, env_offset=rank * n)
         env2.rollout_encode(fuse, obs, rew, fl)
         st = orc.reset(orc.new_state(n))
-        bad, sampled = 0, []
+        bad, bad_obs = 0, 0
         rg, fg = rew.cpu().numpy(), fl.cpu().numpy()
         for k in range(fuse):
             r_o, f_o = orc.rollout_random(st, 1, horizon=HORIZON, options=1, seed=0, env_offset=rank * n, t0=k)
             bad += int(((rg[k] != r_o[0]).any(axis=1) | (fg[k] != f_o[0])).sum())
-            if k in (0, fuse // 2, fuse - 1):
-                sub = slice(0, min(n, 8192))
-                enc_o = orc.encode_lossless(np.ascontiguousarray(st[:, sub]), horizon=HORIZON)
-                bad += int((obs[k, sub].cpu().numpy().astype(np.int32) != enc_o).any(axis=(1, 2, 3, 4)).sum())
-                sampled.append(k)
-        bad += int((env2.get_packed_state() != st).any(axis=(0, 2)).sum())
+            enc_o = torch.from_numpy(O.encode_lossless_u8(orc, st, horizon=HORIZON)).to(dev)
+            bad_obs += int((obs[k] != enc_o).flatten(1).any(dim=1).sum().item())
+        bad_states = int((env2.get_packed_state() != st).any(axis=(0, 2)).sum())
         O.set_threads(1)
         del env2
-        parity = {"envs": n, "steps": fuse, "mismatches": bad, "observations_checked": "steps %s, first %d envs" % (sampled, min(n, 8192)),
-                  "seconds": time.perf_counter() - t_par,
-                  "what": "one %d-step oc_rollout_encode launch from reset: every reward quad and flag byte, the final states and "
-                          "sampled u8 observations against oracle/overcooked_oracle.c" % fuse}
-    # the same step with caller-supplied actions, one call per step (oc_step_encode: what a policy in the loop pays)
-    acts = torch.randint(0, 6, (64, n, 2), dtype=torch.uint8, device=dev)
-    ob1 = obs[0]
-    for i in range(20):
-        env.step_encode(acts[i % 64], torch.uint8, out=ob1)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for i in range(300):
-        env.step_encode(acts[i % 64], torch.uint8, out=ob1)
-    ev1.record()
-    torch.cuda.synchronize(dev)
-    us = ev0.elapsed_time(ev1) / 300 * 1e3
-    one_step = {"us_per_step": us, "value": n / us * 1e6, "unit": "env steps/s (one GPU)",
-                "note": "oc_step_encode: caller-supplied actions resident in HBM, one C call per batched step"}
-    out = {"metric": "env steps/sec (whole node)", "value": float(world) * n * total_steps / wall, "unit": "env steps/s",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / total_steps,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "repeats": repeats, "timed_steps": total_steps, "timed_region_s": wall, "ms_per_step_median": unit_med / fuse,
-           "config": {"workload": workload, "baseline_config": args.config, "envs_per_gpu": n,
-                      "fused_steps_per_launch": fuse},
+        pc = {"envs": n, "steps": fuse, "mismatches": bad + bad_obs + bad_states, "mismatching_env_steps": bad,
+              "mismatching_observations": bad_obs, "mismatching_final_states": bad_states,
+              "observations_checked": "every step (%d) x every env (%d)" % (fuse, n),
+              "seconds": time.perf_counter() - t_par, "oracle_threads": threads,
+              "what": "one %d-step oc_rollout_encode launch from reset: every reward quad and flag byte, the final states and "
+                      "the u8 observation of every env-step against oracle/overcooked_oracle.c" % fuse}
+    out = {"value": float(world) * n * fuse * launches / wall, "unit": "env steps/s", "envs": n, "launches": launches,
+           "timed_region_s": wall, "launch_ms": unit_med, "ms_per_batched_transition": unit_med / fuse, "workload": workload,
            "roofline": {"bound": "hbm", "kernel": "k_rollout_encode", "achieved": unit_bytes / (unit_med * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": unit_bytes / (unit_med * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "traffic_source": {"how": "not collected", "why": "WRITE_SIZE wraps on multi-GB launches"},
                         "bytes_per_launch": unit_bytes, "launch_ms": unit_med,
-                        "note": "algorithmic bytes of one %d-step unit (all its kernels) / its median duration from HIP events" % fuse},
-           "parity_check": parity}
-    # the f32 variant of the observation (what the reference's RLlib wrapper casts to): 10 steps per launch
-    del obs
-    K32 = 10
-    obs32 = torch.empty((K32, n, 2, env.width, env.height, 26), dtype=torch.float32, device=dev)
-    for _ in range(2):
-        env.rollout_encode(K32, obs32, rew[:K32], fl[:K32], dtype=torch.float32)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for _ in range(20):
-        env.rollout_encode(K32, obs32, rew[:K32], fl[:K32], dtype=torch.float32)
-    ev1.record()
-    torch.cuda.synchronize(dev)
-    us = ev0.elapsed_time(ev1) / (20 * K32) * 1e3
-    b32 = n * 2 * env.width * env.height * 26 * 4
-    out["f32_observations"] = {"us_per_step": us, "value": n / us * 1e6, "unit": "env steps/s (one GPU)",
-                               "achieved_GBs": b32 / us / 1e3, "frac": b32 / us / 1e3 / HBM_PEAK_GBS,
-                               "note": "oc_rollout_encode with f32 observations, %d steps per launch into a [steps][envs] buffer" % K32}
-    del obs32
-    out["caller_actions_one_step"] = one_step
+                        "note": "algorithmic bytes of one %d-step launch (state in + out, 17 B outputs and 2*W*H*26 observation "
+                                "bytes per env-step) / its median duration from HIP events" % fuse},
+           "parity_check": pc}
+    if extras:
+        # the same step with caller-supplied actions, one call per step (oc_step_encode: what a policy in the loop pays)
+        acts = torch.randint(0, 6, (64, n, 2), dtype=torch.uint8, device=dev)
+        ob1 = obs[0]
+        for i in range(20):
+            env.step_encode(acts[i % 64], torch.uint8, out=ob1)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for i in range(300):
+            env.step_encode(acts[i % 64], torch.uint8, out=ob1)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        us = ev0.elapsed_time(ev1) / 300 * 1e3
+        out["caller_actions_one_step"] = {"us_per_step": us, "value": n / us * 1e6, "unit": "env steps/s (one GPU)",
+                                          "note": "oc_step_encode: caller-supplied actions resident in HBM, one C call per batched step"}
+        # the f32 variant of the observation (what the reference's RLlib wrapper casts to): 10 steps per launch
+        del obs
+        K32 = 10
+        obs32 = torch.empty((K32, n, 2, env.width, env.height, 26), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            env.rollout_encode(K32, obs32, rew[:K32], fl[:K32], dtype=torch.float32)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(20):
+            env.rollout_encode(K32, obs32, rew[:K32], fl[:K32], dtype=torch.float32)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        us = ev0.elapsed_time(ev1) / (20 * K32) * 1e3
+        b32 = n * 2 * env.width * env.height * 26 * 4
+        out["f32_observations"] = {"us_per_step": us, "value": n / us * 1e6, "unit": "env steps/s (one GPU)",
+                                   "achieved_GBs": b32 / us / 1e3, "frac": b32 / us / 1e3 / HBM_PEAK_GBS,
+                                   "note": "oc_rollout_encode with f32 observations, %d steps per launch into a [steps][envs] buffer" % K32}
+        del obs32
+    return out
+
+
+def run_encode_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world):
+    """--config 3 = BASELINE configs[2]: K bench steps of `--launches-per-step` oc_rollout_encode launches of ENC_FUSE
+    transitions + observations each; same timing protocol as the headline, not the headline line."""
+    lps = args.launches_per_step or ENC_LAUNCHES_PER_STEP
+    m = encode_measure(torch, VecOvercookedEnv, sharding, dev, rank, world, args.envs, launches=args.steps * lps,
+                       warm_launches=args.warmup * lps, parity=not args.no_parity_check, extras=True)
+    out = {"metric": "env steps/sec (whole node)", "value": m["value"], "unit": "env steps/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["timed_region_s"] * 1e3 / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "timed_region_s": m["timed_region_s"], "timed_launches": m["launches"],
+           "ms_per_batched_transition": m["timed_region_s"] * 1e3 / (m["launches"] * ENC_FUSE),
+           "ms_per_batched_transition_median": m["launch_ms"] / ENC_FUSE,
+           "config": {"workload": m["workload"], "baseline_config": args.config, "envs_per_gpu": args.envs,
+                      "fused_transitions_per_launch": ENC_FUSE, "launches_per_step": lps,
+                      "step_definition": "one bench step = %d oc_rollout_encode launches of %d transitions + observations" % (lps, ENC_FUSE)},
+           "roofline": m["roofline"], "parity_check": m["parity_check"],
+           "f32_observations": m.get("f32_observations"), "caller_actions_one_step": m.get("caller_actions_one_step")}
     if rank == 0:
         emit(out)
     sharding.barrier()
@@ -950,7 +1128,7 @@ def bench_single_env_api(dev, torch, episodes=3):
     steps = sum(episode() for _ in range(episodes))
     dt = time.perf_counter() - t0
     return {"value": steps / dt, "unit": "env steps/s", "us_per_step": dt / steps * 1e6, "episodes": episodes,
-            "reference_python": _reference_python()["value"],
+            "reference_python": _reference_python_stored()["value"],
             "note": "OvercookedEnv.step through the single-env drop-in API: state and action written into a pinned host buffer "
                     "the kernel reads and writes in place (no staging copies), one launch + one stream wait per call; "
                     "latency-bound by construction - batch with VecOvercookedEnv for throughput"}

@@ -538,8 +538,8 @@ def _planner_modules():
 def gen_featurize():
     """featurize_state (mdp.py:2579-2898) fixtures.
     (1) The reference's own golden: GreedyHumanModel rollouts of overcooked_test.py:1069-1093 reproduced here with
-        np.random.seed(0); the features are asserted equal to data/testing/test_state_featurization/expected_2.pickle
-        before being stored, together with the states, actions and rewards of those 5 x 400 steps (a second,
+        np.random.seed(0); the features are asserted equal to data/testing/test_state_featurization/expected_{0,1,2}.pickle
+        (num_pots = 0, 1, 2) before being stored, together with the states, actions and rewards of those 5 x 400 steps (a second,
         delivery-rich pin for the transition itself).
     (2) Randomized states (objects in row-major dict order) on several layouts, for counter_goals = [] (the
         reference's default NO_COUNTERS_PARAMS) and counter_goals = all counters."""
@@ -558,6 +558,14 @@ def gen_featurize():
     feats = np.array([[mdp.featurize_state(s, mlam, num_pots=2) for s in ep] for ep in trajs["ep_states"]])
     exp = np.array(pickle.load(open(os.path.join(REF_TESTING, "test_state_featurization", "expected_2.pickle"), "rb")))
     assert feats.shape == exp.shape == (5, 400, 2, 96) and np.array_equal(feats, exp), "reference golden pickle not reproduced"
+    # the reference's test loops num_pots in range(3) (overcooked_test.py:1069-1093): expected_0 / expected_1 as well
+    feats_np = {}
+    for num_pots in (0, 1):
+        f = np.array([[mdp.featurize_state(s, mlam, num_pots=num_pots) for s in ep] for ep in trajs["ep_states"]])
+        e = np.array(pickle.load(open(os.path.join(REF_TESTING, "test_state_featurization", "expected_%d.pickle" % num_pots), "rb")))
+        width = mdp.get_featurize_state_shape(num_pots)[0]
+        assert f.shape == e.shape == (5, 400, 2, width) and np.array_equal(f, e), "expected_%d.pickle not reproduced" % num_pots
+        feats_np[num_pots] = f.reshape(5 * 400, 2, width).astype(np.float32)
     n_planes = 1 + (spec.width * spec.height + 15) // 16
     n_ep, T = 5, 400
     packed = np.zeros((n_planes, n_ep * T, 16), np.uint8)
@@ -570,7 +578,8 @@ def gen_featurize():
             acts[e * T + t] = [Action.ACTION_TO_INDEX[a if isinstance(a, str) else tuple(a)] for a in ja]
             rews[e * T + t] = trajs["ep_rewards"][e][t]
     np.savez_compressed(os.path.join(GOLDEN, "ref_greedy_rollouts.npz"), states=packed, actions=acts, rewards=rews,
-                        features=feats.reshape(n_ep * T, 2, 96).astype(np.float32), n_episodes=np.array(n_ep), horizon=np.array(T))
+                        features=feats.reshape(n_ep * T, 2, 96).astype(np.float32), features_num_pots_0=feats_np[0],
+                        features_num_pots_1=feats_np[1], n_episodes=np.array(n_ep), horizon=np.array(T))
     print("greedy rollouts: reference pickle reproduced; sparse return per episode", rews.reshape(n_ep, T).sum(1))
 
     out = {}

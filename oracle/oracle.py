@@ -281,6 +281,19 @@ class Oracle:
         return obs
 
 
+def encode_lossless_u8(orc, state, horizon=400, layout_id=None):
+    """The same encoding as uint8 [n_envs, 2, W, H, 26], threaded over oracle_set_threads cores (bench.py's check of
+    every observation of a BASELINE configs[2] launch)."""
+    n = state.shape[1]
+    lid = orc._lid(layout_id, n)
+    obs = np.empty((n, 2, orc.W, orc.H, 26), dtype=np.uint8)
+    rc = lib().oracle_encode_lossless_u8(orc.arr, orc.n, _ptr(lid, ctypes.c_uint16),
+                                         _ptr(np.ascontiguousarray(state), ctypes.c_uint8), _ptr(obs, ctypes.c_uint8),
+                                         ctypes.c_int64(n), int(horizon))
+    assert rc == 0, "lossless encoding: 2 players required (mdp.py:2389) / a layer value above 255"
+    return obs
+
+
 def featurize(orc, state, counter_goals="none", num_pots=2, layout_id=None):
     """featurize_state of every env: float32 [n_envs, 2, 2*(num_pots*10+26)+4]. counter_goals: "none" (the reference's
     NO_COUNTERS_PARAMS) or "all" (every counter is a motion goal)."""

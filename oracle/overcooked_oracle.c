@@ -818,6 +818,34 @@ int oracle_encode_lossless(const OracleMdp* mdps, int n_mdps, const uint16_t* la
     return 0;
 }
 
+/* The same encoding narrowed to bytes (every value of the 26 layers is in 0..255: ingredient counts, cook times <= 254,
+ * 0/1 flags), env loop spread over oracle_set_threads cores: what bench.py's parity check of BASELINE configs[2] compares
+ * with the u8 observations of EVERY step of a launch.  Returns -1 for a non-2-player layout, -2 for a value above 255. */
+int oracle_encode_lossless_u8(const OracleMdp* mdps, int n_mdps, const uint16_t* layout_id, const uint8_t* state,
+                              uint8_t* obs, int64_t n_envs, int horizon) {
+    (void)n_mdps;
+    int rc = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+#endif
+    for (int64_t e = 0; e < n_envs; ++e) {
+        const OracleMdp* m = &mdps[layout_id ? layout_id[e] : 0];
+        int32_t tmp[2 * MAX_CELLS * NUM_LAYERS];
+        State s;
+        if (m->n_players != 2) { rc = -1; continue; }
+        const size_t len = (size_t)2 * m->width * m->height * NUM_LAYERS;
+        memset(tmp, 0, len * sizeof(int32_t));
+        unpack_state(m, state, n_envs, e, &s);
+        encode_one(m, &s, horizon, tmp);
+        uint8_t* dst = obs + (size_t)e * len;
+        for (size_t i = 0; i < len; ++i) {
+            if (tmp[i] < 0 || tmp[i] > 255) rc = -2;
+            dst[i] = (uint8_t)tmp[i];
+        }
+    }
+    return rc;
+}
+
 size_t oracle_mdp_size(void) { return sizeof(OracleMdp); }
 
 /* ====================================================================================================

@@ -1,6 +1,7 @@
 """overcooked_ai_amd — MI355X-native batched Overcooked simulator (hot path of HumanCompatibleAI/overcooked_ai).
 
     from overcooked_ai_amd import VecOvercookedEnv            # N envs in HBM, HIP kernels (the fast path)
+    from overcooked_ai_amd import ShardedVecOvercookedEnv     # the same batch partitioned over the GPUs of a node
     from overcooked_ai_amd import OvercookedGridworld, OvercookedEnv, Overcooked   # reference-shaped API
 
 Importing the package does not touch the GPU; the HIP library (liboc_amd.so) is loaded on first use and there is
@@ -14,6 +15,9 @@ def __getattr__(name):  # lazy: these import torch
     if name == "VecOvercookedEnv":
         from .vec_env import VecOvercookedEnv
         return VecOvercookedEnv
+    if name == "ShardedVecOvercookedEnv":
+        from .sharded_env import ShardedVecOvercookedEnv
+        return ShardedVecOvercookedEnv
     if name in ("OvercookedGridworld", "EVENT_TYPES"):
         from . import mdp
         return getattr(mdp, name)

@@ -141,7 +141,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // ------------------------------------------------------------------------------------------
 template <bool LAY_LDS>
 __device__ __forceinline__ Lay stage_layouts(const OcLayout* __restrict__ g_layouts, int n_layouts,
-                                             const uint16_t* __restrict__ layout_id, int64_t e, bool active,
+                                             const uint16_t* layout_id, int64_t e, bool active,
                                              uint4* s_lay) {
     uint32_t lid = 0;
     if (layout_id != nullptr && active) lid = layout_id[e];
@@ -151,6 +151,9 @@ __device__ __forceinline__ Lay stage_layouts(const OcLayout* __restrict__ g_layo
         __syncthreads();
         return Lay{reinterpret_cast<const uint8_t*>(s_lay) + lid * 256u};
     } else {
+        // the callers stage their interact LUT cooperatively just before this call and read it right after: the
+        // barrier belongs to the contract whether or not the layout table itself goes through LDS
+        __syncthreads();
         return Lay{reinterpret_cast<const uint8_t*>(g_layouts) + (size_t)lid * 256u};
     }
 }

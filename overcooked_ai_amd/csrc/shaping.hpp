@@ -42,7 +42,7 @@ __global__ __launch_bounds__(BLOCK) void k_shape_rewards(const float4* __restric
 // ------------------------------------------------------------------------------------------
 template <bool UNIFORM, int MAXP, bool LAY_LDS, bool FAST, bool EVENTS = false>
 __global__ __launch_bounds__(BLOCK) void k_train_step(const OcLayout* __restrict__ g_layouts, int n_layouts,
-                                                      const uint16_t* __restrict__ layout_id, uint4* st,
+                                                      const uint16_t* layout_id, uint4* st,
                                                       const uint8_t* __restrict__ actions, float4* __restrict__ rewards,
                                                       uint8_t* __restrict__ flags, float4* __restrict__ ep_returns,
                                                       float4* __restrict__ ep_out, const uint8_t* __restrict__ plan_blob,
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(BLOCK) void k_train_step(const OcLayout* __restrict
 // ------------------------------------------------------------------------------------------
 template <bool UNIFORM, int MAXP, bool LAY_LDS>
 __global__ __launch_bounds__(BLOCK) void k_train_step1(const OcLayout* __restrict__ g_layouts, int n_layouts,
-                                                       const uint16_t* __restrict__ layout_id, uint4* st,
+                                                       const uint16_t* layout_id, uint4* st,
                                                        const uint8_t* __restrict__ actions, float4* __restrict__ rewards,
                                                        uint8_t* __restrict__ flags, float4* ep_returns,
                                                        float4* __restrict__ ep_out, const uint8_t* __restrict__ plan_blob,

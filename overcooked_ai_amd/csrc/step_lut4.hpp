@@ -447,7 +447,7 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
 template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false,
           bool PIPE = true, bool RU = false, int CW = 2, bool NOCONF = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_rollout4(const OcLayout* __restrict__ g_layouts, int n_layouts,
-                                                    const uint16_t* __restrict__ layout_id, uint4* st,
+                                                    const uint16_t* layout_id, uint4* st,
                                                     float4* __restrict__ rewards, uint8_t* __restrict__ flags,
                                                     float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,
                                                     int horizon, uint32_t options, uint32_t seed_lo, uint32_t seed_hi,

@@ -213,7 +213,7 @@ __device__ __forceinline__ void one_store(const LayC& C, const Lay L, uint4* st,
 
 template <bool UNIFORM, int MAXP, bool LAY_LDS>
 __global__ __launch_bounds__(BLOCK) void k_step1(const OcLayout* __restrict__ g_layouts, int n_layouts,
-                                                 const uint16_t* __restrict__ layout_id, uint4* st,
+                                                 const uint16_t* layout_id, uint4* st,
                                                  const uint8_t* __restrict__ actions, float4* __restrict__ rewards,
                                                  uint8_t* __restrict__ flags, float4* ep_returns, int64_t n, int W,
                                                  int n_obj, int horizon, uint32_t options, StartArgs sa) {

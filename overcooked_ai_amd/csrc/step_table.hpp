@@ -588,7 +588,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__
 // oc_step with d_events != NULL uses k_step, whose predicate-network interact produces the event bits)
 template <bool UNIFORM, int MAXP, bool LAY_LDS, bool FAST = false, bool EVENTS = false>
 __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_layouts, int n_layouts,
-                                                 const uint16_t* __restrict__ layout_id, const uint4* st_in,
+                                                 const uint16_t* layout_id, const uint4* st_in,
                                                  uint4* st_out, const uint8_t* __restrict__ actions,
                                                  float4* __restrict__ rewards, uint8_t* __restrict__ flags,
                                                  float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,

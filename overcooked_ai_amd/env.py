@@ -228,7 +228,8 @@ class OvercookedEnv:
             self.reset(regen_mdp=False)
             if hasattr(agent_pair, "reset"):
                 agent_pair.reset()
-        out = {k: np.array(v, dtype=object) if k in DEFAULT_TRAJ_KEYS[:5] else np.array(v) if k in ("ep_returns", "ep_lengths") else v
+        # every key becomes an ndarray, mdp_params / env_params (object arrays of dicts) included: env.py:574
+        out = {k: np.array(v, dtype=object) if k in DEFAULT_TRAJ_KEYS[:5] else v if k == "metadatas" else np.array(v)
                for k, v in out.items()}
         if out["metadatas"]:  # list of dicts -> dict of lists, like the reference's merge
             keys = out["metadatas"][0].keys()

@@ -372,8 +372,14 @@ class OvercookedGridworld:
         assert self.num_players == 2, "Functionality has to be added to support encondings for > 2 players"
         env = self._env(len(states))
         env.set_packed_state(pack_states(self.spec, states))
-        env.horizon = int(min(max(horizon, 1), 65535))
-        return env.encode_lossless(torch.uint8).cpu().numpy().astype(np.int64)
+        # the urgency layer is `horizon - timestep < 40` (mdp.py:2446-2447) on the caller's horizon — NOT clamped to the
+        # packed timestep's 16 bits: with the reference's default MAX_HORIZON the layer never turns on (int32 range is
+        # all oc_encode_lossless needs: timesteps stop at 65 535)
+        saved, env.horizon = env.horizon, int(min(max(horizon, 1), 2 ** 31 - 1))
+        try:
+            return env.encode_lossless(torch.uint8).cpu().numpy().astype(np.int64)
+        finally:
+            env.horizon = saved
 
     def lossless_state_encoding(self, overcooked_state, horizon=400, debug=False):
         assert type(debug) is bool

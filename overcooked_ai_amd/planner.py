@@ -200,9 +200,11 @@ class MotionPlanner:
         """Fewest actions (INTERACT included) from a (position, orientation) to any of the features; inf when none is
         reachable.  Ties keep the first feature of the list, like the reference's strict '<'."""
         best, arg = np.inf, None
+        (sx, sy), _ = start_pos_and_or
+        assert (sy * self._W + sx) in self._fidx, "start position is not a walkable cell"  # planners.py:402-403
         s = self._state(start_pos_and_or)
         for pos in feature_pos_list:
-            for g in self.motion_goals_for_pos.get(tuple(pos), []):
+            for g in self.motion_goals_for_pos[tuple(pos)]:  # (KeyError for a position that is no feature, as upstream)
                 if g not in self._valid_goal_states:
                     continue
                 d = self._dist[s, self._state(g)]
@@ -216,8 +218,8 @@ class MotionPlanner:
         best, manhattan = np.inf, np.inf
         for p1 in pos_list1:
             for p2 in pos_list2:
-                for g1 in self.motion_goals_for_pos.get(tuple(p1), []):
-                    for g2 in self.motion_goals_for_pos.get(tuple(p2), []):
+                for g1 in self.motion_goals_for_pos[tuple(p1)]:
+                    for g2 in self.motion_goals_for_pos[tuple(p2)]:
                         if self.is_valid_motion_start_goal_pair(g1, g2):
                             best = min(best, self.get_gridworld_distance(g1, g2))
                         elif manhattan_if_fail:

@@ -1,0 +1,193 @@
+"""ShardedVecOvercookedEnv — one batch of envs partitioned over the GPUs of a node as independent shards.
+
+north_star: "env instances partition across the 8 GPUs of one node as independent shards (no collectives on the hot
+path, an optional RCCL reduce over xGMI only for aggregate-return metrics)".  The reference's analogue is the fan-out of
+30 single-env rollout workers (src/human_aware_rl/ppo/ppo_rllib_client.py:97-117); here a shard is a contiguous range of
+global env indices resident in one GPU's HBM (`sharding.shard_range`), stepped by that GPU's own kernels on its own HIP
+stream.  Envs are independent (no cross-env data flow anywhere in mdp.py) and every random stream — the Philox actions
+of `rollout_random`, drawn start states, per-episode layout re-draws — is keyed by the GLOBAL env index
+(`env_offset`), so the shards together reproduce the unsharded batch bit for bit, whatever the number of shards.
+
+Two ways to run it, same class:
+  * single process, several devices (default): one `VecOvercookedEnv` + one stream per device; every call fans out to
+    all shards without a host synchronisation in between (the launches of different GPUs overlap); `aggregate()` sums
+    the per-shard metric vectors on the host side of the first device.
+  * one process per GPU under `torch.distributed` (`from_process_group`): this process owns only its rank's shard;
+    `aggregate()` all-reduces the metric vector (RCCL over xGMI when the backend is nccl).
+
+No scaling curve has been measured on hardware with it in this repo's rounds (no multi-GPU lease): the one-GPU parity
+test (two or three shards on cuda:0 == the unsharded batch) and the CPU gloo tests are what stands behind it.
+"""
+import numpy as np
+import torch
+
+from . import sharding
+from .vec_env import VecOvercookedEnv, as_layout_table
+
+
+class _Shard:
+    __slots__ = ("env", "stream", "start", "stop", "device")
+
+    def __init__(self, env, stream, start, stop):
+        self.env, self.stream, self.start, self.stop, self.device = env, stream, start, stop, env.device
+
+
+class ShardedVecOvercookedEnv:
+    def __init__(self, layouts, n_global, devices=None, layout_id=None, env_offset=0, pad_to=None, ranks=None, **env_kw):
+        """layouts / layout_id / env_kw as for VecOvercookedEnv (layout_id covers all n_global envs).
+        devices: one entry per shard (default: every visible GPU once); a device may appear more than once (several
+        shards on one GPU: what the one-GPU parity test does).  ranks: (rank, world) restricts this object to the shard
+        that rank owns of a world-wide partition (the multi-process form, see from_process_group)."""
+        self.table = as_layout_table(layouts, pad_to)
+        self.n_global = int(n_global)
+        self.env_offset = int(env_offset)
+        if devices is None:
+            devices = ["cuda:%d" % i for i in range(max(1, torch.cuda.device_count()))]
+        devices = [torch.device(d) for d in devices]
+        if layout_id is not None:
+            layout_id = np.asarray(layout_id)
+            if layout_id.shape != (self.n_global,):
+                raise ValueError("layout_id must cover all %d global envs" % self.n_global)
+        self._rank, self._world = (0, 1) if ranks is None else (int(ranks[0]), int(ranks[1]))
+        parts = len(devices) * self._world
+        self.shards = []
+        for i, dev in enumerate(devices):
+            start, stop = sharding.shard_range(self.n_global, self._rank * len(devices) + i, parts)
+            with torch.cuda.device(dev):
+                stream = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(stream):
+                    env = VecOvercookedEnv(self.table, stop - start, device=dev, env_offset=self.env_offset + start,
+                                           layout_id=None if layout_id is None else layout_id[start:stop], **env_kw)
+            self.shards.append(_Shard(env, stream, start, stop))
+        self.width, self.height, self.n_planes = self.table.width, self.table.height, self.table.n_planes
+        self.horizon = self.shards[0].env.horizon
+
+    @classmethod
+    def from_process_group(cls, layouts, n_global, device=None, **kw):
+        """One process per GPU (torch.distributed.run): this process owns the shard of its RANK on cuda:LOCAL_RANK."""
+        rank, local_rank, world = sharding.dist_env()
+        return cls(layouts, n_global, devices=[device or "cuda:%d" % local_rank], ranks=(rank, world), **kw)
+
+    # ------------------------------------------------------------------ fan-out
+    @property
+    def n_local(self):
+        """Envs this object owns (all of them in the single-process form)."""
+        return sum(s.stop - s.start for s in self.shards)
+
+    def ranges(self):
+        return [(s.start, s.stop) for s in self.shards]
+
+    def _each(self, fn):
+        """fn(shard, index) on every shard, on the shard's stream, without host synchronisation in between."""
+        out = []
+        for i, s in enumerate(self.shards):
+            with torch.cuda.device(s.device), torch.cuda.stream(s.stream):
+                out.append(fn(s, i))
+        return out
+
+    def synchronize(self):
+        for s in self.shards:
+            s.stream.synchronize()
+
+    def alloc_outputs(self, n_steps):
+        """Per-shard (rewards [n_steps, n, 4] f32, flags [n_steps, n] u8) buffers on the shards' devices."""
+        return ([torch.zeros((n_steps, s.stop - s.start, 4), dtype=torch.float32, device=s.device) for s in self.shards],
+                [torch.zeros((n_steps, s.stop - s.start), dtype=torch.uint8, device=s.device) for s in self.shards])
+
+    def _split(self, t, per_env_dim=0):
+        """A caller tensor over this object's envs -> per-shard tensors on the shards' devices (async copies)."""
+        if isinstance(t, (list, tuple)):
+            return list(t)
+        base = self.shards[0].start
+        out = []
+        for s in self.shards:
+            sl = [slice(None)] * t.dim()
+            sl[per_env_dim] = slice(s.start - base, s.stop - base)
+            with torch.cuda.device(s.device), torch.cuda.stream(s.stream):
+                out.append(t[tuple(sl)].to(s.device, non_blocking=True).contiguous())
+        return out
+
+    # ------------------------------------------------------------------ env API (lists hold one entry per shard)
+    def reset(self, mask=None, **kw):
+        masks = None if mask is None else self._split(mask)
+        self._each(lambda s, i: s.env.reset(None if masks is None else masks[i], **kw))
+
+    def rollout_random(self, n_steps, rewards_out=None, flags_out=None):
+        """n_steps fused random-policy transitions on every shard (one oc_rollout_random launch per shard, all in flight
+        together).  rewards_out / flags_out: lists from alloc_outputs, or None."""
+        self._each(lambda s, i: s.env.rollout_random(n_steps, None if rewards_out is None else rewards_out[i],
+                                                     None if flags_out is None else flags_out[i]))
+        return rewards_out, flags_out
+
+    def step(self, actions):
+        """actions: uint8 [n_local, 2] (any device / host; split and copied asynchronously) or a per-shard list.
+        Returns (rewards list, flags list) — each shard's own reused buffers, valid after its stream's work is done."""
+        acts = self._split(actions)
+        res = self._each(lambda s, i: s.env.step(acts[i]))
+        return [r for r, _ in res], [f for _, f in res]
+
+    def step_many(self, actions, rewards_out, flags_out):
+        """actions uint8 [K, n_local, 2] (or per-shard list) -> the alloc_outputs(K) buffers."""
+        acts = self._split(actions, per_env_dim=1)
+        self._each(lambda s, i: s.env.step_many(acts[i], rewards_out[i], flags_out[i]))
+        return rewards_out, flags_out
+
+    def encode_lossless(self, dtype=torch.uint8, out=None):
+        """Per-shard [n, 2, W, H, 26] observations (mdp.py:2385)."""
+        return self._each(lambda s, i: s.env.encode_lossless(dtype, out=None if out is None else out[i]))
+
+    def featurize(self, **kw):
+        return self._each(lambda s, i: s.env.featurize(**kw))
+
+    def potential(self, gamma=0.99):
+        return self._each(lambda s, i: s.env.potential(gamma))
+
+    # ------------------------------------------------------------------ gathered views (host; synchronise)
+    def get_packed_state(self):
+        """[n_planes, n_local, 16] — equal to the unsharded batch's slice, plane for plane."""
+        self.synchronize()
+        return np.concatenate([s.env.get_packed_state() for s in self.shards], axis=1)
+
+    def layout_ids(self):
+        self.synchronize()
+        return np.concatenate([s.env.layout_ids() for s in self.shards])
+
+    def ep_returns(self):
+        self.synchronize()
+        return np.concatenate([s.env.ep_returns.cpu().numpy() for s in self.shards], axis=0)
+
+    def gather(self, per_shard, dim=0):
+        """Per-shard tensors -> one host numpy array along the env axis `dim`."""
+        self.synchronize()
+        return np.concatenate([t.cpu().numpy() for t in per_shard], axis=dim)
+
+    # ------------------------------------------------------------------ the only communication: aggregate metrics
+    def aggregate(self, rewards=None, flags=None):
+        """Sum-reduced metrics over every env of every shard (and every rank): running episode returns
+        (sparse0, sparse1, shaped0, shaped1), batched steps done, and — when the output buffers of the last launch are
+        given — the rewards and finished episodes in them.  Each shard reduces on its own GPU (float64), the partial
+        vectors are added on the host side (8 scalars per shard); with a live process group the result is all-reduced
+        (RCCL over xGMI for backend nccl).  Never on the step path."""
+        def partial(s, i):
+            v = torch.zeros((8,), dtype=torch.float64, device=s.device)
+            if s.env.ep_returns is not None:
+                v[0:4] = s.env.ep_returns.sum(dim=0, dtype=torch.float64)
+            if rewards is not None:
+                v[4] = rewards[i][..., 0:2].sum(dtype=torch.float64)
+                v[5] = rewards[i][..., 2:4].sum(dtype=torch.float64)
+            if flags is not None:
+                v[6] = (flags[i] & 1).sum(dtype=torch.float64)
+            v[7] = float(s.env.steps_done) * (s.stop - s.start)
+            return v
+        parts = self._each(partial)
+        self.synchronize()
+        total = torch.stack([p.cpu() for p in parts]).sum(dim=0)
+        if sharding._live():
+            import torch.distributed as dist
+
+            t = total.to(self.shards[0].device) if dist.get_backend() == "nccl" else total
+            sharding.allreduce_metrics(t)
+            total = t.cpu()
+        names = ("ep_sparse_0", "ep_sparse_1", "ep_shaped_0", "ep_shaped_1", "sparse_in_buffers", "shaped_in_buffers",
+                 "episodes_done_in_buffers", "env_steps")
+        return dict(zip(names, (float(x) for x in total)))

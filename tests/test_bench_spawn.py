@@ -1,6 +1,5 @@
 """bench.py's multi-rank plumbing on CPU: `python bench.py --gpus 2` without a launcher spawns its own ranks
-(VERDICT r1 #2); `--stub` swaps the GPU env for a stand-in that steps the C oracle and RCCL for gloo, so the rank spawning, the repeat
-planning, the per-rank shard maps, the parity check and the reductions are exercised.  Nothing here is a measurement."""
+(VERDICT r1 #2); `--stub` swaps the GPU env for a stand-in that steps the C oracle and RCCL for gloo, so the rank spawning, the per-rank shard maps, the parity check and the reductions are exercised.  Nothing here is a measurement."""
 import json
 import os
 import subprocess
@@ -22,23 +21,16 @@ def _run(cmd, env=None):
     return json.loads(lines[0])
 
 
-def test_plan_repeats():
-    import bench
-
-    # 20-step regions, 400-step launches: repeats must be a multiple of 20 and cover >= 0.25 s at 0.5 us/step
-    r = bench.plan_repeats(20, 400, 0.0005, 0.25)
-    assert r % 20 == 0 and r * 20 * 0.0005e-3 >= 0.25 * 1.05 and (r - 20) * 20 * 0.0005e-3 < 0.25 * 1.05
-    assert bench.plan_repeats(20000, 400, 0.0005, 0.25) == 27  # 5 % margin over the warm-up estimate
-    assert bench.plan_repeats(1000, 400, 1.0, 0.25) == 2  # lcm(1000, 400) = 2000 steps = 2 repeats
-    assert bench.plan_repeats(400, 400, 100.0, 0.25) == 1
-
-
-def _check_two_rank_line(out, envs, fuse):
-    assert out["n_gpus"] == 2 and out["data"] == "stub" and out["steps"] == 20 and out["warmup"] == 5
-    assert out["timed_steps"] == 20 * out["repeats"] and out["timed_steps"] % fuse == 0
+def _check_two_rank_line(out, envs, fuse, lps):
+    assert out["n_gpus"] == 2 and out["data"] == "stub" and out["steps"] == 3 and out["warmup"] == 1
+    # exactly K bench steps of `lps` launches of `fuse` transitions are timed; ms_per_step is per bench step
+    assert out["timed_launches"] == 3 * lps and out["timed_transitions_per_env"] == 3 * lps * fuse
+    assert out["config"]["launches_per_step"] == lps and out["config"]["fused_transitions_per_launch"] == fuse
+    assert abs(out["ms_per_step"] * out["steps"] - out["timed_region_s"] * 1e3) < 1e-6 * out["timed_region_s"] * 1e3
+    assert len(out["ms_per_step_each"]) == 3 and all(x > 0 for x in out["ms_per_step_each"])
     assert len(out["ms_per_step_by_rank"]) == 2 and all(x > 0 for x in out["ms_per_step_by_rank"])
     assert out["aggregate"]["reduced_over"] == "gloo all-reduce"
-    assert abs(out["value"] - 2 * envs * out["timed_steps"] / out["timed_region_s"]) < 1e-6 * out["value"]
+    assert abs(out["value"] - 2 * envs * out["timed_transitions_per_env"] / out["timed_region_s"]) < 1e-6 * out["value"]
     # every rank replayed a launch of its own shard (global env offset rank * envs) against the oracle
     pc = out["parity_check"]
     assert pc["mismatches"] == 0 and pc["mismatches_by_rank"] == [0, 0] and pc["envs"] == 2 * envs
@@ -49,9 +41,10 @@ def _check_two_rank_line(out, envs, fuse):
 def test_self_spawn_two_ranks_gloo():
     import bench
 
-    out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--stub", "--envs", "64",
-                "--min-seconds", "0.02"])
-    _check_two_rank_line(out, 64, bench.DEFAULT_FUSE)
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub", "--envs", "64",
+                "--launches-per-step", "2", "--fuse", "800"])
+    _check_two_rank_line(out, 64, 800, 2)
+    assert bench.LAUNCHES_PER_STEP * bench.DEFAULT_FUSE == 1_600_000  # the default bench step (module docstring)
     # the stub steps the oracle: rank 1 owns global envs 64..127, so the all-reduced returns differ from 2 x rank 0's
     assert out["aggregate"]["sparse_return_last_launch"] >= 0 and out["aggregate"]["shaped_return_last_launch"] > 0
     assert out["config"]["baseline_config"] == 2 and "cramped_room" in out["config"]["workload"]
@@ -61,13 +54,13 @@ def test_self_spawn_other_baseline_configs_gloo():
     """BASELINE configs[3] / configs[4] as the 8-GPU runs shard them (--config 4: env e -> layout e % 5;
     --config 5 --envs 131072: env e -> terrain e % 4096, here with a small batch) — per-rank layout ids follow the
     GLOBAL env index, and the per-rank parity_check and ms_per_step_by_rank are in the line."""
-    out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--stub", "--envs", "35",
-                "--config", "4", "--fuse", "600", "--min-seconds", "0.02"])
-    _check_two_rank_line(out, 35, 600)
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub", "--envs", "35",
+                "--config", "4", "--fuse", "600", "--launches-per-step", "1"])
+    _check_two_rank_line(out, 35, 600, 1)
     assert out["config"]["baseline_config"] == 4 and "5 canonical layouts" in out["config"]["workload"]
-    out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--stub", "--envs", "96",
-                "--config", "5", "--fuse", "500", "--min-seconds", "0.02"])
-    _check_two_rank_line(out, 96, 500)
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub", "--envs", "96",
+                "--config", "5", "--fuse", "500", "--launches-per-step", "3"])
+    _check_two_rank_line(out, 96, 500, 3)
     assert out["config"]["baseline_config"] == 5 and "4096 LayoutGenerator" in out["config"]["workload"]
 
 
@@ -92,6 +85,6 @@ def test_workload_layout_ids_follow_the_global_env_index():
 def test_launcher_env_is_respected():
     """Under torch.distributed.run (WORLD_SIZE set by the launcher) bench.py must NOT spawn again."""
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                "127.0.0.1", "--master-port", "29631", "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5",
-                "--stub", "--envs", "64", "--min-seconds", "0.02"])
+                "127.0.0.1", "--master-port", "29631", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1",
+                "--stub", "--envs", "64", "--launches-per-step", "1", "--fuse", "400"])
     assert out["n_gpus"] == 2 and len(out["ms_per_step_by_rank"]) == 2

@@ -459,3 +459,28 @@ def test_overcooked_multi_agent_matches_reference_episodes():
     cfg = dict(OvercookedMultiAgent.DEFAULT_CONFIG)
     env = OvercookedMultiAgent.from_config(cfg)
     assert sorted(env.reset()) == ["ppo_0", "ppo_1"] and env.base_env.horizon == 400
+
+
+def test_urgency_layer_follows_the_callers_horizon_beyond_16_bits():
+    """mdp.py:2446-2447: the urgency layer is `horizon - timestep < 40` on the horizon the caller passes.  With the
+    reference's default MAX_HORIZON (env.py: horizon = 1e10, "never done") it must stay off at t = 65 500, although the
+    packed timestep is a u16 and an earlier version clamped the horizon to 65 535."""
+    from overcooked_ai_amd import OvercookedEnv, OvercookedGridworld
+    from overcooked_ai_amd.env import MAX_HORIZON
+
+    mdp = OvercookedGridworld.from_layout_name("cramped_room")
+    state = mdp.get_standard_start_state()
+    state.timestep = 65500
+    W, H = mdp.shape
+    for horizon, urgent in ((MAX_HORIZON, 0), (10 ** 6, 0), (65540, 0), (65539, 1), (65535, 1), (400, 1)):
+        enc = mdp.lossless_state_encoding(state, horizon=horizon)
+        for p in range(2):
+            assert enc[p].shape == (W, H, 26) and int(enc[p][:, :, 25].sum()) == urgent * W * H, (horizon, p)
+    env = OvercookedEnv.from_mdp(mdp, info_level=0)  # the reference's default horizon
+    env.state = state
+    assert int(np.stack(env.lossless_state_encoding_mdp(state))[:, :, :, 25].sum()) == 0
+    env400 = OvercookedEnv.from_mdp(mdp, horizon=400, info_level=0)
+    state.timestep = 361
+    assert int(np.stack(env400.lossless_state_encoding_mdp(state))[:, :, :, 25].sum()) == 2 * W * H
+    state.timestep = 360
+    assert int(np.stack(env400.lossless_state_encoding_mdp(state))[:, :, :, 25].sum()) == 0

@@ -340,6 +340,41 @@ def test_large_layout_table_global_path(gpu):
     assert np.array_equal(enc, orc.encode_lossless(st_o2, horizon=100, layout_id=lid).astype(np.float32))
 
 
+def test_one_step_kernels_on_a_table_read_from_hbm(gpu):
+    """oc_step in place (k_step1), out of place and with event logging (the event kernel) on a table of more than 32
+    layouts: those instances read the layout records through L2 and stage only the interact LUT in LDS — the
+    workgroup barrier between that staging and the first look-up is part of the prologue whatever the table's
+    size.  Fresh envs every iteration so that every launch is a cold one."""
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    names = ["cramped_room", "cramped_room_tomato", "bonus_order_test", "mdp_test", "simple_o", "simple_o_t",
+             "simple_tomato", "m_shaped_s", "cramped_room_o_3orders"]
+    specs = [spec_from_name(nm) for nm in names] * 4  # 36 entries
+    table = LayoutTable(specs)
+    n = 70000
+    lid = (np.arange(n) * 5 % len(specs)).astype(np.uint16)
+    orc = oracle_for(table.specs)
+    rng = np.random.default_rng(23)
+    st = np.zeros((table.n_planes, n, 16), np.uint8)
+    for l in range(len(specs)):
+        idx = np.nonzero(lid == l)[0]
+        st[:, idx] = random_packed_states(table.specs[l], len(idx), rng, timestep_max=99)
+    for it in range(6):
+        acts = rng.integers(0, 6, size=(n, 2)).astype(np.uint8)
+        st_o, rew_o, fl_o = orc.step(st, acts, horizon=100, options=1, layout_id=lid)
+        env = make_env(table, n, gpu, horizon=100, auto_reset=True, seed=5, layout_id=lid)
+        env.set_packed_state(st)
+        if it % 2 == 0:
+            rew, fl = env.step(torch.from_numpy(acts).to(gpu))
+        else:
+            ev = torch.zeros((n,), dtype=torch.int64, device=gpu)
+            rew, fl = env.step(torch.from_numpy(acts).to(gpu), events_out=ev)
+            assert np.array_equal(u8(ev).view(np.uint64), orc.last_events)
+        assert np.array_equal(env.get_packed_state(), st_o), it
+        assert np.array_equal(u8(rew), rew_o) and np.array_equal(u8(fl), fl_o), it
+        st = st_o
+
+
 def test_every_registry_layout_vs_oracle(gpu):
     """All 1- and 2-player layouts shipped by the reference (grids up to 14x9 = 8 object planes)."""
     from overcooked_ai_amd.layouts import layout_names, spec_from_name
@@ -495,6 +530,8 @@ def test_featurize_state_golden_and_oracle(gpu):
     env = make_env(LayoutSpec(man["cramped_room_none"]["layout"]), d["states"].shape[1], gpu)
     env.set_packed_state(d["states"])
     assert np.array_equal(u8(env.featurize()), d["features"])  # == the reference's expected_2.pickle
+    for num_pots in (0, 1):  # == expected_0.pickle / expected_1.pickle (overcooked_test.py:1069-1093 loops range(3))
+        assert np.array_equal(u8(env.featurize(num_pots=num_pots)), d["features_num_pots_%d" % num_pots]), num_pots
     # symmetry (overcooked_test.py:1094-1110): swapping the players swaps the two feature rows
     sw = env.state.clone()
     sw[0, :, 0:3], sw[0, :, 3:6] = env.state[0, :, 3:6], env.state[0, :, 0:3]

@@ -2,10 +2,11 @@
 """Time the REFERENCE's own Python `OvercookedEnv.step` (SURVEY.md 8d-1 / BASELINE.md 3 protocol) on this machine.
 
 TEST / MEASUREMENT INFRASTRUCTURE: imports the upstream package through oracle/ref_harness.py from
-$OVERCOOKED_REFERENCE_SRC (default /root/reference/src).  The reference cannot travel inside the repo (its sources are
-never copied into it); to time it on a GPU box, tools/gpu_round3_a.sh unpacks a git-ignored tarball of the reference's
-`overcooked_ai_py` package (made by `tools/pack_reference.sh` in the build container) into /tmp and points
-OVERCOOKED_REFERENCE_SRC at it.  Output: one JSON object (kept under profiles/).
+$OVERCOOKED_REFERENCE_SRC (default /root/reference/src).  The reference's sources are never copied into the repo; on a
+GPU box OVERCOOKED_REFERENCE_SRC points at oracle/_ref/src, the reference byte-compiled by oracle/build_ref.py in the
+build container (git-ignored build output that travels with the snapshot like liboc_amd.so) — bench.py's cpu_baseline
+leg runs this script that way, in its own run, on the box's host cores.  Output: one JSON object.
+LAYOUTS=cramped_room[,asymmetric_advantages] and EPISODES=N bound the run.
 
 Protocol: cramped_room (and asymmetric_advantages), OvercookedEnv.from_mdp(mdp, horizon=400, info_level=0), env._mp = object()
 (no MotionPlanner), actions np.random.RandomState(seed).randint(0, 6, (400, 2)) through Action.INDEX_TO_ACTION,
@@ -47,6 +48,16 @@ def cpu_model():
     return platform.processor() or "unknown"
 
 
+def ref_mdp(R, layout):
+    """The reference's OvercookedGridworld for `layout`, built by ITS from_grid (mdp.py:1103) from this repo's own layout
+    data — the byte-compiled reference of oracle/build_ref.py ships no data files, so from_layout_name cannot be used."""
+    from overcooked_ai_amd import layouts as L
+
+    d = dict(L.read_layout_dict(layout))
+    d.pop("grid")
+    return R.OvercookedGridworld.from_grid(L.spec_from_name(layout).grid_rows(), base_layout_params=d)
+
+
 def worker(job):
     layout, episodes, encode, seed = job
     import numpy as np
@@ -54,7 +65,7 @@ def worker(job):
     from oracle import ref_harness
 
     R = ref_harness.load()
-    mdp = R.OvercookedGridworld.from_layout_name(layout)
+    mdp = ref_mdp(R, layout)
     env = R.OvercookedEnv.from_mdp(mdp, horizon=400, info_level=0)
     rng = np.random.RandomState(seed)
     I2A = R.Action.INDEX_TO_ACTION
@@ -106,7 +117,7 @@ def main():
            "reference_src": ref_harness.REFERENCE_SRC, "cpu_model": cpu_model(), "logical_cpus": os.cpu_count(),
            "usable_cores": cores, "python": platform.python_version(), "numpy": np.__version__,
            "episodes_per_process": episodes, "horizon": 400, "host": platform.node()}
-    for layout in ("cramped_room", "asymmetric_advantages"):
+    for layout in os.environ.get("LAYOUTS", "cramped_room,asymmetric_advantages").split(","):
         out[layout] = {
             "step_1core": measure(layout, episodes, False, 1),
             "step_allcores": measure(layout, episodes, False, cores),
