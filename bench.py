@@ -70,7 +70,6 @@ def parse():
                          "lossless encoding every step; 4 = 5-layout mix padded to 9x5; 5 = 4096 generated 9x5 terrains")
     ap.add_argument("--lane-pair", action="store_true", help="force the two-lanes-per-env rollout kernel")
     ap.add_argument("--predicate-interact", action="store_true", help="lane-per-env kernel with the predicate-network interact (v2)")
-    ap.add_argument("--rollout-v3", action="store_true", help="the previous table-driven rollout kernel (k_rollout3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the step-API and encode side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -501,7 +500,7 @@ def measure_traffic(args, kernel):
         return None, {"how": "not collected", "why": "rocprofv3 not found"}
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", str(args.config), "--envs", str(args.envs),
              "--fuse", str(args.fuse), "--layout", args.layout, "--terrains", str(args.terrains)]
-    for flag, on in (("--lane-pair", args.lane_pair), ("--predicate-interact", args.predicate_interact), ("--rollout-v3", args.rollout_v3)):
+    for flag, on in (("--lane-pair", args.lane_pair), ("--predicate-interact", args.predicate_interact)):
         if on:
             child.append(flag)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
@@ -732,7 +731,6 @@ def rollout_workload_env(args, wl, n, rank, dev, VecOvercookedEnv):
                                layout_id=wl["lid"])
         env.lane_pair = getattr(args, "lane_pair", False)
         env.predicate_interact = getattr(args, "predicate_interact", False)
-        env.rollout_v3 = getattr(args, "rollout_v3", False)
         return env
     return make_env
 
@@ -778,8 +776,7 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
     state_bytes = wl["sbytes"]
     bytes_per_launch = n * (2 * state_bytes + OUT_BYTES * fuse)
     achieved = bytes_per_launch / (launch_med * 1e-3) / 1e9
-    kernel = ("k_rollout" if args.predicate_interact else "k_rollout_pair" if args.lane_pair
-              else "k_rollout3" if args.rollout_v3 else "k_rollout4")
+    kernel = "k_rollout" if args.predicate_interact else "k_rollout_pair" if args.lane_pair else "k_rollout4"
     traffic, traffic_src = None, {"how": "not collected", "why": "only rank 0 of a 1-GPU run collects PMC traffic"}
     if rank == 0 and world == 1 and not args.stub:
         if not args.no_traffic:

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define OC_ABI_VERSION 3
+#define OC_ABI_VERSION 4
 
 #define OC_MAX_CELLS 128
 #define OC_MAX_POTS 8
@@ -89,8 +89,7 @@ extern "C" {
 #define OC_OPT_PREDICATE_INTERACT 0x8u /* oc_rollout_random: one-lane-per-env kernel with the predicate-network
                                          interact instead of the table-driven one (kept for cross-checking) */
 
-#define OC_OPT_ROLLOUT_V3 0x10u /* oc_rollout_random: the previous table-driven kernel (k_rollout3) instead of k_rollout4
-                                  (kept for cross-checking) */
+/* 0x10u: reserved (ABI <= 3: OC_OPT_ROLLOUT_V3, the round-1 rollout kernel, retired in ABI 4) */
 #define OC_OPT_ONE_KERNEL 0x20u /* oc_rollout_encode / oc_step_encode: take the single-kernel path (k_rollout_encode)
                                   whenever the table allows it; by default it runs only for batches that give every CU
                                   a workgroup (it keeps 256 envs per CU on chip; smaller batches are faster through the
@@ -178,7 +177,7 @@ int oc_batch_hints(const OcLayout* h_layouts, int n_layouts, OcBatch* batch);
  *      epoch of a restart at step k of the call = epoch + k      (k = 0 for single-step entry points),
  * so a caller that passes epoch = 1 + (steps executed so far) never reuses the draws of its initial
  * oc_reset_random(epoch 0).  Supported by the table-driven kernels (oc_step and oc_step_many without
- * OC_OPT_PREDICATE_INTERACT — with or without event logging —, oc_rollout_random without OC_OPT_ROLLOUT_V3 / LANE_PAIR /
+ * OC_OPT_PREDICATE_INTERACT — with or without event logging —, oc_rollout_random without OC_OPT_LANE_PAIR /
  * PREDICATE_INTERACT, oc_step_encode, oc_rollout_encode, oc_multi_agent_step); the others return OC_EINVAL.
  */
 typedef struct OcStartSpec {

@@ -6,12 +6,11 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OC_AMD_LIB") or os.path.join(PKG, "liboc_amd.so")  # OC_AMD_LIB: developer override
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 F_DONE, F_BAD_ACTION, F_RESET = 0x01, 0x02, 0x04
 OPT_AUTO_RESET = 0x1
 OPT_LANE_PAIR = 0x4
 OPT_PREDICATE_INTERACT = 0x8
-OPT_ROLLOUT_V3 = 0x10
 OPT_ONE_KERNEL = 0x20
 BATCH_TWO_PLAYERS = 0x1
 BATCH_NEW_DYNAMICS = 0x2

@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(PKG, "csrc", "oc_amd.hip")
+SRC = os.path.join(PKG, "csrc", "oc_amd.hip")  # (+ rollout4.hip: UNITS below)
 HDR = os.path.join(os.path.dirname(PKG), "include", "oc_amd.h")
 LIB = os.path.join(PKG, "liboc_amd.so")
 ARCH = "gfx950"
@@ -53,17 +53,41 @@ def is_stale():
     return any(os.path.getmtime(p) > t for p in deps if os.path.exists(p))
 
 
-def build_extension(force=False, verbose=False):
-    if not force and not is_stale():
+UNITS = (("oc_amd.hip", ()), ("rollout4.hip", ("-DOC_R4_PART=0",)), ("rollout4.hip", ("-DOC_R4_PART=1",)),
+         ("rollout4.hip", ("-DOC_R4_PART=2",)))
+
+
+def build_extension(force=False, verbose=False, defines=(), out=None):
+    """Compile the translation units side by side (one hipcc process each) and link them into liboc_amd.so.
+    defines: extra -D flags (e.g. ("-DOC_AMD_TUNING",) for the measurement scripts' environment knobs); out: another
+    output path (variant libraries for A/B runs: OC_AMD_LIB selects one at load time)."""
+    lib = out or LIB
+    if not force and out is None and not is_stale():
         return LIB
-    tmp = LIB + ".%d.tmp" % os.getpid()
-    cmd = [hipcc_path(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", *SCHED, "-shared", "-fPIC", "-o", tmp, SRC]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(tmp, LIB)
-    return LIB
+    objdir = os.path.join(PKG, "csrc", "_obj", "%d" % os.getpid())
+    os.makedirs(objdir, exist_ok=True)
+    csrc = os.path.dirname(SRC)
+    base = [hipcc_path(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", *SCHED, "-fPIC", *defines]
+    procs, objs = [], []
+    for i, (src, flags) in enumerate(UNITS):
+        obj = os.path.join(objdir, "u%d.o" % i)
+        cmd = base + list(flags) + ["-c", "-o", obj, os.path.join(csrc, src)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    tmp = lib + ".%d.tmp" % os.getpid()
+    subprocess.check_call([hipcc_path(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs)
+    os.replace(tmp, lib)
+    for o in objs:
+        os.remove(o)
+    os.rmdir(objdir)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_extension(force="--force" in sys.argv, verbose=True))
+    print(build_extension(force="--force" in sys.argv, verbose=True,
+                          defines=tuple(a for a in sys.argv[1:] if a.startswith("-D"))))

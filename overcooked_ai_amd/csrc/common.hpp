@@ -1,6 +1,6 @@
 // common.hpp — constants, the OcLayout accessor, per-env working registers, Philox, layout staging
-// Part of liboc_amd.so: included by oc_amd.hip inside its anonymous namespace, in this order:
-//   common, reset, step_predicate, step_table, step_one, step_lut4, rollout_pair, encode, rollout_encode, featurize, potential, shaping.
+// Part of liboc_amd.so: included by each translation unit (oc_amd.hip, rollout4.hip) inside its anonymous namespace after
+// shared.hpp, in this order: common, host_util, reset, step_predicate, step_table, [step_one | step_lut4], ...
 #pragma once
 
 constexpr int BLOCK = 256;
@@ -11,7 +11,10 @@ constexpr int L_NCELLS = 2, L_NPOTS = 3, L_NPLAYERS = 4, L_OLDDYN = 5, L_START_P
               L_PCLASS = 24, L_REW = 32, L_COOK = 48, L_VALUE = 64, L_TERRAIN = 128;
 static_assert(sizeof(OcLayout) == 256, "OcLayout must be 256 bytes");
 
-thread_local char g_err[256] = "";
+using oc_detail::g_err;
+using oc_detail::g_lds_refused;
+using oc_detail::StartArgs;
+using oc_detail::EvArgs;
 
 // ------------------------------------------------------------------------------------------
 // Layout accessors.  `base` points at one 256-byte OcLayout, either in LDS or in global memory;

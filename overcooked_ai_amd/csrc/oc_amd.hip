@@ -5,8 +5,10 @@
 //   common.hpp          constants, OcLayout accessor, Philox4x32-10, layout staging
 //   step_predicate.hpp  get_state_transition, mdp.py:1375 (interacts 1432 -> movement 1644 -> env effects 1691) with
 //                       the predicate-network interact that also emits event_infos: k_step, k_rollout
-//   step_table.hpp      the same transition with the table-driven interact: k_step3 (oc_step / oc_step_many), k_rollout3
-//   step_lut4.hpp       the rollout path: key-byte cell words, 16-byte interact LUT, joint move table: k_rollout4
+//   step_table.hpp      the same transition with the table-driven interact: k_step3 (oc_step_many, grids above 64 cells)
+//   step_one.hpp        one transition per launch on the wire format itself: k_step1 (oc_step)
+//   step_lut4.hpp       the rollout path: key-byte cell words, 16-byte interact LUT, joint move table: k_rollout4 — compiled in
+//                       rollout4.hip (three units, see shared.hpp), launched from here through oc_detail::launch_rollout4_*
 //   rollout_pair.hpp    two lanes per env: k_rollout_pair
 //   reset.hpp           get_standard_start_state mdp.py:1297, get_random_start_state_fn 1307: k_reset, k_reset_random
 //   encode.hpp          lossless_state_encoding mdp.py:2385-2561: k_encode, k_encode_uniform
@@ -22,22 +24,25 @@
 // lane % 32 whatever cell a lane touches, so divergent per-lane cell indices never conflict — and
 // the compiled layout table (terrain tile, pot cells, recipe LUTs) is staged in LDS once per
 // workgroup.  See DESIGN.md for the data layout and the roofline of each kernel.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
-#include "../../include/oc_amd.h"
+#include "shared.hpp"
+
+namespace oc_detail {
+thread_local char g_err[256] = "";
+thread_local bool g_lds_refused = false;
+}  // namespace oc_detail
 
 namespace {
 
 #include "common.hpp"
+#include "host_util.hpp"
 #include "reset.hpp"
 #include "step_predicate.hpp"
 #include "step_table.hpp"
 #include "step_one.hpp"
-#include "step_lut4.hpp"
 #include "rollout_pair.hpp"
 #include "encode.hpp"
 #include "rollout_encode.hpp"
@@ -48,39 +53,6 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-int fail(int code, const char* msg) {
-    snprintf(g_err, sizeof(g_err), "%s", msg);
-    return code;
-}
-
-thread_local bool g_lds_refused = false;
-
-int check_launch(const char* what) {
-    if (g_lds_refused) {  // want_lds already wrote the message; nothing was launched
-        g_lds_refused = false;
-        return OC_ELAUNCH;
-    }
-    hipError_t err = hipGetLastError();
-    if (err != hipSuccess) {
-        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(err));
-        return OC_ELAUNCH;
-    }
-    return OC_OK;
-}
-
-// Raise a kernel's dynamic-LDS limit when a launch needs more than the default; a request above what the device
-// offers is reported here (not as a later launch failure).
-template <typename K>
-bool want_lds(K kernel, size_t bytes, size_t dflt = 40 * 1024) {
-    if (bytes <= dflt) return true;
-    const hipError_t err = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (err == hipSuccess) return true;
-    snprintf(g_err, sizeof(g_err), "dynamic LDS request of %zu bytes refused: %s", bytes, hipGetErrorString(err));
-    (void)hipGetLastError();
-    g_lds_refused = true;
-    return false;
-}
-
 int check_batch(const OcBatch* b, int* n_obj) {
     if (!b) return fail(OC_EINVAL, "batch is NULL");
     if (!b->d_layouts) return fail(OC_EINVAL, "batch.d_layouts is NULL");
@@ -93,16 +65,25 @@ int check_batch(const OcBatch* b, int* n_obj) {
     return OC_OK;
 }
 
-// LDS bytes one encode workgroup may fill with output (default 40 KiB = 3 workgroups per CU); OC_ENC_LDS overrides it
-// for tuning runs (read once per process).
+// LDS bytes one encode workgroup may fill with output (40 KiB = 3 workgroups per CU).  The library reads no environment
+// variable unless it is built with -DOC_AMD_TUNING (the knobs of the measurement scripts under tools/: OC_ENC_LDS,
+// OC_STEP_NO_LEAN, OC_ROLLOUT_PIPE, OC_ROLLOUT_NO_MODE2, OC_ROLLOUT_ENCODE_WAVES).
 inline int enc_lds_budget() {
+#ifdef OC_AMD_TUNING
     static int v = []() { const char* e = getenv("OC_ENC_LDS"); return e ? atoi(e) : 40 * 1024; }();
     return v;
+#else
+    return 40 * 1024;
+#endif
 }
 // ... for the persistent single-layout kernel: ~19 envs per group is the measured sweet spot (65 536 cramped_room envs,
 // u8: 18.1 us with a 20 KB image, 20.6 us with 40 KB, 25.2 us with 12 KB; 9x5 grids: 40 KB = 17 envs is best)
 inline size_t enc_uniform_budget(size_t env_bytes) {
+#ifdef OC_AMD_TUNING
     static const bool forced = getenv("OC_ENC_LDS") != nullptr;
+#else
+    constexpr bool forced = false;
+#endif
     const size_t cap = (size_t)enc_lds_budget();
     if (forced) return cap;
     const size_t want = 19 * env_bytes;
@@ -144,28 +125,6 @@ EvArgs ev_args(const OcEventSink* sink, uint64_t* d_events, uint32_t clear_on_do
 }
 inline bool ev_on(const EvArgs& ea) { return ea.events || ea.counts; }
 
-inline unsigned grid_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
-
-// SIMDs of the current device (4 per CU); cached per thread
-inline int64_t simd_count() {
-    thread_local int cached_dev = -1;
-    thread_local int64_t cached = 1024;
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev != cached_dev) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) cached = 4 * (int64_t)cus;
-        cached_dev = dev;
-    }
-    return cached;
-}
-
-// dynamic LDS of a k_rollout4 instance: its tables + the cell words of a workgroup's 256 envs
-template <bool U, int MP, bool LL, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false, bool PIPE = true,
-          bool RU = false, int CW = 2, bool NOCONF = false>
-constexpr size_t lds4_bytes(size_t cell_rows) {
-    return (size_t)Lds4<U, LL, MODE, NF, U || RU, CW>::CELLS + cell_rows * BLOCK * CW;
-}
-
 #define DISPATCH_NOBJ(NOBJ_VALUE, ...)                                  \
     switch (NOBJ_VALUE) {                                               \
         case 1: { constexpr int NOBJ = 1; __VA_ARGS__; } break;         \
@@ -193,17 +152,23 @@ void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_st
     const size_t smem = (size_t)n_obj * 8 * BLOCK * sizeof(uint32_t);
     const dim3 grid(grid_for(b->n_envs)), block(BLOCK);
     if (!(options & OC_OPT_PREDICATE_INTERACT)) {
-        // one step, in place, no event logging, at most 64 cells: the transition on the wire format itself (step_one.hpp)
-        static const bool no_lean = getenv("OC_STEP_NO_LEAN") != nullptr;  // developer knob: k_step3 for every oc_step
-        if (!EVENTS && n_steps == 1 && d_state_in == d_state_out && n_obj <= STEP1_MAX_PLANES && !no_lean) {
+        // one step on a grid of at most 64 cells: the transition on the wire format itself (step_one.hpp) — in place or out of
+        // place, with or without event logging
+#ifdef OC_AMD_TUNING
+        static const bool no_lean = getenv("OC_STEP_NO_LEAN") != nullptr;  // tuning builds: k_step3 for every oc_step
+#else
+        constexpr bool no_lean = false;
+#endif
+        if (n_steps == 1 && n_obj <= STEP1_MAX_PLANES && !no_lean) {
             const size_t smem1 = (size_t)n_obj * BLOCK * sizeof(uint4);
 #define GO1(U, MP, LL)                                                                                                \
-    hipLaunchKernelGGL((k_step1<U, MP, LL>), grid, block, smem1, s, b->d_layouts, b->n_layouts, b->d_layout_id,      \
-                       (uint4*)d_state_out, d_actions, (float4*)d_rewards, d_flags, (float4*)d_ep_returns, b->n_envs, \
-                       b->width, n_obj, horizon, options, sa)
+    hipLaunchKernelGGL((k_step1<U, MP, LL, EVENTS>), grid, block, smem1, s, b->d_layouts, b->n_layouts, b->d_layout_id, \
+                       (uint4*)d_state_in, (uint4*)d_state_out, d_actions, (float4*)d_rewards, d_flags,               \
+                       (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options, sa, ea)
             if (uniform) { if (b->max_pots == 1) GO1(true, 1, true); else if (small) GO1(true, 2, true); else GO1(true, 8, true); }
-            else if (lds) { if (small) GO1(false, 2, true); else GO1(false, 8, true); }
-            else { if (small) GO1(false, 2, false); else GO1(false, 8, false); }
+            else if (lds && small) GO1(false, 2, true);
+            else if (small) GO1(false, 2, false);
+            else GO1(false, 8, false);  // (more than two pots on a mixed table: the general instance reads the table through L2)
 #undef GO1
             return;
         }
@@ -214,11 +179,12 @@ void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_st
                            (const uint4*)d_state_in, (uint4*)d_state_out, d_actions, (float4*)d_rewards, d_flags,    \
                            (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options, n_steps, sa, ea);    \
     } while (0)
+        // (what is left for k_step3: oc_step_many's K transitions per launch and grids above 64 cells)
         if (uniform && fast && b->max_pots == 1) GO3(true, 1, true, true);
         else if (uniform && fast && small) GO3(true, 2, true, true);
-        else if (uniform) { if (b->max_pots == 1) GO3(true, 1, true, false); else if (small) GO3(true, 2, true, false); else GO3(true, 8, true, false); }
-        else if (lds) { if (small) GO3(false, 2, true, false); else GO3(false, 8, true, false); }
-        else { if (small) GO3(false, 2, false, false); else GO3(false, 8, false, false); }
+        else if (uniform) GO3(true, 8, true, false);
+        else if (lds && small) GO3(false, 2, true, false);
+        else GO3(false, 8, false, false);
 #undef GO3
         return;
     }
@@ -230,9 +196,9 @@ void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_st
                            (float4*)d_rewards, d_flags, (float4*)d_ep_returns, ea.events, b->n_envs,        \
                            b->width, n_obj, horizon, options);                                              \
     } while (0)
+    // (the predicate network is the independent second implementation: three instances cover every table)
     if (uniform) { if (small) GO(true, 2, true); else GO(true, 8, true); }
-    else if (lds) { if (small) GO(false, 2, true); else GO(false, 8, true); }
-    else { if (small) GO(false, 2, false); else GO(false, 8, false); }
+    else GO(false, 8, false);
 #undef GO
 }
 
@@ -349,7 +315,7 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
     StartArgs sa;
     if (!start_args(start, &sa, b)) return fail(OC_EINVAL, "oc_rollout_random: start.rnd_obj_prob_thresh must be in [0, 1] and its regen range within the table");
     const EvArgs ea = ev_args(events, nullptr);
-    if ((start || ev_on(ea)) && (options & (OC_OPT_ROLLOUT_V3 | OC_OPT_LANE_PAIR | OC_OPT_PREDICATE_INTERACT)))
+    if ((start || ev_on(ea)) && (options & (OC_OPT_LANE_PAIR | OC_OPT_PREDICATE_INTERACT)))
         return fail(OC_EINVAL, "oc_rollout_random: drawn start states / event logging need the default kernel (k_rollout4)");
     if (start && start->env_offset != env_offset) return fail(OC_EINVAL, "oc_rollout_random: start.env_offset differs from env_offset");
     if (!d_state) return fail(OC_EINVAL, "oc_rollout_random: NULL state pointer");
@@ -387,103 +353,38 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
                                env_offset, t0, n_steps);
         return check_launch("oc_rollout_random");
     }
-    // launches of a few steps cannot amortise k_rollout4's prologue (LUT patching, move table): they run k_rollout3
-    const bool short_launch = n_steps < 8 && !start && !ev_on(ea);
-    if ((options & (OC_OPT_PREDICATE_INTERACT | OC_OPT_ROLLOUT_V3)) == 0 && !short_launch) {
-        // k_rollout4.  JOINT move table: one two-player layout with at most JOINT_MAX_FLOOR free cells (hint from the caller)
+    if ((options & OC_OPT_PREDICATE_INTERACT) == 0) {
+        // k_rollout4 (step_lut4.hpp; its instances are compiled in rollout4.hip, three units).  Which family runs:
+        //   joint   one two-player, one-pot, new-dynamics layout with at most 6 free cells (cramped_room): the JOINT move table.
+        //           Launches of a few steps cannot amortise the ~10 us the workgroups spend building it: they move arithmetically
+        //   mode2   two players everywhere, at most two pots and 64 cells, one set of shaping rewards: per-env terrain with
+        //           the pose one step ahead on a floor mask (BASELINE configs[3] / [4], single layouts with more free cells)
+        //   else    arithmetic movement (MODE 0): any table, either dynamics, event logging
+        oc_detail::Rollout4Call c;
+        c.b = b; c.n_obj = n_obj; c.d_state = d_state; c.d_rewards = d_rewards; c.d_flags = d_flags; c.d_ep_returns = d_ep_returns;
+        c.horizon = horizon; c.options = options; c.seed = seed; c.env_offset = env_offset; c.t0 = t0; c.n_steps = n_steps;
+        c.sa = sa; c.ea = ea; c.stream = s;
         const bool two = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0;
-        const bool joint = uniform && two && b->max_free_cells >= 2 && b->max_free_cells <= (uint32_t)JOINT_MAX_FLOOR;
-        const bool old = (b->batch_flags & OC_BATCH_NEW_DYNAMICS) == 0;  // some layout may use old dynamics
-        const size_t cell_rows = (size_t)n_obj * 16 + 1;  // + one spare word per lane
-        const dim3 grid4(grid_for(b->n_envs)), block4(BLOCK);
-        const bool out = d_rewards != nullptr && d_flags != nullptr;
+        c.uniform = uniform; c.lds = lds; c.small = small; c.events = ev_on(ea);
+        c.old_dyn = (b->batch_flags & OC_BATCH_NEW_DYNAMICS) == 0;  // some layout may use old dynamics
+        c.out = d_rewards != nullptr && d_flags != nullptr;
         // big batches (more than ~1.5 wavefronts per SIMD) hide latency with the other wavefronts: no one-step-ahead reads
-        static const int forced_pipe = []() { const char* e = getenv("OC_ROLLOUT_PIPE"); return e ? atoi(e) : -1; }();  // tuning runs
-        const bool pipe = forced_pipe >= 0 ? forced_pipe != 0 : b->n_envs <= simd_count() * 64 * 3 / 2;
+#ifdef OC_AMD_TUNING
+        static const int forced_pipe = []() { const char* e = getenv("OC_ROLLOUT_PIPE"); return e ? atoi(e) : -1; }();  // tuning builds
+        static const bool no_mode2 = getenv("OC_ROLLOUT_NO_MODE2") != nullptr;
+#else
+        constexpr int forced_pipe = -1;
+        constexpr bool no_mode2 = false;
+#endif
+        c.pipe = forced_pipe >= 0 ? forced_pipe != 0 : b->n_envs <= simd_count() * 64 * 3 / 2;
+        c.joint = uniform && two && b->max_pots == 1 && b->max_free_cells >= 2 && b->max_free_cells <= 6u && c.out &&
+                  !c.old_dyn && n_steps >= 8 && !c.events;
         const bool shaping_uniform = uniform || (b->batch_flags & OC_BATCH_UNIFORM_SHAPING) != 0;
-        static const bool no_mode2 = getenv("OC_ROLLOUT_NO_MODE2") != nullptr;  // tuning / cross-check runs
-        const bool mode2 = !joint && two && !old && out && small && shaping_uniform && b->width * b->height <= 64 &&
-                           !ev_on(ea) && !no_mode2;
-#define GO4(U, MP, LL, MODE, OUT, OLD, NF, ...)                                                                     \
-    do {                                                                                                            \
-        const size_t smem4 = lds4_bytes<U, MP, LL, MODE, OUT, OLD, NF, ##__VA_ARGS__>(cell_rows);                   \
-        if (!want_lds(k_rollout4<U, MP, LL, MODE, OUT, OLD, NF, ##__VA_ARGS__>, smem4)) break;                      \
-        hipLaunchKernelGGL((k_rollout4<U, MP, LL, MODE, OUT, OLD, NF, ##__VA_ARGS__>), grid4, block4, smem4, s, b->d_layouts, \
-                           b->n_layouts, b->d_layout_id, (uint4*)d_state, (float4*)d_rewards, d_flags,              \
-                           (float4*)d_ep_returns, b->n_envs, b->width, n_obj, horizon, options, (uint32_t)seed,     \
-                           (uint32_t)(seed >> 32), env_offset, t0, n_steps, sa, ea);                                \
-    } while (0)
-        if (ev_on(ea)) {  // event logging: the general instances
-            if (joint && b->max_pots == 1) GO4(true, 1, true, 1, false, true, JOINT_MAX_FLOOR, true);
-            else if (uniform) { if (small) GO4(true, 2, true, 0, false, true, 0, true); else GO4(true, 8, true, 0, false, true, 0, true); }
-            else if (lds) { if (small) GO4(false, 2, true, 0, false, true, 0, true); else GO4(false, 8, true, 0, false, true, 0, true); }
-            else { if (small) GO4(false, 2, false, 0, false, true, 0, true); else GO4(false, 8, false, 0, false, true, 0, true); }
-        }
-        else if (joint && b->max_pots == 1 && out && !old && b->max_free_cells <= 6) {
-            // one wavefront per SIMD (or less): read the faced cells a step ahead; more: do not (see PIPE)
-            // one wavefront per SIMD (or less) on a grid of at most 64 cells: 32-bit cell words (no re-masking of values
-            // carried across steps, no shared banks) and the faced cells read a step ahead; more wavefronts: neither
-            const bool noconf = (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0;
-            if (pipe && b->width * b->height <= 64 && noconf) GO4(true, 1, true, 1, true, false, 6, false, true, false, 4, true);
-            else if (pipe && b->width * b->height <= 64) GO4(true, 1, true, 1, true, false, 6, false, true, false, 4);
-            else if (pipe) GO4(true, 1, true, 1, true, false, 6);
-            else GO4(true, 1, true, 1, true, false, 6, false, false);
-        }
-        else if (joint && b->max_pots == 1) GO4(true, 1, true, 1, false, true, JOINT_MAX_FLOOR);
-        else if (joint && small) GO4(true, 2, true, 1, false, true, JOINT_MAX_FLOOR);
-        else if (joint) GO4(true, 8, true, 1, false, true, JOINT_MAX_FLOOR);
-        else if (mode2) {
-            // per-env terrain (or one layout with more free cells than the joint table holds): pose one step ahead on the
-            // per-lane floor mask (MODE 2); one wavefront per SIMD or less reads the faced cells a step ahead, more do not
-#define GO4M2(U, LL, RUF)                                                                                 \
-    do {                                                                                                  \
-        if (b->max_pots == 1) { if (pipe) GO4(U, 1, LL, 2, true, false, 0, false, true, RUF, 4); else GO4(U, 1, LL, 2, true, false, 0, false, false, RUF); } \
-        else { if (pipe) GO4(U, 2, LL, 2, true, false, 0, false, true, RUF, 4); else GO4(U, 2, LL, 2, true, false, 0, false, false, RUF); } \
-    } while (0)
-            if (uniform) GO4M2(true, true, false);
-            else if (lds) GO4M2(false, true, true);
-            else GO4M2(false, false, true);
-#undef GO4M2
-        }
-        else if (uniform && !old && out && small) {
-            if (b->max_pots == 1) GO4(true, 1, true, 0, true, false, 0);
-            else GO4(true, 2, true, 0, true, false, 0);
-        }
-        else if (uniform) {
-            if (b->max_pots == 1) GO4(true, 1, true, 0, false, true, 0);
-            else if (small) GO4(true, 2, true, 0, false, true, 0);
-            else GO4(true, 8, true, 0, false, true, 0);
-        }
-        else if (!old && out && small) {  // mixed table, new dynamics, both output arrays: no per-step NULL / old-dynamics tests
-            if (lds) GO4(false, 2, true, 0, true, false, 0); else GO4(false, 2, false, 0, true, false, 0);
-        }
-        else if (lds) { if (small) GO4(false, 2, true, 0, false, true, 0); else GO4(false, 8, true, 0, false, true, 0); }
-        else { if (small) GO4(false, 2, false, 0, false, true, 0); else GO4(false, 8, false, 0, false, true, 0); }
-#undef GO4
-        return check_launch("oc_rollout_random");
-    }
-    if ((options & OC_OPT_PREDICATE_INTERACT) == 0) {  // OC_OPT_ROLLOUT_V3
-        const bool fast = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0 && b->width * b->height <= 64;
-        const size_t smem3 = (size_t)n_obj * 16 * BLOCK * sizeof(uint16_t);
-        const dim3 grid3(grid_for(b->n_envs)), block3(BLOCK);
-#define GO3(U, MP, LL, ...)                                                                                          \
-    do {                                                                                                             \
-        if (!want_lds(k_rollout3<U, MP, LL, ##__VA_ARGS__>, smem3)) break;                                           \
-        hipLaunchKernelGGL((k_rollout3<U, MP, LL, ##__VA_ARGS__>), grid3, block3, smem3, s, b->d_layouts, b->n_layouts,             \
-                           b->d_layout_id, (uint4*)d_state, (float4*)d_rewards, d_flags, (float4*)d_ep_returns,     \
-                           b->n_envs, b->width, n_obj, horizon, options, (uint32_t)seed, (uint32_t)(seed >> 32),    \
-                           env_offset, t0, n_steps);                                                                 \
-    } while (0)
-        const bool two = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0;
-        const bool out = d_rewards != nullptr && d_flags != nullptr;
-        if (uniform && fast && b->max_pots == 1 && out) GO3(true, 1, true, 3, true);
-        else if (uniform && fast && small && out) GO3(true, 2, true, 3, true);
-        else if (uniform && fast && b->max_pots == 1) GO3(true, 1, true, 3);
-        else if (uniform && fast && small) GO3(true, 2, true, 3);
-        else if (uniform) { if (b->max_pots == 1) GO3(true, 1, true); else if (small) GO3(true, 2, true); else GO3(true, 8, true); }
-        else if (lds) { if (small && two) GO3(false, 2, true, 1); else if (small) GO3(false, 2, true); else GO3(false, 8, true); }
-        else { if (small && two) GO3(false, 2, false, 1); else if (small) GO3(false, 2, false); else GO3(false, 8, false); }
-#undef GO3
+        const bool mode2 = !c.joint && two && !c.old_dyn && c.out && small && shaping_uniform && b->width * b->height <= 64 &&
+                           !c.events && !no_mode2;
+        if (c.joint || c.events) oc_detail::launch_rollout4_joint_events(c);
+        else if (mode2) oc_detail::launch_rollout4_mode2(c);
+        else oc_detail::launch_rollout4_mode0(c);
         return check_launch("oc_rollout_random");
     }
     const size_t smem = (size_t)n_obj * 8 * BLOCK * sizeof(uint32_t);
@@ -497,8 +398,7 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
                            (uint32_t)seed, (uint32_t)(seed >> 32), env_offset, t0, n_steps);                \
     } while (0)
     if (uniform) { if (small) GO(true, 2, true); else GO(true, 8, true); }
-    else if (lds) { if (small) GO(false, 2, true); else GO(false, 8, true); }
-    else { if (small) GO(false, 2, false); else GO(false, 8, false); }
+    else GO(false, 8, false);
 #undef GO
     return check_launch("oc_rollout_random");
 }
@@ -616,7 +516,11 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
                            d_phi_next, d_phi_cur, d_phi_start, reward_shaping_factor, d_shaped, d_done, b->n_envs,    \
                            b->width, b->height, n_obj, horizon, sa, ea);                                              \
     } while (0)
-                static const bool no_lean = getenv("OC_STEP_NO_LEAN") != nullptr;  // developer knob: k_train_step always
+#ifdef OC_AMD_TUNING
+                static const bool no_lean = getenv("OC_STEP_NO_LEAN") != nullptr;  // tuning builds: k_train_step always
+#else
+                constexpr bool no_lean = false;
+#endif
                 if (!ev_on(ea) && n_obj <= STEP1_MAX_PLANES && !no_lean) {  // the transition on the wire format itself (step_one.hpp)
                     const size_t smem1 = (size_t)n_obj * BLOCK * sizeof(uint4);
 #define GOT1(U, MP, LL)                                                                                                \
@@ -631,10 +535,9 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
                     else GOT1(false, 2, false);
 #undef GOT1
                 }
-                else if (uniform && fast && b->max_pots == 1) GOT(true, 1, true, true);
+                // (k_train_step: event counters attached, or a grid above 64 cells)
                 else if (uniform && fast) GOT(true, 2, true, true);
                 else if (uniform) GOT(true, 2, true, false);
-                else if (lds) GOT(false, 2, true, false);
                 else GOT(false, 2, false, false);
 #undef GOT
 #undef GOT_
@@ -847,7 +750,11 @@ int oc_rollout_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions,
         // eight wavefronts (four of them helpers that only encode) when eight images of at least 8 envs fit: small grids,
         // where four wavefronts cannot encode 256 envs in the time HBM takes them (5x4 u8: 14.4 vs 17.4 us per step); 9x5
         // is at the write ceiling either way (30.1 vs 30.4 us), f32 loses with one-env images (128 vs 117 us)
-        static const int forced_nw = []() { const char* e = getenv("OC_ROLLOUT_ENCODE_WAVES"); return e ? atoi(e) : 0; }();  // tuning runs
+#ifdef OC_AMD_TUNING
+        static const int forced_nw = []() { const char* e = getenv("OC_ROLLOUT_ENCODE_WAVES"); return e ? atoi(e) : 0; }();  // tuning builds
+#else
+        constexpr int forced_nw = 0;
+#endif
         int nw = 8;
         int gmax = fixed < budget ? (int)((budget - fixed) / (nw * env_bytes)) : 0;
         if (((gmax < 8 || gmax < unit) && forced_nw != 8) || forced_nw == 4) {

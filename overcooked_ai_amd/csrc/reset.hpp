@@ -51,15 +51,7 @@ struct StartDraw {
     __device__ __forceinline__ uint32_t pot_obj(uint32_t k) const { return ((k < 4u ? pots0 : pots1) >> (8u * (k & 3u))) & 0xFFu; }
 };
 
-// Launch-time description of the start_state_fn (include/oc_amd.h, OcStartSpec), by value in kernel arguments.
-struct StartArgs {
-    uint32_t enabled, seed_lo, seed_hi, epoch;
-    int64_t env_offset;
-    uint64_t thresh;  // floor(rnd_obj_prob_thresh * 2^32)
-    int32_t random_start_pos;
-    uint32_t regen_first, regen_count;  // regen_count > 0: a restarted env moves to layout regen_first + draw % regen_count
-    uint16_t* layout_ids;               // the batch's layout ids, writable (regen_count > 0)
-};
+// (StartArgs — the launch-time form of OcStartSpec — and EvArgs are defined in shared.hpp: they cross translation units)
 
 // The layout of an env's NEXT episode (OvercookedEnv.reset(regen_mdp=True) with a generator that returns a different mdp
 // every time, env.py:288-302; layout_generator.py:110-160): block 15 of the reset stream documented above, word 0.
@@ -70,13 +62,6 @@ __device__ __forceinline__ uint32_t draw_layout(const StartArgs& sa, uint64_t g,
     return sa.regen_first + __umulhi(r[0], sa.regen_count);
 }
 
-// Where the event_infos of a launch go (include/oc_amd.h, OcEventSink), by value in kernel arguments.
-struct EvArgs {
-    uint64_t* events;       // [n_steps][n_envs] masks, or NULL
-    uint32_t* counts;       // [n_envs][25] running counts of the current episode (player 0: bits 0..15, player 1: 16..31), or NULL
-    uint32_t* counts_done;  // [n_envs][25] counts of the last finished episode, or NULL
-    uint32_t clear_on_done; // the caller restarts finished envs itself right after this launch (oc_multi_agent_step)
-};
 constexpr int N_EVENT_TYPES = 25;
 
 // add one step's events to the env's counters; at the end of an episode publish them and start from zero

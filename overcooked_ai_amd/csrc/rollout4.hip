@@ -1,0 +1,96 @@
+// rollout4.hip — the instances of k_rollout4 (step_lut4.hpp), in three translation units: this file is compiled with
+// -DOC_R4_PART=0 (joint move table + event logging), 1 (MODE 2: per-env terrain, pose one step ahead) and 2 (MODE 0:
+// arithmetic movement), so that a clean build runs four hipcc processes side by side (overcooked_ai_amd/build.py) instead
+// of one 80-second compile.  oc_amd.hip (oc_rollout_random) decides the family and calls the unit's launcher.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "shared.hpp"
+
+#ifndef OC_R4_PART
+#error "compile with -DOC_R4_PART=0, 1 or 2"
+#endif
+
+namespace {
+
+#include "common.hpp"
+#include "host_util.hpp"
+#include "reset.hpp"
+#include "step_predicate.hpp"
+#include "step_table.hpp"
+#include "step_lut4.hpp"
+
+// dynamic LDS of a k_rollout4 instance: its tables + the cell words of a workgroup's 256 envs
+template <bool U, int MP, bool LL, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false, bool PIPE = true,
+          bool RU = false, int CW = 2, bool NOCONF = false>
+constexpr size_t lds4_bytes(size_t cell_rows) {
+    return (size_t)Lds4<U, LL, MODE, NF, U || RU, CW>::CELLS + cell_rows * BLOCK * CW;
+}
+
+#define GO4(U, MP, LL, MODE, OUT, OLD, NF, ...)                                                                     \
+    do {                                                                                                            \
+        const size_t smem4 = lds4_bytes<U, MP, LL, MODE, OUT, OLD, NF, ##__VA_ARGS__>(cell_rows);                   \
+        if (!want_lds(k_rollout4<U, MP, LL, MODE, OUT, OLD, NF, ##__VA_ARGS__>, smem4)) break;                      \
+        hipLaunchKernelGGL((k_rollout4<U, MP, LL, MODE, OUT, OLD, NF, ##__VA_ARGS__>), grid4, block4, smem4, c.stream, b->d_layouts, \
+                           b->n_layouts, b->d_layout_id, (uint4*)c.d_state, (float4*)c.d_rewards, c.d_flags,        \
+                           (float4*)c.d_ep_returns, b->n_envs, b->width, c.n_obj, c.horizon, c.options,             \
+                           (uint32_t)c.seed, (uint32_t)(c.seed >> 32), c.env_offset, c.t0, c.n_steps, c.sa, c.ea);  \
+    } while (0)
+
+#define OC_R4_PROLOGUE                                                       \
+    const OcBatch* b = c.b;                                                  \
+    const size_t cell_rows = (size_t)c.n_obj * 16 + 1; /* + one spare word per lane */ \
+    const dim3 grid4(grid_for(b->n_envs)), block4(BLOCK)
+
+}  // namespace
+
+namespace oc_detail {
+
+#if OC_R4_PART == 0
+void launch_rollout4_joint_events(const Rollout4Call& c) {
+    OC_R4_PROLOGUE;
+    if (c.events) {  // event logging: the general instances (arithmetic movement, either dynamics)
+        if (c.uniform && c.small) GO4(true, 2, true, 0, false, true, 0, true);
+        else if (c.lds && c.small) GO4(false, 2, true, 0, false, true, 0, true);
+        else if (c.small) GO4(false, 2, false, 0, false, true, 0, true);
+        else GO4(false, 8, false, 0, false, true, 0, true);
+        return;
+    }
+    // c.joint: one wavefront per SIMD (or less) on a grid of at most 64 cells where no two players can face the same cell
+    // (cramped_room): 32-bit cell words and the faced cells read a step ahead; else 16-bit words, with the one-step-ahead
+    // reads only while a SIMD holds one wavefront (see PIPE in step_lut4.hpp)
+    const bool noconf = (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0;
+    if (c.pipe && b->width * b->height <= 64 && noconf) GO4(true, 1, true, 1, true, false, 6, false, true, false, 4, true);
+    else if (c.pipe) GO4(true, 1, true, 1, true, false, 6);
+    else GO4(true, 1, true, 1, true, false, 6, false, false);
+}
+#elif OC_R4_PART == 1
+void launch_rollout4_mode2(const Rollout4Call& c) {
+    OC_R4_PROLOGUE;
+    // one wavefront per SIMD or less reads the faced cells a step ahead (32-bit cell words), more do not
+#define GO4M2(U, MP, LL, RUF)                                                                             \
+    do {                                                                                                  \
+        if (c.pipe) GO4(U, MP, LL, 2, true, false, 0, false, true, RUF, 4); else GO4(U, MP, LL, 2, true, false, 0, false, false, RUF); \
+    } while (0)
+    if (c.uniform) { if (b->max_pots == 1 && c.pipe) GO4(true, 1, true, 2, true, false, 0, false, true, false, 4); else GO4M2(true, 2, true, false); }
+    else if (c.lds) GO4M2(false, 2, true, true);
+    else if (b->max_pots == 1) GO4M2(false, 1, false, true);
+    else GO4M2(false, 2, false, true);
+#undef GO4M2
+}
+#else
+void launch_rollout4_mode0(const Rollout4Call& c) {
+    OC_R4_PROLOGUE;
+    if (c.uniform && !c.old_dyn && c.out && c.small) GO4(true, 2, true, 0, true, false, 0);
+    else if (c.uniform) { if (c.small) GO4(true, 2, true, 0, false, true, 0); else GO4(true, 8, true, 0, false, true, 0); }
+    else if (!c.old_dyn && c.out && c.small) {  // mixed table, new dynamics, both output arrays: no per-step NULL / old-dynamics tests
+        if (c.lds) GO4(false, 2, true, 0, true, false, 0); else GO4(false, 2, false, 0, true, false, 0);
+    }
+    else if (c.lds && c.small) GO4(false, 2, true, 0, false, true, 0);
+    else if (c.small) GO4(false, 2, false, 0, false, true, 0);
+    else GO4(false, 8, false, 0, false, true, 0);
+}
+#endif
+
+}  // namespace oc_detail

@@ -79,10 +79,10 @@ __device__ __forceinline__ void one_decode(const LayC& C, const Lay L, const uin
 // get_state_transition (mdp.py:1375-1430) for legal actions a0, a1: the sequencing of step3_main (both interacts against
 // the pre-step pots / cells, player 1 again when player 0 changed what it faces), movement on the layout's terrain bytes,
 // step3_env.  r = (sparse0, sparse1, shaped0, shaped1).
-template <int MAXP>
+template <int MAXP, bool EVENTS = false>
 __device__ __forceinline__ void one_transition(const LayC& C, const Lay L, const uint8_t* lut, uint32_t delta4, uint32_t a0,
                                                uint32_t a1, const uint4 (&v)[STEP1_MAX_PLANES], int n_obj,
-                                               const uint8_t* row, One<MAXP>& q, float4& r) {
+                                               const uint8_t* row, One<MAXP>& q, float4& r, uint64_t* ev = nullptr) {
     Env3<MAXP>& s = q.s;
     const bool two = s.pos1 != 0xFFu;
     const bool mv0 = a0 < 4u, mv1 = two & (a1 < 4u);
@@ -94,15 +94,21 @@ __device__ __forceinline__ void one_transition(const LayC& C, const Lay L, const
     const uint32_t t_m0 = L.terrain(m0) & 7u, t_m1 = L.terrain(m1) & 7u;
 
     // ---- resolve_interacts (mdp.py:1432-1579)
-    uint32_t useful_pots = 0;  // pot_states before any interact (mdp.py:1439): ready / cooking / 1..2 idle items
+    uint32_t useful_pots = 0, n_full = 0;  // pot_states before any interact (mdp.py:1439): ready / cooking / 1..2 idle items
+    uint32_t ps_before[MAXP];
 #pragma unroll
-    for (int k = 0; k < MAXP; ++k) useful_pots += ((s.pc[k] != PC_EMPTY) & (s.pc[k] != PC_IDLE3)) ? 1u : 0u;
+    for (int k = 0; k < MAXP; ++k) {
+        useful_pots += ((s.pc[k] != PC_EMPTY) & (s.pc[k] != PC_IDLE3)) ? 1u : 0u;
+        if (EVENTS) n_full += (((uint32_t)k < C.n_pots) & (s.pc[k] >= PC_IDLE3)) ? 1u : 0u;
+        ps_before[k] = s.ps[k];
+    }
     const bool act0 = a0 == OC_A_INTERACT, act1 = two & (a1 == OC_A_INTERACT);
     const uint32_t h0_before = s.held0, h1_before = s.held1;
     const IOut3 r0 = interact3<MAXP, false>(L, lut, act0, s.held0, c_f0, s.ps, s.tk, s.pc);
     IOut3 r1 = interact3<MAXP, false>(L, lut, act1, s.held1, c_f1, s.ps, s.tk, s.pc);
     // loose dishes on counters: only a dish taken from a dispenser asks (wave-uniform branch; the planes are still in registers)
-    if (__builtin_amdgcn_ballot_w64(((r0.flags | r1.flags) & LF_TAKE_DISH) != 0u) != 0ull) {
+    // (EVENTS: always — a dish picked up from a counter asks too, for its USEFUL_DISH_PICKUP event)
+    if (EVENTS || __builtin_amdgcn_ballot_w64(((r0.flags | r1.flags) & LF_TAKE_DISH) != 0u) != 0ull) {
         uint32_t dishes = 0;
 #pragma unroll
         for (int p = 0; p < STEP1_MAX_PLANES; ++p)
@@ -124,6 +130,28 @@ __device__ __forceinline__ void one_transition(const LayC& C, const Lay L, const
     const bool du1 = two & (((s.held0 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (s.dcount == 0);
     const float sh1 = ((r1.flags & LF_PLACE) ? C.rew_place : 0.f) + ((r1.flags & LF_PLATE) ? C.rew_soup : 0.f) +
                       ((((r1.flags & LF_TAKE_DISH) != 0u) & du1) ? C.rew_dish : 0.f);
+    if (EVENTS) {  // event_infos (mdp.py:2121-2308) from the two outcomes, as step3_main does
+        auto faced = [&](uint32_t c16, const uint32_t (&ps)[MAXP]) {  // the object an interact sees: the soup for a pot
+            uint32_t o = c16 & 0xFFu;
+            if (((c16 >> 8) & 7u) == OC_T_POT) {
+#pragma unroll
+                for (int k = 0; k < MAXP; ++k) o = (c16 >> 11) == (uint32_t)k ? ps[k] : o;
+            }
+            return o;
+        };
+        const uint32_t t0_ = act0 ? (c_f0 >> 8) & 7u : 7u, t1_ = act1 ? (c_f1 >> 8) & 7u : 7u;
+        const uint32_t o0 = faced(c_f0, ps_before), o1 = conflict ? faced(c_f1_live, s.ps) : faced(c_f1, ps_before);
+        const bool disp0 = (t0_ == OC_T_ONION_DISP) | (t0_ == OC_T_TOMATO_DISP) | (t0_ == OC_T_DISH_DISP);
+        const bool disp1 = (t1_ == OC_T_ONION_DISP) | (t1_ == OC_T_TOMATO_DISP) | (t1_ == OC_T_DISH_DISP);
+        const int32_t dc_before = s.dcount - r0.ddelta;
+        const bool du0e = two & (((h1_before == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_before == 0);
+        *ev = interact_events<0>(C, t0_, h0_before, o0, (r0.flags & LF_SWAP) != 0u, disp0 & (h0_before == 0u) & (r0.new_h != 0u),
+                                 (r0.flags & LF_PLACE) != 0u, (r0.flags & LF_PLATE) != 0u, (r0.flags & LF_SERVE) != 0u,
+                                 h1_before, du0e, n_full, two) |
+              interact_events<1>(C, t1_, h1_before, o1, (r1.flags & LF_SWAP) != 0u, disp1 & (h1_before == 0u) & (r1.new_h != 0u),
+                                 (r1.flags & LF_PLACE) != 0u, (r1.flags & LF_PLATE) != 0u, (r1.flags & LF_SERVE) != 0u,
+                                 s.held0, du1, n_full, two);
+    }
     s.held1 = r1.new_h;
     apply_pot3<MAXP>(s, r1);
     const bool swap1 = (r1.flags & LF_SWAP) != 0u;
@@ -174,11 +202,48 @@ __device__ __forceinline__ void one_restart(const LayC& C, const Lay L, const St
 }
 
 // write-back: the header always; the planes from scratch for a restarted env, else only the object bytes that changed
+// OOP (state_out != state_in): the changed bytes go into the lane's own LDS rows (`lrow`, where its planes are parked) and
+// every plane of the new state is written from there.
 template <int MAXP>
 __device__ __forceinline__ void one_store(const LayC& C, const Lay L, uint4* st, int64_t n, int64_t e, int n_obj,
-                                          const One<MAXP>& q, bool restarted) {
+                                          const One<MAXP>& q, bool restarted, uint8_t* lrow = nullptr) {
     const Env3<MAXP>& s = q.s;
     uint8_t* gbytes = reinterpret_cast<uint8_t*>(st);
+    if (lrow != nullptr) {  // out of place (wave-uniform: a property of the call)
+        auto put = [&](uint32_t c, uint32_t o) __attribute__((always_inline)) {
+            lrow[(c >> 4) * (uint32_t)(BLOCK * 16) + (c & 15u)] = (uint8_t)o;
+        };
+        uint4 ho;
+        ho.x = s.pos0 | (s.or0 << 8) | (s.held0 << 16) | (s.pos1 << 24);
+        ho.y = s.or1 | (s.held1 << 8) | (min(s.t, 0xFFFFu) << 16);
+        ho.z = 0; ho.w = 0;
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            if ((uint32_t)k < C.n_pots) {
+                if (k < 4) ho.z |= s.tk[k] << (8 * (k & 3));
+                else ho.w |= s.tk[k] << (8 * (k & 3));
+            }
+        }
+        st[e] = ho;
+        if (restarted) {
+#pragma unroll
+            for (int p = 0; p < STEP1_MAX_PLANES; ++p)
+                if (p < n_obj) *reinterpret_cast<uint4*>(lrow + p * (BLOCK * 16)) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k)
+                if ((uint32_t)k < C.n_pots && s.ps[k] != 0u) put(L.pot_cell(k), s.ps[k]);
+        } else {
+            if (q.w0) put(q.f0, q.o0);
+            if (q.w1) put(q.f1, q.o1);
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k)
+                if ((uint32_t)k < C.n_pots && s.ps[k] != q.ps_in[k]) put(L.pot_cell(k), s.ps[k]);
+        }
+#pragma unroll
+        for (int p = 0; p < STEP1_MAX_PLANES; ++p)  // (this lane's own rows: LDS operations of one wavefront execute in order)
+            if (p < n_obj) st[(int64_t)(1 + p) * n + e] = *reinterpret_cast<const uint4*>(lrow + p * (BLOCK * 16));
+        return;
+    }
     auto store_obj = [&](uint32_t c, uint32_t o) __attribute__((always_inline)) {
         gbytes[((int64_t)(1 + (c >> 4)) * n + e) * 16 + (c & 15u)] = (uint8_t)o;
     };
@@ -211,12 +276,12 @@ __device__ __forceinline__ void one_store(const LayC& C, const Lay L, uint4* st,
     }
 }
 
-template <bool UNIFORM, int MAXP, bool LAY_LDS>
+template <bool UNIFORM, int MAXP, bool LAY_LDS, bool EVENTS = false>
 __global__ __launch_bounds__(BLOCK) void k_step1(const OcLayout* __restrict__ g_layouts, int n_layouts,
-                                                 const uint16_t* layout_id, uint4* st,
+                                                 const uint16_t* layout_id, uint4* st, uint4* st_out,
                                                  const uint8_t* __restrict__ actions, float4* __restrict__ rewards,
                                                  uint8_t* __restrict__ flags, float4* ep_returns, int64_t n, int W,
-                                                 int n_obj, int horizon, uint32_t options, StartArgs sa) {
+                                                 int n_obj, int horizon, uint32_t options, StartArgs sa, EvArgs ea) {
     extern __shared__ __attribute__((aligned(16))) uint4 s_rows1[];  // [n_obj][BLOCK]: the object planes, one 16-byte row per lane
     __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];
     __shared__ uint2 s_lut[2 * LUT_ENTRIES];
@@ -240,9 +305,17 @@ __global__ __launch_bounds__(BLOCK) void k_step1(const OcLayout* __restrict__ g_
     if (__builtin_expect(a0 > 5u || a1 > 5u, 0)) {  // get_state_transition raises ValueError (mdp.py:1394-1398): the env stays as it is
         rewards[e] = r;
         flags[e] = (uint8_t)OC_F_BAD_ACTION;
+        if (EVENTS && ea.events) ea.events[e] = 0;
+        if (st_out != st) {
+            st_out[e] = in.h;
+#pragma unroll
+            for (int p = 0; p < STEP1_MAX_PLANES; ++p)
+                if (p < n_obj) st_out[(int64_t)(1 + p) * n + e] = in.v[p];
+        }
         return;
     }
-    one_transition<MAXP>(C, L, lut, make_delta4(W), a0, a1, in.v, n_obj, row, q, r);
+    uint64_t ev = 0;
+    one_transition<MAXP, EVENTS>(C, L, lut, make_delta4(W), a0, a1, in.v, n_obj, row, q, r, &ev);
     // ---- OvercookedEnv.step bookkeeping (env.py:266-267, 321-325)
     ep.x += r.x; ep.y += r.y; ep.z += r.z; ep.w += r.w;
     uint32_t fl = 0;
@@ -259,7 +332,11 @@ __global__ __launch_bounds__(BLOCK) void k_step1(const OcLayout* __restrict__ g_
             restarted = true;
         }
     }
-    one_store<MAXP>(C, L, st, n, e, n_obj, q, restarted);
+    if (EVENTS) {
+        if (ea.events) ea.events[e] = ev;
+        count_events(ea, e, ev, (fl & OC_F_DONE) != 0u, (fl & OC_F_RESET) != 0u);
+    }
+    one_store<MAXP>(C, L, st_out, n, e, n_obj, q, restarted, st_out != st ? reinterpret_cast<uint8_t*>(s_rows1 + threadIdx.x) : nullptr);
     rewards[e] = r;
     flags[e] = (uint8_t)fl;
     if (ep_returns) ep_returns[e] = ep;

@@ -1,4 +1,6 @@
-// step_table.hpp — get_state_transition with the table-driven interact: k_step3, k_rollout3
+// step_table.hpp — get_state_transition with the table-driven interact (8-byte LUT): k_step3, and the device functions
+// k_step1 / k_train_step / k_rollout_encode build on (round 4: its rollout kernel k_rollout3 is gone — k_rollout4 runs every
+// launch length)
 // Part of liboc_amd.so: included by oc_amd.hip inside its anonymous namespace, in this order:
 //   common, reset, step_predicate, step_table, step_one, step_lut4, rollout_pair, encode, rollout_encode, featurize, potential, shaping.
 #pragma once
@@ -463,124 +465,6 @@ __device__ __forceinline__ const uint8_t* stage_lut(uint2* s_lut, uint32_t old_d
     const uint2* src = reinterpret_cast<const uint2*>(&g_lut);
     for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = src[i];
     return reinterpret_cast<const uint8_t*>(s_lut) + (old_dyn ? LUT_ENTRIES * 8 : 0);
-}
-
-// OUT = both output arrays are present (the usual case): their null checks leave the step loop
-template <bool UNIFORM, int MAXP, bool LAY_LDS, int FAST = 0, bool OUT = false>
-__global__ __launch_bounds__(BLOCK) void k_rollout3(const OcLayout* __restrict__ g_layouts, int n_layouts,
-                                                    const uint16_t* __restrict__ layout_id, uint4* st,
-                                                    float4* __restrict__ rewards, uint8_t* __restrict__ flags,
-                                                    float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,
-                                                    int horizon, uint32_t options, uint32_t seed_lo, uint32_t seed_hi,
-                                                    int64_t env_offset, int64_t t0, int n_steps) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t s_cells3[];  // [n_obj * 16][BLOCK]
-    __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];  // one 256-byte record when the batch has one layout
-    __shared__ uint2 s_lut[2 * LUT_ENTRIES];
-    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const bool active = e < n;
-    for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
-    const Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains the barrier
-    __shared__ uint8_t s_move[FAST == 3 ? 64 * 8 : 8];
-    if (FAST == 3) {  // MOVE[cell * 8 + action] for the batch's single layout (at most 64 cells)
-        const int nc = (int)L.u8(L_NCELLS);
-        for (int i = threadIdx.x; i < nc * 8; i += BLOCK) {
-            const int c = i >> 3, a = i & 7;
-            int t = c;
-            if (a < 4) {
-                const int t2 = c + (a == 0 ? -W : a == 1 ? W : a == 2 ? 1 : -1);
-                if (t2 >= 0 && t2 < nc && (L.terrain((uint32_t)t2) & 7u) == OC_T_FLOOR) t = t2;
-            }
-            s_move[i] = (uint8_t)t;
-        }
-        __syncthreads();
-    }
-    if (!active) return;
-    uint16_t* cells = s_cells3 + threadIdx.x;
-    const LayC C = load_consts<UNIFORM>(L);
-    const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut) + (C.old_dyn ? LUT_ENTRIES * 8 : 0);
-    const uint32_t delta4 = make_delta4(W);
-    Env3<MAXP> s;
-    load_env3<MAXP>(C, L, st, n, e, n_obj, s, cells);
-    const uint64_t floor_mask = FAST == 2 ? make_floor_mask(L, (int)L.u8(L_NCELLS)) : 0ull;
-    float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const uint64_t g = (uint64_t)(env_offset + e);
-    const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
-    const StartArgs no_sa = {0, 0, 0, 0, 0, 0, 0};  // (restarts from drawn start states: k_rollout4)
-    uint32_t rnd[4] = {0, 0, 0, 0};
-    // outputs of step k live at [k][e]: a wave-uniform base per step (SALU) + this lane's 32-bit offset
-    float4* const rew_blk = rewards ? rewards + (int64_t)blockIdx.x * BLOCK : nullptr;
-    uint8_t* const flg_blk = flags ? flags + (int64_t)blockIdx.x * BLOCK : nullptr;
-    // (issuing step k+1's cell reads before step k's tail was tried and measured: no gain — the loop is bound by
-    //  instruction issue, not by LDS latency)
-    if (FAST) {
-        // One Philox block = 8 steps: the loop is unrolled over the block so that the word / digit position of every
-        // step is a compile-time constant (x runs through w, 6w, 36w, 216w: no word select, no x36 multiply) and the
-        // refresh test and the back edge are paid once per 8 steps.  A launch may start and end inside a block.
-        // Head (up to the next block boundary) and tail (the last n_steps % 8 steps) run through one rolled copy of the
-        // step; the full blocks in between are 8 unrolled steps without any exit test between them.
-        int k = 0;
-        float4* rew_k = rew_blk;  // wave-uniform row pointers, advanced by n per step
-        uint8_t* flg_k = flg_blk;
-        const int head_end = min(n_steps, (int)((8u - ((uint32_t)t0 & 7u)) & 7u));
-#define OC_STEP(S8)                                                                                      \
-    {                                                                                                    \
-        if (((S8) & 1u) == 0u) x = rnd[(S8) >> 1];                                                       \
-        const uint32_t a0 = __umulhi(x, 6u);                                                             \
-        x *= 6u;                                                                                         \
-        const uint32_t a1 = __umulhi(x, 6u);                                                             \
-        x *= 6u;                                                                                         \
-        float4 r;                                                                                        \
-        env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask, s_move);               \
-        const uint32_t fl = finish_step3<MAXP>(C, L, n_obj, cells, s, horizon, options, r, ep, no_sa, 0, 0);\
-        if (OUT || rew_k) { rew_k[threadIdx.x] = r; rew_k += n; }                                        \
-        if (OUT || flg_k) { flg_k[threadIdx.x] = (uint8_t)fl; flg_k += n; }                              \
-    }
-        for (int phase = 0; phase < 2; ++phase) {
-            const int upto = phase == 0 ? head_end : n_steps;
-            for (; k < upto; ++k) {  // rolled steps
-                const uint64_t t = (uint64_t)(t0 + k);
-                const uint32_t s8 = (uint32_t)t & 7u;
-                if (k == 0 || s8 == 0u) {
-                    const uint64_t blk = t >> 3;
-                    philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, rnd);
-                }
-                uint32_t a0, a1;
-                draw_actions(rnd, s8, a0, a1);
-                float4 r;
-                env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask, s_move);
-                const uint32_t fl = finish_step3<MAXP>(C, L, n_obj, cells, s, horizon, options, r, ep, no_sa, 0, 0);
-                if (OUT || rew_k) { rew_k[threadIdx.x] = r; rew_k += n; }
-                if (OUT || flg_k) { flg_k[threadIdx.x] = (uint8_t)fl; flg_k += n; }
-            }
-            if (phase == 0) {
-                for (; n_steps - k >= 8; k += 8) {  // whole Philox blocks
-                    const uint64_t blk = (uint64_t)(t0 + k) >> 3;
-                    philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, rnd);
-                    uint32_t x = 0;
-                    OC_STEP(0u) OC_STEP(1u) OC_STEP(2u) OC_STEP(3u) OC_STEP(4u) OC_STEP(5u) OC_STEP(6u) OC_STEP(7u)
-                }
-            }
-        }
-#undef OC_STEP
-    } else {
-        for (int k = 0; k < n_steps; ++k) {
-            const uint64_t t = (uint64_t)(t0 + k);
-            const uint32_t s8 = (uint32_t)t & 7u;
-            if (k == 0 || s8 == 0u) {
-                const uint64_t blk = t >> 3;
-                philox4x32_10((uint32_t)blk, g_lo, g_hi, (uint32_t)(blk >> 32), seed_lo, seed_hi, rnd);
-            }
-            uint32_t a0, a1;
-            draw_actions(rnd, s8, a0, a1);
-            float4 r;
-            env_step3<MAXP, FAST>(C, L, lut, cells, s, delta4, a0, a1, r, floor_mask, s_move);
-            const uint32_t fl = finish_step3<MAXP>(C, L, n_obj, cells, s, horizon, options, r, ep, no_sa, 0, 0);
-            if (rew_blk) (rew_blk + (int64_t)k * n)[threadIdx.x] = r;
-            if (flg_blk) (flg_blk + (int64_t)k * n)[threadIdx.x] = (uint8_t)fl;
-        }
-    }
-    store_env3<MAXP>(C, L, st, n, e, n_obj, s, cells);
-    if (ep_returns) ep_returns[e] = ep;
 }
 
 // k_step3: transitions with caller-supplied actions (one per launch for oc_step, K for oc_step_many), table-driven

@@ -43,7 +43,6 @@ class VecOvercookedEnv:
         self.auto_reset = bool(auto_reset)
         self.lane_pair = False     # rollout_random: force the lane-pair kernel where the table allows it
         self.predicate_interact = False  # rollout_random: lane-per-env kernel with the predicate-network interact
-        self.rollout_v3 = False          # rollout_random: k_rollout3 instead of k_rollout4 (cross-checks)
         self.one_kernel = False          # step_encode / rollout_encode: the single-kernel path whatever the batch size
         self.seed = int(seed)
         self.env_offset = int(env_offset)
@@ -131,8 +130,7 @@ class VecOvercookedEnv:
     @property
     def options(self):
         return ((_lib.OPT_AUTO_RESET if self.auto_reset else 0)
-                | (_lib.OPT_LANE_PAIR if self.lane_pair else 0) | (_lib.OPT_PREDICATE_INTERACT if self.predicate_interact else 0)
-                | (_lib.OPT_ROLLOUT_V3 if self.rollout_v3 else 0))
+                | (_lib.OPT_LANE_PAIR if self.lane_pair else 0) | (_lib.OPT_PREDICATE_INTERACT if self.predicate_interact else 0))
 
     @property
     def reset_epoch(self):

@@ -64,12 +64,12 @@ def spec_from_fixture(layout_dict):
     return L.LayoutSpec(layout_dict)
 
 
-ROLLOUT_KERNELS = ("default", "rollout_v3", "lane_pair", "predicate_interact")
+ROLLOUT_KERNELS = ("default", "lane_pair", "predicate_interact")
 
 
 def select_kernel(env, kernel):
     """Pick the rollout kernel family a VecOvercookedEnv launches: "default" / None = k_rollout4 (what ships), the others
-    are the cross-check families (k_rollout3, the lane-pair kernel, the predicate-network kernel)."""
+    are the cross-check families (the lane-pair kernel, the predicate-network kernel)."""
     assert kernel in (None, "step") + ROLLOUT_KERNELS, kernel
     for name in ROLLOUT_KERNELS[1:]:
         setattr(env, name, name == kernel)

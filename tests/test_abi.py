@@ -23,7 +23,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
     for s in syms:
         assert getattr(L, s) is not None
-    assert L.oc_abi_version() == 3
+    assert L.oc_abi_version() == 4
     assert L.oc_layout_size() == 256
     assert L.oc_state_planes(5, 4) == 3 and L.oc_state_planes(9, 5) == 4 and L.oc_state_planes(14, 9) == 9
 
@@ -124,9 +124,9 @@ def test_vec_env_fails_loudly_without_gpu():
         VecOvercookedEnv("cramped_room", 4, device="cpu")
 
 
-def _code_object(tmp_path):
-    """The gfx950 code object inside the built library (llvm-objcopy + clang-offload-bundler of the ROCm toolchain)."""
-    import shutil
+def _code_objects(tmp_path):
+    """The gfx950 code objects inside the built library, one per translation unit (llvm-objcopy dumps .hip_fatbin — the
+    units' offload bundles back to back —, clang-offload-bundler unbundles each)."""
     import subprocess
 
     from overcooked_ai_amd import _lib
@@ -135,12 +135,21 @@ def _code_object(tmp_path):
     tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
     if not all(os.path.exists(t) for t in tools) or not os.path.exists(_lib.LIB_PATH):
         pytest.skip("ROCm llvm tools or the built library not available")
-    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "co.elf")
+    fat = str(tmp_path / "fat.bin")
     subprocess.check_call([tools[0], "--dump-section", ".hip_fatbin=" + fat, _lib.LIB_PATH])
-    subprocess.check_call([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
-                           "--input=" + fat, "--output=" + co])
-    assert shutil.os.path.getsize(co) > 0
-    return co, tools[2]
+    raw = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [i for i in range(len(raw)) if raw.startswith(magic, i)]
+    assert starts, "no offload bundle in .hip_fatbin"
+    cos = []
+    for k, a in enumerate(starts):
+        part, co = str(tmp_path / ("fat%d.bin" % k)), str(tmp_path / ("co%d.elf" % k))
+        open(part, "wb").write(raw[a:starts[k + 1] if k + 1 < len(starts) else len(raw)])
+        subprocess.check_call([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                               "--input=" + part, "--output=" + co])
+        assert os.path.getsize(co) > 0
+        cos.append(co)
+    return cos, tools[2]
 
 
 def test_no_kernel_keeps_a_stack_object_or_reads_the_dispatch_packet(tmp_path):
@@ -152,35 +161,35 @@ def test_no_kernel_keeps_a_stack_object_or_reads_the_dispatch_packet(tmp_path):
     import struct
     import subprocess
 
-    co, readelf = _code_object(tmp_path)
-    notes = subprocess.check_output([readelf, "--notes", co], text=True)
-    name, seen = None, 0
-    for line in notes.splitlines():
-        line = line.strip()
-        if line.startswith(".name:") and "_Z" in line:
-            name = line.split(":", 1)[1].strip()
-        elif line.startswith(".private_segment_fixed_size:") and name:
-            size = int(line.split(":", 1)[1])
-            seen += 1
-            assert size == 0 or "11k_potentialE" in name, "%s keeps %d bytes of scratch" % (name, size)
-    assert seen > 100
-    # kernel descriptors (<kernel>.kd, 64 bytes): kernel_code_properties at byte 56, bit 1 = ENABLE_SGPR_DISPATCH_PTR, bit 2 = QUEUE_PTR
-    # (checked against a probe kernel known to read the packet: tools/launch_floor.hip)
-    raw = open(co, "rb").read()
-    shoff, shentsize, shnum = struct.unpack_from("<Q", raw, 0x28)[0], *struct.unpack_from("<HH", raw, 0x3A)
-    sections = [struct.unpack_from("<IIQQQQIIQQ", raw, shoff + i * shentsize) for i in range(shnum)]
-    symtab = next(s for s in sections if s[1] == 2)  # SHT_SYMTAB
-    strtab = sections[symtab[6]]
-    checked = 0
-    for i in range(symtab[5] // 24):
-        st_name, st_info, st_other, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", raw, symtab[4] + 24 * i)
-        end = raw.index(b"\0", strtab[4] + st_name)
-        sym = raw[strtab[4] + st_name:end].decode()
-        if not sym.endswith(".kd") or st_shndx == 0 or st_shndx >= shnum:
-            continue
-        sec = sections[st_shndx]
-        kd = raw[sec[4] + (st_value - sec[3]):][:64]
-        props = struct.unpack_from("<H", kd, 56)[0]
-        assert not (props & 0x6), "%s reads the dispatch packet / queue (kernel_code_properties %#x)" % (sym, props)
-        checked += 1
-    assert checked > 100
+    cos, readelf = _code_objects(tmp_path)
+    seen = checked = 0
+    for co in cos:
+        notes = subprocess.check_output([readelf, "--notes", co], text=True)
+        name = None
+        for line in notes.splitlines():
+            line = line.strip()
+            if line.startswith(".name:") and "_Z" in line:
+                name = line.split(":", 1)[1].strip()
+            elif line.startswith(".private_segment_fixed_size:") and name:
+                size = int(line.split(":", 1)[1])
+                seen += 1
+                assert size == 0 or "11k_potentialE" in name, "%s keeps %d bytes of scratch" % (name, size)
+        # kernel descriptors (<kernel>.kd, 64 bytes): kernel_code_properties at byte 56, bit 1 = ENABLE_SGPR_DISPATCH_PTR, bit 2 = QUEUE_PTR
+        # (checked against a probe kernel known to read the packet: tools/launch_floor.hip)
+        raw = open(co, "rb").read()
+        shoff, shentsize, shnum = struct.unpack_from("<Q", raw, 0x28)[0], *struct.unpack_from("<HH", raw, 0x3A)
+        sections = [struct.unpack_from("<IIQQQQIIQQ", raw, shoff + i * shentsize) for i in range(shnum)]
+        symtab = next(s for s in sections if s[1] == 2)  # SHT_SYMTAB
+        strtab = sections[symtab[6]]
+        for i in range(symtab[5] // 24):
+            st_name, st_info, st_other, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", raw, symtab[4] + 24 * i)
+            end = raw.index(b"\0", strtab[4] + st_name)
+            sym = raw[strtab[4] + st_name:end].decode()
+            if not sym.endswith(".kd") or st_shndx == 0 or st_shndx >= shnum:
+                continue
+            sec = sections[st_shndx]
+            kd = raw[sec[4] + (st_value - sec[3]):][:64]
+            props = struct.unpack_from("<H", kd, 56)[0]
+            assert not (props & 0x6), "%s reads the dispatch packet / queue (kernel_code_properties %#x)" % (sym, props)
+            checked += 1
+    assert len(cos) == 4 and seen > 80 and checked > 80  # four translation units (oc_amd.hip + rollout4.hip x 3)

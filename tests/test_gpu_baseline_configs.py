@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 N = 65536
-KERNELS = ["default", "rollout_v3", "lane_pair", "predicate_interact"]
+KERNELS = ["default", "lane_pair", "predicate_interact"]
 
 
 @pytest.fixture(scope="module")

@@ -120,7 +120,7 @@ def test_reference_golden_trajectory(manifest, gpu):
     assert total == d["ep_rewards"][: n - 1].sum()
 
 
-@pytest.mark.parametrize("kernel", ["default", "rollout_v3", "lane_pair", "predicate_interact"])
+@pytest.mark.parametrize("kernel", ["default", "lane_pair", "predicate_interact"])
 @pytest.mark.parametrize("name", ROLLOUT_CONFIGS)
 def test_golden_rollouts_fused(name, kernel, manifest, gpu):
     """Both fused Philox rollout kernels against episodes run through the reference's OvercookedEnv.step."""
@@ -229,7 +229,7 @@ def test_step_vs_oracle_random_states(n_envs, gpu):
         assert np.array_equal(u8(rew2), rew_o) and np.array_equal(u8(flags2), fl_o) and np.array_equal(u8(lean.ep_returns), ep_o)
 
 
-@pytest.mark.parametrize("kernel", ["default", "rollout_v3", "lane_pair", "predicate_interact"])
+@pytest.mark.parametrize("kernel", ["default", "lane_pair", "predicate_interact"])
 def test_full_size_rollout_vs_oracle(kernel, gpu):
     """BASELINE config 2 at full size: 65 536 cramped_room envs, random policy, horizon 400 with auto-reset."""
     from overcooked_ai_amd.layouts import spec_from_name
@@ -277,7 +277,7 @@ def test_full_size_rollout_vs_oracle(kernel, gpu):
     assert torch.equal(shard.state, env3.state[:, a:b])
 
 
-@pytest.mark.parametrize("kernel", ["default", "rollout_v3", "lane_pair", "predicate_interact"])
+@pytest.mark.parametrize("kernel", ["default", "lane_pair", "predicate_interact"])
 def test_mixed_layout_batch_vs_oracle(kernel, gpu):
     """BASELINE config 4 (one GPU's shard): env e uses canonical layout e % 5, all padded to 9x5."""
     from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
@@ -390,7 +390,7 @@ def test_every_registry_layout_vs_oracle(gpu):
         env = make_env(spec, n, gpu, horizon=400, auto_reset=True, seed=3)
         st_o = st.copy()
         rew_o, _ = orc.rollout_random(st_o, 60, horizon=400, options=1, seed=3)
-        for kernel in ("default", "rollout_v3", "lane_pair", "predicate_interact"):  # lane_pair falls back where it does not apply
+        for kernel in ("default", "lane_pair", "predicate_interact"):  # lane_pair falls back where it does not apply
             select_kernel(env, kernel)
             env.set_packed_state(st)
             env.t_global = 0
@@ -803,7 +803,7 @@ def test_no_out_of_bounds_writes_with_ragged_batches(gpu):
         K = 7
         r_raw, rew = guarded((K, n, 4), torch.float32); bufs.append((r_raw, rew))
         f_raw, fl = guarded((K, n), torch.uint8); bufs.append((f_raw, fl))
-        for mode in (None, "default", "rollout_v3", "lane_pair", "predicate_interact"):
+        for mode in (None, "default", "lane_pair", "predicate_interact"):
             select_kernel(env, mode)
             env.rollout_random(K, rew, fl)
         s_raw, st_out = guarded(tuple(env.state.shape), torch.uint8); bufs.append((s_raw, st_out))
@@ -927,7 +927,7 @@ def test_random_starts_inside_the_fused_auto_reset(layouts, gpu):
     assert np.array_equal(env.get_packed_state(), st) and np.array_equal(env.ep_returns.cpu().numpy(), ep_o)
     # kernels that cannot draw start states refuse instead of silently restarting from the standard state
     from overcooked_ai_amd._lib import OcAmdError
-    env.rollout_v3 = True
+    env.predicate_interact = True
     with pytest.raises(OcAmdError):
         env.rollout_random(3)
 
@@ -1089,7 +1089,7 @@ def test_timestep_saturates_at_the_packing_limit(gpu):
     rng = np.random.default_rng(11)
     st = random_packed_states(spec, n, rng)
     st[0, :, 6], st[0, :, 7] = 0xFC, 0xFF  # timestep 65 532
-    for kernel in ("default", "rollout_v3", "lane_pair", "predicate_interact", "step", "step_predicate"):
+    for kernel in ("default", "lane_pair", "predicate_interact", "step", "step_predicate"):
         env = make_env(spec, n, gpu, horizon=65535, auto_reset=False, seed=2)
         select_kernel(env, "predicate_interact" if kernel == "step_predicate" else kernel)
         env.set_packed_state(st)

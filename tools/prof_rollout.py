@@ -1,5 +1,5 @@
 """Tiny driver for rocprofv3 counter passes over the fused rollout kernel (keeps the rocpd database small):
-    MODE=<rollout_v3|lane_pair|predicate_interact> LAYOUT=<name> ENVS=<n> STEPS=<fused steps> python tools/prof_rollout.py
+    MODE=<lane_pair|predicate_interact> LAYOUT=<name> ENVS=<n> STEPS=<fused steps> python tools/prof_rollout.py
     CONFIG=4 | CONFIG=5: the 5-layout mix / the 4 096 generated terrains of BASELINE configs[3] / [4] instead of one layout"""
 import os
 import sys

@@ -12,7 +12,6 @@ layout = sys.argv[1] if len(sys.argv) > 1 else "cramped_room"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 dev = torch.device("cuda:0")
 env = VecOvercookedEnv(layout, n, horizon=400, device=dev, auto_reset=True, seed=0)
-env.rollout_v3 = "v3" in sys.argv[3:]
 T = 400
 rew = torch.zeros((T, n, 4), dtype=torch.float32, device=dev)
 fl = torch.zeros((T, n), dtype=torch.uint8, device=dev)
@@ -30,4 +29,4 @@ torch.cuda.synchronize()
 ms = sorted(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
 med = ms[len(ms) // 2]
 print("%s n=%d %s: launch median %.1f us, min %.1f us -> %.3f us/step, %.1f G env-steps/s" % (
-    layout, n, "v3" if env.rollout_v3 else "v4", med * 1e3, ms[0] * 1e3, med * 1e3 / T, n * T / (med * 1e-3) / 1e9))
+    layout, n, "v4", med * 1e3, ms[0] * 1e3, med * 1e3 / T, n * T / (med * 1e-3) / 1e9))
