@@ -431,6 +431,32 @@ int oc_phi_table_size(void);
  */
 int oc_reset(const OcBatch* batch, void* d_state, const uint8_t* d_mask, float* d_ep_returns, void* stream);
 
+/*
+ * oc_mailbox_* — ONE env stepped per call without a kernel launch per call: what the reference's
+ * OvercookedEnv.step (overcooked_env.py:244) -> OvercookedGridworld.get_state_transition (overcooked_mdp.py:1375) does for
+ * an agent loop.  oc_mailbox_open starts a resident one-wavefront kernel that serves transitions of the batch's single
+ * layout from a 4 KiB mailbox in pinned, GPU-mapped host memory; the caller writes the packed state (oc_state_planes()
+ * planes of 16 bytes, as [plane][16]) at OC_MB_STATE_IN and the two action indices at OC_MB_ACTIONS of oc_mailbox_buffer(),
+ * calls oc_mailbox_step (which posts the request and spins until the kernel has answered: two PCIe round trips, no
+ * launch) and reads the next state at OC_MB_STATE_OUT, float rewards[4] = (sparse0, sparse1, shaped0, shaped1) at
+ * OC_MB_REWARDS, the OC_F_* flags (u32; DONE when the new timestep >= horizon, BAD_ACTION leaves the state as it was) at
+ * OC_MB_FLAGS and the event_infos mask (u64, bit 2*k + p) at OC_MB_EVENTS.  Same transition, bit for bit, as oc_step.
+ * The kernel leaves on its own after ~2 ms without a request (and after ~2 s in any case) and is relaunched by the next
+ * oc_mailbox_step, so a device-wide synchronisation elsewhere waits at most that long.  One layout (batch.n_layouts == 1),
+ * grids of at most 64 cells; not thread-safe per mailbox.  Returns OC_EINVAL for other batches (use oc_step).
+ */
+typedef struct OcMailbox OcMailbox;
+#define OC_MB_STATE_IN 256
+#define OC_MB_ACTIONS 336
+#define OC_MB_STATE_OUT 512
+#define OC_MB_REWARDS 592
+#define OC_MB_FLAGS 608
+#define OC_MB_EVENTS 616
+int oc_mailbox_open(const OcBatch* batch, int horizon, OcMailbox** mailbox);
+void* oc_mailbox_buffer(OcMailbox* mailbox);
+int oc_mailbox_step(OcMailbox* mailbox);
+int oc_mailbox_close(OcMailbox* mailbox);
+
 #ifdef __cplusplus
 }
 #endif

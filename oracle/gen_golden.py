@@ -846,6 +846,12 @@ def gen_agent_pair_rollouts():
 
 
 def main():
+    if "--rollouts-only" in sys.argv:  # (only the episodes driven by the Philox action stream)
+        for i, (name, lname, ov) in enumerate(CONFIGS):
+            if name in ("cramped_room", "asymmetric_advantages", "counter_circuit", "mdp_test", "cramped_room_old_dynamics"):
+                gen_rollouts(name, lname, ov, n_envs=24, seed=77 + i)
+                print("rollouts", name)
+        return
     if "--queries-only" in sys.argv:
         gen_state_queries()
         gen_agent_pair_rollouts()

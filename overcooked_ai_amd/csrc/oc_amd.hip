@@ -27,6 +27,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "shared.hpp"
 
@@ -43,6 +44,7 @@ namespace {
 #include "step_predicate.hpp"
 #include "step_table.hpp"
 #include "step_one.hpp"
+#include "mailbox.hpp"
 #include "rollout_pair.hpp"
 #include "encode.hpp"
 #include "rollout_encode.hpp"
@@ -806,6 +808,107 @@ int oc_rollout_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions,
         if (rc) return rc;
         if ((rc = oc_encode_lossless(b, d_state, (uint8_t*)d_obs + (int64_t)k * obs_step_stride, obs_dtype, horizon, stream))) return rc;
     }
+    return OC_OK;
+}
+
+// ---- the single-env mailbox (mailbox.hpp)
+}  // extern "C"
+
+struct OcMailbox {
+    uint8_t* h;             // the mailbox (pinned host memory, mapped into the GPU's address space)
+    uint8_t* d;             // its device address
+    hipStream_t stream;     // the resident kernel's own stream
+    const OcLayout* d_layout;
+    int W, n_obj, horizon, device;
+    uint32_t seq;
+    uint64_t idle_ticks, life_ticks;
+};
+
+namespace {
+static_assert(OC_MB_STATE_IN == MB_IN && OC_MB_ACTIONS == MB_ACT && OC_MB_STATE_OUT == MB_OUT && OC_MB_REWARDS == MB_REW &&
+              OC_MB_FLAGS == MB_FLAGS && OC_MB_EVENTS == MB_EV, "mailbox offsets of include/oc_amd.h");
+
+int mailbox_launch(OcMailbox* m) {
+    *reinterpret_cast<volatile uint32_t*>(m->h + MB_ALIVE) = 1u;
+    hipLaunchKernelGGL(k_mailbox, dim3(1), dim3(64), 0, m->stream, m->d_layout, m->d, m->W, m->n_obj, m->horizon, m->idle_ticks,
+                       m->life_ticks);
+    return check_launch("oc_mailbox: launch");
+}
+}  // namespace
+
+extern "C" {
+
+int oc_mailbox_open(const OcBatch* b, int horizon, OcMailbox** out) {
+    int n_obj = 0;
+    if (!out) return fail(OC_EINVAL, "oc_mailbox_open: NULL result pointer");
+    *out = nullptr;
+    if (int rc = check_batch(b, &n_obj)) return rc;
+    if (b->n_layouts != 1 || n_obj > STEP1_MAX_PLANES) return fail(OC_EINVAL, "oc_mailbox_open: one layout, grids of at most 64 cells");
+    if (horizon < 1 || horizon > 65535) return fail(OC_EINVAL, "oc_mailbox_open: horizon must be in 1..65535");
+    OcMailbox* m = new OcMailbox();
+    if (hipGetDevice(&m->device) != hipSuccess || hipHostMalloc((void**)&m->h, MB_BYTES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        delete m;
+        (void)hipGetLastError();
+        return fail(OC_ELAUNCH, "oc_mailbox_open: pinned host memory refused");
+    }
+    memset(m->h, 0, MB_BYTES);
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, m->device) != hipSuccess || khz <= 0) khz = 100000;  // 100 MHz
+    if (hipHostGetDevicePointer((void**)&m->d, m->h, 0) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipHostFree(m->h);
+        delete m;
+        (void)hipGetLastError();
+        return fail(OC_ELAUNCH, "oc_mailbox_open: device mapping / stream refused");
+    }
+    m->d_layout = b->d_layouts; m->W = b->width; m->n_obj = n_obj; m->horizon = horizon; m->seq = 0;
+    m->idle_ticks = (uint64_t)khz * 2;     // 2 ms without a request
+    m->life_ticks = (uint64_t)khz * 2000;  // 2 s in any case
+    if (int rc = mailbox_launch(m)) { (void)oc_mailbox_close(m); return rc; }
+    *out = m;
+    return OC_OK;
+}
+
+void* oc_mailbox_buffer(OcMailbox* m) { return m ? m->h : nullptr; }
+
+int oc_mailbox_step(OcMailbox* m) {
+    if (!m) return fail(OC_EINVAL, "oc_mailbox_step: NULL mailbox");
+    volatile uint32_t* req = reinterpret_cast<volatile uint32_t*>(m->h + MB_REQ);
+    volatile uint32_t* rsp = reinterpret_cast<volatile uint32_t*>(m->h + MB_RSP);
+    volatile uint32_t* alive = reinterpret_cast<volatile uint32_t*>(m->h + MB_ALIVE);
+    uint32_t seq = m->seq + 1u;
+    if (seq == MB_STOP || seq == 0u) seq = 1u;
+    m->seq = seq;
+    __atomic_store_n(const_cast<uint32_t*>(req), seq, __ATOMIC_RELEASE);  // the payload is in place: publish the request
+    uint32_t spins = 0;
+    struct timespec t0 = {0, 0};
+    while (__atomic_load_n(const_cast<uint32_t*>(rsp), __ATOMIC_ACQUIRE) != seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0x3FFu) != 0u) continue;
+        if (*alive == 0u && *rsp != seq) {  // the kernel has left (idle / lifetime): the next incarnation finds the request
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (dev != m->device) (void)hipSetDevice(m->device);
+            const int rc = mailbox_launch(m);
+            if (dev != m->device) (void)hipSetDevice(dev);
+            if (rc) return rc;
+        }
+        struct timespec now;
+        clock_gettime(CLOCK_MONOTONIC, &now);
+        if (t0.tv_sec == 0 && t0.tv_nsec == 0) t0 = now;
+        else if ((now.tv_sec - t0.tv_sec) > 5) return fail(OC_ELAUNCH, "oc_mailbox_step: no answer from the resident kernel within 5 s");
+    }
+    return OC_OK;
+}
+
+int oc_mailbox_close(OcMailbox* m) {
+    if (!m) return OC_OK;
+    __atomic_store_n(reinterpret_cast<uint32_t*>(m->h + MB_REQ), MB_STOP, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize(m->stream);
+    (void)hipStreamDestroy(m->stream);
+    (void)hipHostFree(m->h);
+    (void)hipGetLastError();
+    delete m;
     return OC_OK;
 }
 

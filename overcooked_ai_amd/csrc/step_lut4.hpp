@@ -155,19 +155,8 @@ __device__ __forceinline__ uint32_t interact4(const uint4 ent, uint32_t h, uint3
     const uint32_t pool = __builtin_amdgcn_perm(cw, h, CW == 2 ? 0x05040401u : 0x07060601u) + ent.z;  // [hand][object][object + add][key byte]
     return __builtin_amdgcn_perm(ent.y, pool, ent.x);                           // [flags][new hand][new object][new key byte]
 }
-// LDS address of a player's LUT entry.  BC = false: `off` = LDS address of the table variant to use (the "interacts" entries,
-// or their all-no-op copy 240 entries further for a player that does not interact).
-// BC = true (one LUT variant staged at LDS address 0): `off` is a MASK — ~0xF for a player that interacts, 0 otherwise — so
-// every lane that does not interact (5 of 6 under the random policy) reads entry 0 (a floor cell in front of an empty hand: a
-// no-op like every entry of the old copy), and identical addresses are a broadcast for the LDS: what is left to conflict in
-// the 16-lane groups of a ds_read_b128 are the few lanes that do interact.  Same instruction count as the plain form: the
-// key byte is taken with its low nibble of garbage ((cw >> 20) = 16 * key byte + 4 object bits) and the mask clears it.
-#ifndef OC_BCAST
-#define OC_BCAST 1
-#endif
-template <int CW, bool BC = false>
+template <int CW>
 __device__ __forceinline__ uint32_t lut4_addr(uint32_t off, uint32_t h, uint32_t cw) {
-    if (BC) return (min((h >> 8) & 0xFFu, 4u) * 96u + (cw >> (CW == 2 ? 4 : 20))) & off;
     return (min((h >> 8) & 0xFFu, 4u) * 6u + cw_kb<CW>(cw)) * 16u + off;
 }
 
@@ -397,13 +386,9 @@ template <bool UNIFORM, bool LAY_LDS, int MODE, int NF, bool ONE_LUT = UNIFORM, 
 struct Lds4 {
     static constexpr int MVJ_CAP = MODE == 1 ? ((16 * NF * NF * Mvj<CW>::ROW_BYTES + 15) & ~15) : 0;
     static constexpr bool TABLE_FIRST = CW == 2;
-    // BC (see lut4_addr): one LUT variant, staged at LDS address 0 without its no-op copy; not with a u16 move table in front
-    static constexpr bool BC = OC_BCAST && ONE_LUT && !(TABLE_FIRST && MODE == 1);
-    static constexpr int ACT_P1 = 40 * CW, ACT_BYTES = MODE == 1 ? 2 * ACT_P1 : 0;  // [player][40] u16 / u32
-    static constexpr int LUT_BYTES = BC ? LUT4_KEYS * 16 : (ONE_LUT ? LUT4_BYTES : 2 * LUT4_BYTES);
-    static constexpr int ACT = BC ? LUT_BYTES : (TABLE_FIRST ? MVJ_CAP : 0);
-    static constexpr int LUT = BC ? 0 : ACT + ACT_BYTES;
-    static constexpr int LAY = BC ? ACT + ACT_BYTES : LUT + LUT_BYTES, LAY_BYTES = LAY_LDS ? (UNIFORM ? 256 : LDS_LAYOUT_MAX * 256) : 16;
+    static constexpr int ACT = TABLE_FIRST ? MVJ_CAP : 0, ACT_P1 = 40 * CW, ACT_BYTES = MODE == 1 ? 2 * ACT_P1 : 0;  // [player][40] u16 / u32
+    static constexpr int LUT = ACT + ACT_BYTES, LUT_BYTES = ONE_LUT ? LUT4_BYTES : 2 * LUT4_BYTES;
+    static constexpr int LAY = LUT + LUT_BYTES, LAY_BYTES = LAY_LDS ? (UNIFORM ? 256 : LDS_LAYOUT_MAX * 256) : 16;
     static constexpr int FL = LAY + LAY_BYTES, FI = FL + 16, CT = FI + (MODE == 1 ? OC_MAX_CELLS : 0);
     static constexpr int MVJ = TABLE_FIRST ? 0 : CT + 32;  // LDS address of the move table
     static constexpr int CELLS = TABLE_FIRST ? CT + 32 : MVJ + MVJ_CAP;
@@ -470,8 +455,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn4[];
     constexpr bool RUX = UNIFORM || RU;  // one LUT variant, patched with the reward floats
     using M = Lds4<UNIFORM, LAY_LDS, MODE, NF, RUX, CW>;
-    constexpr bool BC = M::BC;  // the players' `off` values are masks (lut4_addr)
-    constexpr uint32_t OFF_ACT = BC ? 0xFFFFFFF0u : 0u, OFF_NOT = BC ? 0u : (uint32_t)(LUT4_KEYS * 16);  // + lut_var when !BC
     static_assert(CW == 2 || CW == 4, "cell words are u16 or u32");
     if ((uint32_t)(uintptr_t)(OC_LDS uint8_t*)s_dyn4 != 0u) __builtin_trap();  // folds away: the region starts at address 0
     uint4* const s_lay = reinterpret_cast<uint4*>(s_dyn4 + M::LAY);
@@ -483,7 +466,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
     Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains a barrier
     {
         const uint4* src = reinterpret_cast<const uint4*>(&g_lut4);
-        const int first = RUX ? (L.old_dynamics() ? 2 * LUT4_KEYS : 0) : 0, count = BC ? LUT4_KEYS : RUX ? 2 * LUT4_KEYS : 4 * LUT4_KEYS;
+        const int first = RUX ? (L.old_dynamics() ? 2 * LUT4_KEYS : 0) : 0, count = RUX ? 2 * LUT4_KEYS : 4 * LUT4_KEYS;
         for (int i = threadIdx.x; i < count; i += BLOCK) {
             uint4 ent = src[first + i];
             if (RUX)  // one layout (or one set of shaping rewards for the whole table): the entry carries the shaped reward itself
@@ -497,8 +480,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
     }
     if (MODE == 1) {
         if (threadIdx.x < 36) {  // the LUT's LDS address is folded into the offsets
-            const uint32_t a0 = (BC ? 0u : (uint32_t)M::LUT) + (threadIdx.x / 6 == 5 ? OFF_ACT : OFF_NOT);
-            const uint32_t a1 = (BC ? 0u : (uint32_t)M::LUT) + (threadIdx.x % 6 == 5 ? OFF_ACT : OFF_NOT);
+            const uint32_t a0 = (uint32_t)(M::LUT + (threadIdx.x / 6 == 5 ? 0 : LUT4_KEYS * 16));
+            const uint32_t a1 = (uint32_t)(M::LUT + (threadIdx.x % 6 == 5 ? 0 : LUT4_KEYS * 16));
             if (CW == 2) {
                 reinterpret_cast<uint16_t*>(s_dyn4 + M::ACT)[threadIdx.x] = (uint16_t)a0;
                 reinterpret_cast<uint16_t*>(s_dyn4 + M::ACT + M::ACT_P1)[threadIdx.x] = (uint16_t)a1;
@@ -595,13 +578,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
     auto look_up = [&](uint32_t off0, uint32_t off1, uint32_t c0, uint32_t c1, const uint32_t (&pw)[MAXP]) __attribute__((always_inline)) {
         if (CW == 2) {  // (values read with ds_read_u16 a step earlier: tell the compiler they are still 16 bits wide)
             __builtin_assume(c0 <= 0xFFFFu); __builtin_assume(c1 <= 0xFFFFu);
-            if (!BC) { __builtin_assume(off0 <= 0xFFFFu); __builtin_assume(off1 <= 0xFFFFu); }
+            __builtin_assume(off0 <= 0xFFFFu); __builtin_assume(off1 <= 0xFFFFu);
 #pragma unroll
             for (int k = 0; k < MAXP; ++k) __builtin_assume(pw[k] <= 0xFFFFu);
         }
         Looked q;
-        q.e0 = lds_rd128(lut4_addr<CW, BC>(off0, s.h0, c0));
-        q.e1 = lds_rd128(lut4_addr<CW, BC>(off1, s.h1, c1));
+        q.e0 = lds_rd128(lut4_addr<CW>(off0, s.h0, c0));
+        q.e1 = lds_rd128(lut4_addr<CW>(off1, s.h1, c1));
         q.cookv = FAST_START ? cook_time(cw_obj<CW>(pw[0])) : 0u;
         return q;
     };
@@ -697,7 +680,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
         if (__builtin_expect(rare, 0)) {
             bool grid_changed = false;  // something below wrote to the grid after the prefetch
             if (conflict) {
-                e1 = lds_rd128(lut4_addr<CW, BC>(off1, h1_before, cw0));
+                e1 = lds_rd128(lut4_addr<CW>(off1, h1_before, cw0));
                 r1 = interact4<CW>(e1, h1_before, cw0);
                 nh1 = r1;
                 cw_wr<CW>(fo1, cw_of_result<CW>(r1));
@@ -1011,14 +994,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             c1 = cw_rd<CW>(fo1);
         }
         rd_pots(pw);
-        const uint32_t lut_i = (BC ? 0u : lut_var) + OFF_ACT, lut_n = (BC ? 0u : lut_var) + OFF_NOT;  // (lut_var is fixed: RUX)
+        constexpr uint32_t NOI = (uint32_t)(LUT4_KEYS * 16);
         auto mstep = [&](uint32_t a0, uint32_t a1, int k8) __attribute__((always_inline)) {  // the two actions of THIS step
             if (!PIPE) {
                 c0 = cw_rd<CW>(fo0);
                 c1 = cw_rd<CW>(fo1);
                 rd_pots(pw);
             }
-            const uint32_t off0 = a0 == 5u ? lut_i : lut_n, off1 = a1 == 5u ? lut_i : lut_n;
+            const uint32_t off0 = lut_var + (a0 == 5u ? 0u : NOI), off1 = lut_var + (a1 == 5u ? 0u : NOI);
             const Looked looked = look_up(off0, off1, c0, c1, pw);
             // resolve_movement (mdp.py:1644-1727) on the static terrain: the pose of the NEXT step
             const uint32_t t0_ = ahead(P0, a0), t1_ = ahead(P1, a1);
@@ -1065,9 +1048,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) v
             const uint32_t m0 = a0 < 4u ? step_cell(s.pos0, a0, delta4) : s.pos0;
             const uint32_t m1 = (two & (a1 < 4u)) ? step_cell(s.pos1, a1, delta4) : (two ? s.pos1 : s.pos0);
             const uint32_t fo0 = col + f0 * (BLOCK * CW), fo1 = col + f1 * (BLOCK * CW);
-            const uint32_t lv = BC ? 0u : lut_var;  // (BC: masks)
-            const uint32_t off0 = lv + (a0 == OC_A_INTERACT ? OFF_ACT : OFF_NOT);
-            const uint32_t off1 = lv + ((two & (a1 == OC_A_INTERACT)) ? OFF_ACT : OFF_NOT);
+            const uint32_t off0 = lut_var + (a0 == OC_A_INTERACT ? 0u : (uint32_t)(LUT4_KEYS * 16));
+            const uint32_t off1 = lut_var + ((two & (a1 == OC_A_INTERACT)) ? 0u : (uint32_t)(LUT4_KEYS * 16));
             const uint32_t c0 = cw_rd<CW>(fo0), c1 = cw_rd<CW>(fo1);
             const uint32_t cm0 = cw_rd<CW>(col + m0 * (BLOCK * CW)), cm1 = cw_rd<CW>(col + m1 * (BLOCK * CW));
             uint32_t pw[MAXP];

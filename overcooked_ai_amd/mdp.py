@@ -51,11 +51,12 @@ class _Infos(dict):
 
 
 class _SingleEnvPort:
-    """One env stepped by the HIP kernel with no Python objects in between: the single-state calls of the drop-in API
-    (`get_state_transition`, hence `OvercookedEnv.step`) write the packed state and the joint action into ONE pinned host
-    buffer, launch `oc_step` on pointers INTO that buffer (pinned host memory is mapped into the GPU's address space, so
-    the kernel reads its inputs and writes next state, rewards, flags and the event mask over PCIe: no staging copies,
-    no device allocation) and wait on the stream once."""
+    """One env stepped by the GPU with no Python objects and no kernel launch in between: the single-state calls of the
+    drop-in API (`get_state_transition`, hence `OvercookedEnv.step`) write the packed state and the joint action into the
+    MAILBOX of a resident kernel (oc_mailbox_*, include/oc_amd.h: 4 KiB of pinned, GPU-mapped host memory), post the request
+    and spin until the kernel has written next state, rewards, flags and the event mask back — two PCIe round trips per
+    step instead of a launch and a stream wait.  Grids above 64 cells (which the mailbox kernel does not serve) take the
+    round-3 form: `oc_step` launched on pointers into a pinned buffer, one stream wait per call."""
 
     def __init__(self, mdp):
         import ctypes
@@ -70,27 +71,38 @@ class _SingleEnvPort:
         self.lib, self.bref = env.lib, env._bref
         self.n_state = env.n_planes * 16
         self.codec = SingleStateCodec(mdp.spec, env.n_planes)
-        off = lambda x: (x + 15) & ~15
-        self.o_in, self.o_act = 0, off(self.n_state)
-        self.o_out = self.o_act + 16
-        self.o_rew = self.o_out + off(self.n_state)
-        self.o_flag, self.o_ev = self.o_rew + 16, self.o_rew + 32
-        total = self.o_ev + 16
-        self.pinned = torch.zeros((total,), dtype=torch.uint8).pin_memory()
-        self.np = self.pinned.numpy()
+        self.device, self.dev_index, self.torch, self.num_players = env.device, env._dev_index, torch, mdp.num_players
+        self.mailbox = None
+        if env.n_planes <= 5 and not os.environ.get("OC_AMD_NO_MAILBOX"):
+            mb = ctypes.c_void_p()
+            with torch.cuda.device(env.device):
+                _lib.check(self.lib.oc_mailbox_open(self.bref, 65535, ctypes.byref(mb)), "oc_mailbox_open")
+            self.mailbox = mb
+            buf = (ctypes.c_uint8 * _lib.MB_BYTES).from_address(self.lib.oc_mailbox_buffer(mb))
+            self.np = np.frombuffer(buf, dtype=np.uint8)
+            self.o_in, self.o_act, self.o_out = _lib.MB_STATE_IN, _lib.MB_ACTIONS, _lib.MB_STATE_OUT
+            self.o_rew, self.o_flag, self.o_ev = _lib.MB_REWARDS, _lib.MB_FLAGS, _lib.MB_EVENTS
+            self._step = self.lib.oc_mailbox_step
+            import weakref
+
+            weakref.finalize(self, self.lib.oc_mailbox_close, mb)  # (also runs at interpreter exit: the kernel is told to leave)
+        else:
+            off = lambda x: (x + 15) & ~15
+            self.o_in, self.o_act = 0, off(self.n_state)
+            self.o_out = self.o_act + 16
+            self.o_rew = self.o_out + off(self.n_state)
+            self.o_flag, self.o_ev = self.o_rew + 16, self.o_rew + 32
+            self.pinned = torch.zeros((self.o_ev + 16,), dtype=torch.uint8).pin_memory()
+            self.np = self.pinned.numpy()
+            base = self.pinned.data_ptr()
+            self.ptrs = tuple(ctypes.c_void_p(base + o) for o in (self.o_in, self.o_out, self.o_act, self.o_rew, self.o_flag, self.o_ev))
+            self.stream = torch.cuda.Stream(device=env.device)
+            self.stream_ptr = ctypes.c_void_p(self.stream.cuda_stream)
         self.mv = memoryview(self.np)
         self.mv_in = self.mv[self.o_in:self.o_in + self.n_state]
         self.mv_out = self.mv[self.o_out:self.o_out + self.n_state]
         self.rew = self.np[self.o_rew:self.o_rew + 16].view(np.float32)
         self.ev = self.np[self.o_ev:self.o_ev + 8].view(np.uint64)
-        base = self.pinned.data_ptr()
-        self.ptrs = tuple(ctypes.c_void_p(base + o) for o in (self.o_in, self.o_out, self.o_act, self.o_rew, self.o_flag, self.o_ev))
-        self.stream = torch.cuda.Stream(device=env.device)
-        self.stream_ptr = ctypes.c_void_p(self.stream.cuda_stream)
-        self.device = env.device
-        self.dev_index = env._dev_index
-        self.torch = torch
-        self.num_players = mdp.num_players
 
     def transition(self, state, a0, a1):
         """(next_state, rewards float32[4], event mask int) or None when the state needs the general path."""
@@ -99,6 +111,12 @@ class _SingleEnvPort:
         mv = self.mv
         mv[self.o_act] = a0
         mv[self.o_act + 1] = a1
+        if self.mailbox is not None:
+            rc = self._step(self.mailbox)
+            if rc:
+                from . import _lib
+                _lib.check(rc, "oc_mailbox_step")
+            return self.codec.unpack(self.mv_out), self.rew, int(self.ev[0])
         p = self.ptrs
         if self.torch.cuda.current_device() == self.dev_index:
             rc = self.lib.oc_step(self.bref, p[0], p[1], p[2], p[3], p[4], None, p[5], 65535, 0, None, None, self.stream_ptr)
