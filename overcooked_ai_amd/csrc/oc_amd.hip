@@ -830,8 +830,11 @@ static_assert(OC_MB_STATE_IN == MB_IN && OC_MB_ACTIONS == MB_ACT && OC_MB_STATE_
 
 int mailbox_launch(OcMailbox* m) {
     *reinterpret_cast<volatile uint32_t*>(m->h + MB_ALIVE) = 1u;
-    hipLaunchKernelGGL(k_mailbox, dim3(1), dim3(64), 0, m->stream, m->d_layout, m->d, m->W, m->n_obj, m->horizon, m->idle_ticks,
-                       m->life_ticks);
+    DISPATCH_NOBJ(m->n_obj, {
+        if (NOBJ <= STEP1_MAX_PLANES)
+            hipLaunchKernelGGL((k_mailbox<(NOBJ <= STEP1_MAX_PLANES ? NOBJ : 1)>), dim3(1), dim3(64), 0, m->stream, m->d_layout, m->d,
+                               m->W, m->horizon, m->idle_ticks, m->life_ticks);
+    });
     return check_launch("oc_mailbox: launch");
 }
 }  // namespace
@@ -873,19 +876,29 @@ void* oc_mailbox_buffer(OcMailbox* m) { return m ? m->h : nullptr; }
 
 int oc_mailbox_step(OcMailbox* m) {
     if (!m) return fail(OC_EINVAL, "oc_mailbox_step: NULL mailbox");
-    volatile uint32_t* req = reinterpret_cast<volatile uint32_t*>(m->h + MB_REQ);
-    volatile uint32_t* rsp = reinterpret_cast<volatile uint32_t*>(m->h + MB_RSP);
-    volatile uint32_t* alive = reinterpret_cast<volatile uint32_t*>(m->h + MB_ALIVE);
     uint32_t seq = m->seq + 1u;
     if (seq == MB_STOP || seq == 0u) seq = 1u;
     m->seq = seq;
-    __atomic_store_n(const_cast<uint32_t*>(req), seq, __ATOMIC_RELEASE);  // the payload is in place: publish the request
+    const int n_state = 16 * (1 + m->n_obj);
+    const int n_req = (n_state + 2 + 3) / 4, n_rsp = (n_state + 28) / 4;
+    // ---- the request: state planes + the two action bytes as 8-byte granules {u32 payload, u32 tag}, one 8-byte store each
+    uint32_t pay[MB_REQ_WORDS] = {0};
+    memcpy(pay, m->h + MB_IN, (size_t)n_state);
+    pay[n_state / 4] = (uint32_t)m->h[MB_ACT] | ((uint32_t)m->h[MB_ACT + 1] << 8);
+    for (int g = 0; g < n_req; ++g)
+        __atomic_store_n(reinterpret_cast<uint64_t*>(m->h + MB_REQG + 8 * g), (uint64_t)pay[g] | ((uint64_t)seq << 32), __ATOMIC_RELEASE);
+    // ---- the response: every granule carries the tag once the kernel has answered
+    volatile uint32_t* alive = reinterpret_cast<volatile uint32_t*>(m->h + MB_ALIVE);
     uint32_t spins = 0;
     struct timespec t0 = {0, 0};
-    while (__atomic_load_n(const_cast<uint32_t*>(rsp), __ATOMIC_ACQUIRE) != seq) {
+    for (;;) {
+        int ok = 1;
+        for (int g = n_rsp - 1; g >= 0 && ok; --g)
+            ok = (uint32_t)(__atomic_load_n(reinterpret_cast<uint64_t*>(m->h + MB_RSPG + 8 * g), __ATOMIC_ACQUIRE) >> 32) == seq;
+        if (ok) break;
         __builtin_ia32_pause();
         if ((++spins & 0x3FFu) != 0u) continue;
-        if (*alive == 0u && *rsp != seq) {  // the kernel has left (idle / lifetime): the next incarnation finds the request
+        if (*alive == 0u) {  // the kernel has left (idle / lifetime): the next incarnation finds the request
             int dev = 0;
             (void)hipGetDevice(&dev);
             if (dev != m->device) (void)hipSetDevice(m->device);
@@ -898,12 +911,19 @@ int oc_mailbox_step(OcMailbox* m) {
         if (t0.tv_sec == 0 && t0.tv_nsec == 0) t0 = now;
         else if ((now.tv_sec - t0.tv_sec) > 5) return fail(OC_ELAUNCH, "oc_mailbox_step: no answer from the resident kernel within 5 s");
     }
+    uint32_t rspw[MB_RSP_WORDS];
+    for (int g = 0; g < n_rsp; ++g) rspw[g] = (uint32_t)__atomic_load_n(reinterpret_cast<uint64_t*>(m->h + MB_RSPG + 8 * g), __ATOMIC_RELAXED);
+    const uint8_t* rsp = reinterpret_cast<const uint8_t*>(rspw);
+    memcpy(m->h + MB_OUT, rsp, (size_t)n_state);
+    memcpy(m->h + MB_REW, rsp + n_state, 16);
+    memcpy(m->h + MB_FLAGS, rsp + n_state + 16, 4);
+    memcpy(m->h + MB_EV, rsp + n_state + 20, 8);
     return OC_OK;
 }
 
 int oc_mailbox_close(OcMailbox* m) {
     if (!m) return OC_OK;
-    __atomic_store_n(reinterpret_cast<uint32_t*>(m->h + MB_REQ), MB_STOP, __ATOMIC_RELEASE);
+    __atomic_store_n(reinterpret_cast<uint64_t*>(m->h + MB_REQG), (uint64_t)MB_STOP << 32, __ATOMIC_RELEASE);  // granule 0's tag
     (void)hipStreamSynchronize(m->stream);
     (void)hipStreamDestroy(m->stream);
     (void)hipHostFree(m->h);

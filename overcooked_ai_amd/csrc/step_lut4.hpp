@@ -446,7 +446,10 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
 //   more than the latency it hides (131 072 cramped_room envs: 0.48 vs 0.65 us per batched step), so big batches turn it off
 template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false,
           bool PIPE = true, bool RU = false, int CW = 2, bool NOCONF = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_rollout4(const OcLayout* __restrict__ g_layouts, int n_layouts,
+#ifndef OC_R4_WAVES_MAX
+#define OC_R4_WAVES_MAX 4
+#endif
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_WAVES_MAX))) void k_rollout4(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                     const uint16_t* layout_id, uint4* st,
                                                     float4* __restrict__ rewards, uint8_t* __restrict__ flags,
                                                     float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,

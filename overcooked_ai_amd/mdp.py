@@ -46,8 +46,45 @@ def default_device():
 
 class _Infos(dict):
     """The infos dict of get_state_transition (same keys as the reference's) that also remembers the kernel's event bit
-    mask, so that OvercookedEnv._update_game_stats need not walk 25 x 2 flags."""
-    __slots__ = ("event_mask",)
+    mask, so that OvercookedEnv._update_game_stats need not walk 25 x 2 flags.  `event_infos` — 25 lists of booleans — is
+    built from the mask the first time somebody asks for it (OvercookedEnv.step never does)."""
+    __slots__ = ("event_mask", "num_players")
+
+    def __missing__(self, key):
+        if key != "event_infos":
+            raise KeyError(key)
+        v = self["event_infos"] = events_from_mask(self.event_mask, self.num_players)
+        return v
+
+    def _all(self):
+        self["event_infos"]
+        return self
+
+    def keys(self):
+        return dict.keys(self._all())
+
+    def items(self):
+        return dict.items(self._all())
+
+    def values(self):
+        return dict.values(self._all())
+
+    def __iter__(self):
+        return dict.__iter__(self._all())
+
+    def __len__(self):
+        return dict.__len__(self._all())
+
+    def __contains__(self, key):
+        return key == "event_infos" or dict.__contains__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __eq__(self, other):
+        return dict.__eq__(self._all(), other._all() if isinstance(other, _Infos) else other)
+
+    __hash__ = None
 
 
 class _SingleEnvPort:
@@ -347,10 +384,9 @@ class OvercookedGridworld:
         nxt, rew, mask = out
         n = self.num_players
         r = rew.tolist()  # four Python floats; all-zero on most steps
-        infos = _Infos(event_infos=events_from_mask(mask, n),
-                       sparse_reward_by_agent=[0] * n if not (r[0] or r[1]) else [_num(v) for v in r[0:n]],
+        infos = _Infos(sparse_reward_by_agent=[0] * n if not (r[0] or r[1]) else [_num(v) for v in r[0:n]],
                        shaped_reward_by_agent=[0] * n if not (r[2] or r[3]) else [_num(v) for v in r[2:2 + n]])
-        infos.event_mask = mask
+        infos.event_mask, infos.num_players = mask, n
         return nxt, infos
 
     def get_state_transition(self, state, joint_action, display_phi=False, motion_planner=None):

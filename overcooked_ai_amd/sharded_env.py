@@ -78,21 +78,34 @@ class ShardedVecOvercookedEnv:
         return [(s.start, s.stop) for s in self.shards]
 
     def _each(self, fn):
-        """fn(shard, index) on every shard, on the shard's stream, without host synchronisation in between."""
+        """fn(shard, index) on every shard, on the shard's stream, without host synchronisation in between.  Each shard
+        stream first waits (on the device, an event) for what the caller has enqueued on ITS current stream of that device —
+        buffers it has just filled or zeroed, action tensors it has just produced — so a call is ordered after the caller's
+        earlier work exactly as a call on one stream would be."""
         out = []
         for i, s in enumerate(self.shards):
-            with torch.cuda.device(s.device), torch.cuda.stream(s.stream):
-                out.append(fn(s, i))
+            with torch.cuda.device(s.device):
+                s.stream.wait_stream(torch.cuda.current_stream(s.device))
+                with torch.cuda.stream(s.stream):
+                    out.append(fn(s, i))
         return out
 
     def synchronize(self):
+        """Host-side wait for every shard's stream."""
         for s in self.shards:
             s.stream.synchronize()
 
+    def join(self):
+        """Device-side: the caller's current stream of every shard's device waits for that shard's stream (no host
+        synchronisation) — call it before consuming per-shard results on the caller's own stream."""
+        for s in self.shards:
+            with torch.cuda.device(s.device):
+                torch.cuda.current_stream(s.device).wait_stream(s.stream)
+
     def alloc_outputs(self, n_steps):
         """Per-shard (rewards [n_steps, n, 4] f32, flags [n_steps, n] u8) buffers on the shards' devices."""
-        return ([torch.zeros((n_steps, s.stop - s.start, 4), dtype=torch.float32, device=s.device) for s in self.shards],
-                [torch.zeros((n_steps, s.stop - s.start), dtype=torch.uint8, device=s.device) for s in self.shards])
+        return (self._each(lambda s, i: torch.zeros((n_steps, s.stop - s.start, 4), dtype=torch.float32, device=s.device)),
+                self._each(lambda s, i: torch.zeros((n_steps, s.stop - s.start), dtype=torch.uint8, device=s.device)))
 
     def _split(self, t, per_env_dim=0):
         """A caller tensor over this object's envs -> per-shard tensors on the shards' devices (async copies)."""
@@ -103,8 +116,11 @@ class ShardedVecOvercookedEnv:
         for s in self.shards:
             sl = [slice(None)] * t.dim()
             sl[per_env_dim] = slice(s.start - base, s.stop - base)
-            with torch.cuda.device(s.device), torch.cuda.stream(s.stream):
-                out.append(t[tuple(sl)].to(s.device, non_blocking=True).contiguous())
+            with torch.cuda.device(s.device):
+                if t.is_cuda:  # (ordered after whatever produced `t` on its device's current stream)
+                    s.stream.wait_stream(torch.cuda.current_stream(t.device))
+                with torch.cuda.stream(s.stream):
+                    out.append(t[tuple(sl)].to(s.device, non_blocking=True).contiguous())
         return out
 
     # ------------------------------------------------------------------ env API (lists hold one entry per shard)

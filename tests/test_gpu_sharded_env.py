@@ -77,7 +77,8 @@ def test_sharded_mixed_table_with_layout_redraws(gpu):
     rew = torch.zeros((K, n, 4), dtype=torch.float32, device=gpu)
     fl = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
     whole.rollout_random(K, rew, fl)
-    rews, fls = sh.alloc_outputs(K)
+    rews = [torch.full((K, b - a, 4), 7.0, dtype=torch.float32, device=gpu) for a, b in sh.ranges()]  # caller-made buffers, filled
+    fls = [torch.full((K, b - a), 9, dtype=torch.uint8, device=gpu) for a, b in sh.ranges()]          # on the caller's stream
     sh.rollout_random(K, rews, fls)
     assert np.array_equal(sh.layout_ids(), whole.layout_ids()) and not np.array_equal(whole.layout_ids(), lid)
     assert np.array_equal(sh.get_packed_state(), whole.get_packed_state())

@@ -38,22 +38,37 @@ t1 = time.perf_counter()
 for _ in range(N):
     port.codec.unpack(port.mv_in)
 t2 = time.perf_counter()
-p = port.ptrs
-for _ in range(N):
-    port.lib.oc_step(port.bref, p[0], p[1], p[2], p[3], p[4], None, p[5], 65535, 0, None, None, port.stream_ptr)
-port.stream.synchronize()
-t3 = time.perf_counter()
-for _ in range(N):
-    port.lib.oc_step(port.bref, p[0], p[1], p[2], p[3], p[4], None, p[5], 65535, 0, None, None, port.stream_ptr)
-    port.stream.synchronize()
-t4 = time.perf_counter()
-for _ in range(N):
-    port.lib.oc_step(port.bref, p[0], p[1], p[2], p[3], p[4], None, p[5], 65535, 0, None, None, port.stream_ptr)
-    while not port.stream.query():
-        pass
-t5 = time.perf_counter()
-for _ in range(N):
-    port.transition(state, 4, 4)
 t6 = time.perf_counter()
-print("pack %.1f us, unpack %.1f us, launch only (async, back to back) %.1f us, launch + synchronize %.1f us, launch + query spin %.1f us, "
-      "port.transition %.1f us" % tuple(x / N * 1e6 for x in (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)))
+if port.mailbox is not None:  # the resident kernel: post + spin, no launch
+    for _ in range(N):
+        port._step(port.mailbox)
+    t3 = time.perf_counter()
+    for _ in range(N):
+        port.transition(state, 4, 4)
+    t6 = time.perf_counter()
+    print("pack %.1f us, unpack %.1f us, oc_mailbox_step alone (post + spin) %.1f us, port.transition %.1f us"
+          % tuple(x / N * 1e6 for x in (t1 - t0, t2 - t1, t3 - t2, t6 - t3)))
+else:
+    p = port.ptrs
+    for _ in range(N):
+        port.lib.oc_step(port.bref, p[0], p[1], p[2], p[3], p[4], None, p[5], 65535, 0, None, None, port.stream_ptr)
+    port.stream.synchronize()
+    t3 = time.perf_counter()
+    for _ in range(N):
+        port.lib.oc_step(port.bref, p[0], p[1], p[2], p[3], p[4], None, p[5], 65535, 0, None, None, port.stream_ptr)
+        port.stream.synchronize()
+    t4 = time.perf_counter()
+    for _ in range(N):
+        port.transition(state, 4, 4)
+    t6 = time.perf_counter()
+    print("pack %.1f us, unpack %.1f us, launch only (async, back to back) %.1f us, launch + synchronize %.1f us, port.transition %.1f us"
+          % tuple(x / N * 1e6 for x in (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t6 - t4)))
+# the Python layers above the port
+import cProfile
+import pstats
+
+pr = cProfile.Profile()
+pr.enable()
+episode()
+pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(14)
