@@ -1099,7 +1099,7 @@ def bench_step_api(env, dev, torch, iters=2000):
 
 def bench_single_env_api(dev, torch, episodes=3):
     """The drop-in single-env surface existing agents hit: OvercookedEnv.step -> OvercookedGridworld.get_state_transition
-    (one env per call: pack -> H2D -> k_step -> D2H -> unpack), same protocol as the reference's CPU measurement
+    (one env per call: pack -> mailbox of the resident kernel -> unpack), same protocol as the reference's CPU measurement
     (cramped_room, horizon 400, random joint actions, info_level 0).  Reported next to the reference's 16.4 k steps/s."""
     import numpy as np
 
@@ -1126,8 +1126,8 @@ def bench_single_env_api(dev, torch, episodes=3):
     dt = time.perf_counter() - t0
     return {"value": steps / dt, "unit": "env steps/s", "us_per_step": dt / steps * 1e6, "episodes": episodes,
             "reference_python": _reference_python_stored()["value"],
-            "note": "OvercookedEnv.step through the single-env drop-in API: state and action written into a pinned host buffer "
-                    "the kernel reads and writes in place (no staging copies), one launch + one stream wait per call; "
+            "note": "OvercookedEnv.step through the single-env drop-in API: state and action written into the pinned mailbox of "
+                    "a resident kernel (oc_mailbox_*: no launch per call; ~7 us per transition, the rest is Python); "
                     "latency-bound by construction - batch with VecOvercookedEnv for throughput"}
 
 

@@ -437,8 +437,8 @@ int oc_reset(const OcBatch* batch, void* d_state, const uint8_t* d_mask, float* 
  * an agent loop.  oc_mailbox_open starts a resident one-wavefront kernel that serves transitions of the batch's single
  * layout from a 4 KiB mailbox in pinned, GPU-mapped host memory; the caller writes the packed state (oc_state_planes()
  * planes of 16 bytes, as [plane][16]) at OC_MB_STATE_IN and the two action indices at OC_MB_ACTIONS of oc_mailbox_buffer(),
- * calls oc_mailbox_step (which posts the request and spins until the kernel has answered: two PCIe round trips, no
- * launch) and reads the next state at OC_MB_STATE_OUT, float rewards[4] = (sparse0, sparse1, shaped0, shaped1) at
+ * calls oc_mailbox_step (which posts the request and spins until the kernel has answered: ~7 us instead of the ~16 us of a
+ * launch + stream wait) and reads the next state at OC_MB_STATE_OUT, float rewards[4] = (sparse0, sparse1, shaped0, shaped1) at
  * OC_MB_REWARDS, the OC_F_* flags (u32; DONE when the new timestep >= horizon, BAD_ACTION leaves the state as it was) at
  * OC_MB_FLAGS and the event_infos mask (u64, bit 2*k + p) at OC_MB_EVENTS.  Same transition, bit for bit, as oc_step.
  * The kernel leaves on its own after ~2 ms without a request (and after ~2 s in any case) and is relaunched by the next

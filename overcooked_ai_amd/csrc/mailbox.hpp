@@ -11,39 +11,50 @@
 // mailbox and publishes a response word; the host (oc_mailbox_step) spins on that word.  A call then costs two PCIe
 // round trips (the GPU's poll sees the request, the host's poll sees the response) instead of a launch.
 //
-// Protocol: data-tagged 8-byte granules, {u32 payload, u32 tag = the request's sequence number}, in the 4 KiB host mailbox,
-// read and written with ONE system-scope 8-byte access each (MI355X_MICROARCH.md, "handoff-1to1": whoever reads a granule with
-// the expected tag has its payload too — no separate flag, no fence between payload and flag, and each direction costs ONE
-// round trip).  The accesses are system-scope atomics: a plain or non-temporal load of host memory may be served from the
-// GPU's caches and never see the host's next write (seen on the box: the first version polled with non-temporal loads and
-// every step ran into the idle timeout).
-//   host:  request granules (state planes + the two action bytes)   ... spins until every response granule carries the tag
-//   GPU :  polls ALL request granules at once (s_sleep between polls) until they agree on a new tag -> step -> response
-//          granules (next state, rewards, flags, events)
-// The kernel never outlives its usefulness: it leaves when granule 0 carries MB_STOP, after idle_ticks of wall_clock64
+// Protocol (4 KiB host mailbox; what each form cost is in docs/NOTEBOOK.md, round 4):
+//   host:  payload (state planes at MB_IN, the two action bytes at MB_ACT) -> request word = seq (x86 stores stay in order)
+//          ... spins until every RESPONSE GRANULE carries seq -> copies the outputs out
+//   GPU :  polls the request word with a system-scope atomic load (s_sleep between polls) -> acquire fence (drops whatever
+//          the GPU's caches hold of the mailbox) -> payload -> step -> response granules: 16 bytes each, {12 payload bytes,
+//          u32 tag = seq}, one store per granule.  An aligned 16-byte store is one PCIe write on one cache line, so a granule
+//          that shows the tag has its payload too: no flag behind a release fence, no wait for write acknowledgements.
+// Measured on the box (oc_mailbox_step alone, cramped_room): request word + response word behind a release fence 7.9 us;
+// this form 7.0 us; all-granule requests read with 8-byte system-scope atomic loads (one round trip on the request side
+// too) 7.6 us — no better, so the request stays a word + fence; 8-byte granules both ways 11.1 us (13 reads + 19 fabric
+// writes per step).  Stores that are not write-through (plain, non-temporal) stay in the GPU's L2 until the kernel's final
+// release: every step then took the 2 ms idle timeout and was answered by the NEXT incarnation of the kernel.
+// The kernel never outlives its usefulness: it leaves when the request word is MB_STOP, after idle_ticks of wall_clock64
 // without a request, or after life_ticks in total, and says so (alive = 0); oc_mailbox_step relaunches it when needed.  It
 // serves one layout (the mailbox's batch holds one layout record), any number of pots, grids of at most 64 cells.
 // ==========================================================================================
 constexpr uint32_t MB_STOP = 0xFFFFFFFFu;
-// byte offsets inside the mailbox.  IN / ACT / OUT / REW / FLAGS / EV are the caller's plain views (include/oc_amd.h):
-// oc_mailbox_step packs IN + ACT into the request granules and unpacks the response granules into OUT .. EV.
-constexpr int MB_ALIVE = 128, MB_IN = 256 /* 5 planes x 16 B */, MB_ACT = MB_IN + 80, MB_OUT = 512 /* 5 planes */,
-              MB_REW = MB_OUT + 80, MB_FLAGS = MB_REW + 16, MB_EV = MB_FLAGS + 8, MB_REQG = 1024, MB_RSPG = 2048, MB_BYTES = 4096;
-constexpr int MB_REQ_WORDS = (80 + 2 + 3) / 4;       // 21 granules at most: header + 4 planes + the action bytes
-constexpr int MB_RSP_WORDS = (80 + 16 + 4 + 8) / 4;  // 27: new state, rewards, flags, events
+// byte offsets inside the mailbox.  IN / ACT / OUT / REW / FLAGS / EV are the caller's plain views (include/oc_amd.h);
+// oc_mailbox_step unpacks the response granules into OUT .. EV.
+constexpr int MB_REQ = 0, MB_ALIVE = 128, MB_IN = 256 /* 5 planes x 16 B */, MB_ACT = MB_IN + 80, MB_OUT = 512 /* 5 planes */,
+              MB_REW = MB_OUT + 80, MB_FLAGS = MB_REW + 16, MB_EV = MB_FLAGS + 8, MB_RSPG = 2048, MB_BYTES = 4096;
+constexpr int MB_RSP_BYTES = 80 + 16 + 4 + 8, MB_RSP_GRANULES = (MB_RSP_BYTES + 11) / 12;  // 9
 
-__device__ __forceinline__ uint64_t mb_load8(const uint8_t* p) {  // one granule, at system scope (past the GPU's caches)
-    return __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+typedef uint32_t mb_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t mb_load(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ __forceinline__ void mb_store8(uint8_t* p, uint32_t payload, uint32_t tag) {
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(p), (uint64_t)payload | ((uint64_t)tag << 32), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
+// A response granule: ONE 16-byte write-through store at system scope.  (`sc0 sc1` is what makes it leave the GPU's L2 now: a
+// plain or non-temporal store stays there until the kernel's final release — measured: every step then took the idle
+// timeout.)  Inline asm, because no builtin emits a 16-byte system-scope store; the wait at the end of the block keeps the
+// data registers alive until the store has read them (the compiler does not see asm stores: NOTEBOOK 4.2c).
+template <int N>
+__device__ __forceinline__ void mb_store_granules(uint8_t* base, const mb_u32x4 (&g)[N]) {
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i)  // granule 0 last: the next incarnation of the kernel reads `served` from it
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(base + 16 * i), "v"(g[i]) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 }
 
-template <int NOBJ>  // object planes of the grid (1..4): every index into the granule words is a compile-time constant
+// NOBJ: object planes of the grid (1..4; every index into the granule words is a compile-time constant); MAXP: pot slots
+template <int NOBJ, int MAXP>
 __global__ __launch_bounds__(64) void k_mailbox(const OcLayout* __restrict__ g_layout, uint8_t* mb, int W, int horizon,
                                                 uint64_t idle_ticks, uint64_t life_ticks) {
-    constexpr int MAXP = OC_MAX_POTS, n_obj = NOBJ;
+    constexpr int n_obj = NOBJ;
     __shared__ uint4 s_rows[STEP1_MAX_PLANES * BLOCK];  // the lane's planes, [plane][BLOCK] rows of 16 bytes (one_obj's layout)
     __shared__ uint4 s_out[1 + STEP1_MAX_PLANES];       // the new state: header + planes
     __shared__ uint4 s_lay[16];
@@ -57,42 +68,29 @@ __global__ __launch_bounds__(64) void k_mailbox(const OcLayout* __restrict__ g_l
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut) + (C.old_dyn ? LUT_ENTRIES * 8 : 0);
     // granules a request / a response of this layout really needs (n_obj object planes + the header)
     constexpr int n_state = 16 * (1 + n_obj);
-    constexpr int n_req = (n_state + 2 + 3) / 4, n_rsp = (n_state + 28) / 4;
-    uint32_t served = (uint32_t)(mb_load8(mb + MB_RSPG) >> 32);  // the last request answered (by an earlier incarnation of this kernel)
+    constexpr int n_rsp = (n_state + 28 + 11) / 12;
+    const uint32_t* const req = reinterpret_cast<const uint32_t*>(mb + MB_REQ);
+    const uint4* const in = reinterpret_cast<const uint4*>(mb + MB_IN);
+    uint32_t served = mb_load(reinterpret_cast<const uint32_t*>(mb + MB_RSPG + 12));  // the last request answered (by an earlier incarnation)
     const uint64_t born = wall_clock64();
     uint64_t last = born;
     for (;;) {
-        uint32_t w[MB_REQ_WORDS];  // the request's payload words
-        uint32_t tag = 0;
-        bool same = true;
-#pragma unroll
-        for (int g = 0; g < MB_REQ_WORDS; ++g) {
-            if (g < n_req) {
-                const uint64_t v = mb_load8(mb + MB_REQG + 8 * g);
-                w[g] = (uint32_t)v;
-                if (g == 0) tag = (uint32_t)(v >> 32); else same &= (uint32_t)(v >> 32) == tag;
-            } else {
-                w[g] = 0u;
-            }
-        }
+        const uint32_t tag = mb_load(req);
         if (tag == MB_STOP) break;
-        if (tag == served || !same) {  // nothing new (or a request still being written)
+        if (tag == served) {  // nothing new
             const uint64_t now = wall_clock64();
             if (now - last > idle_ticks || now - born > life_ticks) break;
             __builtin_amdgcn_s_sleep(4);
             continue;
         }
-        // ---- the request: payload bytes 0 .. n_state - 1 = header + object planes, then the two action bytes
-        auto byte_at = [&](int i) __attribute__((always_inline)) { return (w[i >> 2] >> (8 * (i & 3))) & 0xFFu; };
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);  // the payload was written before the request word; drop cached copies of it
+        // ---- the request: header, object planes, the two action bytes
         OneIn q_in;
-        q_in.h = make_uint4(w[0], w[1], w[2], w[3]);
+        q_in.h = in[0];
 #pragma unroll
-        for (int p = 0; p < STEP1_MAX_PLANES; ++p)
-            q_in.v[p] = p < n_obj ? make_uint4(w[4 + 4 * p], w[5 + 4 * p], w[6 + 4 * p], w[7 + 4 * p]) : make_uint4(0u, 0u, 0u, 0u);
-        uint32_t a0 = 0, a1 = 0;
-#pragma unroll
-        for (int p = 0; p <= STEP1_MAX_PLANES; ++p)  // (the action bytes follow the last plane: n_state is 16 * (1 + n_obj))
-            if (p == n_obj) { a0 = byte_at(16 * (1 + p)); a1 = byte_at(16 * (1 + p) + 1); }
+        for (int p = 0; p < STEP1_MAX_PLANES; ++p) q_in.v[p] = p < n_obj ? in[1 + p] : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t a01 = *reinterpret_cast<const uint16_t*>(mb + MB_ACT);
+        const uint32_t a0 = a01 & 0xFFu, a1 = a01 >> 8;
 #pragma unroll
         for (int p = 0; p < STEP1_MAX_PLANES; ++p)
             if (p < n_obj) s_rows[p * BLOCK] = q_in.v[p];
@@ -117,18 +115,19 @@ __global__ __launch_bounds__(64) void k_mailbox(const OcLayout* __restrict__ g_l
             for (int p = 0; p <= STEP1_MAX_PLANES; ++p) o[p] = s_out[p];
         }
         // ---- the response: payload = new state (n_state bytes), rewards (16), flags (4), events (8); tag = the request's
-        uint32_t r[MB_RSP_WORDS];
+        uint32_t r[3 * MB_RSP_GRANULES + 4];
 #pragma unroll
-        for (int i = 0; i < MB_RSP_WORDS; ++i) r[i] = 0u;
+        for (int i = 0; i < 3 * MB_RSP_GRANULES + 4; ++i) r[i] = 0u;
         int k = 0;
 #pragma unroll
         for (int p = 0; p <= STEP1_MAX_PLANES; ++p)
             if (p <= n_obj) { r[k] = o[p].x; r[k + 1] = o[p].y; r[k + 2] = o[p].z; r[k + 3] = o[p].w; k += 4; }
         r[k] = __float_as_uint(rw.x); r[k + 1] = __float_as_uint(rw.y); r[k + 2] = __float_as_uint(rw.z); r[k + 3] = __float_as_uint(rw.w);
         r[k + 4] = fl; r[k + 5] = (uint32_t)ev; r[k + 6] = (uint32_t)(ev >> 32);
+        mb_u32x4 gr[n_rsp];
 #pragma unroll
-        for (int g = MB_RSP_WORDS - 1; g >= 0; --g)  // granule 0 last: the next incarnation reads `served` from it
-            if (g < n_rsp) mb_store8(mb + MB_RSPG + 8 * g, r[g], tag);
+        for (int g = 0; g < n_rsp; ++g) gr[g] = mb_u32x4{r[3 * g], r[3 * g + 1], r[3 * g + 2], tag};
+        mb_store_granules<n_rsp>(mb + MB_RSPG, gr);
         served = tag;
         last = wall_clock64();
     }

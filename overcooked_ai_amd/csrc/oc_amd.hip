@@ -819,7 +819,7 @@ struct OcMailbox {
     uint8_t* d;             // its device address
     hipStream_t stream;     // the resident kernel's own stream
     const OcLayout* d_layout;
-    int W, n_obj, horizon, device;
+    int W, n_obj, horizon, device, max_pots;
     uint32_t seq;
     uint64_t idle_ticks, life_ticks;
 };
@@ -831,9 +831,15 @@ static_assert(OC_MB_STATE_IN == MB_IN && OC_MB_ACTIONS == MB_ACT && OC_MB_STATE_
 int mailbox_launch(OcMailbox* m) {
     *reinterpret_cast<volatile uint32_t*>(m->h + MB_ALIVE) = 1u;
     DISPATCH_NOBJ(m->n_obj, {
-        if (NOBJ <= STEP1_MAX_PLANES)
-            hipLaunchKernelGGL((k_mailbox<(NOBJ <= STEP1_MAX_PLANES ? NOBJ : 1)>), dim3(1), dim3(64), 0, m->stream, m->d_layout, m->d,
-                               m->W, m->horizon, m->idle_ticks, m->life_ticks);
+        constexpr int NO = NOBJ <= STEP1_MAX_PLANES ? NOBJ : 1;
+        if (NOBJ <= STEP1_MAX_PLANES) {
+            if (m->max_pots <= 2)
+                hipLaunchKernelGGL((k_mailbox<NO, 2>), dim3(1), dim3(64), 0, m->stream, m->d_layout, m->d, m->W, m->horizon,
+                                   m->idle_ticks, m->life_ticks);
+            else
+                hipLaunchKernelGGL((k_mailbox<NO, OC_MAX_POTS>), dim3(1), dim3(64), 0, m->stream, m->d_layout, m->d, m->W,
+                                   m->horizon, m->idle_ticks, m->life_ticks);
+        }
     });
     return check_launch("oc_mailbox: launch");
 }
@@ -865,6 +871,7 @@ int oc_mailbox_open(const OcBatch* b, int horizon, OcMailbox** out) {
         return fail(OC_ELAUNCH, "oc_mailbox_open: device mapping / stream refused");
     }
     m->d_layout = b->d_layouts; m->W = b->width; m->n_obj = n_obj; m->horizon = horizon; m->seq = 0;
+    m->max_pots = b->max_pots > 0 ? b->max_pots : OC_MAX_POTS;  // (hint of oc_batch_hints; unknown: the general instance)
     m->idle_ticks = (uint64_t)khz * 2;     // 2 ms without a request
     m->life_ticks = (uint64_t)khz * 2000;  // 2 s in any case
     if (int rc = mailbox_launch(m)) { (void)oc_mailbox_close(m); return rc; }
@@ -880,13 +887,9 @@ int oc_mailbox_step(OcMailbox* m) {
     if (seq == MB_STOP || seq == 0u) seq = 1u;
     m->seq = seq;
     const int n_state = 16 * (1 + m->n_obj);
-    const int n_req = (n_state + 2 + 3) / 4, n_rsp = (n_state + 28) / 4;
-    // ---- the request: state planes + the two action bytes as 8-byte granules {u32 payload, u32 tag}, one 8-byte store each
-    uint32_t pay[MB_REQ_WORDS] = {0};
-    memcpy(pay, m->h + MB_IN, (size_t)n_state);
-    pay[n_state / 4] = (uint32_t)m->h[MB_ACT] | ((uint32_t)m->h[MB_ACT + 1] << 8);
-    for (int g = 0; g < n_req; ++g)
-        __atomic_store_n(reinterpret_cast<uint64_t*>(m->h + MB_REQG + 8 * g), (uint64_t)pay[g] | ((uint64_t)seq << 32), __ATOMIC_RELEASE);
+    const int n_rsp = (n_state + 28 + 11) / 12;
+    // ---- the request: the payload is where the caller wrote it (MB_IN, MB_ACT); publish it
+    __atomic_store_n(reinterpret_cast<uint32_t*>(m->h + MB_REQ), seq, __ATOMIC_RELEASE);
     // ---- the response: every granule carries the tag once the kernel has answered
     volatile uint32_t* alive = reinterpret_cast<volatile uint32_t*>(m->h + MB_ALIVE);
     uint32_t spins = 0;
@@ -894,7 +897,7 @@ int oc_mailbox_step(OcMailbox* m) {
     for (;;) {
         int ok = 1;
         for (int g = n_rsp - 1; g >= 0 && ok; --g)
-            ok = (uint32_t)(__atomic_load_n(reinterpret_cast<uint64_t*>(m->h + MB_RSPG + 8 * g), __ATOMIC_ACQUIRE) >> 32) == seq;
+            ok = __atomic_load_n(reinterpret_cast<uint32_t*>(m->h + MB_RSPG + 16 * g + 12), __ATOMIC_ACQUIRE) == seq;
         if (ok) break;
         __builtin_ia32_pause();
         if ((++spins & 0x3FFu) != 0u) continue;
@@ -911,9 +914,8 @@ int oc_mailbox_step(OcMailbox* m) {
         if (t0.tv_sec == 0 && t0.tv_nsec == 0) t0 = now;
         else if ((now.tv_sec - t0.tv_sec) > 5) return fail(OC_ELAUNCH, "oc_mailbox_step: no answer from the resident kernel within 5 s");
     }
-    uint32_t rspw[MB_RSP_WORDS];
-    for (int g = 0; g < n_rsp; ++g) rspw[g] = (uint32_t)__atomic_load_n(reinterpret_cast<uint64_t*>(m->h + MB_RSPG + 8 * g), __ATOMIC_RELAXED);
-    const uint8_t* rsp = reinterpret_cast<const uint8_t*>(rspw);
+    uint8_t rsp[12 * MB_RSP_GRANULES];
+    for (int g = 0; g < n_rsp; ++g) memcpy(rsp + 12 * g, m->h + MB_RSPG + 16 * g, 12);
     memcpy(m->h + MB_OUT, rsp, (size_t)n_state);
     memcpy(m->h + MB_REW, rsp + n_state, 16);
     memcpy(m->h + MB_FLAGS, rsp + n_state + 16, 4);
@@ -923,7 +925,7 @@ int oc_mailbox_step(OcMailbox* m) {
 
 int oc_mailbox_close(OcMailbox* m) {
     if (!m) return OC_OK;
-    __atomic_store_n(reinterpret_cast<uint64_t*>(m->h + MB_REQG), (uint64_t)MB_STOP << 32, __ATOMIC_RELEASE);  // granule 0's tag
+    __atomic_store_n(reinterpret_cast<uint32_t*>(m->h + MB_REQ), MB_STOP, __ATOMIC_RELEASE);
     (void)hipStreamSynchronize(m->stream);
     (void)hipStreamDestroy(m->stream);
     (void)hipHostFree(m->h);
