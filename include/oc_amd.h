@@ -329,7 +329,12 @@ int oc_rollout_encode(const OcBatch* batch, void* d_state, const uint8_t* d_acti
  *       floor_index[128] (cell -> index among the free cells, row-major) followed by
  *       cost[(floor_index[cell] * 4 + orientation) * row_stride + feature_cell] = fewest actions to stand next to the
  *       feature facing it, 255 = unreachable or not a motion goal (counters outside MotionPlanner.counter_goals);
- *       row_stride = n_cells rounded up to a multiple of 16 (rows are fetched as 16-byte words), padding = 255
+ *       row_stride = n_cells rounded up to a multiple of 16 (rows are fetched as 16-byte words), padding = 255.
+ *       ABI 4: d_plan_off holds 2 * n_layouts entries; at byte d_plan_off[n_layouts + layout] starts the layout's WALK
+ *       SECTION, {u32 record_stride, 12 pad bytes} + one record per (free cell, orientation) state: what a walk over the
+ *       whole grid would find as far as it depends on the terrain alone — u32[4] arg-min keys (cost << 9 | cell,
+ *       0xFFFFFFFF = none) of the closest onion / tomato / dish dispenser and serving cell, u32[4] the four closest pots in
+ *       ascending key order, u8 n + u8[n] the goal counters in ascending (cost, cell) order (planner.walk_records)
  *   d_features  [n_envs][2][2 * (num_pots * 10 + 26) + 4] float32, 16-byte aligned; row i = features for player i
  *   num_pots    0..4 (the reference's default is 2 -> 96 features)
  * Ties between equally cheap counter objects are broken by cell order (row-major); the reference breaks them by the

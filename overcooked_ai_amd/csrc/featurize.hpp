@@ -48,45 +48,36 @@ __global__ __launch_bounds__(BLOCK) void k_featurize(const OcLayout* __restrict_
         const uint8_t* plan = plan_blob + plan_off[lid];
         const uint32_t pos = se[3 * p], ori = se[3 * p + 1], held = se[3 * p + 2];
         const uint32_t opos = se[3 * (1 - p)];
-        const uint32_t cells = (uint32_t)(W * H);
         const uint32_t inv_w = 65536u / (uint32_t)W + 1u;
         const uint32_t py = (pos * inv_w) >> 16, px = pos - py * (uint32_t)W;
-        const uint4* cost_row = reinterpret_cast<const uint4*>(plan + 128 + ((uint32_t)plan[pos] * 4u + ori) * (uint32_t)(n_planes - 1) * 16u);
-        // arg-min keys: 0 onion, 1 tomato, 2 dish, 3 counter soup, 4 serving, 5 empty counter; two best pots
-        uint32_t best[6] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
-        uint32_t pot1 = ~0u, pot2 = ~0u, pot3 = ~0u, pot4 = ~0u;
-        // 16 cells per iteration: their costs (one 16-byte global load, the next one already in flight), terrain
-        // and objects (LDS) arrive as words; the terrain branches are wave-uniform when the batch has one layout
-        uint4 cw4 = cost_row[0];
-        for (int pl = 0; pl < n_planes - 1; ++pl) {
-            const uint4 cur = cw4;
-            if (pl + 2 < n_planes) cw4 = cost_row[pl + 1];
-            const uint4 tw4 = *reinterpret_cast<const uint4*>(L.base + L_TERRAIN + 16 * pl);
-            const uint4 ow4 = *reinterpret_cast<const uint4*>(se + 16 + 16 * pl);
-            const uint32_t cw[4] = {cur.x, cur.y, cur.z, cur.w}, tw[4] = {tw4.x, tw4.y, tw4.z, tw4.w},
-                           ow[4] = {ow4.x, ow4.y, ow4.z, ow4.w};
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t c = (uint32_t)(16 * pl + j);
-                if (c >= cells) break;
-                const uint32_t type = (tw[j >> 2] >> (8 * (j & 3))) & 7u;
-                if (type == OC_T_FLOOR) continue;
-                const uint32_t cost = (cw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                if (cost == 255u) continue;
-                const uint32_t o = (ow[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                if (type == OC_T_ONION_DISP) best[0] = min(best[0], feat_key(cost, 0, c));
-                else if (type == OC_T_TOMATO_DISP) best[1] = min(best[1], feat_key(cost, 0, c));
-                else if (type == OC_T_DISH_DISP) best[2] = min(best[2], feat_key(cost, 0, c));
-                else if (type == OC_T_SERVE) best[4] = min(best[4], feat_key(cost, 0, c));
-                else if (type == OC_T_POT) {
-                    const uint32_t k = feat_key(cost, 0, c);  // keep the four smallest keys in order
-                    if (k < pot1) { pot4 = pot3; pot3 = pot2; pot2 = pot1; pot1 = k; }
-                    else if (k < pot2) { pot4 = pot3; pot3 = pot2; pot2 = k; }
-                    else if (k < pot3) { pot4 = pot3; pot3 = k; }
-                    else if (k < pot4) pot4 = k;
-                } else {  // counter
-                    if (o == 0u) best[5] = min(best[5], feat_key(cost, 0, c));
-                    else if (o == OC_O_ONION) best[0] = min(best[0], feat_key(cost, 1, c));
+        const uint32_t state = (uint32_t)plan[pos] * 4u + ori;  // (free cell, orientation)
+        const uint8_t* cost_row = plan + 128 + state * (uint32_t)(n_planes - 1) * 16u;
+        // What depends on the terrain alone was found on the host (planner.walk_records): the closest dispenser of each
+        // kind, the closest serving cell, the four closest pots, and the goal counters in the order the reference's
+        // arg-min would prefer them.  (Up to round 3 every lane walked the whole grid for this: 7.4 of the kernel's 18.7 us.)
+        const uint8_t* wsec = plan_blob + plan_off[n_layouts + lid];
+        const uint8_t* rec = wsec + 16 + state * *reinterpret_cast<const uint32_t*>(wsec);
+        const uint4 sb = *reinterpret_cast<const uint4*>(rec), pk = *reinterpret_cast<const uint4*>(rec + 16);
+        // arg-min keys: 0 onion, 1 tomato, 2 dish, 3 counter soup, 4 serving, 5 empty counter; the four best pots
+        uint32_t best[6] = {sb.x, sb.y, sb.z, ~0u, sb.w, ~0u};
+        const uint32_t pot1 = pk.x, pot2 = pk.y, pot3 = pk.z, pot4 = pk.w;
+        const uint32_t n_goal = rec[32];
+        if (n_goal != 0u) {  // counters are motion goals (not the reference's default NO_COUNTERS_PARAMS)
+            for (uint32_t i = 0; i < n_goal; ++i) {  // the closest empty counter: the first of the sorted list without an object
+                const uint32_t c = rec[33 + i];
+                if (se[16 + c] == 0u) { best[5] = feat_key(cost_row[c], 0, c); break; }
+            }
+            const uint32_t obj_dwords = (uint32_t)(n_planes - 1) * 4u;
+            for (uint32_t j = 0; j < obj_dwords; ++j) {  // what lies on the counters competes with the dispensers (group 1)
+                uint32_t w = reinterpret_cast<const uint32_t*>(se + 16)[j];
+                while (w != 0u) {
+                    const uint32_t b4 = (uint32_t)(__ffs((int)w) - 1) >> 3;
+                    const uint32_t o = (w >> (8u * b4)) & 0xFFu, c = 4u * j + b4;
+                    w &= ~(0xFFu << (8u * b4));
+                    if ((L.terrain(c) & 7u) != OC_T_COUNTER) continue;  // (a pot's soup is no counter object)
+                    const uint32_t cost = cost_row[c];
+                    if (cost == 255u) continue;
+                    if (o == OC_O_ONION) best[0] = min(best[0], feat_key(cost, 1, c));
                     else if (o == OC_O_TOMATO) best[1] = min(best[1], feat_key(cost, 1, c));
                     else if (o == OC_O_DISH) best[2] = min(best[2], feat_key(cost, 1, c));
                     else best[3] = min(best[3], feat_key(cost, 0, c));

@@ -95,10 +95,37 @@ def feature_costs(spec, counter_goals="none"):
     return floor_index, cost
 
 
+def walk_records(spec, cost):
+    """Per (free cell, orientation) state, what `k_featurize` would find by walking the whole grid, as far as it depends
+    on the terrain alone (round 4: the kernel walked 45 cells per lane for what is mostly static):
+      [4 x u32]  arg-min keys (cost << 9 | cell; 0xFFFFFFFF = none reachable) of the onion / tomato / dish dispensers and the
+                 serving cells — min_cost_to_feature's ties go to the first position in list order = the lower cell index;
+      [4 x u32]  the (up to) four closest pots, ascending keys;
+      [u8 n][n x u8]  the counters that are motion goals, ascending (cost, cell): the closest EMPTY one is the first of the
+                 list without an object; a counter that holds something competes through its own cost-row byte.
+    Returns (uint8 [n_states, stride], stride) with stride a multiple of 16."""
+    W = spec.width
+    n_states, n_cells = cost.shape
+    cells = {t: [y * W + x for (x, y) in spec.cells_of(t)] for t in "OTDSPX"}
+    n_goal_counters = max((int((cost[s, cells["X"]] < UNREACHABLE).sum()) if cells["X"] else 0) for s in range(n_states)) if n_states else 0
+    stride = (32 + 1 + n_goal_counters + 15) & ~15
+    rec = np.zeros((n_states, stride), dtype=np.uint8)
+    for s in range(n_states):
+        def keys(kind):
+            return sorted((int(cost[s, c]) << 9) | c for c in cells[kind] if cost[s, c] < UNREACHABLE)
+        words = [(keys(k) or [0xFFFFFFFF])[0] for k in "OTDS"] + (keys("P") + [0xFFFFFFFF] * 4)[:4]
+        rec[s, :32] = np.asarray(words, dtype=np.uint32).view(np.uint8)
+        goal = [k & 0x7F for k in keys("X")]
+        rec[s, 32] = len(goal)
+        rec[s, 33:33 + len(goal)] = goal
+    return rec, stride
+
+
 def pack_plan_tables(specs, counter_goals="none"):
-    """Blob + offsets for a layout table: per layout [floor_index: 128 B][cost: n_states rows of n_cells bytes, each
-    row padded to a multiple of 16 bytes], 16-byte aligned."""
-    offs, parts, pos = [], [], 0
+    """Blob + offsets for a layout table.  offsets[l] (l < n): per layout [floor_index: 128 B][cost: n_states rows of
+    n_cells bytes, each row padded to a multiple of 16 bytes], 16-byte aligned — what oc_potential and oc_featurize index;
+    offsets[n + l]: the layout's walk section for oc_featurize, [u32 stride, 12 B pad][n_states records of walk_records]."""
+    offs, walk_offs, parts, pos = [], [], [], 0
     for s in specs:
         fi, cost = feature_costs(s, counter_goals)
         stride = (cost.shape[1] + 15) & ~15
@@ -109,7 +136,12 @@ def pack_plan_tables(specs, counter_goals="none"):
         offs.append(pos)
         parts.append(raw)
         pos += len(raw)
-    return np.frombuffer(b"".join(parts), dtype=np.uint8).copy(), np.asarray(offs, dtype=np.uint32)
+        rec, rstride = walk_records(s, cost)
+        raw = np.asarray([rstride, 0, 0, 0], dtype=np.uint32).tobytes() + rec.tobytes()
+        walk_offs.append(pos)
+        parts.append(raw)
+        pos += len(raw)
+    return np.frombuffer(b"".join(parts), dtype=np.uint8).copy(), np.asarray(offs + walk_offs, dtype=np.uint32)
 
 
 class MotionPlanner:
