@@ -1,4 +1,4 @@
-"""Time oc_encode_lossless: python tools/time_encode.py [layout] [n_envs]   (OC_ENC_LDS=<bytes> varies the LDS image budget)"""
+"""Time oc_encode_lossless: python tools/time_encode.py [layout] [n_envs]   (OC_ENC_LDS=<bytes> varies the LDS image budget in a library built with `python -m overcooked_ai_amd.build --force -DOC_AMD_TUNING`)"""
 import os
 import sys
 
