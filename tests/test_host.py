@@ -371,3 +371,36 @@ def test_reference_layout_generator_draws_are_reproduced():
     tail = {s.to_layout_dict()["grid"] for s in mine[len(recorded):]}
     assert len(tail) >= 49 and all(s.width == 9 and s.height == 5 and s.num_players == 2 for s in mine[-50:])
     assert generate_reference_layouts(3, seed=1)[0].to_layout_dict()["grid"] != mine[0].to_layout_dict()["grid"]
+
+
+def test_walk_records_equal_a_walk_over_the_grid():
+    """planner.walk_records (what k_featurize reads instead of walking the grid): for every (free cell, orientation) state the
+    static arg-min keys, the pot order and the goal-counter order equal a brute-force walk over all cells in row-major order
+    with the reference's tie rule — the lexicographic minimum of (cost, cell) (min_cost_to_feature, planners.py:391-423)."""
+    from overcooked_ai_amd import planner as P
+    from overcooked_ai_amd.layouts import spec_from_name
+
+    for name in ("cramped_room", "asymmetric_advantages", "counter_circuit", "forced_coordination", "mdp_test"):
+        spec = spec_from_name(name)
+        W = spec.width
+        for cg in ("none", "all"):
+            fi, cost = P.feature_costs(spec, cg)
+            rec, stride = P.walk_records(spec, cost)
+            assert stride % 16 == 0 and rec.shape == (cost.shape[0], stride)
+            blob, offs = P.pack_plan_tables([spec], cg)
+            assert len(offs) == 2 and int(blob[offs[1]:offs[1] + 4].view(np.uint32)[0]) == stride
+            assert np.array_equal(blob[offs[1] + 16:offs[1] + 16 + rec.size], rec.reshape(-1))
+            for s in range(cost.shape[0]):
+                words = rec[s, :32].view(np.uint32)
+                for k, kind in enumerate("OTDS"):
+                    best = 0xFFFFFFFF
+                    for (x, y) in spec.cells_of(kind):
+                        c = y * W + x
+                        if cost[s, c] < 255:
+                            best = min(best, (int(cost[s, c]) << 9) | c)
+                    assert int(words[k]) == best, (name, cg, s, kind)
+                pots = sorted((int(cost[s, y * W + x]) << 9) | (y * W + x) for (x, y) in spec.cells_of("P") if cost[s, y * W + x] < 255)
+                assert [int(v) for v in words[4:8]] == (pots + [0xFFFFFFFF] * 4)[:4], (name, cg, s)
+                goal = sorted((int(cost[s, y * W + x]), y * W + x) for (x, y) in spec.cells_of("X") if cost[s, y * W + x] < 255)
+                assert int(rec[s, 32]) == len(goal) and [int(v) for v in rec[s, 33:33 + len(goal)]] == [c for _, c in goal]
+                assert (cg == "all") == (len(goal) > 0) or not spec.cells_of("X")
