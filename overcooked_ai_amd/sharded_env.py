@@ -25,6 +25,14 @@ from . import sharding
 from .vec_env import VecOvercookedEnv, as_layout_table
 
 
+def shard_plan(n_global, n_devices, rank=0, world=1):
+    """[(start, stop)] of the shards a process with `n_devices` local devices owns as rank `rank` of `world` processes:
+    the global env range is cut into world * n_devices contiguous parts (sizes differ by at most one) and this process
+    takes parts rank * n_devices .. rank * n_devices + n_devices - 1.  Pure arithmetic (CPU-testable)."""
+    parts = int(n_devices) * int(world)
+    return [sharding.shard_range(n_global, int(rank) * int(n_devices) + i, parts) for i in range(int(n_devices))]
+
+
 class _Shard:
     __slots__ = ("env", "stream", "start", "stop", "device")
 
@@ -49,10 +57,8 @@ class ShardedVecOvercookedEnv:
             if layout_id.shape != (self.n_global,):
                 raise ValueError("layout_id must cover all %d global envs" % self.n_global)
         self._rank, self._world = (0, 1) if ranks is None else (int(ranks[0]), int(ranks[1]))
-        parts = len(devices) * self._world
         self.shards = []
-        for i, dev in enumerate(devices):
-            start, stop = sharding.shard_range(self.n_global, self._rank * len(devices) + i, parts)
+        for dev, (start, stop) in zip(devices, shard_plan(self.n_global, len(devices), self._rank, self._world)):
             with torch.cuda.device(dev):
                 stream = torch.cuda.Stream(device=dev)
                 with torch.cuda.stream(stream):

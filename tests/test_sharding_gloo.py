@@ -90,3 +90,21 @@ def test_two_rank_gloo_shards_reproduce_the_unsharded_batch(tmp_path):
         assert np.array_equal(d["state"], st[:, a:b])          # shard == slice of the unsharded run
         assert np.allclose(d["metrics"], expect)                # all-reduced aggregate metrics
         assert d["tmax"][0] == world - 1
+
+
+def test_shard_plan_of_the_sharded_env_covers_the_batch_once():
+    """ShardedVecOvercookedEnv's partition arithmetic (the class itself needs GPUs: tests/test_gpu_sharded_env.py): for any
+    batch size, device count and world size the shards of all ranks tile [0, n_global) exactly once, in order."""
+    torch = __import__("pytest").importorskip("torch")  # (the module imports torch at the top)
+    from overcooked_ai_amd.sharded_env import shard_plan
+
+    for n_global in (1, 7, 4099, 65536 * 8, 1048576):
+        for n_dev in (1, 2, 8):
+            for world in (1, 2, 3):
+                got = [r for rank in range(world) for r in shard_plan(n_global, n_dev, rank, world)]
+                assert got[0][0] == 0 and got[-1][1] == n_global
+                assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
+                sizes = [b - a for a, b in got]
+                assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 0
+    assert shard_plan(524288, 8) == [(i * 65536, (i + 1) * 65536) for i in range(8)]   # BASELINE configs[3]
+    assert shard_plan(1048576, 1, 3, 8) == [(3 * 131072, 4 * 131072)]                   # configs[4], rank 3 of 8
