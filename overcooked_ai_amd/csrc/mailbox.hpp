@@ -40,14 +40,25 @@ __device__ __forceinline__ uint32_t mb_load(const uint32_t* p) {
 }
 // A response granule: ONE 16-byte write-through store at system scope.  (`sc0 sc1` is what makes it leave the GPU's L2 now: a
 // plain or non-temporal store stays there until the kernel's final release — measured: every step then took the idle
-// timeout.)  Inline asm, because no builtin emits a 16-byte system-scope store; the wait at the end of the block keeps the
-// data registers alive until the store has read them (the compiler does not see asm stores: NOTEBOOK 4.2c).
-template <int N>
-__device__ __forceinline__ void mb_store_granules(uint8_t* base, const mb_u32x4 (&g)[N]) {
-#pragma unroll
-    for (int i = N - 1; i >= 0; --i)  // granule 0 last: the next incarnation of the kernel reads `served` from it
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(base + 16 * i), "v"(g[i]) : "memory");
-    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+// timeout.)  Inline asm, because no builtin emits a 16-byte system-scope store (and the compiler does not see asm stores'
+// hazards: NOTEBOOK 4.2c).
+// ONE asm block for all nine granules and the wait: nothing the compiler schedules can land between a store and the moment it
+// has read its data registers (granules past the response's length carry zeros: the host never looks at them).
+__device__ __forceinline__ void mb_store_granules(uint8_t* base, const mb_u32x4 (&g)[MB_RSP_GRANULES]) {
+    asm volatile(
+        "global_store_dwordx4 %0, %9, off offset:128 sc0 sc1\n\t"
+        "global_store_dwordx4 %0, %8, off offset:112 sc0 sc1\n\t"
+        "global_store_dwordx4 %0, %7, off offset:96 sc0 sc1\n\t"
+        "global_store_dwordx4 %0, %6, off offset:80 sc0 sc1\n\t"
+        "global_store_dwordx4 %0, %5, off offset:64 sc0 sc1\n\t"
+        "global_store_dwordx4 %0, %4, off offset:48 sc0 sc1\n\t"
+        "global_store_dwordx4 %0, %3, off offset:32 sc0 sc1\n\t"
+        "global_store_dwordx4 %0, %2, off offset:16 sc0 sc1\n\t"
+        "global_store_dwordx4 %0, %1, off sc0 sc1\n\t"  // granule 0 last: the next incarnation of the kernel reads `served` from it
+        "s_waitcnt vmcnt(0)"
+        :
+        : "v"(base), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]), "v"(g[8])
+        : "memory");
 }
 
 // NOBJ: object planes of the grid (1..4; every index into the granule words is a compile-time constant); MAXP: pot slots
@@ -124,10 +135,10 @@ __global__ __launch_bounds__(64) void k_mailbox(const OcLayout* __restrict__ g_l
             if (p <= n_obj) { r[k] = o[p].x; r[k + 1] = o[p].y; r[k + 2] = o[p].z; r[k + 3] = o[p].w; k += 4; }
         r[k] = __float_as_uint(rw.x); r[k + 1] = __float_as_uint(rw.y); r[k + 2] = __float_as_uint(rw.z); r[k + 3] = __float_as_uint(rw.w);
         r[k + 4] = fl; r[k + 5] = (uint32_t)ev; r[k + 6] = (uint32_t)(ev >> 32);
-        mb_u32x4 gr[n_rsp];
+        mb_u32x4 gr[MB_RSP_GRANULES];
 #pragma unroll
-        for (int g = 0; g < n_rsp; ++g) gr[g] = mb_u32x4{r[3 * g], r[3 * g + 1], r[3 * g + 2], tag};
-        mb_store_granules<n_rsp>(mb + MB_RSPG, gr);
+        for (int g = 0; g < MB_RSP_GRANULES; ++g) gr[g] = g < n_rsp ? mb_u32x4{r[3 * g], r[3 * g + 1], r[3 * g + 2], tag} : mb_u32x4{0u, 0u, 0u, 0u};
+        mb_store_granules(mb + MB_RSPG, gr);
         served = tag;
         last = wall_clock64();
     }
