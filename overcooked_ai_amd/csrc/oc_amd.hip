@@ -184,7 +184,6 @@ void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_st
         // (what is left for k_step3: oc_step_many's K transitions per launch and grids above 64 cells)
         if (uniform && fast && b->max_pots == 1) GO3(true, 1, true, true);
         else if (uniform && fast && small) GO3(true, 2, true, true);
-        else if (uniform) GO3(true, 8, true, false);
         else if (lds && small) GO3(false, 2, true, false);
         else GO3(false, 8, false, false);
 #undef GO3
@@ -538,7 +537,6 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
 #undef GOT1
                 }
                 // (k_train_step: event counters attached, or a grid above 64 cells)
-                else if (uniform && fast) GOT(true, 2, true, true);
                 else if (uniform) GOT(true, 2, true, false);
                 else GOT(false, 2, false, false);
 #undef GOT

@@ -52,17 +52,15 @@ void launch_rollout4_joint_events(const Rollout4Call& c) {
     OC_R4_PROLOGUE;
     if (c.events) {  // event logging: the general instances (arithmetic movement, either dynamics)
         if (c.uniform && c.small) GO4(true, 2, true, 0, false, true, 0, true);
-        else if (c.lds && c.small) GO4(false, 2, true, 0, false, true, 0, true);
-        else if (c.small) GO4(false, 2, false, 0, false, true, 0, true);
+        else if (c.small) GO4(false, 2, false, 0, false, true, 0, true);  // (mixed tables: the records are read through L2)
         else GO4(false, 8, false, 0, false, true, 0, true);
         return;
     }
     // c.joint: one wavefront per SIMD (or less) on a grid of at most 64 cells where no two players can face the same cell
-    // (cramped_room): 32-bit cell words and the faced cells read a step ahead; else 16-bit words, with the one-step-ahead
-    // reads only while a SIMD holds one wavefront (see PIPE in step_lut4.hpp)
+    // (cramped_room): 32-bit cell words and the faced cells read a step ahead; else (big batches, shared faced cells, grids
+    // above 64 cells) 16-bit words without the one-step-ahead reads (see PIPE in step_lut4.hpp)
     const bool noconf = (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0;
     if (c.pipe && b->width * b->height <= 64 && noconf) GO4(true, 1, true, 1, true, false, 6, false, true, false, 4, true);
-    else if (c.pipe) GO4(true, 1, true, 1, true, false, 6);
     else GO4(true, 1, true, 1, true, false, 6, false, false);
 }
 #elif OC_R4_PART == 1
@@ -83,13 +81,12 @@ void launch_rollout4_mode2(const Rollout4Call& c) {
 void launch_rollout4_mode0(const Rollout4Call& c) {
     OC_R4_PROLOGUE;
     if (c.uniform && !c.old_dyn && c.out && c.small) GO4(true, 2, true, 0, true, false, 0);
-    else if (c.uniform) { if (c.small) GO4(true, 2, true, 0, false, true, 0); else GO4(true, 8, true, 0, false, true, 0); }
+    else if (c.uniform && c.small) GO4(true, 2, true, 0, false, true, 0);
     else if (!c.old_dyn && c.out && c.small) {  // mixed table, new dynamics, both output arrays: no per-step NULL / old-dynamics tests
         if (c.lds) GO4(false, 2, true, 0, true, false, 0); else GO4(false, 2, false, 0, true, false, 0);
     }
-    else if (c.lds && c.small) GO4(false, 2, true, 0, false, true, 0);
-    else if (c.small) GO4(false, 2, false, 0, false, true, 0);
-    else GO4(false, 8, false, 0, false, true, 0);
+    else if (c.small) GO4(false, 2, false, 0, false, true, 0);  // (old dynamics / no output arrays: the records through L2)
+    else GO4(false, 8, false, 0, false, true, 0);               // more than two pots: one general instance
 }
 #endif
 
