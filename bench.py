@@ -848,10 +848,23 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
         out["configs"] = side_legs(args, torch, VecOvercookedEnv, sharding, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stub:  # the CPU leg runs at N = 1 only
         wl_cpu = make_workload(args, rank)
-        out["cpu_baseline"] = cpu_baseline(wl_cpu, n, args.cpu_seconds)
-        out["cpu_baseline"]["reference_python"] = reference_python(args)
+        port = cpu_baseline(wl_cpu, n, args.cpu_seconds)
+        ref = reference_python(args)
+        if ref.get("same_run") and args.config == 2:
+            # north_star: "next to the reference Python OvercookedEnv.step timed on the same box's host cores (core count
+            # stated)": the reference itself (oracle/_ref, byte-compiled) is the CPU baseline, the C oracle sits beside it
+            out["cpu_baseline"] = {
+                "value": ref["all_cores"]["value"], "unit": "env steps/s", "cores": ref["all_cores"]["cores"], "kind": "reference",
+                "single_core": ref["value"], "with_lossless_encoding": ref["with_lossless_encoding"],
+                "sample": "the reference's own OvercookedEnv.step (overcooked_env.py:244) on cramped_room, horizon 400, random joint "
+                          "actions: 25 episodes per process after 1 warm-up, one env per process on every usable core "
+                          "(multiprocessing.Pool), and on one core; %.1f s in this run" % ref.get("seconds", 0.0),
+                "where": ref["where"], "source": ref["source"], "same_run": True, "same_box": True,
+                "port": port, "reference_python": ref}
+        else:
+            out["cpu_baseline"] = dict(port, reference_python=ref)
         if "single_env_api" in out:
-            out["single_env_api"]["reference_python"] = out["cpu_baseline"]["reference_python"]["value"]
+            out["single_env_api"]["reference_python"] = ref["value"]
     if rank == 0:
         emit(out)
     sharding.barrier()
