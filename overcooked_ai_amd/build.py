@@ -15,7 +15,7 @@ LIB = os.path.join(PKG, "liboc_amd.so")
 ARCH = "gfx950"
 # The step kernels run one wavefront per SIMD at the headline batch size, so latency has to be hidden inside the
 # wavefront: LLVM's max-ILP scheduling strategy (instead of the default, which schedules for occupancy) is worth
-# +14 % on k_rollout3 and is neutral for the bandwidth-bound kernels.
+# +14 % on the round-1 rollout kernel and is neutral for the bandwidth-bound kernels.
 # Scheduling the pre-RA list top-down (default: bidirectional) is worth another +1.3 % on k_rollout4 at 65 536 envs and
 # +4 % on its per-env-terrain instances (BASELINE configs[3] / [4]); post-RA scheduling off, bottom-up or no memop
 # clustering measured equal or worse.

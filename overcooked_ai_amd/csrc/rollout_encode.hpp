@@ -9,7 +9,7 @@
 //
 // One launch of a one-step kernel is a ~6 us latency chain and the observation kernel has ~6 us of fill time of its
 // own; stepping inside the persistent observation kernel once per 19-env group was measured slower.
-// Here the roles are the other way round: the env stays with its lane for all K steps exactly as in k_rollout3
+// Here the roles are the other way round: the env stays with its lane for all K steps exactly as in the fused rollout kernels
 // (registers + [cell][lane] words in LDS), and after each step every WAVEFRONT encodes its own 64 envs by itself:
 //   * the wire-format header of each env (players, timestep, pot ticks) goes to a 16-byte LDS slot, the pots' soup
 //     codes back into their cell words — then any lane can read any env of its wavefront;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_encode(const OcLayout* __re
     const uint4* whdr = s_hdr + ow * 64;
 
     for (int k = 0; k < n_steps; ++k) {
-        // ---- the transition (get_state_transition + OvercookedEnv.step bookkeeping), as k_rollout3 / k_step3 do it
+        // ---- the transition (get_state_transition + OvercookedEnv.step bookkeeping), as k_step3 does it
         bool urgent = false;
         if (active) {
             uint32_t a0, a1;

@@ -6,7 +6,7 @@
 // v4: everything a step looks at is one look-up away.
 //
 // At 65 536 envs every SIMD holds ONE wavefront, so a batched step costs (instructions per step) x (issue time):
-// k_rollout3 spends ~235 instructions per env-step (199 VALU).  v4 restructures the data so that the common step is
+// the round-1 kernel (k_rollout3, retired in round 4) spent ~235 instructions per env-step (199 VALU).  v4 restructures the data so that the common step is
 // ~90 instructions:
 //
 //  * cell word (LDS, u16 [cell][lane]) = object code (low byte, wire format) | KEY BYTE (high byte) with

@@ -153,7 +153,7 @@ def _code_objects(tmp_path):
 
 
 def test_no_kernel_keeps_a_stack_object_or_reads_the_dispatch_packet(tmp_path):
-    """Two silent performance traps, checked on the built code object: a private segment (scratch) in a
+    """Two silent performance traps, checked on the built code object (docs/NOTEBOOK.md 4.2c / 4.4): a private segment (scratch) in a
     step / rollout kernel — a stack object that only the restart path touches still makes the step loop wait, through vmcnt,
     for its output stores: 272 instead of 300+ G env-steps/s on the headline — and the dispatch-packet pointer among a kernel's
     user SGPRs (a private array the compiler parks in LDS makes it read the workgroup size from host memory: ~10 us per
