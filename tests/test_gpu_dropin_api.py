@@ -484,3 +484,24 @@ def test_urgency_layer_follows_the_callers_horizon_beyond_16_bits():
     assert int(np.stack(env400.lossless_state_encoding_mdp(state))[:, :, :, 25].sum()) == 2 * W * H
     state.timestep = 360
     assert int(np.stack(env400.lossless_state_encoding_mdp(state))[:, :, :, 25].sum()) == 0
+
+
+def test_one_player_env_fixed_plan():
+    """The reference's test_one_player_env (overcooked_test.py:1187-1194): a fixed plan on cramped_room_single, horizon 12
+    (a FixedPlanAgent stays once its plan is used up), ends at ((2, 1), NORTH)."""
+    from overcooked_ai_amd import Action, Direction, OvercookedEnv, OvercookedGridworld
+
+    stay, interact = Action.STAY, Action.INTERACT
+    n, s, e, w = Direction.NORTH, Direction.SOUTH, Direction.EAST, Direction.WEST
+    mdp = OvercookedGridworld.from_layout_name("cramped_room_single")
+    assert mdp.num_players == 1
+    env = OvercookedEnv.from_mdp(mdp, horizon=12, info_level=0)
+    plan = [stay, w, w, e, e, n, e, interact, w, n, interact]
+    done, t = False, 0
+    while not done:
+        _, _, done, _ = env.step((plan[t] if t < len(plan) else stay,))
+        t += 1
+    assert t == 12 and env.state.players_pos_and_or == (((2, 1), (0, -1)),)
+    env4 = OvercookedEnv.from_mdp(OvercookedGridworld.from_layout_name("multiplayer_schelling"), horizon=4, info_level=0)
+    with pytest.raises(ValueError, match="1- and 2-player"):  # four players: outside the packed format (DESIGN 1), refused loudly
+        env4.step((stay,) * 4)
