@@ -404,3 +404,29 @@ def test_walk_records_equal_a_walk_over_the_grid():
                 goal = sorted((int(cost[s, y * W + x]), y * W + x) for (x, y) in spec.cells_of("X") if cost[s, y * W + x] < 255)
                 assert int(rec[s, 32]) == len(goal) and [int(v) for v in rec[s, 33:33 + len(goal)]] == [c for _, c in goal]
                 assert (cg == "all") == (len(goal) > 0) or not spec.cells_of("X")
+
+
+def test_lazy_infos_dict_behaves_like_the_reference_infos():
+    """mdp._Infos builds `event_infos` (25 lists of booleans, mdp.py:1416-1419) from the kernel's bit mask only when somebody
+    asks: every way of looking at the dict must still show the reference's three keys."""
+    import copy
+    import json
+
+    from overcooked_ai_amd.mdp import EVENT_TYPES, _Infos, events_from_mask
+
+    mask = (1 << (2 * 3 + 1)) | (1 << (2 * 10))  # event 3 for agent 1, event 10 for agent 0
+    def make():
+        d = _Infos(sparse_reward_by_agent=[0, 20], shaped_reward_by_agent=[3, 0])
+        d.event_mask, d.num_players = mask, 2
+        return d
+    full = {"event_infos": events_from_mask(mask, 2), "sparse_reward_by_agent": [0, 20], "shaped_reward_by_agent": [3, 0]}
+    assert make()["event_infos"][EVENT_TYPES[3]] == [False, True] and make()["event_infos"][EVENT_TYPES[10]] == [True, False]
+    assert "event_infos" in make() and make().get("event_infos") == full["event_infos"] and make().get("phi_s") is None
+    assert set(make().keys()) == set(full) and len(make()) == 3 and dict(make().items()) == full
+    assert make() == full and dict(make()) == full and {**make()} == full and sorted(make()) == sorted(full)
+    assert json.loads(json.dumps(make())) == full and copy.deepcopy(make()) == full
+    with pytest.raises(KeyError):
+        make()["nope"]
+    one = _Infos(sparse_reward_by_agent=[0], shaped_reward_by_agent=[0])
+    one.event_mask, one.num_players = 0, 1
+    assert all(v == [False] for v in one["event_infos"].values()) and len(one["event_infos"]) == len(EVENT_TYPES)
