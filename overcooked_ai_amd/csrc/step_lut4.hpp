@@ -97,13 +97,14 @@ constexpr Lut4Table make_lut4() {
 }
 __device__ const Lut4Table g_lut4 = make_lut4();
 
+constexpr uint32_t DC0 = 0xFFFFFFFFu;
 template <int MAXP>
 struct Env4 {
     uint32_t h0, h1;                 // hands: wire object code in BYTE 1 (the other bytes are whatever the last interact left)
     uint32_t J;                      // JOINT: byte offset of this joint pose's row in the move table
     uint32_t pos0, or0, pos1, or1;   // arithmetic movement: cell index / orientation
     uint32_t tleft, over;            // timestep = horizon - 1 - tleft + over (over > 0: running past the horizon)
-    uint32_t dcount;                 // loose dishes on counters
+    uint32_t dcount;                 // loose dishes on counters MINUS ONE (from DC0): "none" is the sign bit
     uint32_t rem[MAXP];              // steps until the pot is ready (REM_IDLE when it is not cooking)
     uint32_t tk[MAXP];               // wire tick byte the pot arrived with (its tick when the countdown never ran)
     uint32_t poff[MAXP];             // byte offset of the pot's cell word in this lane's LDS column
@@ -160,6 +161,10 @@ __device__ __forceinline__ uint32_t lut4_addr(uint32_t off, uint32_t h, uint32_t
     return (min((h >> 8) & 0xFFu, 4u) * 6u + cw_kb<CW>(cw)) * 16u + off;
 }
 
+// Two spare cell words per lane behind the grid: row n_obj * 16 takes the "ready" stores of pots that are not ripe, row
+// n_obj * 16 + 1 is what the unused pot slots of a lane point at (an empty pot for ever: no pot slot needs a validity test)
+template <int CW> __device__ __forceinline__ uint32_t nopot_off(int n_obj) { return ((uint32_t)n_obj * 16u + 1u) * (BLOCK * CW); }
+
 template <int MAXP, int CW>
 __device__ __forceinline__ void load_env4(const LayC& C, const Lay L, const uint4* __restrict__ st, int64_t n, int64_t e,
                                           int n_obj, int horizon, Env4<MAXP>& s, uint32_t col) {
@@ -184,11 +189,12 @@ __device__ __forceinline__ void load_env4(const LayC& C, const Lay L, const uint
             }
         }
     }
-    s.dcount = dishes;
+    s.dcount = dishes + DC0;
     s.exotic = 0; s.pending = 0;
+    cw_wr<CW>(col + nopot_off<CW>(n_obj), cw_make<CW>(0u, KB_POT + PC_EMPTY));  // what unused pot slots read: an empty pot, never written
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
-        s.rem[k] = REM_IDLE; s.tk[k] = 0; s.poff[k] = 0;
+        s.rem[k] = REM_IDLE; s.tk[k] = 0; s.poff[k] = nopot_off<CW>(n_obj);
         if ((uint32_t)k < C.n_pots) {
             s.poff[k] = L.pot_cell(k) * (BLOCK * CW);
             uint32_t o = cw_obj<CW>(cw_rd<CW>(col + s.poff[k]));
@@ -253,7 +259,7 @@ template <int MAXP, int CW>
 __device__ __forceinline__ void env_reset4(const LayC& C, const Lay L, int n_obj, int horizon, Env4<MAXP>& s, uint32_t col) {
     s.pos0 = L.u8(L_START_POS); s.pos1 = L.u8(L_START_POS + 1);
     s.or0 = L.u8(L_START_OR); s.or1 = s.pos1 == 0xFFu ? 0u : L.u8(L_START_OR + 1);
-    s.h0 = s.h1 = 0; s.dcount = 0; s.exotic = 0; s.pending = 0;
+    s.h0 = s.h1 = 0; s.dcount = DC0; s.exotic = 0; s.pending = 0;
     s.tleft = (uint32_t)horizon - 1u; s.over = 0;
     for (int c = 0; c < n_obj * 16; ++c) cw_wr<CW>(col + (uint32_t)c * (BLOCK * CW), cw_make<CW>(0u, (L.terrain((uint32_t)c) & 7u) * 30u));
 #pragma unroll
@@ -401,15 +407,6 @@ __device__ __forceinline__ void store_flag_byte(uint8_t* row, uint32_t lane_off,
     asm volatile("global_store_byte %0, %1, %2" : : "v"(lane_off), "v"(v), "s"(row) : "memory");
 }
 
-// rewards[k][e] through the same addressing, as a plain C++ store (the compiler must see it: a store of more than 8 bytes
-// needs wait states before its data registers may be rewritten, which it inserts only for stores it knows).  The empty asm
-// keeps the zero-extension of the offset next to the store — hoisted out of the loop it becomes a 64-bit VGPR pair and the
-// store a 64-bit VGPR address computation instead of  global_store_dwordx4 v_off, v[data], s[row].
-__device__ __forceinline__ void store_quad(float4* row, uint32_t lane_off, float4 v) {
-    asm volatile("" : "+v"(lane_off));
-    *reinterpret_cast<float4*>(reinterpret_cast<uint8_t*>(row) + lane_off) = v;
-}
-
 // a randomized start (get_random_start_state_fn, mdp.py:1307-1369) drawn by draw_start, in Env4 / key-byte form
 template <int MAXP, int CW>
 __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int n_obj, int horizon, Env4<MAXP>& s, uint32_t col,
@@ -444,8 +441,10 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
 // PIPE (MODE 1, 2): the next step's faced cells are read one step ahead.  That hides the read behind the tail of the step
 //   when a SIMD holds one wavefront (65 536 envs); with two or more wavefronts per SIMD the extra LDS traffic costs
 //   more than the latency it hides (131 072 cramped_room envs: 0.48 vs 0.65 us per batched step), so big batches turn it off
+// UC (FAST_START instances): every recipe of the layout cooks in the same number of steps (hint OC_BATCH_UNIFORM_COOK): the
+//   countdown a starting pot is loaded with is a wave-uniform constant instead of a look-up by what the pot holds
 template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false,
-          bool PIPE = true, bool RU = false, int CW = 2, bool NOCONF = false>
+          bool PIPE = true, bool RU = false, int CW = 2, bool NOCONF = false, bool UC = false>
 #ifndef OC_R4_WAVES_MAX
 #define OC_R4_WAVES_MAX 4
 #endif
@@ -523,6 +522,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
     };
     if (MODE == 1) s.J = joint_row();
     float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    // The episode's shaped returns live in one register pair and gain the upper half of every step's reward quad (a player
+    // earns at most one shaped reward per step, so quad.zw IS what the returns gain; a restart leaves -quad.zw behind so
+    // that the sum comes out as zero)
+    f32x2 epsh = {ep.z, ep.w};
     const uint64_t g = (uint64_t)(env_offset + e);
     const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
     float4* rew_k = rewards ? rewards + (int64_t)blockIdx.x * BLOCK : nullptr;  // wave-uniform row pointers
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
     //      address of (this lane's table, does the player interact), c*: the faced cell words (already read).
     //      m0..m3: the caller's movement result for this step, overwritten inside the horizon branch when the env is put
     //      back to its start state — MODE 1: (row of the next pose, its faced cells, row of the pose after that; ja2n = the
-    //      next step's joint action * 2), MODE 0: (pos0, pos1, or0, or1), MODE 2: (pos0, faced-cell offsets, pos1, or0, or1 = m4)
+    //      next step's joint action * 2), MODE 0: (pos0, pos1, or0, or1), MODE 2: (pos0, -, pos1, or0, or1 = m4; the faced cells' LDS addresses in nf0 / nf1)
     //      of the next step's pose.
     //      pw[k]: pot k's cell word read BEFORE this step's interacts (its class is the "pot_states" of mdp.py:1439),
     //      cookv[k]: the cook time of what that pot holds (FAST_START only), MAXP <= 2.
@@ -547,6 +552,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
     auto cook_time = [&](uint32_t soup) __attribute__((always_inline)) {
         return UNIFORM ? (uint32_t)*(const OC_LDS uint8_t*)(uintptr_t)((uint32_t)M::CT + (soup & 31u)) : cook_of(C, soup);
     };
+    static_assert(!UC || (UNIFORM && MAXP == 1 && !OLD && PIPE), "UC is a variant of the FAST_START instances");
+    const uint32_t cook_const = UC ? uni<true>(L.cook_time(1)) : 0u;  // (UC: the one cook time of the layout's recipes)
     // some recipe of the batch's layout cooks in zero steps (FAST_START handles that start in the rare branch)
     bool zero_cook = false;
     if (FAST_START) {
@@ -588,16 +595,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
         Looked q;
         q.e0 = lds_rd128(lut4_addr<CW>(off0, s.h0, c0));
         q.e1 = lds_rd128(lut4_addr<CW>(off1, s.h1, c1));
-        q.cookv = FAST_START ? cook_time(cw_obj<CW>(pw[0])) : 0u;
+        q.cookv = FAST_START ? (UC ? cook_const : cook_time(cw_obj<CW>(pw[0]))) : 0u;
         return q;
     };
     // Outputs of a step whose stores (and episode-return additions) are put off to the next step of the same unrolled block,
     // where they run while that step's look-ups are in flight.
-    struct Pend { float4 rw; uint32_t fl; float add0, add1; };
+    struct Pend { uint64_t lo, hi; uint32_t fl; };  // the reward quad as two register pairs (sparse, shaped) and the flag byte
     auto flush = [&](const Pend& p, int k8) __attribute__((always_inline)) {
-        store_quad(rew_k, rew_off[k8 & 7], p.rw);
-        store_flag_byte(flg_k, flg_off[k8 & 7], p.fl);
-        ep.z += p.add0; ep.w += p.add1;
+        // One block, straight from (row SGPR pair, lane offset) — no copy of the offset to keep the compiler from folding it
+        // into a 64-bit address, no four-register tuple to assemble: the sparse pair, the shaped pair, the flag byte, and the
+        // episode's shaped returns as one packed add
+        asm volatile("global_store_dwordx2 %1, %2, %4\n\tglobal_store_dwordx2 %1, %3, %4 offset:8\n\tglobal_store_byte %5, %6, %7\n\t"
+                     "v_pk_add_f32 %0, %0, %3"
+                     : "+v"(epsh)
+                     : "v"(rew_off[k8 & 7]), "v"(p.lo), "v"(p.hi), "s"(rew_k), "v"(flg_off[k8 & 7]), "v"(p.fl), "s"(flg_k)
+                     : "memory");
     };
     // k8: index of the step inside an unrolled block of 8 (stores through the block's row + offset), or -1 (rolled step);
     // defer: where to leave the step's outputs instead of storing them (flush() follows), or nullptr
@@ -625,7 +637,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
 #pragma unroll
         for (int k = 0; k < MAXP; ++k) {
             rem_before[k] = s.rem[k];
-            if (FAST_START) s.rem[k] = ((r0 | r1) & F4_START) ? cookv : s.rem[k];
+            if (FAST_START) {  // (v_bfe_i32 + v_bfi_b32: no compare, no SGPR pair)
+                const uint32_t sm = (uint32_t)__builtin_amdgcn_sbfe((int)(r0 | r1), 3u, 1u);  // all ones where somebody starts the pot
+                static_assert(F4_START == 8, "bit 3");
+                uint32_t sel;  // (written out in C++ the compiler turns it back into and + compare + select)
+                if (UC) asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(sel) : "v"(sm), "s"(cookv), "v"(s.rem[k]));
+                else asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(sel) : "v"(sm), "v"(cookv), "v"(s.rem[k]));
+                s.rem[k] = sel;
+            }
             s.rem[k] -= 1u;
             ripe[k] = s.rem[k] == 0u;
             if (PIPE) {
@@ -634,7 +653,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
                 cw_wr_kb<CW>(col + s.poff[k], KB_POT + PC_READY);
             }
         }
-        if (MODE == 1 || MODE == 2) {  // LDS addresses of the next step's faced cells (its fo0 / fo1)
+        if (MODE == 1) {  // LDS addresses of the next step's faced cells (its fo0 / fo1); MODE 2: the caller has put them in nf0 / nf1
             nf0 = col + (m1 & 0xFFFFu);
             nf1 = col + (m1 >> 16);
         }
@@ -653,32 +672,39 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
         const float sh0 = shaped_of(e0.w);
         float sh1 = shaped_of(e1.w);
         const bool done = s.tleft == 0u;
-        s.tleft -= 1u;
-        // ---- ONE branch for everything rare (~0.5 % of the lane-steps); it only corrects state afterwards -----------
-        //  * player 1 faces the cell player 0 has just changed: its interact is redone on the new cell (Q2 of SURVEY 8a)
-        //  * deliveries (recipe value), dish pick-ups that may be useful, the horizon; cooking starts where the straight
-        //    line does not do them
-        // A dish taken from the dispenser can only be "useful" when some pot is (pot_states before the interacts) and no
-        // dish lies on a counter — before, or after player 0's own pick-up.
         const bool conflict = NOCONF ? false : (fo0 == fo1) & ((r0 & F4_CHG) != 0u);
-        bool dish_ok = min(dc_before, dc_mid) == 0u;
+        // ---- ONE branch for everything rare; its test is integer arithmetic up to one compare (no SGPR hand-offs) ----
+        // bit 0 (= F4_TAKE_DISH) of `take`: a dish taken from the dispenser may be "useful" — some pot was (pot_states
+        // before the interacts: class idle 1, idle 2, cooking or ready) and no dish lay on a counter, before or after
+        // player 0's own pick-up
+        static_assert(F4_TAKE_DISH == 1, "the gate is built in bit 0");
+        constexpr uint32_t USEFUL_CLASSES = (1u << PC_IDLE1) | (1u << PC_IDLE2) | (1u << PC_COOKING) | (1u << PC_READY);
+        uint32_t take = (uint32_t)min((int32_t)dc_before, (int32_t)dc_mid) >> 31;  // (counts run from -1)
         if (PW) {
-            bool any_useful = false;
+            uint32_t ub = 0;
 #pragma unroll
-            for (int k = 0; k < MAXP; ++k) {  // (unused slots read cell 0, whose key byte is no pot class unless it is pot 0)
-                const uint32_t kb = cw_kb<CW>(pw[k]);
-                any_useful |= (kb - (KB_POT + PC_IDLE1) <= (uint32_t)(PC_READY - PC_IDLE1)) & (kb != KB_POT + PC_IDLE3);
-            }
-            dish_ok &= any_useful;
+            for (int k = 0; k < MAXP; ++k) ub |= USEFUL_CLASSES >> (cw_kb<CW>(pw[k]) - KB_POT);  // (every slot reads a pot word: nopot_off)
+            take &= ub;
         }
-        uint32_t gate = dish_ok ? (uint32_t)(F4_SERVE | F4_TAKE_DISH) : (uint32_t)F4_SERVE;
-        if (!FAST_START || zero_cook) gate |= F4_START;
+        uint32_t gate = (uint32_t)F4_SERVE;
+        if (!FAST_START) gate |= F4_START;
+        else gate |= zero_cook ? (uint32_t)F4_START : 0u;
         if (OLD) gate |= C.old_dyn ? (uint32_t)F4_PLACE : 0u;  // old dynamics: the third item starts the pot (Q11)
-        bool rare = (((r0 | r1) & gate) != 0u) | done | conflict;
-        if (OLD) rare |= s.pending != 0u;
+        const uint32_t tleft_new = s.tleft - 1u;               // the horizon: the sign bit (tleft < 2^31)
+        s.tleft = tleft_new;
+        uint32_t rare_bits = ((r0 | r1) & (take | gate)) | (tleft_new & 0x80000000u);
+        if (OLD) rare_bits |= s.pending;
+        bool rare = (rare_bits != 0u) | conflict;
         uint32_t nh0 = r0, nh1 = r1;  // the hands after the step
-        float add0 = sh0, add1 = sh1; // what the episode's shaped returns gain
         float4 rw = make_float4(0.f, 0.f, sh0, sh1);  // this step's reward quad and flag byte: stored ONCE, after the branch
+        uint64_t q_lo = 0, q_hi = 0;  // the same quad as two register pairs (what the unrolled blocks store; the rare branch rewrites both whole)
+        if (RUX) {  // the entries carry the floats in .w: (e0.w, e1.w) -> one register pair with v_pk_mov_b32, the zeros with v_mov_b64
+            const uint64_t a64 = ((uint64_t)e0.w << 32) | e0.z, b64 = ((uint64_t)e1.w << 32) | e1.z;
+            asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1]" : "=v"(q_hi) : "v"(a64), "v"(b64));
+            asm("v_mov_b64 %0, 0" : "=v"(q_lo));
+        } else {
+            q_hi = ((uint64_t)__float_as_uint(sh1) << 32) | __float_as_uint(sh0);
+        }
         uint32_t fl = 0;                              // (a second store to the same address would wait for the first)
         if (__builtin_expect(rare, 0)) {
             bool grid_changed = false;  // something below wrote to the grid after the prefetch
@@ -689,7 +715,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
                 cw_wr<CW>(fo1, cw_of_result<CW>(r1));
                 dcount = dc_mid + (uint32_t)((int32_t)e1.y >> 24);
                 sh1 = shaped_of(e1.w);
-                add1 = sh1;
                 grid_changed = true;
             }
             // cooking starts.  Old dynamics: a pot that has just received its third item — or arrived full and idle —
@@ -750,8 +775,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
                     useful_pots += (kb != KB_POT + PC_EMPTY && kb != KB_POT + PC_IDLE3) ? 1u : 0u;
                 }
                 // is_dish_pickup_useful (mdp.py:2180-2204): live hands / counters, stale pots
-                const bool du0 = two & (((hb1 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_before == 0u);
-                const bool du1 = two & (((hn0 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_mid == 0u);
+                const bool du0 = two & (((hb1 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_before == DC0);
+                const bool du1 = two & (((hn0 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_mid == DC0);
                 float4 r;
                 r.z = (((r0 & F4_TAKE_DISH) != 0u) & du0) ? C.rew_dish : 0.f;
                 r.w = (((r1 & F4_TAKE_DISH) != 0u) & du1) ? C.rew_dish : 0.f;
@@ -760,7 +785,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
                     r.x = (r0 & F4_SERVE) ? L.value(recipe_idx(hb0) & 15u) : 0.f;
                     r.y = (r1 & F4_SERVE) ? L.value(recipe_idx(hb1) & 15u) : 0.f;
                 }
-                ep.x += r.x; ep.y += r.y; ep.z += r.z; ep.w += r.w;
+                ep.x += r.x; ep.y += r.y;
                 rw = make_float4(r.x, r.y, r.z + sh0, r.w + sh1);
             } else {
                 rw.w = sh1;
@@ -777,7 +802,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
                             C = load_consts<UNIFORM>(L);
                             lut_var = (uint32_t)M::LUT + (RUX ? 0u : (C.old_dyn ? (uint32_t)LUT4_BYTES : 0u));
 #pragma unroll
-                            for (int k = 0; k < MAXP; ++k) s.poff[k] = (uint32_t)k < C.n_pots ? L.pot_cell(k) * (BLOCK * CW) : 0u;
+                            for (int k = 0; k < MAXP; ++k) s.poff[k] = (uint32_t)k < C.n_pots ? L.pot_cell(k) * (BLOCK * CW) : nopot_off<CW>(n_obj);
                             if (MODE == 0) two = L.n_players() == 2u;
                             if (MODE == 2) fm = floor_mask_of(L);
                         }
@@ -788,9 +813,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
                         env_reset4<MAXP, CW>(C, L, n_obj, horizon, s, col);
                         nh0 = nh1 = 0;
                     }
-                    dcount = 0;
+                    dcount = DC0;
                     ep = zero4;        // the episode ends with this step: its returns restart from zero,
-                    add0 = add1 = 0.f; // and this step's shaped rewards are not carried into the next one
+                    epsh.x = -rw.z; epsh.y = -rw.w;
                     fl |= OC_F_RESET;
                     grid_changed = true;
                     if (MODE == 1) {  // redo the look-ahead from the start pose
@@ -799,7 +824,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
                         m2 = CW == 2 ? lds_rd16(m0 + ja2n) : lds_rd32(m0 + ja2n);
                     } else if (MODE == 2) {
                         m0 = s.pos0; m2 = s.pos1; m3 = s.or0; m4 = s.or1;
-                        m1 = (step_cell(s.pos0, s.or0, delta4) * (BLOCK * CW)) | ((step_cell(s.pos1, s.or1, delta4) * (BLOCK * CW)) << 16);
+                        nf0 = col + step_cell(s.pos0, s.or0, delta4) * (BLOCK * CW);
+                        nf1 = col + step_cell(s.pos1, s.or1, delta4) * (BLOCK * CW);
                     } else {
                         m0 = s.pos0; m1 = s.pos1; m2 = s.or0; m3 = s.or1;
                     }
@@ -808,7 +834,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
                     s.over += 1u;
                 }
             }
-            if ((MODE == 1 || MODE == 2) && grid_changed) {  // (the restart may have changed the next pose)
+            if (MODE == 1 && grid_changed) {  // (the restart may have changed the next pose)
                 nf0 = col + (m1 & 0xFFFFu);
                 nf1 = col + (m1 >> 16);
             }
@@ -817,6 +843,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
                 nc1 = cw_rd<CW>(nf1);
                 rd_pots(npw);
             }
+            q_lo = ((uint64_t)__float_as_uint(rw.y) << 32) | __float_as_uint(rw.x);
+            q_hi = ((uint64_t)__float_as_uint(rw.w) << 32) | __float_as_uint(rw.z);
         }
         if (EV) {  // event_infos of the step (mdp.py:2121-2308), from the outcomes above
             uint64_t ev = 0;
@@ -840,8 +868,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
                     useful_pots += (kb != KB_POT + PC_EMPTY && kb != KB_POT + PC_IDLE3) ? 1u : 0u;
                     n_full += kb >= KB_POT + PC_IDLE3 ? 1u : 0u;
                 }
-                const bool du0 = two & (((hb1 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_before == 0u);
-                const bool du1 = two & (((hn0 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_mid == 0u);
+                const bool du0 = two & (((hb1 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_before == DC0);
+                const bool du1 = two & (((hn0 == OC_O_DISH) ? 1u : 0u) < useful_pots) & (dc_mid == DC0);
                 const uint32_t t0_ = (cw_kb<CW>(c0) * 137u) >> 12, t1_ = (cw_kb<CW>(cc1) * 137u) >> 12;  // key byte / 30 = terrain type
                 const bool disp0 = (t0_ == OC_T_ONION_DISP) | (t0_ == OC_T_TOMATO_DISP) | (t0_ == OC_T_DISH_DISP);
                 const bool disp1 = (t1_ == OC_T_ONION_DISP) | (t1_ == OC_T_TOMATO_DISP) | (t1_ == OC_T_DISH_DISP);
@@ -857,10 +885,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
         }
         const bool deferred = OUT && k8 >= 0 && defer != nullptr;
         if (deferred) {  // stored by the next step of the block, in the shadow of its look-ups
-            defer->rw = rw; defer->fl = fl; defer->add0 = add0; defer->add1 = add1;
+            defer->fl = fl;
+            defer->lo = q_lo; defer->hi = q_hi;
         } else if (OUT && k8 >= 0) {  // a step of an unrolled block: the block's first row + this step's precomputed offset
-            store_quad(rew_k, rew_off[k8 & 7], rw);
-            store_flag_byte(flg_k, flg_off[k8 & 7], fl);
+            Pend now = {q_lo, q_hi, fl};
+            flush(now, k8);  // (with the episode returns' packed add)
         } else {
             if (OUT || rew_k) rew_k[threadIdx.x] = rw;
             if (OUT || flg_k) store_flag_byte(flg_k, lane, fl);
@@ -870,7 +899,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
         s.h0 = nh0;
         s.h1 = nh1;
         s.dcount = dcount;
-        if (!deferred) { ep.z += add0; ep.w += add1; }
+        if (!(OUT && k8 >= 0)) { epsh.x += rw.z; epsh.y += rw.w; }
         step_k += 1u;
     };
     // after the eight steps of an unrolled block
@@ -903,7 +932,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
         uint32_t c0 = cw_rd<CW>(fo0), c1 = cw_rd<CW>(fo1);
         uint32_t pw[MAXP];
         rd_pots(pw);
-        Pend pend = {zero4, 0u, 0.f, 0.f};
+        Pend pend = {0ull, 0ull, 0u};
         PhxInc inc = {0, 0, 0, 0, 0, 0};
         // One step.  On entry: Jc / Jn = rows of the poses of this step and the next, fo* = this step's faced cells, off* = the
         // LUT addresses for this step's actions, c* / pw = the cell words (PIPE).  xn = Philox word holding the NEXT step's
@@ -1008,13 +1037,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
             const Looked looked = look_up(off0, off1, c0, c1, pw);
             // resolve_movement (mdp.py:1644-1727) on the static terrain: the pose of the NEXT step
             const uint32_t t0_ = ahead(P0, a0), t1_ = ahead(P1, a1);
-            const uint32_t np0 = ((fm >> t0_) & 1ull) ? t0_ : P0, np1 = ((fm >> t1_) & 1ull) ? t1_ : P1;
+            // (the floor bit is tested as a 32-bit value — the empty asm keeps the compiler from widening the test back to 64
+            //  bits, which costs a zero register per operand and two 64-bit compares)
+            uint32_t fb0 = (uint32_t)(fm >> t0_), fb1 = (uint32_t)(fm >> t1_);
+            asm("" : "+v"(fb0));
+            asm("" : "+v"(fb1));
+            const uint32_t np0 = (fb0 & 1u) ? t0_ : P0, np1 = (fb1 & 1u) ? t1_ : P1;
             const bool collide = (np0 == np1) | ((np0 == P1) & (np1 == P0));
             uint32_t q0 = collide ? P0 : np0, q1 = collide ? P1 : np1;
             uint32_t o0 = a0 < 4u ? a0 : O0, o1 = a1 < 4u ? a1 : O1;
-            uint32_t fa_n = (ahead(q0, o0) * (BLOCK * CW)) | ((ahead(q1, o1) * (BLOCK * CW)) << 16);
-            uint32_t nf0 = 0, nf1 = 0, nc0 = 0, nc1 = 0, npw[MAXP];
-            core(fo0, fo1, off0, off1, c0, c1, 0u, pw, q0, fa_n, q1, o0, o1, nf0, nf1, nc0, nc1, npw, k8, looked);
+            uint32_t unused1 = 0, nc0 = 0, nc1 = 0, npw[MAXP];
+            uint32_t nf0 = col + ahead(q0, o0) * (BLOCK * CW), nf1 = col + ahead(q1, o1) * (BLOCK * CW);  // the next pose's faced cells
+            core(fo0, fo1, off0, off1, c0, c1, 0u, pw, q0, unused1, q1, o0, o1, nf0, nf1, nc0, nc1, npw, k8, looked);
             P0 = q0; P1 = q1; O0 = o0; O1 = o1; fo0 = nf0; fo1 = nf1;
             if (PIPE) {
                 c0 = nc0; c1 = nc1;
@@ -1098,5 +1132,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
     }
 #undef OC_JA_AT
     store_env4<MAXP, CW>(C, L, st, n, e, n_obj, horizon, s, col);
+    ep.z = epsh.x; ep.w = epsh.y;
     if (ep_returns) ep_returns[e] = ep;
 }
