@@ -102,9 +102,6 @@ extern "C" {
                                          never face the same cell (cramped_room), so the interact order needs no replay */
 #define OC_BATCH_UNIFORM_SHAPING 0x4u /* every layout of the table has the same rew_shaping_params and old_dynamics flag:
                                          the interact table then carries the reward floats for the whole batch */
-#define OC_BATCH_UNIFORM_COOK 0x10u /* within every layout of the table all recipes (1..3 ingredients) take the same number of
-                                       steps to cook (Recipe.time, mdp.py:163-188: true of every layout that sets one
-                                       `cook_time` or none): a starting pot's countdown is a constant, not a look-up */
 
 /* obs dtypes of oc_encode_lossless */
 #define OC_OBS_U8 0

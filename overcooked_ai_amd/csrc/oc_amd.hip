@@ -216,12 +216,9 @@ int oc_batch_hints(const OcLayout* h_layouts, int n_layouts, OcBatch* batch) {
     if (!h_layouts || !batch || n_layouts < 1) return fail(OC_EINVAL, "oc_batch_hints: NULL table / batch or no layouts");
     int max_pots = 0;
     uint32_t max_free = 0;
-    bool two = true, any_old = false, same_shaping = true, shared_faces = false, one_cook = true;
+    bool two = true, any_old = false, same_shaping = true, shared_faces = false;
     for (int i = 0; i < n_layouts; ++i) {
         const OcLayout& l = h_layouts[i];
-        for (int no = 0; no <= 3; ++no)
-            for (int nt = 0; no + nt <= 3; ++nt)
-                if (no + nt > 0) one_cook = one_cook && l.cook_time[no + 4 * nt] == l.cook_time[1];
         any_old = any_old || l.old_dynamics != 0;
         same_shaping = same_shaping && l.old_dynamics == h_layouts[0].old_dynamics &&
                        l.rew_placement_in_pot == h_layouts[0].rew_placement_in_pot &&
@@ -247,7 +244,7 @@ int oc_batch_hints(const OcLayout* h_layouts, int n_layouts, OcBatch* batch) {
     }
     batch->max_pots = max_pots;
     batch->batch_flags = (two ? OC_BATCH_TWO_PLAYERS : 0u) | (any_old ? 0u : OC_BATCH_NEW_DYNAMICS) |
-                         (same_shaping ? OC_BATCH_UNIFORM_SHAPING : 0u) | (shared_faces ? 0u : OC_BATCH_NO_SHARED_FACES) | (one_cook ? OC_BATCH_UNIFORM_COOK : 0u);
+                         (same_shaping ? OC_BATCH_UNIFORM_SHAPING : 0u) | (shared_faces ? 0u : OC_BATCH_NO_SHARED_FACES);
     batch->max_free_cells = max_free;
     return OC_OK;
 }

@@ -441,10 +441,8 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
 // PIPE (MODE 1, 2): the next step's faced cells are read one step ahead.  That hides the read behind the tail of the step
 //   when a SIMD holds one wavefront (65 536 envs); with two or more wavefronts per SIMD the extra LDS traffic costs
 //   more than the latency it hides (131 072 cramped_room envs: 0.48 vs 0.65 us per batched step), so big batches turn it off
-// UC (FAST_START instances): every recipe of the layout cooks in the same number of steps (hint OC_BATCH_UNIFORM_COOK): the
-//   countdown a starting pot is loaded with is a wave-uniform constant instead of a look-up by what the pot holds
 template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false,
-          bool PIPE = true, bool RU = false, int CW = 2, bool NOCONF = false, bool UC = false>
+          bool PIPE = true, bool RU = false, int CW = 2, bool NOCONF = false>
 #ifndef OC_R4_WAVES_MAX
 #define OC_R4_WAVES_MAX 4
 #endif
@@ -552,8 +550,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
     auto cook_time = [&](uint32_t soup) __attribute__((always_inline)) {
         return UNIFORM ? (uint32_t)*(const OC_LDS uint8_t*)(uintptr_t)((uint32_t)M::CT + (soup & 31u)) : cook_of(C, soup);
     };
-    static_assert(!UC || (UNIFORM && MAXP == 1 && !OLD && PIPE), "UC is a variant of the FAST_START instances");
-    const uint32_t cook_const = UC ? uni<true>(L.cook_time(1)) : 0u;  // (UC: the one cook time of the layout's recipes)
     // some recipe of the batch's layout cooks in zero steps (FAST_START handles that start in the rare branch)
     bool zero_cook = false;
     if (FAST_START) {
@@ -595,7 +591,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
         Looked q;
         q.e0 = lds_rd128(lut4_addr<CW>(off0, s.h0, c0));
         q.e1 = lds_rd128(lut4_addr<CW>(off1, s.h1, c1));
-        q.cookv = FAST_START ? (UC ? cook_const : cook_time(cw_obj<CW>(pw[0]))) : 0u;
+        q.cookv = FAST_START ? cook_time(cw_obj<CW>(pw[0])) : 0u;
         return q;
     };
     // Outputs of a step whose stores (and episode-return additions) are put off to the next step of the same unrolled block,
@@ -603,12 +599,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
     struct Pend { uint64_t lo, hi; uint32_t fl; };  // the reward quad as two register pairs (sparse, shaped) and the flag byte
     auto flush = [&](const Pend& p, int k8) __attribute__((always_inline)) {
         // One block, straight from (row SGPR pair, lane offset) — no copy of the offset to keep the compiler from folding it
-        // into a 64-bit address, no four-register tuple to assemble: the sparse pair, the shaped pair, the flag byte, and the
-        // episode's shaped returns as one packed add
-        asm volatile("global_store_dwordx2 %1, %2, %4\n\tglobal_store_dwordx2 %1, %3, %4 offset:8\n\tglobal_store_byte %5, %6, %7\n\t"
+        // into a 64-bit address: the quad (its two pairs sit in one four-register tuple), the flag byte, and the episode's
+        // shaped returns as one packed add.  A store of more than 8 bytes needs two wait states before its data registers
+        // may be rewritten: the two instructions behind it.
+        typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+        const u64x2 q = {p.lo, p.hi};
+        asm volatile("global_store_dwordx4 %1, %2, %4\n\tglobal_store_byte %5, %6, %7\n\t"
                      "v_pk_add_f32 %0, %0, %3"
                      : "+v"(epsh)
-                     : "v"(rew_off[k8 & 7]), "v"(p.lo), "v"(p.hi), "s"(rew_k), "v"(flg_off[k8 & 7]), "v"(p.fl), "s"(flg_k)
+                     : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k), "v"(flg_off[k8 & 7]), "v"(p.fl), "s"(flg_k)
                      : "memory");
     };
     // k8: index of the step inside an unrolled block of 8 (stores through the block's row + offset), or -1 (rolled step);
@@ -637,14 +636,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
 #pragma unroll
         for (int k = 0; k < MAXP; ++k) {
             rem_before[k] = s.rem[k];
-            if (FAST_START) {  // (v_bfe_i32 + v_bfi_b32: no compare, no SGPR pair)
-                const uint32_t sm = (uint32_t)__builtin_amdgcn_sbfe((int)(r0 | r1), 3u, 1u);  // all ones where somebody starts the pot
-                static_assert(F4_START == 8, "bit 3");
-                uint32_t sel;  // (written out in C++ the compiler turns it back into and + compare + select)
-                if (UC) asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(sel) : "v"(sm), "s"(cookv), "v"(s.rem[k]));
-                else asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(sel) : "v"(sm), "v"(cookv), "v"(s.rem[k]));
-                s.rem[k] = sel;
-            }
+            if (FAST_START) s.rem[k] = ((r0 | r1) & F4_START) ? cookv : s.rem[k];
             s.rem[k] -= 1u;
             ripe[k] = s.rem[k] == 0u;
             if (PIPE) {

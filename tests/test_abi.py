@@ -49,14 +49,10 @@ def test_batch_hints_from_a_host_table():
 
     other_shaping = dict(spec_from_name("cramped_room").to_layout_dict(),
                          rew_shaping_params={"PLACEMENT_IN_POT_REW": 1, "DISH_PICKUP_REWARD": 3, "SOUP_PICKUP_REWARD": 5})
-    per_recipe_times = dict(spec_from_name("cramped_room").to_layout_dict(), onion_time=5, tomato_time=9)
-    per_recipe_times.pop("cook_time", None)
     # flags: two players everywhere (1) | new dynamics (2) | one set of shaping rewards for the whole table (4) | no non-floor
-    # cell touches two floor cells (8: true for cramped_room, not for asymmetric_advantages) | every layout's recipes all cook
-    # in the same time (16: not with per-ingredient times)
-    for names, pots, free, flags in ((["cramped_room"], 1, 6, 31), (["asymmetric_advantages", "cramped_room"], 2, None, 23),
-                                     (["cramped_room", LayoutSpec(other_shaping)], 1, 6, 27),
-                                     ([LayoutSpec(per_recipe_times)], 1, 6, 15)):
+    # cell touches two floor cells (8: true for cramped_room, not for asymmetric_advantages)
+    for names, pots, free, flags in ((["cramped_room"], 1, 6, 15), (["asymmetric_advantages", "cramped_room"], 2, None, 7),
+                                     (["cramped_room", LayoutSpec(other_shaping)], 1, 6, 11)):
         table = LayoutTable([spec_from_name(nm) if isinstance(nm, str) else nm for nm in names],
                             pad_to=(9, 5) if len(names) > 1 else None)
         rec = np.ascontiguousarray(table.records)

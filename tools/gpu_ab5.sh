@@ -1,0 +1,26 @@
+#!/bin/bash
+# sustained (driver-length, 7 s) headline runs alternating between the libs in $LIBS on one box
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/${OUT_TAG:-ab5}
+mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+for rep in $(seq 1 ${REPS:-2}); do
+for lib in ${LIBS}; do
+  tag=$(basename $lib .so)
+  export OC_AMD_LIB=$R/$lib
+  timeout 300 python3 bench.py --steps ${STEPS:-20} --warmup 5 --no-extras --no-cpu-baseline --no-traffic ${PARITY:---no-parity-check} > $O/${tag}_long_$rep.json 2>> $O/err.log
+done
+done
+unset OC_AMD_LIB
+python3 - <<PY
+import json, glob, os
+for f in sorted(glob.glob("$O/*_[1-9].json")):
+    try:
+        d = json.load(open(f))
+        print("%-40s %7.1f G  frac %.3f  launch_ms %.4f  region %.2f s  parity %s" % (os.path.basename(f), d["value"] / 1e9, d["roofline"]["frac"], d["roofline"]["launch_ms"], d.get("timed_region_s", 0), (d.get("parity_check") or {}).get("mismatches")))
+    except Exception as e:
+        print(os.path.basename(f), "ERR", e)
+PY
+tail -3 $O/err.log 2>/dev/null

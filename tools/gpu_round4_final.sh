@@ -10,6 +10,10 @@ export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -2 $O/smoke.log
 ( time timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/r04_driver_cmd_bench.json 2> $O/bench_driver_cmd.err ) 2> $O/bench_driver_cmd.time; echo "bench rc=$?"; tail -3 $O/bench_driver_cmd.time
+if [ -n "${CONTROL_LIB:-}" ]; then  # the previous build's headline on this box, same sustained region (same-box reference for the notebook)
+  for rep in 1 2; do OC_AMD_LIB=$R/$CONTROL_LIB timeout 300 python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-traffic --no-parity-check > $O/control_long_$rep.json 2>> $O/bench_other.err; done
+  timeout 300 python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-traffic --no-parity-check > $O/shipped_long_2.json 2>> $O/bench_other.err
+fi
 timeout 300 python3 bench.py --gpus 2 --single-process --steps 2 --warmup 1 --envs 32768 > $O/r04_single_process_2shards_1gpu.json 2> $O/bench_sp.err; echo "single-process rc=$?"
 timeout 300 python3 bench.py --envs 1048576 --steps 1 --warmup 1 --launches-per-step 20 --no-extras --no-cpu-baseline --no-traffic --no-parity-check > $O/r04_bench_1M_envs.json 2>> $O/bench_other.err
 OC_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 timeout 300 python3 bench.py --gpus 1 --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-traffic > $O/r04_force_dist_nccl_1rank.json 2> $O/r04_force_dist_nccl_1rank.err; echo "nccl rc=$?"
@@ -30,6 +34,9 @@ for k,v in (d.get("configs") or {}).items():
     print("config", k, v.get("value"), (v.get("roofline") or {}).get("frac"), (v.get("parity_check") or {}).get("mismatches"), v.get("error"))
 print("single_env", d.get("single_env_api",{}).get("value"), "ref", d.get("cpu_baseline",{}).get("reference_python",{}).get("value"))
 print("featurize", d["encode"]["featurize_state"]["frac"], "training", d["training_env"]["obs_u8"]["us_per_batched_step"])
+import glob
+for f in sorted(glob.glob("$O/control_long_*.json") + glob.glob("$O/shipped_long_*.json")):
+    j=json.load(open(f)); print(f.split("/")[-1], "%.1f G" % (j["value"]/1e9), j["roofline"]["frac"], j["roofline"]["launch_ms"])
 for f in ("r04_bench_1M_envs.json","r04_single_process_2shards_1gpu.json","r04_force_dist_nccl_1rank.json"):
     try:
         j=json.load(open("$O/"+f)); print(f, "%.1f G" % (j["value"]/1e9), (j.get("roofline") or {}).get("frac"), (j.get("parity_check") or {}).get("mismatches"))
