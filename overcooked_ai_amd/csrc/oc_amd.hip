@@ -745,8 +745,17 @@ int oc_rollout_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions,
         int unit = 1;
         while (((env_bytes * unit) & 15u) != 0) unit *= 2;  // 1, 2 or 4 envs per template
         const size_t cell_bytes = (size_t)n_obj * 16 * BLOCK * sizeof(uint16_t);
-        const size_t fixed = cell_bytes + env_bytes * unit + (size_t)BLOCK * 16;
-        const size_t budget = 150 * 1024;
+        const size_t fixed = cell_bytes + env_bytes * unit + (size_t)BLOCK * 16 + RE_LIST_BYTES;
+        const bool fast = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0 && cells <= 64;
+        // what a workgroup may ask for on top of the kernel's static LDS (160 KiB per CU)
+        auto dynamic_lds = [](const void* kernel) {
+            hipFuncAttributes fa;
+            if (hipFuncGetAttributes(&fa, kernel) != hipSuccess) { (void)hipGetLastError(); return (size_t)(144 * 1024); }
+            return (size_t)160 * 1024 - (size_t)fa.sharedSizeBytes - 64;  // (the eight-wavefront instances keep 32 bytes more)
+        };
+        const size_t budget = obs_dtype == OC_OBS_U8
+            ? (fast ? dynamic_lds((const void*)k_rollout_encode<2, 3, uint8_t, 4>) : dynamic_lds((const void*)k_rollout_encode<2, 0, uint8_t, 4>))
+            : (fast ? dynamic_lds((const void*)k_rollout_encode<2, 3, float, 4>) : dynamic_lds((const void*)k_rollout_encode<2, 0, float, 4>));
         // eight wavefronts (four of them helpers that only encode) when eight images of at least 8 envs fit: small grids,
         // where four wavefronts cannot encode 256 envs in the time HBM takes them (5x4 u8: 14.4 vs 17.4 us per step); 9x5
         // is at the write ceiling either way (30.1 vs 30.4 us), f32 loses with one-env images (128 vs 117 us)
@@ -769,7 +778,6 @@ int oc_rollout_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions,
             g = (g + unit - 1) / unit * unit;
             if (g > gmax) g = gmax / unit * unit;
             const size_t smem = fixed + (size_t)nw * g * env_bytes;
-            const bool fast = (b->batch_flags & OC_BATCH_TWO_PLAYERS) != 0 && cells <= 64;
             const dim3 grid(grid_for(b->n_envs));
 #define GORE(FAST, T, NW)                                                                                              \
     do {                                                                                                               \

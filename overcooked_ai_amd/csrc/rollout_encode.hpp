@@ -21,7 +21,16 @@
 // output stores, just under the ~28 us HBM needs for the 153 MB of a step — the loop runs at the encoder's write rate.
 // NW = 8 (small grids, where four wavefronts cannot keep up with HBM) adds four helper wavefronts that own no env and
 // encode every other sub-group, between two workgroup barriers per step.
+// What lies on the grid is scattered from a COMPACT LIST (round 4): right after its transition every lane walks its own
+// env's object bytes once (lane = env: all 64 lanes busy) and leaves (cell | object << 8) entries in LDS, at most
+// RE_LIST_CAP per env, plus the sub-group's largest count; the sub-group's scatter then runs lane = (env, k-th object) over
+// next_pow2(largest count) slots per env instead of lane = (env, object dword) over every dword of the grid, most of which
+// are empty (9x5: 3 x 16 slots per four envs, a divergent loop over the bytes of each).  A sub-group with an env above the
+// cap takes the dword loop.  Cell -> item offsets come from a 64-entry table instead of a divide by W.
 // ------------------------------------------------------------------------------------------
+constexpr int RE_LIST_CAP = 14;  // (what fits next to four 12-env images of a 9x5 grid in 160 KB)
+// dynamic LDS behind the cell words, the template and the headers: the lists, their counts (include in the carve of oc_rollout_encode)
+constexpr size_t RE_LIST_BYTES = (size_t)RE_LIST_CAP * BLOCK * sizeof(uint16_t) + BLOCK;
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -42,6 +51,8 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_encode(const OcLayout* __re
     __shared__ uint2 s_lut[2 * LUT_ENTRIES];
     __shared__ uint8_t s_move[FAST == 3 ? 64 * 8 : 8];
     __shared__ uint64_t s_urgent[4];  // (NW = 8) per owner wavefront: which of its envs are in their last 40 steps
+    __shared__ uint16_t s_ioff[64];   // cell -> offset of its item in a view, in values: 26 * (x * H + y)
+    __shared__ uint32_t s_gmax[4][64];  // per owner wavefront and sub-group: the largest object count of its envs
     static_assert(NW == 4 || NW == 8, "four owner wavefronts, optionally four helpers");
     const int cells_n = W * H;
     const int items_per_env = 2 * cells_n;
@@ -50,8 +61,10 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_encode(const OcLayout* __re
     const int img_chunks = unit_chunks * (group_envs / unit);   // one wavefront's image: group_envs envs
     uint4* s_tmpl = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(s_cells3) + (size_t)n_obj * 16 * BLOCK * sizeof(uint16_t));
     uint4* s_hdr = s_tmpl + unit_chunks;                        // [BLOCK] wire-format plane 0 of each env
+    uint16_t* s_list = reinterpret_cast<uint16_t*>(s_hdr + BLOCK);  // [RE_LIST_CAP][BLOCK] cell | object << 8, in cell order
+    uint8_t* s_cnt = reinterpret_cast<uint8_t*>(s_list + RE_LIST_CAP * BLOCK);  // [BLOCK] objects on the env's grid (255 = more)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint4* img = s_hdr + BLOCK + (size_t)wave * img_chunks;
+    uint4* img = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(s_hdr + BLOCK) + RE_LIST_BYTES) + (size_t)wave * img_chunks;
     T* imgT = reinterpret_cast<T*>(img);
     T* tmpl = reinterpret_cast<T*>(s_tmpl);
     const uint32_t inv_w = 65536u / (uint32_t)W + 1u;
@@ -67,6 +80,10 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_encode(const OcLayout* __re
     for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
     for (int i = threadIdx.x; i < unit_chunks; i += BLOCK) s_tmpl[i] = make_uint4(0, 0, 0, 0);
     const Lay L = stage_layouts<true>(g_layouts, 1, nullptr, e, active, s_lay);  // contains the barrier
+    if (threadIdx.x < 64) {
+        const uint32_t c = threadIdx.x, y = (c * inv_w) >> 16, x = c - y * (uint32_t)W;
+        s_ioff[c] = (uint16_t)((x * (uint32_t)H + y) * OC_NUM_LAYERS);  // (cells beyond the grid are never looked up)
+    }
     if (FAST == 3) {  // MOVE[cell * 8 + action] for the batch's single layout (at most 64 cells)
         const int nc = (int)L.u8(L_NCELLS);
         for (int i = threadIdx.x; i < nc * 8; i += BLOCK) {
@@ -114,6 +131,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_encode(const OcLayout* __re
     const uint16_t* wcells = s_cells3 + ow * 64;  // cell c of the owner wavefront's env l: wcells[c * BLOCK + l]
     const uint4* whdr = s_hdr + ow * 64;
 
+    const int my_group = lane / group_envs;  // the sub-group this lane's env is encoded with
     for (int k = 0; k < n_steps; ++k) {
         // ---- the transition (get_state_transition + OvercookedEnv.step bookkeeping), as k_step3 does it
         bool urgent = false;
@@ -157,6 +175,28 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_encode(const OcLayout* __re
             s_hdr[threadIdx.x] = h;
             urgent = (horizon - (int)s.t) < 40;
         }
+        // the compact list of what lies on this lane's grid, and the largest count of each sub-group
+        if (owner) {
+            s_gmax[ow][lane] = 0u;
+            wave_fence();
+            if (active) {
+                uint32_t cnt = 0;
+                for (int j = 0; j < obj_dwords; ++j) {
+                    const uint32_t c0 = cells[(4 * j + 0) * BLOCK], c1 = cells[(4 * j + 1) * BLOCK];
+                    const uint32_t c2 = cells[(4 * j + 2) * BLOCK], c3 = cells[(4 * j + 3) * BLOCK];
+                    uint32_t w = (c0 & 0xFFu) | ((c1 & 0xFFu) << 8) | ((c2 & 0xFFu) << 16) | (c3 << 24);  // the four object bytes
+                    while (w != 0u) {
+                        const uint32_t b4 = (uint32_t)(__ffs((int)w) - 1) >> 3;
+                        const uint32_t o = (w >> (8u * b4)) & 0xFFu;
+                        w &= ~(0xFFu << (8u * b4));
+                        if (cnt < (uint32_t)RE_LIST_CAP) s_list[cnt * BLOCK + threadIdx.x] = (uint16_t)((4u * (uint32_t)j + b4) | (o << 8));
+                        ++cnt;
+                    }
+                }
+                s_cnt[threadIdx.x] = (uint8_t)min(cnt, 255u);
+                atomicMax(&s_gmax[ow][my_group], cnt);
+            }
+        }
         uint64_t urgent_mask = __ballot(urgent);
         if (NW == 8) {
             if (owner && lane == 0) s_urgent[ow] = urgent_mask;
@@ -186,16 +226,38 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_encode(const OcLayout* __re
                 const uint32_t ori = pl == 0 ? ((hw.x >> 8) & 0xFFu) : (hw.y & 0xFFu);
                 const uint32_t held = pl == 0 ? ((hw.x >> 16) & 0xFFu) : ((hw.y >> 8) & 0xFFu);
                 if (pos != 0xFFu) {
-                    const uint32_t y = (pos * inv_w) >> 16, x = pos - y * (uint32_t)W, i = x * (uint32_t)H + y;
-                    T* own = imgT + ((size_t)le * items_per_env + (size_t)pl * cells_n + i) * OC_NUM_LAYERS;        // view pl
-                    T* other = imgT + ((size_t)le * items_per_env + (size_t)(1 - pl) * cells_n + i) * OC_NUM_LAYERS;  // the other view
+                    const uint32_t io = s_ioff[pos & 63u];
+                    T* own = imgT + ((uint32_t)le * (uint32_t)items_per_env + (uint32_t)pl * (uint32_t)cells_n) * OC_NUM_LAYERS + io;        // view pl
+                    T* other = imgT + ((uint32_t)le * (uint32_t)items_per_env + (uint32_t)(1 - pl) * (uint32_t)cells_n) * OC_NUM_LAYERS + io;  // the other view
                     own[0] = (T)1; own[2 + ori] = (T)1;
                     other[1] = (T)1; other[6 + ori] = (T)1;
                     if (held) { enc_object_writes<T>(own, held, false, 0u, 0u); enc_object_writes<T>(other, held, false, 0u, 0u); }
                 }
             }
-            // objects on the grid (mdp.py:2482-2534): lane = (env, object dword), slots of 8 or 16 dwords per env
-            {
+            // objects on the grid (mdp.py:2482-2534) from the compact lists: lane = (env, k-th object of its grid)
+            const uint32_t kmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_gmax[ow][l0 / group_envs]);
+            if (kmax <= (uint32_t)RE_LIST_CAP) {
+                if (kmax != 0u) {
+                    const int sh = kmax <= 1u ? 0 : 32 - __builtin_clz(kmax - 1u);  // slots per env: the next power of two
+                    const int tasks = ne << sh;
+                    for (int t = lane; t < tasks; t += 64) {
+                        const int le = t >> sh, l = l0 + le;
+                        const uint32_t k = (uint32_t)t & ((1u << sh) - 1u);
+                        if (k < (uint32_t)s_cnt[ow * 64 + l]) {
+                            const uint32_t ent = s_list[k * BLOCK + ow * 64 + l];
+                            const uint32_t c = ent & 0xFFu, o = ent >> 8;
+                            const uint32_t tkw = whdr[l].z;
+                            const uint32_t tc = L.terrain(c);
+                            const bool in_pot = (tc & 7u) == OC_T_POT;
+                            const uint32_t tk = (tkw >> (8u * ((tc >> 3) & 3u))) & 0xFFu;
+                            const uint32_t ct = L.cook_time(recipe_idx(o) & 15u);
+                            T* item = imgT + (uint32_t)le * (uint32_t)items_per_env * OC_NUM_LAYERS + s_ioff[c & 63u];
+                            enc_object_writes<T>(item, o, in_pot, tk, ct);
+                            enc_object_writes<T>(item + (uint32_t)cells_n * OC_NUM_LAYERS, o, in_pot, tk, ct);
+                        }
+                    }
+                }
+            } else {  // an env of the sub-group holds more objects than a list takes: lane = (env, object dword), 8 or 16 slots per env
                 const int sh = obj_dwords <= 8 ? 3 : 4;
                 for (int le = lane >> sh; le < ne; le += (64 >> sh)) {
                     const int j = lane & ((1 << sh) - 1);

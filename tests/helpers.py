@@ -6,10 +6,11 @@ from overcooked_ai_amd import layouts as L
 CANONICAL_5 = ["cramped_room", "asymmetric_advantages", "coordination_ring", "forced_coordination", "counter_circuit"]
 
 
-def random_packed_states(spec, n, rng, timestep_max=399):
+def random_packed_states(spec, n, rng, timestep_max=399, counter_fill=None):
     """Random VALID states of `spec` in the packed wire format [n_planes, n, 16] (include/oc_amd.h):
-    players on distinct floor cells, random held objects (cooked soups only), random objects on counters,
-    pots empty / idle / cooking / ready with ticks within the recipe's cook time."""
+    players on distinct floor cells, random held objects (cooked soups only), random objects on counters (each with
+    probability 0 / 0.1 / 0.35 drawn per env, or `counter_fill(e)` when given), pots empty / idle / cooking / ready with
+    ticks within the recipe's cook time."""
     W, H = spec.width, spec.height
     n_planes = 1 + (W * H + 15) // 16
     out = np.zeros((n_planes, n, 16), np.uint8)
@@ -43,7 +44,7 @@ def random_packed_states(spec, n, rng, timestep_max=399):
             out[0, e, 3] = 0xFF
         t = int(rng.integers(0, timestep_max + 1))
         out[0, e, 6], out[0, e, 7] = t & 0xFF, t >> 8
-        p_counter = rng.choice([0.0, 0.1, 0.35])
+        p_counter = rng.choice([0.0, 0.1, 0.35]) if counter_fill is None else counter_fill(e)
         for c in counters:
             if rng.random() < p_counter:
                 out[1 + (c >> 4), e, c & 15] = loose_obj()

@@ -1217,6 +1217,42 @@ def test_rollout_with_observations_edge_sizes(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["u8", "f32"])
+def test_rollout_with_observations_crowded_grids(dtype, gpu):
+    """k_rollout_encode scatters what lies on the grid from per-env compact lists of at most 14 objects; an env with more
+    sends its sub-group through the object-dword loop.  Batches whose envs carry something on (nearly) every counter, next
+    to sparse ones in the same wavefront, against the one-step kernels."""
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    rng = np.random.default_rng(29)
+    tdt = torch.uint8 if dtype == "u8" else torch.float32
+    for layout, n in (("asymmetric_advantages", 130), ("counter_circuit", 70), ("cramped_room", 96)):
+        table = LayoutTable([spec_from_name(layout)])
+        # every third env crowded (more than 14 objects on the bigger grids), the next one half full, the next one sparse
+        st = random_packed_states(table.specs[0], n, rng, timestep_max=3, counter_fill=lambda e: (0.95, 0.5, 0.05)[e % 3])
+        n_obj = (st[1:] != 0).sum(axis=(0, 2))  # objects on each env's grid (pots included)
+        if layout != "cramped_room":
+            assert n_obj.max() > 14 and n_obj.min() <= 14
+        W, H, K = table.width, table.height, 5
+        a = make_env(table, n, gpu, horizon=400, auto_reset=True, seed=3)
+        b = make_env(table, n, gpu, horizon=400, auto_reset=True, seed=3)
+        a.one_kernel = True
+        a.set_packed_state(st)
+        b.set_packed_state(st)
+        obs_a = torch.full((K, n, 2, W, H, 26), 7, dtype=tdt, device=gpu)
+        obs_b = torch.zeros_like(obs_a)
+        rew_a = torch.zeros((K, n, 4), dtype=torch.float32, device=gpu)
+        fl_a = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
+        rew_b, fl_b = torch.zeros_like(rew_a), torch.zeros_like(fl_a)
+        a.rollout_encode(K, obs_a, rew_a, fl_a, dtype=tdt)
+        for k in range(K):
+            b.rollout_random(1, rew_b[k:k + 1], fl_b[k:k + 1])
+            obs_b[k].copy_(b.encode_lossless(tdt))
+        assert torch.equal(obs_a, obs_b) and torch.equal(a.state, b.state), layout
+        assert torch.equal(rew_a, rew_b) and torch.equal(fl_a, fl_b), layout
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("layout", ["cramped_room", "asymmetric_advantages", "counter_circuit"])
 def test_rollout_with_float32_observations(layout, gpu):
     """k_rollout_encode<float>: the f32 observation of every step == oc_encode_lossless(f32) after each one-step call."""
