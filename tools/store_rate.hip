@@ -49,6 +49,53 @@ void run(const char* name, uint4* d, size_t total_chunks, int cus, int wpc, int 
            bytes / (ms * 1e-3) / cus / 2.4e9, ms / 8);
 }
 
+
+// The rollout's own output pattern with nothing else in the loop: in step k wavefront w stores its 64 reward quads (1 KiB at
+// rewards[k][64 w ...]) and its 64 flag bytes (flags[k][64 w ...]) — 17 bytes per env-step, rows of n = 64 x n_waves envs.
+template <int PAUSE, int FLAGS = 1>
+__global__ __launch_bounds__(256) void k_outputs(float4* __restrict__ rew, uint8_t* __restrict__ fl, int n_steps) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const size_t n = (size_t)gridDim.x * blockDim.x;
+    float4 v = make_float4(0.f, 0.f, (float)lane, 1.f);
+    uint32_t acc = lane;
+    for (int k = 0; k < n_steps; ++k) {
+        rew[(size_t)k * n + wave * 64 + lane] = v;
+        if (FLAGS == 1) fl[(size_t)k * n + wave * 64 + lane] = (uint8_t)acc;
+        if (FLAGS == 2 && (k & 15) == 15) {  // the flag bytes of 16 steps in one store: lane -> (row k - 15 + lane / 4, 16-byte segment lane % 4)
+            *reinterpret_cast<uint4*>(fl + (size_t)(k - 15 + (lane >> 2)) * n + wave * 64 + (lane & 3) * 16) = make_uint4(acc, 1, 2, 3);
+        }
+        if (FLAGS == 3 && (k & 3) == 3) {  // four steps: lane -> (row k - 3 + lane / 16, dword lane % 16)
+            *reinterpret_cast<uint32_t*>(fl + (size_t)(k - 3 + (lane >> 4)) * n + wave * 64 + (lane & 15) * 4) = acc;
+        }
+        if (PAUSE) {
+#pragma unroll 1
+            for (int j = 0; j < PAUSE; ++j) acc = acc * 1664525u + 1013904223u;
+            v.w = (float)(acc & 1u);
+        }
+    }
+}
+
+template <int PAUSE, int FLAGS = 1>
+void run_outputs(const char* name, void* d, int cus, int wpc, int n_steps) {
+    const int waves = cus * wpc;
+    const size_t n = (size_t)waves * 64;
+    float4* rew = (float4*)d;
+    uint8_t* fl = (uint8_t*)d + (size_t)n_steps * n * 16;
+    dim3 grid(waves / 4), block(256);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k_outputs<PAUSE, FLAGS>), grid, block, 0, 0, rew, fl, n_steps);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 8; ++r) hipLaunchKernelGGL((k_outputs<PAUSE, FLAGS>), grid, block, 0, 0, rew, fl, n_steps);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = 8.0 * (FLAGS ? 17.0 : 16.0) * (double)n * n_steps;  // (n_steps: a multiple of 16)
+    printf("%-44s %7zu envs x %d steps: %6.2f TB/s = %5.3f of 8 TB/s, %6.1f G env-steps/s, %.1f clk per step at 2.4 GHz\n", name, n, n_steps,
+           bytes / (ms * 1e-3) / 1e12, bytes / (ms * 1e-3) / 8e12, 8.0 * n * n_steps / (ms * 1e-3) / 1e9, ms * 1e-3 / 8 / n_steps * 2.4e9);
+}
+
 int main() {
     int cus = 256;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
@@ -59,6 +106,14 @@ int main() {
     for (size_t region : {1, 2, 4, 8, 18, 28, 64, 146, 585}) run<1, 0>("LDS-sourced, no pause", d, chunks, cus, 4, 28, region);
     for (size_t region : {1, 18, 146}) run<1, 400>("LDS, 28-store bursts, ~3.2k clk pause", d, chunks, cus, 4, 28, region);
     for (size_t region : {1, 18, 146}) run<0, 0>("registers, no pause", d, chunks, cus, 16, 28, region);
+    run_outputs<0>("rollout outputs only (quad + flag byte)", d, cus, 4, 3800);
+    run_outputs<0>("rollout outputs only (quad + flag byte), again", d, cus, 4, 3800);
+    run_outputs<0, 0>("reward quads only", d, cus, 4, 3808);
+    run_outputs<0, 2>("quads + flags of 16 steps per dwordx4 store", d, cus, 4, 3808);
+    run_outputs<0, 3>("quads + flags of 4 steps per dword store", d, cus, 4, 3808);
+    run_outputs<0, 1>("quads + flag byte per step (as shipped)", d, cus, 4, 3808);
+    run_outputs<0>("rollout outputs only, 2 wavefronts per SIMD", d, cus, 8, 1900);
+    run_outputs<0>("rollout outputs only, 16 wavefronts per CU", d, cus, 16, 950);
     hipMemset(d, 0, 1 << 20);
     hipFree(d);
     return 0;
