@@ -77,11 +77,11 @@ __global__ __launch_bounds__(256) void k_outputs(float4* __restrict__ rew, uint8
 }
 
 template <int PAUSE, int FLAGS = 1>
-void run_outputs(const char* name, void* d, int cus, int wpc, int n_steps) {
+void run_outputs(const char* name, void* d, int cus, int wpc, int n_steps, size_t fl_shift = 0) {
     const int waves = cus * wpc;
     const size_t n = (size_t)waves * 64;
     float4* rew = (float4*)d;
-    uint8_t* fl = (uint8_t*)d + (size_t)n_steps * n * 16;
+    uint8_t* fl = (uint8_t*)d + (size_t)n_steps * n * 16 + fl_shift;
     dim3 grid(waves / 4), block(256);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -92,7 +92,7 @@ void run_outputs(const char* name, void* d, int cus, int wpc, int n_steps) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     const double bytes = 8.0 * (FLAGS ? 17.0 : 16.0) * (double)n * n_steps;  // (n_steps: a multiple of 16)
-    printf("%-44s %7zu envs x %d steps: %6.2f TB/s = %5.3f of 8 TB/s, %6.1f G env-steps/s, %.1f clk per step at 2.4 GHz\n", name, n, n_steps,
+    printf("%-44s (flags + %8zu B) %7zu envs x %d steps: %6.2f TB/s = %5.3f of 8 TB/s, %6.1f G env-steps/s, %.1f clk per step at 2.4 GHz\n", name, fl_shift, n, n_steps,
            bytes / (ms * 1e-3) / 1e12, bytes / (ms * 1e-3) / 8e12, 8.0 * n * n_steps / (ms * 1e-3) / 1e9, ms * 1e-3 / 8 / n_steps * 2.4e9);
 }
 
@@ -112,6 +112,8 @@ int main() {
     run_outputs<0, 2>("quads + flags of 16 steps per dwordx4 store", d, cus, 4, 3808);
     run_outputs<0, 3>("quads + flags of 4 steps per dword store", d, cus, 4, 3808);
     run_outputs<0, 1>("quads + flag byte per step (as shipped)", d, cus, 4, 3808);
+    for (size_t sh : {(size_t)0, (size_t)64, (size_t)128, (size_t)256, (size_t)1024, (size_t)4096, (size_t)16384, (size_t)65536, (size_t)262144, (size_t)1048576, (size_t)(2 << 20), (size_t)(3 << 19), (size_t)(5 << 18)})
+        run_outputs<0, 1>("quads + flag byte, flags array shifted", d, cus, 4, 3808, sh);
     run_outputs<0>("rollout outputs only, 2 wavefronts per SIMD", d, cus, 8, 1900);
     run_outputs<0>("rollout outputs only, 16 wavefronts per CU", d, cus, 16, 950);
     hipMemset(d, 0, 1 << 20);
