@@ -265,10 +265,7 @@ int oc_step_many(const OcBatch* batch, void* d_state, const uint8_t* d_actions, 
  * Same transition function as oc_step; state stays on chip between the fused steps.  A launch costs ~16 us outside its
  * step loop (table staging, state load / store, dispatch): 12 % of a 400-step launch of 65 536 envs, 1.5 % of a 4 000-step
  * one (207 vs 244 G env-steps/s on MI355X) — prefer few long launches.
- *   d_rewards  [n_steps][n_envs][4] or NULL;  d_flags [n_steps][n_envs] or NULL.  A wavefront stores its 64 flag bytes of a
- *              step as one 64-byte piece: keep d_flags 128-byte aligned and n_envs a multiple of 128 when the rate matters (a
- *              piece that straddles two 128-byte lines costs a quarter of the output rate: 269 vs 352 G env-steps/s for the
- *              stores alone, tools/store_rate.hip)
+ *   d_rewards  [n_steps][n_envs][4] or NULL;  d_flags [n_steps][n_envs] or NULL
  *   env_offset global index of local env 0 (multi-GPU shards draw disjoint streams)
  *   t0         global step index of the first fused step
  */
