@@ -65,6 +65,11 @@ __global__ __launch_bounds__(256) void k_outputs(float4* __restrict__ rew, uint8
         if (FLAGS == 2 && (k & 15) == 15) {  // the flag bytes of 16 steps in one store: lane -> (row k - 15 + lane / 4, 16-byte segment lane % 4)
             *reinterpret_cast<uint4*>(fl + (size_t)(k - 15 + (lane >> 2)) * n + wave * 64 + (lane & 3) * 16) = make_uint4(acc, 1, 2, 3);
         }
+        if (FLAGS == 4 && (k & 15) == 15 && (wave & 1) == 0) {  // even wavefronts store the pair's flag bytes of 16 steps: 16 rows x 128 B = FULL lines
+#pragma unroll
+            for (int h = 0; h < 2; ++h)  // lane -> (row k - 15 + 8 h + lane / 8, 16-byte segment lane % 8 of the pair's 128 bytes)
+                *reinterpret_cast<uint4*>(fl + (size_t)(k - 15 + 8 * h + (lane >> 3)) * n + wave * 64 + (lane & 7) * 16) = make_uint4(acc, 1, 2, 3);
+        }
         if (FLAGS == 3 && (k & 3) == 3) {  // four steps: lane -> (row k - 3 + lane / 16, dword lane % 16)
             *reinterpret_cast<uint32_t*>(fl + (size_t)(k - 3 + (lane >> 4)) * n + wave * 64 + (lane & 15) * 4) = acc;
         }
@@ -110,10 +115,8 @@ int main() {
     run_outputs<0>("rollout outputs only (quad + flag byte), again", d, cus, 4, 3800);
     run_outputs<0, 0>("reward quads only", d, cus, 4, 3808);
     run_outputs<0, 2>("quads + flags of 16 steps per dwordx4 store", d, cus, 4, 3808);
-    run_outputs<0, 3>("quads + flags of 4 steps per dword store", d, cus, 4, 3808);
+    run_outputs<0, 4>("quads + a wavefront PAIR's flags of 16 steps, full lines", d, cus, 4, 3808);
     run_outputs<0, 1>("quads + flag byte per step (as shipped)", d, cus, 4, 3808);
-    for (size_t sh : {(size_t)0, (size_t)64, (size_t)128, (size_t)256, (size_t)1024, (size_t)4096, (size_t)16384, (size_t)65536, (size_t)262144, (size_t)1048576, (size_t)(2 << 20), (size_t)(3 << 19), (size_t)(5 << 18)})
-        run_outputs<0, 1>("quads + flag byte, flags array shifted", d, cus, 4, 3808, sh);
     run_outputs<0>("rollout outputs only, 2 wavefronts per SIMD", d, cus, 8, 1900);
     run_outputs<0>("rollout outputs only, 16 wavefronts per CU", d, cus, 16, 950);
     hipMemset(d, 0, 1 << 20);
