@@ -246,6 +246,38 @@ def timed_launches(torch, dev, sharding, launch, n_launches):
     return time.perf_counter() - t0, tm.launch_ms()
 
 
+def measure_store_only(torch, dev, env, n, fuse, rew, fl, rate_per_gpu, launch_med_ms, reps=12):
+    """The ceiling of the output format: `reps` launches of oc_output_stores_only — per env-step one 16-byte reward quad and
+    one flag byte into the same [step][env] arrays the rollout writes, no state, no game — timed with HIP events."""
+    import ctypes
+
+    lib = env.lib
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def launch():
+        rc = lib.oc_output_stores_only(n, fuse, rew.data_ptr(), fl.data_ptr(), stream)
+        if rc:
+            raise RuntimeError("oc_output_stores_only: rc %d" % rc)
+
+    for _ in range(3):
+        launch()
+    tm = _Timer(torch, dev, reserve=reps + 1)
+    tm.sync()
+    for _ in range(reps):
+        tm.mark()
+        launch()
+    tm.mark()
+    tm.sync()
+    ms = sorted(tm.launch_ms())
+    med = ms[len(ms) // 2]
+    rate = n * fuse / (med * 1e-3)
+    return {"what": "oc_output_stores_only: nothing but the rollout's output stores (16-byte quad + flag byte per env-step, same "
+                    "arrays, same launch shape), median of %d launches" % reps,
+            "launch_ms": med, "env_steps_per_s": rate, "GBs": n * fuse * OUT_BYTES / (med * 1e-3) / 1e9,
+            "frac_of_peak": n * fuse * OUT_BYTES / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "rollout_over_store_only": (n * fuse / (launch_med_ms * 1e-3)) / rate}
+
+
 def launches_for(torch, dev, launch, seconds, lo=3):
     """How many launches fill `seconds` (side legs: a bounded region, not a step count): 3 calibration launches."""
     cal = _Timer(torch, dev)
@@ -803,6 +835,15 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
         if args.stub:
             parity["stub"] = "oracle compared with itself: plumbing only"
 
+    # what the output format itself admits on this device at this batch size: the rollout's output stores and nothing else
+    # (oc_output_stores_only, include/oc_amd.h), same arrays, after everything that reads them
+    store_only = None
+    if rank == 0 and not args.stub:
+        try:
+            store_only = measure_store_only(torch, dev, env, n, fuse, rew, fl, value / world, launch_med)
+        except Exception as exc:  # an aid, never a reason to lose the line
+            store_only = {"error": repr(exc)}
+
     out = {
         "metric": "env steps/sec (whole node), 65k parallel cramped_room envs" if args.config == 2 else "env steps/sec (whole node)",
         "value": value, "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -828,7 +869,7 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
                      "launch_ms_mean": dev_ms / max(1, launches), "launch_timing": "per-launch HIP events on the launch stream, median",
                      "bytes_model": "n_envs*(2*S + 17*T): S=%d B state in+out once per launch, 17 B outputs per env-step, actions in-kernel" % state_bytes,
                      "survey_8d_per_step_model_GBs": n * (2 * state_bytes + OUT_BYTES) * fuse / (launch_med * 1e-3) / 1e9,
-                     "issue_bound": issue},
+                     "issue_bound": issue, "store_only": store_only},
         "parity_check": parity,
         "device_ms_timed_region": dev_ms,
         "aggregate": {"sparse_return_last_launch": float(metrics[0]), "shaped_return_last_launch": float(metrics[1]),

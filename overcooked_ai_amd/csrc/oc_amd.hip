@@ -203,6 +203,18 @@ void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_st
 #undef GO
 }
 
+// oc_output_stores_only: the output stores of a rollout and nothing else (include/oc_amd.h)
+__global__ __launch_bounds__(BLOCK) void k_output_stores_only(float4* __restrict__ rewards, uint8_t* __restrict__ flags, int64_t n,
+                                                              int n_steps) {
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= n) return;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < n_steps; ++k) {
+        rewards[(int64_t)k * n + e] = zero4;
+        if (flags) flags[(int64_t)k * n + e] = 0;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -927,6 +939,15 @@ int oc_mailbox_step(OcMailbox* m) {
     memcpy(m->h + MB_FLAGS, rsp + n_state + 16, 4);
     memcpy(m->h + MB_EV, rsp + n_state + 20, 8);
     return OC_OK;
+}
+
+int oc_output_stores_only(int64_t n_envs, int n_steps, float* d_rewards, uint8_t* d_flags, void* stream) {
+    if (n_envs < 0 || n_steps < 0 || !d_rewards) return fail(OC_EINVAL, "oc_output_stores_only: negative sizes or no rewards array");
+    if (((uintptr_t)d_rewards & 15u) != 0) return fail(OC_EINVAL, "oc_output_stores_only: d_rewards must be 16-byte aligned");
+    if (n_envs == 0 || n_steps == 0) return OC_OK;
+    hipLaunchKernelGGL(k_output_stores_only, dim3(grid_for(n_envs)), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)d_rewards, d_flags,
+                       n_envs, n_steps);
+    return check_launch("oc_output_stores_only");
 }
 
 int oc_mailbox_close(OcMailbox* m) {

@@ -1217,6 +1217,27 @@ def test_rollout_with_observations_edge_sizes(gpu):
 
 
 @pytest.mark.gpu
+def test_output_stores_only_writes_every_output_of_a_rollout_shape(gpu):
+    """oc_output_stores_only (the ceiling bench.py reports next to the roofline): every reward quad and flag byte of a
+    [steps][envs] rollout is written (zeros), nothing beyond the arrays, ragged batch sizes and quads-only included."""
+    import ctypes
+
+    from overcooked_ai_amd import _lib
+
+    L = _lib.load()
+    for n, steps, with_flags in ((1000, 37, True), (256, 8, True), (65, 5, False)):
+        rew = torch.full((steps + 1, n, 4), 7.0, dtype=torch.float32, device=gpu)   # one guard row behind the arrays
+        fl = torch.full((steps + 1, n), 9, dtype=torch.uint8, device=gpu)
+        with torch.cuda.device(gpu):
+            rc = L.oc_output_stores_only(n, steps, rew.data_ptr(), fl.data_ptr() if with_flags else None,
+                                         ctypes.c_void_p(torch.cuda.current_stream(gpu).cuda_stream))
+        assert rc == 0
+        torch.cuda.synchronize(gpu)
+        assert float(rew[:steps].abs().sum()) == 0.0 and bool((rew[steps] == 7.0).all())
+        assert bool((fl[steps] == 9).all()) and bool((fl[:steps] == (0 if with_flags else 9)).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["u8", "f32"])
 def test_rollout_with_observations_crowded_grids(dtype, gpu):
     """k_rollout_encode scatters what lies on the grid from per-env compact lists of at most 14 objects; an env with more
