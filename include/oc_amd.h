@@ -466,7 +466,8 @@ int oc_mailbox_close(OcMailbox* mailbox);
  * Measurement aid (round 4): nothing but oc_rollout_random's OUTPUT STORES — one lane per env, per step one reward quad
  * (16 bytes, zeros) at d_rewards[k][e] and one flag byte (0) at d_flags[k][e], same workgroup shape and row addressing as the
  * rollout kernels, no state, no game.  Timing it says what the [step][env] output format of oc_rollout_random admits on the
- * device at this batch size (MI355X, 65 536 envs: 350-352 G env-steps/s = 0.75 of the HBM peak), i.e. the ceiling bench.py
+ * device at this batch size (MI355X, 65 536 envs: 370-375 G env-steps/s = 0.79-0.80 of the HBM peak on one box, and
+ * sensitive to the loop around the stores: 352 G for tools/store_rate.hip's loop on the same box), i.e. the ceiling bench.py
  * reports next to the roofline.  d_flags may be NULL (quads only).  Leaves the arrays zeroed.
  */
 int oc_output_stores_only(int64_t n_envs, int n_steps, float* d_rewards, uint8_t* d_flags, void* stream);

@@ -203,15 +203,20 @@ void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_st
 #undef GO
 }
 
-// oc_output_stores_only: the output stores of a rollout and nothing else (include/oc_amd.h)
+// oc_output_stores_only: the output stores of a rollout and nothing else (include/oc_amd.h) — one store of each kind per step,
+// in step order, through (row pointer of the step, lane offset) exactly as k_rollout4 addresses its rows
 __global__ __launch_bounds__(BLOCK) void k_output_stores_only(float4* __restrict__ rewards, uint8_t* __restrict__ flags, int64_t n,
                                                               int n_steps) {
     const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (e >= n) return;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* rew_k = rewards + (int64_t)blockIdx.x * BLOCK;                      // wave-uniform row pointers
+    uint8_t* flg_k = flags ? flags + (int64_t)blockIdx.x * BLOCK : nullptr;
+#pragma unroll 1
     for (int k = 0; k < n_steps; ++k) {
-        rewards[(int64_t)k * n + e] = zero4;
-        if (flags) flags[(int64_t)k * n + e] = 0;
+        rew_k[threadIdx.x] = zero4;
+        if (flg_k) { flg_k[threadIdx.x] = 0; flg_k += n; }
+        rew_k += n;
     }
 }
 
