@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -2 $O/smoke.log
 ( time timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/r04_driver_cmd_bench.json 2> $O/bench_driver_cmd.err ) 2> $O/bench_driver_cmd.time; echo "bench rc=$?"; tail -3 $O/bench_driver_cmd.time
-if [ -n "${CONTROL_LIB:-}" ]; then  # the previous build's headline on this box, same sustained region (same-box reference for the notebook)
+if [ -n "${CONTROL_LIB:-}" ]; then  # another build's headline on this box, same sustained region (it must export what _lib.py binds)
   for rep in 1 2; do OC_AMD_LIB=$R/$CONTROL_LIB timeout 300 python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-traffic --no-parity-check > $O/control_long_$rep.json 2>> $O/bench_other.err; done
   timeout 300 python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-traffic --no-parity-check > $O/shipped_long_2.json 2>> $O/bench_other.err
 fi
