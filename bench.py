@@ -84,6 +84,9 @@ def parse():
     ap.add_argument("--stub", action="store_true",
                     help="CPU-only plumbing test (gloo, no kernels): exercises rank spawning and the reductions; never a measurement")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of one launch after the timed region")
+    ap.add_argument("--flags-layout", choices=("tiled8", "step"), default="tiled8",
+                    help="layout of the flags output of the headline's oc_rollout_random launches: tiled8 = [steps/8][envs][8] "
+                         "(OC_OPT_FLAGS_TILED8, where the batch allows it; default), step = [steps][envs]")
     ap.add_argument("--parity-steps", type=int, default=0,
                     help="steps of the launch the parity check replays from reset (default: one whole --fuse launch at 1 GPU, "
                          "1 200 steps per rank otherwise)")
@@ -468,7 +471,7 @@ def make_workload(args, rank):
                         "envs/GPU, random policy, horizon %d auto-reset, outputs every step" % (K, K, n, HORIZON)}
 
 
-def parity_check(torch, wl, make_env, n, rank, steps, rew, fl, threads):
+def parity_check(torch, wl, make_env, n, rank, steps, rew, fl, threads, tiled8=False):
     """Replay ONE launch of the timed shape from reset and compare every reward row, every flag byte, the final packed
     states and the episode returns with the C oracle (the checker, not the thing measured), in 400-step chunks."""
     import numpy as np
@@ -477,7 +480,13 @@ def parity_check(torch, wl, make_env, n, rank, steps, rew, fl, threads):
 
     t_start = time.perf_counter()
     env = make_env()
-    env.rollout_random(steps, rew[:steps], fl[:steps])
+    if tiled8:  # the timed launches' own flags layout: [steps / 8][envs][8], untiled for the comparison
+        steps -= steps % 8
+        flt = fl.view(-1)[:steps * n].view(steps // 8, n, 8)
+        env.rollout_random(steps, rew[:steps], flt, flags_tiled8=True)
+        fl = env.untile_flags(flt)
+    else:
+        env.rollout_random(steps, rew[:steps], fl[:steps])
     threads = O.set_threads(max(1, threads))
     orc = O.Oracle([O.mdp_from_layout_dict(sp.to_layout_dict()) for sp in wl["specs"]])
     lid = wl["lid"]
@@ -503,6 +512,25 @@ def parity_check(torch, wl, make_env, n, rank, steps, rew, fl, threads):
                     "oracle/overcooked_oracle.c" % (steps, rank * n)}
 
 
+def flags_tiled8_ok(args, env, fuse, rew, fl):
+    """Does this batch / launch shape take the tiled flags layout (OC_OPT_FLAGS_TILED8: the pipelined joint-table kernel,
+    launches of whole 8-step blocks)?  Asked by trying one launch; the env is put back to where it was."""
+    if getattr(args, "flags_layout", "step") != "tiled8" or args.stub or fuse % 8 or not hasattr(env, "untile_flags"):
+        return False
+    n = fl.shape[1]
+    saved = (env.state.clone(), env.t_global, env.steps_done, env._epoch, env.ep_returns.clone() if env.ep_returns is not None else None)
+    try:
+        env.rollout_random(8, rew[:8], fl.view(-1)[:8 * n].view(1, n, 8), flags_tiled8=True)
+        ok = True
+    except Exception:
+        ok = False
+    env.state.copy_(saved[0])
+    env.t_global, env.steps_done, env._epoch = saved[1], saved[2], saved[3]
+    if saved[4] is not None:
+        env.ep_returns.copy_(saved[4])
+    return ok
+
+
 def pmc_child(args, torch, VecOvercookedEnv, dev):
     """The process the --pmc passes wrap: the same batch, reset, then 3 launches of the timed shape and nothing else."""
     wl = make_workload(args, 0)
@@ -510,8 +538,12 @@ def pmc_child(args, torch, VecOvercookedEnv, dev):
     env = rollout_workload_env(args, wl, n, 0, dev, VecOvercookedEnv)()
     rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
+    tiled8 = flags_tiled8_ok(args, env, fuse, rew, fl)
     for _ in range(3):
-        env.rollout_random(fuse, rew, fl)
+        if tiled8:
+            env.rollout_random(fuse, rew, fl.view(fuse // 8, n, 8), flags_tiled8=True)
+        else:
+            env.rollout_random(fuse, rew, fl)
     torch.cuda.synchronize(dev)
 
 
@@ -779,8 +811,14 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
     rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
 
+    tiled8 = flags_tiled8_ok(args, env, fuse, rew, fl)
+    fl_t = fl.view(fuse // 8, n, 8) if tiled8 else None
+
     def launch():
-        env.rollout_random(fuse, rew, fl)
+        if tiled8:
+            env.rollout_random(fuse, rew, fl_t, flags_tiled8=True)
+        else:
+            env.rollout_random(fuse, rew, fl)
 
     for _ in range(max(1, args.warmup * lps)):  # W bench steps, untimed (at least one launch)
         launch()
@@ -799,7 +837,7 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
     sharding.allreduce_metrics(per_rank)  # disjoint slots: the sum is a gather
     # aggregate-return metric: the only collective, outside the hot path (RCCL all-reduce of 3 scalars)
     metrics = torch.stack([rew[..., 0:2].sum().to(torch.float64), rew[..., 2:4].sum().to(torch.float64),
-                           (fl[-1] & 1).sum().to(torch.float64)])
+                           ((fl_t[-1, :, 7] if tiled8 else fl[-1]) & 1).sum().to(torch.float64)])
     sharding.allreduce_metrics(metrics)
 
     value = float(world) * n * transitions / wall_max
@@ -825,7 +863,7 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
     if not args.no_parity_check:
         psteps = args.parity_steps or (fuse if world == 1 else min(fuse, 1200))
         psteps = min(psteps, fuse)
-        mine = parity_check(torch, wl, make_env, n, rank, psteps, rew, fl, max(1, usable_cores() // max(1, world)))
+        mine = parity_check(torch, wl, make_env, n, rank, psteps, rew, fl, max(1, usable_cores() // max(1, world)), tiled8=tiled8)
         pr = torch.zeros((world, 2), dtype=torch.float64, device=dev)
         pr[rank, 0], pr[rank, 1] = mine["mismatches"], mine["seconds"]
         sharding.allreduce_metrics(pr)
@@ -856,6 +894,8 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
         "ms_per_step_each": step_each, "ms_per_step_by_rank": [float(x) for x in per_rank.tolist()],
         "warmup_launches_run": max(1, args.warmup * lps),
         "config": {"workload": wl["workload"], "baseline_config": args.config,
+                   "flags_layout": "[steps/8][envs][8] (OC_OPT_FLAGS_TILED8: the flag bytes of 8 steps of an env side by side; "
+                                   "17 B per env-step as before; parity_check untiles them)" if tiled8 else "[steps][envs]",
                    "envs_per_gpu": n, "fused_transitions_per_launch": fuse, "launches_per_step": lps, "launches": launches,
                    "parallelism": "env-shard x%d" % world, "numa_node_rank0": numa,
                    "step_definition": "one bench step = %d back-to-back oc_rollout_random launches of %d transitions = %d "

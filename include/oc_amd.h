@@ -94,6 +94,14 @@ extern "C" {
                                   whenever the table allows it; by default it runs only for batches that give every CU
                                   a workgroup (it keeps 256 envs per CU on chip; smaller batches are faster through the
                                   one-step kernels, whose observation kernel spreads over all CUs) */
+#define OC_OPT_FLAGS_TILED8 0x40u /* oc_rollout_random: d_flags is tiled by 8 steps, [n_steps / 8][n_envs][8] — byte
+                                     (k / 8, e, k % 8) holds the OC_F_* bits of env e after step k of the call — so that a
+                                     wavefront writes the flags of 8 steps as 512 contiguous bytes instead of 64 bytes in each
+                                     of 8 rows (worth ~6 % of the rollout rate and its run-to-run spread on MI355X).  Needs
+                                     t0 and n_steps to be multiples of 8, d_rewards and an 8-byte aligned d_flags, and a
+                                     batch the pipelined joint-table kernel serves (one two-player, one-pot layout with at
+                                     most 6 free cells and no shared faced cells — cramped_room —, at most ~98 000 envs, no
+                                     event sink); OC_EINVAL otherwise */
 
 /* OcBatch.batch_flags */
 #define OC_BATCH_TWO_PLAYERS 0x1u /* every layout of the table has exactly 2 players */
@@ -265,7 +273,7 @@ int oc_step_many(const OcBatch* batch, void* d_state, const uint8_t* d_actions, 
  * Same transition function as oc_step; state stays on chip between the fused steps.  A launch costs ~16 us outside its
  * step loop (table staging, state load / store, dispatch): 12 % of a 400-step launch of 65 536 envs, 1.5 % of a 4 000-step
  * one (207 vs 244 G env-steps/s on MI355X) — prefer few long launches.
- *   d_rewards  [n_steps][n_envs][4] or NULL;  d_flags [n_steps][n_envs] or NULL
+ *   d_rewards  [n_steps][n_envs][4] or NULL;  d_flags [n_steps][n_envs] or NULL ([n_steps / 8][n_envs][8] with OC_OPT_FLAGS_TILED8)
  *   env_offset global index of local env 0 (multi-GPU shards draw disjoint streams)
  *   t0         global step index of the first fused step
  */

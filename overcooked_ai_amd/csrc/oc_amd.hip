@@ -339,6 +339,15 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
     if (!d_state) return fail(OC_EINVAL, "oc_rollout_random: NULL state pointer");
     if (horizon < 1 || horizon > 65535) return fail(OC_EINVAL, "oc_rollout_random: horizon must be in 1..65535");
     if (n_steps < 0 || n_steps > (1 << 30)) return fail(OC_EINVAL, "oc_rollout_random: n_steps must be in 0..2^30");
+    const bool tiled8 = (options & OC_OPT_FLAGS_TILED8) != 0;
+    if (tiled8) {  // the launch-shape half of the option's conditions (the batch half follows the kernel choice below)
+        if (!d_rewards || !d_flags || ((uintptr_t)d_flags & 7u) != 0)
+            return fail(OC_EINVAL, "oc_rollout_random: OC_OPT_FLAGS_TILED8 needs d_rewards and an 8-byte aligned d_flags");
+        if ((t0 & 7) != 0 || (n_steps & 7) != 0)
+            return fail(OC_EINVAL, "oc_rollout_random: OC_OPT_FLAGS_TILED8 needs t0 and n_steps to be multiples of 8");
+        if (ev_on(ea) || (options & (OC_OPT_LANE_PAIR | OC_OPT_PREDICATE_INTERACT)))
+            return fail(OC_EINVAL, "oc_rollout_random: OC_OPT_FLAGS_TILED8 goes with the default kernel and no event sink");
+    }
     if (b->n_envs == 0 || n_steps == 0) return OC_OK;
     hipStream_t s = (hipStream_t)stream;
     const bool uniform = b->n_layouts == 1;
@@ -400,6 +409,11 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         const bool shaping_uniform = uniform || (b->batch_flags & OC_BATCH_UNIFORM_SHAPING) != 0;
         const bool mode2 = !c.joint && two && !c.old_dyn && c.out && small && shaping_uniform && b->width * b->height <= 64 &&
                            !c.events && !no_mode2;
+        c.tiled8 = tiled8;
+        if (tiled8 && !(c.joint && c.pipe && b->width * b->height <= 64 && (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0 &&
+                        b->n_envs < ((int64_t)1 << 24)))
+            return fail(OC_EINVAL, "oc_rollout_random: OC_OPT_FLAGS_TILED8 is served by the pipelined joint-table kernel only (one "
+                                   "two-player, one-pot layout with <= 6 free cells and no shared faced cells, <= ~98 000 envs)");
         if (c.joint || c.events) oc_detail::launch_rollout4_joint_events(c);
         else if (mode2) oc_detail::launch_rollout4_mode2(c);
         else oc_detail::launch_rollout4_mode0(c);

@@ -23,7 +23,7 @@ namespace {
 
 // dynamic LDS of a k_rollout4 instance: its tables + the cell words of a workgroup's 256 envs
 template <bool U, int MP, bool LL, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false, bool PIPE = true,
-          bool RU = false, int CW = 2, bool NOCONF = false>
+          bool RU = false, int CW = 2, bool NOCONF = false, bool FT8 = false>
 constexpr size_t lds4_bytes(size_t cell_rows) {
     return (size_t)Lds4<U, LL, MODE, NF, U || RU, CW>::CELLS + cell_rows * BLOCK * CW;
 }
@@ -60,6 +60,10 @@ void launch_rollout4_joint_events(const Rollout4Call& c) {
     // (cramped_room): 32-bit cell words and the faced cells read a step ahead; else (big batches, shared faced cells, grids
     // above 64 cells) 16-bit words without the one-step-ahead reads (see PIPE in step_lut4.hpp)
     const bool noconf = (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0;
+    if (c.tiled8) {  // (oc_rollout_random has checked that this instance serves the batch and the launch)
+        GO4(true, 1, true, 1, true, false, 6, false, true, false, 4, true, true);
+        return;
+    }
     if (c.pipe && b->width * b->height <= 64 && noconf) GO4(true, 1, true, 1, true, false, 6, false, true, false, 4, true);
     else GO4(true, 1, true, 1, true, false, 6, false, false);
 }

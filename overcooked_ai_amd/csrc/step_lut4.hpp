@@ -438,11 +438,15 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
 // NOCONF: no non-floor cell of the layout touches two floor cells (hint OC_BATCH_NO_SHARED_FACES; cramped_room): the two players
 //   can never face the same cell, so player 1 never has to redo its interact on a cell player 0 has just changed
 // CW: bytes of a cell word (2, or 4 for the one-wavefront-per-SIMD instance of small single layouts: see cw_rd)
+// FT8 (MODE 1 with PIPE; option OC_OPT_FLAGS_TILED8): the flags array is tiled by 8 steps — flags[k / 8][e][k % 8] — so that a
+//   wavefront stores the flag bytes of a whole unrolled block as ONE 512-byte piece of full lines instead of eight 64-byte
+//   pieces in eight far-apart rows (which cost the rollout ~6 % and its run-to-run spread: NOTEBOOK, round 4).  The launch
+//   must start on a block boundary and run whole blocks (t0 and n_steps multiples of 8): no rolled steps
 // PIPE (MODE 1, 2): the next step's faced cells are read one step ahead.  That hides the read behind the tail of the step
 //   when a SIMD holds one wavefront (65 536 envs); with two or more wavefronts per SIMD the extra LDS traffic costs
 //   more than the latency it hides (131 072 cramped_room envs: 0.48 vs 0.65 us per batched step), so big batches turn it off
 template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false,
-          bool PIPE = true, bool RU = false, int CW = 2, bool NOCONF = false>
+          bool PIPE = true, bool RU = false, int CW = 2, bool NOCONF = false, bool FT8 = false>
 #ifndef OC_R4_WAVES_MAX
 #define OC_R4_WAVES_MAX 4
 #endif
@@ -530,7 +534,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
     const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
     float4* rew_k = rewards ? rewards + (int64_t)blockIdx.x * BLOCK : nullptr;  // wave-uniform row pointers
     const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));  // first lane of this wavefront
-    uint8_t* flg_k = flags ? flags + (int64_t)blockIdx.x * BLOCK + wave_base : nullptr;
+    static_assert(!FT8 || (MODE == 1 && OUT && PIPE && !EV), "the tiled flags array is served by the pipelined joint-table instances");
+    uint8_t* flg_k = flags ? flags + ((int64_t)blockIdx.x * BLOCK + wave_base) * (FT8 ? 8 : 1) : nullptr;  // (FT8: the tile row of 8 steps)
+    uint32_t flt_lo = 0, flt_hi = 0;  // FT8: the flag bytes of the block's steps 0..3 / 4..7
     const uint32_t lane = threadIdx.x & 63u;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t step_k = 0;  // index of the step within this launch (wave-uniform): the epoch offset of a restart
@@ -604,11 +610,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
         // may be rewritten: the two instructions behind it.
         typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
         const u64x2 q = {p.lo, p.hi};
-        asm volatile("global_store_dwordx4 %1, %2, %4\n\tglobal_store_byte %5, %6, %7\n\t"
-                     "v_pk_add_f32 %0, %0, %3"
-                     : "+v"(epsh)
-                     : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k), "v"(flg_off[k8 & 7]), "v"(p.fl), "s"(flg_k)
-                     : "memory");
+        if (FT8) {  // (the flag byte has gone into the block's tile; the second wait state is a no-op)
+            asm volatile("global_store_dwordx4 %1, %2, %4\n\tv_pk_add_f32 %0, %0, %3\n\ts_nop 0"
+                         : "+v"(epsh) : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k) : "memory");
+        } else {
+            asm volatile("global_store_dwordx4 %1, %2, %4\n\tglobal_store_byte %5, %6, %7\n\t"
+                         "v_pk_add_f32 %0, %0, %3"
+                         : "+v"(epsh)
+                         : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k), "v"(flg_off[k8 & 7]), "v"(p.fl), "s"(flg_k)
+                         : "memory");
+        }
     };
     // k8: index of the step inside an unrolled block of 8 (stores through the block's row + offset), or -1 (rolled step);
     // defer: where to leave the step's outputs instead of storing them (flush() follows), or nullptr
@@ -875,6 +886,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
             if (ea.events) ea.events[(int64_t)step_k * n + e] = ev;
             count_events(ea, e, ev, done, (options & OC_OPT_AUTO_RESET) != 0u);
         }
+        if (FT8 && k8 >= 0) {  // this step's byte of the block's flag tile (k8 is a constant of the unrolled step)
+            uint32_t& half = (k8 & 4) ? flt_hi : flt_lo;
+            half = (k8 & 3) == 0 ? fl : (half | (fl << (8 * (k8 & 3))));
+        }
         const bool deferred = OUT && k8 >= 0 && defer != nullptr;
         if (deferred) {  // stored by the next step of the block, in the shadow of its look-ups
             defer->fl = fl;
@@ -995,6 +1010,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
             pstep(w.w3, true, 6, 1);
             w = inc.words();
             pstep(w.w0, false, 7, 0);  // the look-ahead digit of step 7 is the next block's first
+            if (FT8) {  // the block's flag tile: 8 bytes per env, 512 contiguous bytes per wavefront
+                const uint64_t tile = ((uint64_t)flt_hi << 32) | flt_lo;
+                asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lane * 8u), "v"(tile), "s"(flg_k) : "memory");
+            }
             advance_rows();
         }
         for (; k < n_steps; ++k) { const uint32_t xn = word_of(t0 + k + 1); pstep(xn, ((t0 + k + 1) & 1) != 0, -1, 0); }  // the tail

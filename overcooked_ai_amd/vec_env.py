@@ -296,12 +296,16 @@ class VecOvercookedEnv:
         self._advance(int(K))
         return rewards_out, flags_out
 
-    def rollout_random(self, n_steps, rewards_out=None, flags_out=None, events_out=None):
+    def rollout_random(self, n_steps, rewards_out=None, flags_out=None, events_out=None, flags_tiled8=False):
         """n_steps fused random-policy transitions in one launch (Philox actions, see include/oc_amd.h).  A launch
         costs ~16 us outside its step loop (tables, state load / store, dispatch): 12 % of a 400-step launch at 65 536
         envs, 3 % of a 2 000-step one — prefer few long launches.
         rewards_out: float32 [n_steps, n_envs, 4] or None; flags_out: uint8 [n_steps, n_envs] or None; events_out:
-        int64 [n_steps, n_envs] event masks or None."""
+        int64 [n_steps, n_envs] event masks or None.
+        flags_tiled8 (OC_OPT_FLAGS_TILED8): flags_out is [n_steps // 8, n_envs, 8] — byte [k // 8, e, k % 8] = step k of env e
+        (`untile_flags` gives the [n_steps, n_envs] view's copy) —, which the kernel writes as full lines: worth ~6 % on the
+        joint-table kernel (one cramped_room-like layout, up to ~98 000 envs; n_steps and the step counter multiples of 8;
+        ValueError via OC_EINVAL otherwise)."""
         if events_out is not None:
             self._check(events_out, torch.int64, int(n_steps) * self.n_envs, "events_out")
         if rewards_out is not None:
@@ -314,12 +318,19 @@ class VecOvercookedEnv:
                 rewards_out.data_ptr() if rewards_out is not None else None,
                 flags_out.data_ptr() if flags_out is not None else None,
                 self.ep_returns.data_ptr() if self.ep_returns is not None else None,
-                self.horizon, self.options, self.seed, self.env_offset, self.t_global, int(n_steps),
-                self._start_spec() if self.auto_reset else None, self._event_sink(events_out), self._stream())
+                self.horizon, self.options | (_lib.OPT_FLAGS_TILED8 if flags_tiled8 else 0), self.seed, self.env_offset,
+                self.t_global, int(n_steps), self._start_spec() if self.auto_reset else None, self._event_sink(events_out),
+                self._stream())
         _lib.check(rc, "oc_rollout_random")
         self.t_global += int(n_steps)
         self._advance(int(n_steps))
         return rewards_out, flags_out
+
+    @staticmethod
+    def untile_flags(flags_tiled):
+        """[n_steps // 8, n_envs, 8] (OC_OPT_FLAGS_TILED8) -> a [n_steps, n_envs] copy."""
+        t, n, _ = flags_tiled.shape
+        return flags_tiled.permute(0, 2, 1).reshape(t * 8, n)
 
     def rollout_encode(self, n_steps, obs_out, rewards_out=None, flags_out=None, actions=None, dtype=torch.uint8):
         """n_steps transitions with the lossless observation after every step, one C call (oc_rollout_encode; a single

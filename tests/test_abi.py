@@ -98,6 +98,17 @@ def test_argument_validation_without_gpu():
     assert L.oc_rollout_encode(br, 4096, None, None, None, None, 4096, 0, 0, 400, 1, 0, 0, 0, 0, None, None) == 0  # no steps: nothing to do
     assert L.oc_step_encode(br, 4096, 4096, 4096, 4096, None, None, 0, 400, 1, None, None) == -1
     assert b"NULL pointer" in L.oc_last_error()
+    # OC_OPT_FLAGS_TILED8 (0x40): the launch-shape conditions are checked before anything is launched
+    assert L.oc_rollout_random(br, 4096, 4096, 4096, None, 400, 0x41, 0, 0, 0, 12, None, None, None) == -1
+    assert b"multiples of 8" in L.oc_last_error()
+    assert L.oc_rollout_random(br, 4096, 4096, 4096, None, 400, 0x41, 0, 0, 4, 16, None, None, None) == -1
+    assert b"multiples of 8" in L.oc_last_error()
+    assert L.oc_rollout_random(br, 4096, 4096, 4100, None, 400, 0x41, 0, 0, 0, 16, None, None, None) == -1
+    assert b"8-byte aligned" in L.oc_last_error()
+    assert L.oc_rollout_random(br, 4096, None, 4096, None, 400, 0x41, 0, 0, 0, 16, None, None, None) == -1
+    assert b"needs d_rewards" in L.oc_last_error()
+    assert L.oc_rollout_random(br, 4096, 4096, 4096, None, 400, 0x45, 0, 0, 0, 16, None, None, None) == -1
+    assert b"default kernel" in L.oc_last_error()
     # the measurement aid: argument checks before the launch, nothing to do for an empty job
     assert L.oc_output_stores_only(64, 8, None, None, None) == -1 and b"no rewards array" in L.oc_last_error()
     assert L.oc_output_stores_only(64, 8, 4100, None, None) == -1 and b"16-byte aligned" in L.oc_last_error()

@@ -1217,6 +1217,48 @@ def test_rollout_with_observations_edge_sizes(gpu):
 
 
 @pytest.mark.gpu
+def test_rollout_random_with_flags_tiled_by_8_steps(gpu):
+    """OC_OPT_FLAGS_TILED8: flags[k // 8][e][k % 8] from the pipelined joint-table kernel == the [step][env] flags of the
+    default call, rewards / states / episode returns identical, across in-kernel restarts and a second launch that starts at
+    step 16; launches that are not whole 8-step blocks and batches other kernels serve are refused."""
+    from overcooked_ai_amd import _lib
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+    from overcooked_ai_amd.vec_env import VecOvercookedEnv
+
+    table = LayoutTable([spec_from_name("cramped_room")])
+    rng = np.random.default_rng(41)
+    for n, horizon in ((1000, 20), (4096, 400), (65536, 12)):
+        st = random_packed_states(table.specs[0], n, rng, timestep_max=min(horizon - 1, 9))
+        a = make_env(table, n, gpu, horizon=horizon, auto_reset=True, seed=11)
+        b = make_env(table, n, gpu, horizon=horizon, auto_reset=True, seed=11)
+        a.set_packed_state(st)
+        b.set_packed_state(st)
+        for K in (16, 48):
+            rew_a = torch.full((K, n, 4), 3.0, dtype=torch.float32, device=gpu)
+            rew_b = torch.zeros_like(rew_a)
+            fl_a = torch.full((K // 8, n, 8), 0x55, dtype=torch.uint8, device=gpu)
+            fl_b = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
+            a.rollout_random(K, rew_a, fl_a, flags_tiled8=True)
+            b.rollout_random(K, rew_b, fl_b)
+            assert torch.equal(VecOvercookedEnv.untile_flags(fl_a), fl_b), (n, horizon, K)
+            assert torch.equal(rew_a, rew_b) and torch.equal(a.state, b.state) and torch.equal(a.ep_returns, b.ep_returns), (n, horizon, K)
+            assert int((fl_b & 1).sum()) > 0 or horizon == 400  # (episode ends are inside the launches)
+    # refused: a launch that is not whole blocks, a step counter off a block boundary, a batch another kernel serves
+    a = make_env(table, 256, gpu, horizon=400, auto_reset=True, seed=1)
+    rew = torch.zeros((16, 256, 4), dtype=torch.float32, device=gpu)
+    fl = torch.zeros((2, 256, 8), dtype=torch.uint8, device=gpu)
+    with pytest.raises((_lib.OcAmdError, ValueError)):
+        a.rollout_random(12, rew[:12], fl.view(-1)[:12 * 256].view(12, 256), flags_tiled8=True)
+    a.rollout_random(4, rew[:4], fl.view(-1)[:4 * 256].view(4, 256))  # step counter -> 4
+    with pytest.raises((_lib.OcAmdError, ValueError)):
+        a.rollout_random(16, rew, fl, flags_tiled8=True)
+    t2 = LayoutTable([spec_from_name("asymmetric_advantages")])
+    c = make_env(t2, 256, gpu, horizon=400, auto_reset=True, seed=1)
+    with pytest.raises((_lib.OcAmdError, ValueError)):
+        c.rollout_random(16, rew, fl, flags_tiled8=True)
+
+
+@pytest.mark.gpu
 def test_output_stores_only_writes_every_output_of_a_rollout_shape(gpu):
     """oc_output_stores_only (the ceiling bench.py reports next to the roofline): every reward quad and flag byte of a
     [steps][envs] rollout is written (zeros), nothing beyond the arrays, ragged batch sizes and quads-only included."""

@@ -27,6 +27,10 @@ if mode:
 T = int(os.environ.get("STEPS", "100"))
 rew = torch.zeros((T, n, 4), dtype=torch.float32, device=dev)
 fl = torch.zeros((T, n), dtype=torch.uint8, device=dev)
+tiled8 = os.environ.get("TILED8", "") == "1"  # OC_OPT_FLAGS_TILED8: what bench.py's headline launches use
 for _ in range(12):
-    env.rollout_random(T, rew, fl)
+    if tiled8:
+        env.rollout_random(T, rew, fl.view(T // 8, n, 8), flags_tiled8=True)
+    else:
+        env.rollout_random(T, rew, fl)
 torch.cuda.synchronize()
