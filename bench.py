@@ -538,7 +538,7 @@ def pmc_child(args, torch, VecOvercookedEnv, dev):
     env = rollout_workload_env(args, wl, n, 0, dev, VecOvercookedEnv)()
     rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
-    tiled8 = flags_tiled8_ok(args, env, fuse, rew, fl)
+    tiled8 = args.flags_layout == "tiled8"  # (decided by the parent, which has tried it)
     for _ in range(3):
         if tiled8:
             env.rollout_random(fuse, rew, fl.view(fuse // 8, n, 8), flags_tiled8=True)
@@ -547,7 +547,7 @@ def pmc_child(args, torch, VecOvercookedEnv, dev):
     torch.cuda.synchronize(dev)
 
 
-def measure_traffic(args, kernel):
+def measure_traffic(args, kernel, tiled8=False):
     """roofline.traffic measured by THIS run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE — they do not fit one
     pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots') over a child of this same command that runs 3 launches of the timed
     shape.  KiB -> bytes; FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 B, same
@@ -563,7 +563,8 @@ def measure_traffic(args, kernel):
     if not os.path.exists(rocprof):
         return None, {"how": "not collected", "why": "rocprofv3 not found"}
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", str(args.config), "--envs", str(args.envs),
-             "--fuse", str(args.fuse), "--layout", args.layout, "--terrains", str(args.terrains)]
+             "--fuse", str(args.fuse), "--layout", args.layout, "--terrains", str(args.terrains),
+             "--flags-layout", "tiled8" if tiled8 else "step"]  # (the child takes the parent's decision: no probe launch in the counters)
     for flag, on in (("--lane-pair", args.lane_pair), ("--predicate-interact", args.predicate_interact)):
         if on:
             child.append(flag)
@@ -850,7 +851,7 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
     traffic, traffic_src = None, {"how": "not collected", "why": "only rank 0 of a 1-GPU run collects PMC traffic"}
     if rank == 0 and world == 1 and not args.stub:
         if not args.no_traffic:
-            traffic, traffic_src = measure_traffic(args, kernel)
+            traffic, traffic_src = measure_traffic(args, kernel, tiled8)
         if traffic is None:
             why = traffic_src.get("why")
             traffic, traffic_src = traffic_from_file(kernel, n, fuse, args.layout if args.config == 2 else "", bytes_per_launch)
