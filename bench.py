@@ -965,7 +965,8 @@ def side_legs(args, torch, VecOvercookedEnv, sharding, dev):
         legs["3"] = {"error": repr(exc)[:300]}
     for cfg, envs in ((4, N_ENVS_PER_GPU), (5, 2 * N_ENVS_PER_GPU)):
         try:
-            a = argparse.Namespace(config=cfg, envs=envs, layout="cramped_room", terrains=4096, stub=False)
+            a = argparse.Namespace(config=cfg, envs=envs, layout="cramped_room", terrains=4096, stub=False,
+                                   flags_layout=getattr(args, "flags_layout", "step"))
             wl = make_workload(a, 0)
             make_env = rollout_workload_env(a, wl, envs, 0, dev, VecOvercookedEnv)
             env = make_env()
@@ -973,8 +974,14 @@ def side_legs(args, torch, VecOvercookedEnv, sharding, dev):
             rew = torch.zeros((fuse, envs, 4), dtype=torch.float32, device=dev)
             fl = torch.zeros((fuse, envs), dtype=torch.uint8, device=dev)
 
+            tiled8 = flags_tiled8_ok(a, env, fuse, rew, fl)
+            fl_t = fl.view(fuse // 8, envs, 8) if tiled8 else None
+
             def launch():
-                env.rollout_random(fuse, rew, fl)
+                if tiled8:
+                    env.rollout_random(fuse, rew, fl_t, flags_tiled8=True)
+                else:
+                    env.rollout_random(fuse, rew, fl)
 
             launch()
             k = launches_for(torch, dev, launch, args.leg_seconds)
@@ -984,13 +991,14 @@ def side_legs(args, torch, VecOvercookedEnv, sharding, dev):
             bpl = envs * (2 * wl["sbytes"] + OUT_BYTES * fuse)
             leg = {"value": envs * fuse * k / wall, "unit": "env steps/s (one GPU)", "envs": envs, "launches": k,
                    "timed_region_s": wall, "launch_ms": med, "launch_ms_min": ms[0], "workload": wl["workload"],
+                   "flags_layout": "[steps/8][envs][8] (OC_OPT_FLAGS_TILED8)" if tiled8 else "[steps][envs]",
                    "roofline": {"bound": "hbm", "kernel": "k_rollout4", "achieved": bpl / (med * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bpl / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "bytes_per_launch": bpl, "traffic": None,
                                 "traffic_source": {"how": "not collected", "why": "side leg; `bench.py --config %d` collects it" % cfg},
                                 "bytes_model": "n_envs*(2*S + 17*T), S=%d B (SURVEY 8d)" % wl["sbytes"]}}
             if not args.no_parity_check:
-                leg["parity_check"] = parity_check(torch, wl, make_env, envs, 0, 1200, rew, fl, usable_cores())
+                leg["parity_check"] = parity_check(torch, wl, make_env, envs, 0, 1200, rew, fl, usable_cores(), tiled8=tiled8)
             legs[str(cfg)] = leg
             del env, rew, fl
         except Exception as exc:

@@ -410,10 +410,15 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         const bool mode2 = !c.joint && two && !c.old_dyn && c.out && small && shaping_uniform && b->width * b->height <= 64 &&
                            !c.events && !no_mode2;
         c.tiled8 = tiled8;
-        if (tiled8 && !(c.joint && c.pipe && b->width * b->height <= 64 && (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0 &&
-                        b->n_envs < ((int64_t)1 << 24)))
-            return fail(OC_EINVAL, "oc_rollout_random: OC_OPT_FLAGS_TILED8 is served by the pipelined joint-table kernel only (one "
-                                   "two-player, one-pot layout with <= 6 free cells and no shared faced cells, <= ~98 000 envs)");
+        if (tiled8) {  // which instances write the tiled flags array: the pipelined joint-table one, the per-env-terrain ones of
+                       // mixed tables in LDS (pipelined) and of one-pot tables in HBM
+            const bool by_joint = c.joint && c.pipe && b->width * b->height <= 64 && (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0;
+            const bool by_mode2 = mode2 && !uniform && ((lds && c.pipe) || (!lds && b->max_pots == 1));
+            if (!(by_joint || by_mode2) || b->n_envs >= ((int64_t)1 << 24))
+                return fail(OC_EINVAL, "oc_rollout_random: OC_OPT_FLAGS_TILED8 is served by the pipelined joint-table kernel (one two-player, "
+                                       "one-pot layout with <= 6 free cells and no shared faced cells, <= ~98 000 envs) and by the per-env-"
+                                       "terrain kernels of mixed tables (<= 32 layouts: <= ~98 000 envs; one-pot tables beyond that)");
+        }
         if (c.joint || c.events) oc_detail::launch_rollout4_joint_events(c);
         else if (mode2) oc_detail::launch_rollout4_mode2(c);
         else oc_detail::launch_rollout4_mode0(c);

@@ -75,6 +75,12 @@ void launch_rollout4_mode2(const Rollout4Call& c) {
     do {                                                                                                  \
         if (c.pipe) GO4(U, MP, LL, 2, true, false, 0, false, true, RUF, 4); else GO4(U, MP, LL, 2, true, false, 0, false, false, RUF); \
     } while (0)
+    if (c.tiled8) {  // OC_OPT_FLAGS_TILED8: the instances BASELINE configs[3] / [4] run (oc_rollout_random has checked the conditions)
+        if (c.lds) GO4(false, 2, true, 2, true, false, 0, false, true, true, 4, false, true);               // mixed table in LDS, pipelined
+        else if (c.pipe) GO4(false, 1, false, 2, true, false, 0, false, true, true, 4, false, true);        // one-pot table in HBM
+        else GO4(false, 1, false, 2, true, false, 0, false, false, true, 2, false, true);
+        return;
+    }
     if (c.uniform) { if (b->max_pots == 1 && c.pipe) GO4(true, 1, true, 2, true, false, 0, false, true, false, 4); else GO4M2(true, 2, true, false); }
     else if (c.lds) GO4M2(false, 2, true, true);
     else if (b->max_pots == 1) GO4M2(false, 1, false, true);

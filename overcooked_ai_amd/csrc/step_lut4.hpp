@@ -438,7 +438,7 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
 // NOCONF: no non-floor cell of the layout touches two floor cells (hint OC_BATCH_NO_SHARED_FACES; cramped_room): the two players
 //   can never face the same cell, so player 1 never has to redo its interact on a cell player 0 has just changed
 // CW: bytes of a cell word (2, or 4 for the one-wavefront-per-SIMD instance of small single layouts: see cw_rd)
-// FT8 (MODE 1 with PIPE; option OC_OPT_FLAGS_TILED8): the flags array is tiled by 8 steps — flags[k / 8][e][k % 8] — so that a
+// FT8 (MODE 1 / 2 instances; option OC_OPT_FLAGS_TILED8): the flags array is tiled by 8 steps — flags[k / 8][e][k % 8] — so that a
 //   wavefront stores the flag bytes of a whole unrolled block as ONE 512-byte piece of full lines instead of eight 64-byte
 //   pieces in eight far-apart rows (which cost the rollout ~6 % and its run-to-run spread: NOTEBOOK, round 4).  The launch
 //   must start on a block boundary and run whole blocks (t0 and n_steps multiples of 8): no rolled steps
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
     const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
     float4* rew_k = rewards ? rewards + (int64_t)blockIdx.x * BLOCK : nullptr;  // wave-uniform row pointers
     const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));  // first lane of this wavefront
-    static_assert(!FT8 || (MODE == 1 && OUT && PIPE && !EV), "the tiled flags array is served by the pipelined joint-table instances");
+    static_assert(!FT8 || ((MODE == 1 || MODE == 2) && OUT && !EV), "the tiled flags array is served by joint-table and per-env-terrain instances");
     uint8_t* flg_k = flags ? flags + ((int64_t)blockIdx.x * BLOCK + wave_base) * (FT8 ? 8 : 1) : nullptr;  // (FT8: the tile row of 8 steps)
     uint32_t flt_lo = 0, flt_hi = 0;  // FT8: the flag bytes of the block's steps 0..3 / 4..7
     const uint32_t lane = threadIdx.x & 63u;
@@ -909,8 +909,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
         if (!(OUT && k8 >= 0)) { epsh.x += rw.z; epsh.y += rw.w; }
         step_k += 1u;
     };
-    // after the eight steps of an unrolled block
+    // after the eight steps of an unrolled block (FT8: first the block's flag tile — 8 bytes per env, 512 contiguous bytes
+    // per wavefront)
     auto advance_rows = [&]() __attribute__((always_inline)) {
+        if (FT8) {
+            const uint64_t tile = ((uint64_t)flt_hi << 32) | flt_lo;
+            asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lane * 8u), "v"(tile), "s"(flg_k) : "memory");
+        }
         if (OUT) { rew_k += 8 * n; flg_k += 8 * n; }
     };
 
@@ -1010,10 +1015,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
             pstep(w.w3, true, 6, 1);
             w = inc.words();
             pstep(w.w0, false, 7, 0);  // the look-ahead digit of step 7 is the next block's first
-            if (FT8) {  // the block's flag tile: 8 bytes per env, 512 contiguous bytes per wavefront
-                const uint64_t tile = ((uint64_t)flt_hi << 32) | flt_lo;
-                asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lane * 8u), "v"(tile), "s"(flg_k) : "memory");
-            }
             advance_rows();
         }
         for (; k < n_steps; ++k) { const uint32_t xn = word_of(t0 + k + 1); pstep(xn, ((t0 + k + 1) & 1) != 0, -1, 0); }  // the tail

@@ -1243,6 +1243,32 @@ def test_rollout_random_with_flags_tiled_by_8_steps(gpu):
             assert torch.equal(VecOvercookedEnv.untile_flags(fl_a), fl_b), (n, horizon, K)
             assert torch.equal(rew_a, rew_b) and torch.equal(a.state, b.state) and torch.equal(a.ep_returns, b.ep_returns), (n, horizon, K)
             assert int((fl_b & 1).sum()) > 0 or horizon == 400  # (episode ends are inside the launches)
+    # the per-env-terrain instances that write the tiled array: the 5-layout mix (table in LDS, one wavefront per SIMD or less)
+    # and a one-pot table of more than 32 layouts (in HBM), with and without the one-step-ahead reads (131 072 envs)
+    mix = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+    forty = LayoutTable([spec_from_name(nm) for nm in ("cramped_room", "forced_coordination_tomato", "cramped_room_tomato",
+                                                         "cramped_room_single") if spec_from_name(nm).num_players == 2
+                         and len(spec_from_name(nm).cells_of("P")) == 1] * 20, pad_to=(9, 5))
+    assert len(forty) > 32 and forty.max_pots == 1
+    for tab, n, K in ((mix, 3000, 48), (forty, 2500, 32), (forty, 131072, 16)):
+        lid = (np.arange(n) % len(tab)).astype(np.uint16)
+        st = np.zeros((tab.n_planes, n, 16), np.uint8)
+        for l in range(len(tab)):
+            idx = np.nonzero(lid == l)[0]
+            st[:, idx] = random_packed_states(tab.specs[l], len(idx), rng, timestep_max=9)
+        a = make_env(tab, n, gpu, horizon=24, auto_reset=True, seed=5, layout_id=lid)
+        b = make_env(tab, n, gpu, horizon=24, auto_reset=True, seed=5, layout_id=lid)
+        a.set_packed_state(st)
+        b.set_packed_state(st)
+        rew_a = torch.full((K, n, 4), 3.0, dtype=torch.float32, device=gpu)
+        rew_b = torch.zeros_like(rew_a)
+        fl_a = torch.full((K // 8, n, 8), 0x55, dtype=torch.uint8, device=gpu)
+        fl_b = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
+        a.rollout_random(K, rew_a, fl_a, flags_tiled8=True)
+        b.rollout_random(K, rew_b, fl_b)
+        assert torch.equal(VecOvercookedEnv.untile_flags(fl_a), fl_b), (len(tab), n)
+        assert torch.equal(rew_a, rew_b) and torch.equal(a.state, b.state) and torch.equal(a.ep_returns, b.ep_returns), (len(tab), n)
+        assert int((fl_b & 4).sum()) > 0
     # refused: a launch that is not whole blocks, a step counter off a block boundary, a batch another kernel serves
     a = make_env(table, 256, gpu, horizon=400, auto_reset=True, seed=1)
     rew = torch.zeros((16, 256, 4), dtype=torch.float32, device=gpu)
