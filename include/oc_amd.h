@@ -98,10 +98,13 @@ extern "C" {
                                      (k / 8, e, k % 8) holds the OC_F_* bits of env e after step k of the call — so that a
                                      wavefront writes the flags of 8 steps as 512 contiguous bytes instead of 64 bytes in each
                                      of 8 rows (worth ~6 % of the rollout rate and its run-to-run spread on MI355X).  Needs
-                                     t0 and n_steps to be multiples of 8, d_rewards and an 8-byte aligned d_flags, and a
-                                     batch the pipelined joint-table kernel serves (one two-player, one-pot layout with at
-                                     most 6 free cells and no shared faced cells — cramped_room —, at most ~98 000 envs, no
-                                     event sink); OC_EINVAL otherwise */
+                                     t0 and n_steps to be multiples of 8, d_rewards and an 8-byte aligned d_flags, no event
+                                     sink, and a batch one of these kernels serves: the pipelined joint-table kernel (one
+                                     two-player, one-pot layout with at most 6 free cells and no shared faced cells —
+                                     cramped_room —, at most ~98 000 envs) or the per-env-terrain kernels of mixed two-player
+                                     tables (up to 32 layouts: at most ~98 000 envs; one-pot tables of more layouts: any
+                                     batch size) — BASELINE configs[1], [3], [4]; OC_EINVAL otherwise, so a caller can try
+                                     it once and fall back */
 
 /* OcBatch.batch_flags */
 #define OC_BATCH_TWO_PLAYERS 0x1u /* every layout of the table has exactly 2 players */
