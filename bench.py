@@ -3,7 +3,9 @@
 
 Workload (BASELINE.json configs[1] / SURVEY.md §8d-2): 65 536 parallel cramped_room envs PER GPU, uniform random
 policy drawn in-kernel with Philox, horizon 400 with auto-reset to the standard start state, outputs written
-every step (4 x f32 rewards + 1 flag byte per env-step).  A "step" is one batched transition of all envs of a
+every step (4 x f32 rewards + 1 flag byte per env-step; the flag bytes as flags[step / 8][env][step % 8], the C-ABI's
+OC_OPT_FLAGS_TILED8 layout, wherever the kernel that serves the batch writes it — `config.flags_layout` says which, and
+`--flags-layout step` asks for flags[step][env]).  A "step" is one batched transition of all envs of a
 GPU.  The timed region launches oc_rollout_random with --fuse transitions per launch; `value` is whole-job env-steps/s
 over all ranks (weak scaling: every rank owns 65 536 envs, disjoint Philox streams via env_offset).
 
