@@ -72,6 +72,8 @@ def parse():
                          "lossless encoding every step; 4 = 5-layout mix padded to 9x5; 5 = 4096 generated 9x5 terrains")
     ap.add_argument("--lane-pair", action="store_true", help="force the two-lanes-per-env rollout kernel")
     ap.add_argument("--predicate-interact", action="store_true", help="lane-per-env kernel with the predicate-network interact (v2)")
+    ap.add_argument("--one-wavefront", action="store_true",
+                    help="OC_OPT_ONE_WAVEFRONT: keep every env-step in one wavefront (no mover / interact split of the per-env-terrain step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the step-API and encode side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -567,7 +569,8 @@ def measure_traffic(args, kernel, tiled8=False):
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", str(args.config), "--envs", str(args.envs),
              "--fuse", str(args.fuse), "--layout", args.layout, "--terrains", str(args.terrains),
              "--flags-layout", "tiled8" if tiled8 else "step"]  # (the child takes the parent's decision: no probe launch in the counters)
-    for flag, on in (("--lane-pair", args.lane_pair), ("--predicate-interact", args.predicate_interact)):
+    for flag, on in (("--lane-pair", args.lane_pair), ("--predicate-interact", args.predicate_interact),
+                     ("--one-wavefront", args.one_wavefront)):
         if on:
             child.append(flag)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
@@ -798,6 +801,7 @@ def rollout_workload_env(args, wl, n, rank, dev, VecOvercookedEnv):
                                layout_id=wl["lid"])
         env.lane_pair = getattr(args, "lane_pair", False)
         env.predicate_interact = getattr(args, "predicate_interact", False)
+        env.one_wavefront = getattr(args, "one_wavefront", False)
         return env
     return make_env
 

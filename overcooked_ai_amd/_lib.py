@@ -13,6 +13,7 @@ OPT_LANE_PAIR = 0x4
 OPT_PREDICATE_INTERACT = 0x8
 OPT_ONE_KERNEL = 0x20
 OPT_FLAGS_TILED8 = 0x40
+OPT_ONE_WAVEFRONT = 0x80
 BATCH_TWO_PLAYERS = 0x1
 BATCH_NEW_DYNAMICS = 0x2
 BATCH_UNIFORM_SHAPING = 0x4

@@ -29,18 +29,53 @@ def hipcc_path():
     return "hipcc"
 
 
+_SRC_SUFFIXES = (".hip", ".hpp", ".h")
+
+
+def _source_files():
+    """The regular source files the library is built from (kernel sources + the C-ABI header): build debris in csrc/
+    (object directories of a running or interrupted build) is not a dependency."""
+    csrc = os.path.dirname(SRC)
+    files = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(_SRC_SUFFIXES)]
+    return [p for p in files if os.path.isfile(p)] + [HDR]
+
+
+def strip_comments(text):
+    """C/C++ source without comments and with whitespace runs collapsed: what the compiler sees, near enough.  String
+    and character literals are kept verbatim (a '//' inside one is not a comment)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            out.append(" ")
+            i = n if j < 0 else j + 2
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def source_hash():
-    """sha256 (first 16 hex digits) over the kernel sources and the C-ABI header: profiles that bench.py replays
-    (profiles/traffic.json, profiles/sq_counters.json) carry it, and are dropped when it no longer matches."""
+    """sha256 (first 16 hex digits) over the comment-stripped, whitespace-normalised kernel sources and C-ABI header:
+    profiles that bench.py replays (profiles/traffic.json, profiles/sq_counters.json) carry it and are dropped when it
+    no longer matches.  Comment-only edits (docs in oc_amd.h) leave it unchanged, so that they do not void the stored
+    profiles of a binary they did not change."""
     import hashlib
 
     h = hashlib.sha256()
-    csrc = os.path.dirname(SRC)
-    for p in sorted(os.listdir(csrc)) + [HDR]:
-        path = p if os.path.isabs(p) else os.path.join(csrc, p)
-        if os.path.isfile(path):
-            h.update(os.path.basename(path).encode())
-            h.update(open(path, "rb").read())
+    for path in _source_files():
+        h.update(os.path.basename(path).encode())
+        h.update(strip_comments(open(path, "r", encoding="utf-8", errors="replace").read()).encode())
     return h.hexdigest()[:16]
 
 
@@ -48,9 +83,7 @@ def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    csrc = os.path.dirname(SRC)
-    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [HDR]
-    return any(os.path.getmtime(p) > t for p in deps if os.path.exists(p))
+    return any(os.path.getmtime(p) > t for p in _source_files() if os.path.exists(p))
 
 
 UNITS = (("oc_amd.hip", ()), ("rollout4.hip", ("-DOC_R4_PART=0",)), ("rollout4.hip", ("-DOC_R4_PART=1",)),
@@ -64,27 +97,40 @@ def build_extension(force=False, verbose=False, defines=(), out=None):
     lib = out or LIB
     if not force and out is None and not is_stale():
         return LIB
-    objdir = os.path.join(PKG, "csrc", "_obj", "%d" % os.getpid())
-    os.makedirs(objdir, exist_ok=True)
+    import shutil
+    import tempfile
+
+    # objects go to a private temporary directory OUTSIDE csrc/ (round 4 kept them in csrc/_obj, whose mtime then
+    # marked the library stale after every build)
+    objdir = tempfile.mkdtemp(prefix="oc_amd_obj_")
     csrc = os.path.dirname(SRC)
     base = [hipcc_path(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", *SCHED, "-fPIC", *defines]
     procs, objs = [], []
-    for i, (src, flags) in enumerate(UNITS):
-        obj = os.path.join(objdir, "u%d.o" % i)
-        cmd = base + list(flags) + ["-c", "-o", obj, os.path.join(csrc, src)]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
-    for cmd, p in procs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
     tmp = lib + ".%d.tmp" % os.getpid()
-    subprocess.check_call([hipcc_path(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs)
-    os.replace(tmp, lib)
-    for o in objs:
-        os.remove(o)
-    os.rmdir(objdir)
+    try:
+        for i, (src, flags) in enumerate(UNITS):
+            obj = os.path.join(objdir, "u%d.o" % i)
+            cmd = base + list(flags) + ["-c", "-o", obj, os.path.join(csrc, src)]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+            objs.append(obj)
+        failed = None
+        for cmd, p in procs:
+            if p.wait() != 0 and failed is None:
+                failed = (p.returncode, cmd)
+        if failed:
+            raise subprocess.CalledProcessError(*failed)
+        subprocess.check_call([hipcc_path(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs)
+        os.replace(tmp, lib)
+    finally:
+        for _, p in procs:  # a failed sibling: do not leave compilers running behind the exception
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+        shutil.rmtree(objdir, ignore_errors=True)
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return lib
 
 

@@ -38,6 +38,17 @@ constexpr size_t lds4_bytes(size_t cell_rows) {
                            (uint32_t)c.seed, (uint32_t)(c.seed >> 32), c.env_offset, c.t0, c.n_steps, c.sa, c.ea);  \
     } while (0)
 
+// MODE 3 (two wavefronts per 64 envs: step_lut4.hpp): workgroups of 2 x BLOCK threads over BLOCK envs, a third spare cell row
+#define GO4D(U, MP, LL, FT8F)                                                                                       \
+    do {                                                                                                            \
+        const size_t smem4 = lds4_bytes<U, MP, LL, 3, true, false, 0, false, true, true, 4, false, FT8F>(cell_rows + 1); \
+        if (!want_lds(k_rollout4<U, MP, LL, 3, true, false, 0, false, true, true, 4, false, FT8F>, smem4)) break;   \
+        hipLaunchKernelGGL((k_rollout4<U, MP, LL, 3, true, false, 0, false, true, true, 4, false, FT8F>), grid4, dim3(2 * BLOCK), smem4, c.stream, \
+                           b->d_layouts, b->n_layouts, b->d_layout_id, (uint4*)c.d_state, (float4*)c.d_rewards, c.d_flags, \
+                           (float4*)c.d_ep_returns, b->n_envs, b->width, c.n_obj, c.horizon, c.options,             \
+                           (uint32_t)c.seed, (uint32_t)(c.seed >> 32), c.env_offset, c.t0, c.n_steps, c.sa, c.ea);  \
+    } while (0)
+
 #define OC_R4_PROLOGUE                                                       \
     const OcBatch* b = c.b;                                                  \
     const size_t cell_rows = (size_t)c.n_obj * 16 + 2; /* + two spare words per lane (nopot_off) */ \
@@ -75,6 +86,11 @@ void launch_rollout4_mode2(const Rollout4Call& c) {
     do {                                                                                                  \
         if (c.pipe) GO4(U, MP, LL, 2, true, false, 0, false, true, RUF, 4); else GO4(U, MP, LL, 2, true, false, 0, false, false, RUF); \
     } while (0)
+    if (c.duo) {  // whole workgroups of envs, whole 8-step blocks, at most one workgroup per CU: mover + interact wavefronts
+        if (c.lds) { if (c.tiled8) GO4D(false, 2, true, true); else GO4D(false, 2, true, false); }
+        else { if (c.tiled8) GO4D(false, 2, false, true); else GO4D(false, 2, false, false); }
+        return;
+    }
     if (c.tiled8) {  // OC_OPT_FLAGS_TILED8: the instances BASELINE configs[3] / [4] run (oc_rollout_random has checked the conditions)
         if (c.lds) GO4(false, 2, true, 2, true, false, 0, false, true, true, 4, false, true);               // mixed table in LDS, pipelined
         else if (c.pipe) GO4(false, 1, false, 2, true, false, 0, false, true, true, 4, false, true);        // one-pot table in HBM

@@ -126,6 +126,15 @@ __device__ __forceinline__ uint4 lds_rd128(uint32_t a) {
     const oc_u32x4 v = *(const OC_LDS oc_u32x4*)(uintptr_t)a;
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+typedef uint32_t oc_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 lds_rd64(uint32_t a) {
+    const oc_u32x2 v = *(const OC_LDS oc_u32x2*)(uintptr_t)a;
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void lds_wr64(uint32_t a, uint32_t x, uint32_t y) {
+    const oc_u32x2 v = {x, y};
+    *(OC_LDS oc_u32x2*)(uintptr_t)a = v;
+}
 __device__ __forceinline__ void lds_wr16(uint32_t a, uint32_t v) { *(OC_LDS uint16_t*)(uintptr_t)a = (uint16_t)v; }
 __device__ __forceinline__ void lds_wr32(uint32_t a, uint32_t v) { *(OC_LDS uint32_t*)(uintptr_t)a = v; }
 __device__ __forceinline__ void lds_wr8(uint32_t a, uint32_t v) { *(OC_LDS uint8_t*)(uintptr_t)a = (uint8_t)v; }
@@ -164,6 +173,11 @@ __device__ __forceinline__ uint32_t lut4_addr(uint32_t off, uint32_t h, uint32_t
 // Two spare cell words per lane behind the grid: row n_obj * 16 takes the "ready" stores of pots that are not ripe, row
 // n_obj * 16 + 1 is what the unused pot slots of a lane point at (an empty pot for ever: no pot slot needs a validity test)
 template <int CW> __device__ __forceinline__ uint32_t nopot_off(int n_obj) { return ((uint32_t)n_obj * 16u + 1u) * (BLOCK * CW); }
+// MODE 3, a third spare word per lane (row n_obj * 16 + 2): what a player that does NOT interact "faces" — terrain type 7, whose
+// LUT entries are no-ops for every hand (the result is the word itself and the hand unchanged), so that the interact
+// wavefront runs the same look-up for every player and step: no second LUT variant, no address select
+constexpr uint32_t KB_NOTHING = 7u * 30u;
+template <int CW> __device__ __forceinline__ uint32_t noact_off(int n_obj) { return ((uint32_t)n_obj * 16u + 2u) * (BLOCK * CW); }
 
 template <int MAXP, int CW>
 __device__ __forceinline__ void load_env4(const LayC& C, const Lay L, const uint4* __restrict__ st, int64_t n, int64_t e,
@@ -384,7 +398,8 @@ __device__ __forceinline__ uint32_t joint_action_of(uint32_t w0, uint32_t w1, ui
 //    LAY               staged layout records
 //    FL / FI           free-cell list / cell -> free-cell index (MODE 1)
 //    CT                [32] cook time by the low five bits of the soup code (one layout)
-//    CELLS             cell words u16 / u32 [n_obj * 16 + 1][BLOCK]
+//    RING              MODE 3 only: mover -> interact records, [3][8][BLOCK] x 8 bytes
+//    CELLS             cell words u16 / u32 [n_obj * 16 + 2 (+ 1 with MODE 3)][BLOCK]
 // With u16 table entries (CW = 2) the move table comes first, so that row addresses and the LUT addresses in ACT fit 16 bits;
 // with u32 entries (CW = 4, an 85 KB move table) the small tables come first instead, so that THEIR addresses stay below
 // 64 KiB and fold into the 16-bit offset field of the DS instructions.
@@ -397,7 +412,12 @@ struct Lds4 {
     static constexpr int LAY = LUT + LUT_BYTES, LAY_BYTES = LAY_LDS ? (UNIFORM ? 256 : LDS_LAYOUT_MAX * 256) : 16;
     static constexpr int FL = LAY + LAY_BYTES, FI = FL + 16, CT = FI + (MODE == 1 ? OC_MAX_CELLS : 0);
     static constexpr int MVJ = TABLE_FIRST ? 0 : CT + 32;  // LDS address of the move table
-    static constexpr int CELLS = TABLE_FIRST ? CT + 32 : MVJ + MVJ_CAP;
+    // MODE 3: the ring the mover wavefronts feed the interact wavefronts through — three buffers of one 8-step block each,
+    // [step in block][lane] records of two u32 (the LDS addresses of the two cell words the players act on in that step)
+    static constexpr int RING_BUF = 8 * BLOCK * 8, RING_BYTES = MODE == 3 ? 3 * RING_BUF : 0;
+    static constexpr int RING = TABLE_FIRST ? CT + 32 : MVJ + MVJ_CAP;
+    static constexpr int CELLS = RING + RING_BYTES;
+    static_assert(MODE != 3 || (CW == 4 && RING % 8 == 0), "the ring goes with 32-bit cell words");
     static_assert(CW == 4 || MVJ_CAP + ACT_BYTES + LUT4_KEYS * 16 < 65536, "row / LUT addresses are u16 in the tables");
     static_assert(CW == 2 || CT + 32 < 65536, "the small tables' addresses must fit the DS offset field");
 };
@@ -431,6 +451,17 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
 //   static terrain, so the pose runs ONE STEP AHEAD of the interacts on a per-lane 64-bit floor mask (no cell reads for the
 //   move targets), the faced cells of the next step are read as soon as this step's cell writes are issued (PIPE), and the
 //   ~25 VALU of the movement fill the shadow of this step's LUT reads
+// MODE 3: MODE 2's transition with the work of an env-step split between TWO wavefronts (workgroups of 2 x BLOCK threads:
+//   wavefronts 0..3 interact, wavefronts 4..7 move).  A wavefront alone on its SIMD issues one instruction every 6-8 clocks
+//   (tools/issue_rate.hip: a dependent integer VALU stream with LDS look-ups; the VALU itself is busy 4 clocks per
+//   instruction), and at 65 536 envs every SIMD holds exactly one: MODE 2's ~125 instructions per env-step cost ~780 clocks
+//   however little each of them does.  resolve_movement needs only the static terrain and the actions, so the whole pose
+//   chain — Philox block, action digits, floor test, both collision rules, orientations, the horizon with its restart pose,
+//   the flag bytes — is computed by a MOVER wavefront that runs up to two 8-step blocks ahead and leaves, per step and lane,
+//   the LDS addresses of the two cell words the players act on (the faced cell, or a spare "nothing to interact with" word
+//   when the action is not INTERACT: one LUT variant, no address select) in a ring in LDS; the INTERACT wavefront of the same
+//   64 envs runs look-up, interact, cell writes, env effects, rewards and the rare branch.  One s_barrier per 8-step
+//   block keeps the mover at most two blocks ahead; the two wavefronts of a SIMD fill each other's waits.
 // RU: every layout of the table has the same shaping rewards and dynamics flag (hint OC_BATCH_UNIFORM_SHAPING): one LUT
 //   variant whose entries carry the reward floats, as with a single layout
 // OLD: some layout of the table may use old dynamics (auto-start of full pots in the env effects)
@@ -450,7 +481,7 @@ template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, in
 #ifndef OC_R4_WAVES_MAX
 #define OC_R4_WAVES_MAX 4
 #endif
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_WAVES_MAX))) void k_rollout4(const OcLayout* __restrict__ g_layouts, int n_layouts,
+__global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_WAVES_MAX))) void k_rollout4(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                     const uint16_t* layout_id, uint4* st,
                                                     float4* __restrict__ rewards, uint8_t* __restrict__ flags,
                                                     float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,
@@ -465,8 +496,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
     uint4* const s_lut = reinterpret_cast<uint4*>(s_dyn4 + M::LUT);
     uint8_t* const s_fl = s_dyn4 + M::FL;
     uint8_t* const s_fi = s_dyn4 + M::FI;
-    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const bool active = e < n;
+    // MODE 3: lanes tid of the two halves of the workgroup share env e — threads 0..BLOCK-1 interact, the others move
+    static_assert(MODE != 3 || (MAXP <= 2 && OUT && !OLD && !EV && PIPE && (UNIFORM || RU) && CW == 4 && !NOCONF),
+                  "MODE 3 = the pipelined MODE 2 instance, split");
+    const uint32_t tid = MODE == 3 ? (threadIdx.x & (uint32_t)(BLOCK - 1)) : threadIdx.x;
+    const bool mover = MODE == 3 && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + tid;
+    const bool active = e < n;  // (MODE 3: the host launches whole workgroups only — every wavefront meets every barrier)
     Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains a barrier
     {
         const uint4* src = reinterpret_cast<const uint4*>(&g_lut4);
@@ -497,15 +533,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
         build_joint_table<CW>(L, W, s_dyn4 + M::MVJ, (uint32_t)M::MVJ, s_fl, s_fi, s_dyn4 + M::CELLS);  // (scratch: the cell words come later)
     }
     __syncthreads();
-    if (!active) return;
-    const uint32_t col = (uint32_t)M::CELLS + threadIdx.x * (uint32_t)CW;  // LDS address of this lane's column of cell words
+    if (MODE != 3 && !active) return;
+    const uint32_t col = (uint32_t)M::CELLS + tid * (uint32_t)CW;  // LDS address of this lane's column of cell words
     // (L, C, lut_var, two and MODE 2's floor mask change when a restart moves the env to another layout: StartArgs.regen_count)
     LayC C = load_consts<UNIFORM>(L);
     uint32_t lut_var = (uint32_t)M::LUT + (RUX ? 0u : (C.old_dyn ? (uint32_t)LUT4_BYTES : 0u));  // this lane's LUT
     const uint32_t delta4 = make_delta4(W);
     Env4<MAXP> s;
-    load_env4<MAXP, CW>(C, L, st, n, e, n_obj, horizon, s, col);
-    bool two = MODE == 1 || MODE == 2 || s.pos1 != 0xFFu;
+    if (!mover) load_env4<MAXP, CW>(C, L, st, n, e, n_obj, horizon, s, col);
+    if (MODE == 3 && !mover) cw_wr<CW>(col + noact_off<CW>(n_obj), cw_make<CW>(0u, KB_NOTHING));
+    bool two = MODE == 1 || MODE == 2 || MODE == 3 || s.pos1 != 0xFFu;
     uint64_t fm = 0;  // MODE 2: bit c = cell c is floor (static per layout)
     auto floor_mask_of = [&](const Lay Lx) __attribute__((always_inline)) {
         uint64_t m = 0;
@@ -517,7 +554,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
         }
         return m;
     };
-    if (MODE == 2) fm = floor_mask_of(L);
+    if (MODE == 2 || (MODE == 3 && mover)) fm = floor_mask_of(L);
     auto joint_row = [&]() {  // LDS address of the row of the joint pose (pos0, or0, pos1, or1)
         const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR];
         return (uint32_t)M::MVJ + ((s_fi[s.pos0] * 4u + s.or0) * NP + (s_fi[s.pos1] * 4u + s.or1)) * (uint32_t)Mvj<CW>::ROW_BYTES;
@@ -533,11 +570,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
     const uint64_t g = (uint64_t)(env_offset + e);
     const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
     float4* rew_k = rewards ? rewards + (int64_t)blockIdx.x * BLOCK : nullptr;  // wave-uniform row pointers
-    const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));  // first lane of this wavefront
-    static_assert(!FT8 || ((MODE == 1 || MODE == 2) && OUT && !EV), "the tiled flags array is served by joint-table and per-env-terrain instances");
+    const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u));  // first lane of this wavefront
+    static_assert(!FT8 || ((MODE == 1 || MODE == 2 || MODE == 3) && OUT && !EV), "the tiled flags array is served by joint-table and per-env-terrain instances");
     uint8_t* flg_k = flags ? flags + ((int64_t)blockIdx.x * BLOCK + wave_base) * (FT8 ? 8 : 1) : nullptr;  // (FT8: the tile row of 8 steps)
     uint32_t flt_lo = 0, flt_hi = 0;  // FT8: the flag bytes of the block's steps 0..3 / 4..7
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = tid & 63u;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t step_k = 0;  // index of the step within this launch (wave-uniform): the epoch offset of a restart
 
@@ -580,7 +617,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
     uint32_t rew_off[8], flg_off[8];
 #pragma unroll
     for (int k8 = 0; k8 < 8; ++k8) {
-        rew_off[k8] = (threadIdx.x + (uint32_t)k8 * (uint32_t)n) * 16u;
+        rew_off[k8] = (tid + (uint32_t)k8 * (uint32_t)n) * 16u;
         flg_off[k8] = lane + (uint32_t)k8 * (uint32_t)n;
     }
     // The look-ups of a step: both players' LUT entries against the pre-step cells (resolve_interacts, mdp.py:1432-1579)
@@ -610,7 +647,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
         // may be rewritten: the two instructions behind it.
         typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
         const u64x2 q = {p.lo, p.hi};
-        if (FT8) {  // (the flag byte has gone into the block's tile; the second wait state is a no-op)
+        if (FT8 || MODE == 3) {  // (the flag byte has gone into the block's tile — MODE 3: the mover stores the flags; the second wait state is a no-op)
             asm volatile("global_store_dwordx4 %1, %2, %4\n\tv_pk_add_f32 %0, %0, %3\n\ts_nop 0"
                          : "+v"(epsh) : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k) : "memory");
         } else {
@@ -660,7 +697,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
             nf0 = col + (m1 & 0xFFFFu);
             nf1 = col + (m1 >> 16);
         }
-        if ((MODE == 1 || MODE == 2) && PIPE) {  // the next step's cells: everything this step writes to the grid has been issued
+        if ((MODE == 1 || MODE == 2 || MODE == 3) && PIPE) {  // the next step's cells: everything this step writes to the grid has been issued
             nc0 = cw_rd<CW>(nf0);
             nc1 = cw_rd<CW>(nf1);
             rd_pots(npw);
@@ -825,6 +862,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
                         m0 = joint_row();
                         m1 = lds_rd32(m0 + (uint32_t)Mvj<CW>::FACES);
                         m2 = CW == 2 ? lds_rd16(m0 + ja2n) : lds_rd32(m0 + ja2n);
+                    } else if (MODE == 3) {
+                        // (the mover has seen the same horizon: its record of the next step already faces from the start pose)
                     } else if (MODE == 2) {
                         m0 = s.pos0; m2 = s.pos1; m3 = s.or0; m4 = s.or1;
                         nf0 = col + step_cell(s.pos0, s.or0, delta4) * (BLOCK * CW);
@@ -841,7 +880,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
                 nf0 = col + (m1 & 0xFFFFu);
                 nf1 = col + (m1 >> 16);
             }
-            if ((MODE == 1 || MODE == 2) && PIPE && grid_changed) {  // read the next step's cells again
+            if ((MODE == 1 || MODE == 2 || MODE == 3) && PIPE && grid_changed) {  // read the next step's cells again
                 nc0 = cw_rd<CW>(nf0);
                 nc1 = cw_rd<CW>(nf1);
                 rd_pots(npw);
@@ -886,7 +925,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
             if (ea.events) ea.events[(int64_t)step_k * n + e] = ev;
             count_events(ea, e, ev, done, (options & OC_OPT_AUTO_RESET) != 0u);
         }
-        if (FT8 && k8 >= 0) {  // this step's byte of the block's flag tile (k8 is a constant of the unrolled step)
+        if (FT8 && MODE != 3 && k8 >= 0) {  // this step's byte of the block's flag tile (k8 is a constant of the unrolled step)
             uint32_t& half = (k8 & 4) ? flt_hi : flt_lo;
             half = (k8 & 3) == 0 ? fl : (half | (fl << (8 * (k8 & 3))));
         }
@@ -898,7 +937,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
             Pend now = {q_lo, q_hi, fl};
             flush(now, k8);  // (with the episode returns' packed add)
         } else {
-            if (OUT || rew_k) rew_k[threadIdx.x] = rw;
+            if (OUT || rew_k) rew_k[tid] = rw;
             if (OUT || flg_k) store_flag_byte(flg_k, lane, fl);
             if (OUT || rew_k) rew_k += n;
             if (OUT || flg_k) flg_k += n;
@@ -912,12 +951,112 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
     // after the eight steps of an unrolled block (FT8: first the block's flag tile — 8 bytes per env, 512 contiguous bytes
     // per wavefront)
     auto advance_rows = [&]() __attribute__((always_inline)) {
-        if (FT8) {
+        if (FT8 && MODE != 3) {
             const uint64_t tile = ((uint64_t)flt_hi << 32) | flt_lo;
             asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lane * 8u), "v"(tile), "s"(flg_k) : "memory");
         }
         if (OUT) { rew_k += 8 * n; flg_k += 8 * n; }
     };
+
+
+    // ---- MODE 3, the MOVER wavefronts: resolve_movement (mdp.py:1644-1727) for the whole launch, one 8-step block at a time,
+    //      up to two blocks ahead of the interact wavefronts.  Per step and lane one ring record {a0, a1}: the LDS address of the
+    //      cell word player p acts on at that step — the cell it faces when its action is INTERACT, else the lane's "nothing"
+    //      word.  The horizon is decided here as well (it depends on the step count alone): the flag bytes are stored by the
+    //      mover, and a restart puts the pose back to the start pose (standard, drawn, or on a re-drawn layout — the same
+    //      counter-based draws as the interact wavefront's env_reset4_draw, keyed by (seed, global env, epoch)).
+    //      Block n_steps / 8 (one past the launch) is a stub: record 0 = {nothing, nothing} for the last step's look-ahead
+    //      and record 1 = the final pose, which the interact wavefront puts into the stored state.
+    constexpr uint32_t RING_SLOT = (uint32_t)BLOCK * 8u;  // bytes of one step's records
+#define OC_DUO_BARRIER_MOVER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define OC_DUO_BARRIER() asm volatile("s_barrier" ::: "memory")
+    if (MODE == 3 && mover) {
+        auto ahead = [&](uint32_t c, uint32_t d) __attribute__((always_inline)) {
+            return c + (uint32_t)(int32_t)(int8_t)(uint8_t)__builtin_amdgcn_perm(0u, delta4, d);
+        };
+        const uint4 h = st[e];
+        uint32_t P0 = h.x & 0xFFu, O0 = (h.x >> 8) & 0xFFu, P1 = h.x >> 24, O1 = h.y & 0xFFu;
+        const uint32_t t_in = h.y >> 16;
+        uint32_t tleft = t_in < (uint32_t)horizon ? (uint32_t)horizon - 1u - t_in : 0u;
+        const uint32_t noact = col + noact_off<CW>(n_obj);
+        const uint32_t ring0 = (uint32_t)M::RING + tid * 8u;
+        const int n_blocks = n_steps >> 3;
+        auto produce = [&](int b, uint32_t ring) __attribute__((always_inline)) {
+            if (b >= n_blocks) {  // the stub block
+                lds_wr64(ring, noact, noact);
+                lds_wr64(ring + RING_SLOT, P0 | (O0 << 8) | (P1 << 16) | (O1 << 24), 0u);
+                return;
+            }
+            const Phx4 wb = philox_words(((uint64_t)t0 >> 3) + (uint64_t)b, g_lo, g_hi, seed_lo, seed_hi);
+            uint32_t tile_lo = 0, tile_hi = 0;
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) {
+                // the actions of this step: the base-6 digits of the block's word k8 / 2 (second pair of digits: 36 x)
+                uint32_t x = (k8 >> 1) == 0 ? wb.w0 : (k8 >> 1) == 1 ? wb.w1 : (k8 >> 1) == 2 ? wb.w2 : wb.w3;
+                if (k8 & 1) x *= 36u;
+                const uint32_t a0 = __umulhi(x, 6u), a1 = __umulhi(x * 6u, 6u);
+                const uint32_t f0 = col + ahead(P0, O0) * (BLOCK * CW), f1 = col + ahead(P1, O1) * (BLOCK * CW);
+                lds_wr64(ring + (uint32_t)k8 * RING_SLOT, a0 == 5u ? f0 : noact, a1 == 5u ? f1 : noact);
+                // the pose of the next step, on the static terrain (as MODE 2)
+                const uint32_t t0_ = ahead(P0, a0), t1_ = ahead(P1, a1);
+                uint32_t fb0 = (uint32_t)(fm >> t0_), fb1 = (uint32_t)(fm >> t1_);
+                asm("" : "+v"(fb0));
+                asm("" : "+v"(fb1));
+                const uint32_t np0 = (fb0 & 1u) ? t0_ : P0, np1 = (fb1 & 1u) ? t1_ : P1;
+                const bool collide = (np0 == np1) | ((np0 == P1) & (np1 == P0));
+                const uint32_t q0 = collide ? P0 : np0, q1 = collide ? P1 : np1;
+                O0 = a0 < 4u ? a0 : O0; O1 = a1 < 4u ? a1 : O1;
+                P0 = q0; P1 = q1;
+                // OvercookedEnv.step at the horizon (env.py:266-267, 321-325): the flag byte; a restart moves the players
+                uint32_t fl = 0;
+                const bool done = tleft == 0u;
+                tleft -= 1u;
+                if (__builtin_expect(done, 0)) {
+                    fl = OC_F_DONE;
+                    tleft = 0u;
+                    if (options & OC_OPT_AUTO_RESET) {
+                        fl |= OC_F_RESET;
+                        tleft = (uint32_t)horizon - 1u;
+                        const uint32_t ep_k = sa.epoch + (uint32_t)(b * 8 + k8);
+                        if (sa.enabled) {
+                            if (!UNIFORM && sa.regen_count) {  // (the interact wavefront records the new id in layout_ids)
+                                const uint32_t lid = draw_layout(sa, g, ep_k);
+                                L = LAY_LDS ? Lay{reinterpret_cast<const uint8_t*>(s_lay) + lid * 256u}
+                                            : Lay{reinterpret_cast<const uint8_t*>(g_layouts) + (size_t)lid * 256u};
+                                fm = floor_mask_of(L);
+                            }
+                            const StartDraw d = draw_start(L, g, ep_k, sa.seed_lo, sa.seed_hi, sa.random_start_pos, sa.thresh);
+                            P0 = d.pos0; P1 = d.pos1;
+                        } else {
+                            P0 = L.u8(L_START_POS); P1 = L.u8(L_START_POS + 1);
+                        }
+                        O0 = L.u8(L_START_OR); O1 = L.u8(L_START_OR + 1);
+                    }
+                }
+                if (FT8) {
+                    uint32_t& half = (k8 & 4) ? tile_hi : tile_lo;
+                    half = (k8 & 3) == 0 ? fl : (half | (fl << (8 * (k8 & 3))));
+                } else {
+                    store_flag_byte(flg_k, flg_off[k8], fl);
+                }
+            }
+            if (FT8) {
+                const uint64_t tile = ((uint64_t)tile_hi << 32) | tile_lo;
+                asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lane * 8u), "v"(tile), "s"(flg_k) : "memory");
+            }
+            flg_k += 8 * n;
+        };
+        produce(0, ring0);
+        produce(1, ring0 + (uint32_t)M::RING_BUF);
+        OC_DUO_BARRIER_MOVER();
+        uint32_t wbuf = 2u * (uint32_t)M::RING_BUF;  // (wave-uniform) offset of the buffer block b + 1 goes to
+        for (int b = 1; b < n_blocks; ++b) {
+            produce(b + 1, ring0 + wbuf);
+            wbuf = wbuf == 2u * (uint32_t)M::RING_BUF ? 0u : wbuf + (uint32_t)M::RING_BUF;
+            OC_DUO_BARRIER_MOVER();
+        }
+        return;
+    }
 
     Phx4 w = {0, 0, 0, 0};  // the Philox block of the step being looked at
 #define OC_JA_AT(T, FIRST)                                                                                   \
@@ -1091,6 +1230,43 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
             }
         }
         s.pos0 = P0; s.or0 = O0; s.pos1 = P1; s.or1 = O1;
+    } else if (MODE == 3) {
+        // The INTERACT wavefronts of MODE 3: the step of MODE 2 without its movement — the two cell words a step acts on come
+        // out of the mover's ring (the next step's record is read while this step's look-ups are in flight, its cells right
+        // after this step's cell writes).  Block b's barrier: the mover has finished block b + 1 (whose first record step 7
+        // looks ahead to) and may go on to block b + 2, into the buffer this wavefront has just left.
+        const uint32_t ring0 = (uint32_t)M::RING + tid * 8u;
+        const int n_blocks = n_steps >> 3;
+        OC_DUO_BARRIER();
+        uint32_t fo0, fo1, c0, c1, pw[MAXP];
+        {
+            const uint2 rec = lds_rd64(ring0);
+            fo0 = rec.x; fo1 = rec.y;
+        }
+        c0 = cw_rd<CW>(fo0);
+        c1 = cw_rd<CW>(fo1);
+        rd_pots(pw);
+        auto dstep = [&](int k8, uint32_t next_rec) __attribute__((always_inline)) {
+            const Looked looked = look_up(lut_var, lut_var, c0, c1, pw);
+            const uint2 nrec = lds_rd64(next_rec);
+            uint32_t u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0, nf0 = nrec.x, nf1 = nrec.y, nc0 = 0, nc1 = 0, npw[MAXP];
+            core(fo0, fo1, lut_var, lut_var, c0, c1, 0u, pw, u0, u1, u2, u3, u4, nf0, nf1, nc0, nc1, npw, k8, looked);
+            fo0 = nf0; fo1 = nf1; c0 = nc0; c1 = nc1;
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k) pw[k] = npw[k];
+        };
+        uint32_t rbuf = 0;  // (wave-uniform) offset of the ring buffer that holds the block being run
+        for (int b = 0; b < n_blocks; ++b) {
+            if (b) OC_DUO_BARRIER();
+            const uint32_t cur = ring0 + rbuf;
+            rbuf = rbuf == 2u * (uint32_t)M::RING_BUF ? 0u : rbuf + (uint32_t)M::RING_BUF;
+#pragma unroll
+            for (int k8 = 0; k8 < 7; ++k8) dstep(k8, cur + (uint32_t)(k8 + 1) * RING_SLOT);
+            dstep(7, ring0 + rbuf);
+            advance_rows();
+        }
+        const uint32_t pose = lds_rd32(ring0 + rbuf + RING_SLOT);  // the stub block's second record: the pose after the last step
+        s.pos0 = pose & 0xFFu; s.or0 = (pose >> 8) & 0xFFu; s.pos1 = (pose >> 16) & 0xFFu; s.or1 = pose >> 24;
     } else {
         auto astep = [&](uint32_t a0, uint32_t a1) __attribute__((always_inline)) {
             const uint32_t f0 = step_cell(s.pos0, s.or0, delta4), f1 = two ? step_cell(s.pos1, s.or1, delta4) : f0;
@@ -1143,6 +1319,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_
         }
     }
 #undef OC_JA_AT
+#undef OC_DUO_BARRIER
+#undef OC_DUO_BARRIER_MOVER
     store_env4<MAXP, CW>(C, L, st, n, e, n_obj, horizon, s, col);
     ep.z = epsh.x; ep.w = epsh.y;
     if (ep_returns) ep_returns[e] = ep;

@@ -42,6 +42,7 @@ class VecOvercookedEnv:
             raise _lib.OcAmdError("VecOvercookedEnv needs a ROCm GPU device (got %r); there is no CPU fallback" % device)
         self.auto_reset = bool(auto_reset)
         self.lane_pair = False     # rollout_random: force the lane-pair kernel where the table allows it
+        self.one_wavefront = False # rollout_random: keep every env-step in one wavefront (OC_OPT_ONE_WAVEFRONT: no mover / interact split)
         self.predicate_interact = False  # rollout_random: lane-per-env kernel with the predicate-network interact
         self.one_kernel = False          # step_encode / rollout_encode: the single-kernel path whatever the batch size
         self.seed = int(seed)
@@ -130,7 +131,8 @@ class VecOvercookedEnv:
     @property
     def options(self):
         return ((_lib.OPT_AUTO_RESET if self.auto_reset else 0)
-                | (_lib.OPT_LANE_PAIR if self.lane_pair else 0) | (_lib.OPT_PREDICATE_INTERACT if self.predicate_interact else 0))
+                | (_lib.OPT_LANE_PAIR if self.lane_pair else 0) | (_lib.OPT_PREDICATE_INTERACT if self.predicate_interact else 0)
+                | (_lib.OPT_ONE_WAVEFRONT if self.one_wavefront else 0))
 
     @property
     def reset_epoch(self):

@@ -34,21 +34,27 @@ def _oracle(specs):
     return O.Oracle([O.mdp_from_layout_dict(s.to_layout_dict()) for s in specs])
 
 
-def _long_launch_against_oracle(gpu, table, n, lid=None, env_offset=0, seed=0, steps=T, horizon=HORIZON, start=None, **env_kw):
+def _long_launch_against_oracle(gpu, table, n, lid=None, env_offset=0, seed=0, steps=T, horizon=HORIZON, start=None,
+                                flags_tiled8=False, one_wavefront=False, **env_kw):
+    """flags_tiled8: the launch writes the OC_OPT_FLAGS_TILED8 layout (the instances bench.py times), untiled before the
+    comparison; one_wavefront: OC_OPT_ONE_WAVEFRONT (no mover / interact split where the batch would get it)."""
     from overcooked_ai_amd.vec_env import VecOvercookedEnv
 
     env = VecOvercookedEnv(table, n, horizon=horizon, device=gpu, auto_reset=True, seed=seed, env_offset=env_offset,
                            layout_id=lid, **env_kw)
+    env.one_wavefront = one_wavefront
     orc = _oracle(env.table.specs)
     rew = torch.zeros((steps, n, 4), dtype=torch.float32, device=gpu)
-    fl = torch.zeros((steps, n), dtype=torch.uint8, device=gpu)
+    fl = torch.zeros((steps // 8, n, 8) if flags_tiled8 else (steps, n), dtype=torch.uint8, device=gpu)
     st = env.get_packed_state().copy()
     st_o = orc.reset(orc.new_state(n), layout_id=lid)
     if start is None:
         assert np.array_equal(st, st_o)
     else:
         st_o = st
-    env.rollout_random(steps, rew, fl)  # ONE launch
+    env.rollout_random(steps, rew, fl, flags_tiled8=flags_tiled8)  # ONE launch
+    if flags_tiled8:
+        fl = VecOvercookedEnv.untile_flags(fl)
     ep_o = np.zeros((n, 4), np.float32)
     restarts = shaped = sparse = 0
     for c0 in range(0, steps, 400):
@@ -100,6 +106,104 @@ def test_config3_launch_shape_five_layout_mix_65536_x_4000(gpu):
     lid = ((np.arange(n) + rank * n) % 5).astype(np.uint16)
     sparse, _ = _long_launch_against_oracle(gpu, table, n, lid=lid, env_offset=rank * n)
     assert sparse > 0
+
+
+def _mix_table_and_ids(n, rank):
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    table = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+    return table, ((np.arange(n) + rank * n) % 5).astype(np.uint16)
+
+
+@pytest.mark.parametrize("shape", ["cramped_room_65536", "five_layout_mix_65536", "generated_4096_131072"])
+def test_tiled_flags_launch_shapes_against_oracle(shape, gpu):
+    """The OC_OPT_FLAGS_TILED8 instances — the ones every number of bench.py's default line is timed on (headline: joint-table
+    kernel; configs[3]: the mover / interact kernel on the 5-layout mix; configs[4]: the one-pot per-env-terrain kernel at
+    131 072 envs) — against the ORACLE at exactly those launch shapes: 4 000 fused steps, flags untiled, every reward quad and
+    flag byte, final states, episode returns (VERDICT r4 #3: they used to be compared with their [step][env] siblings only)."""
+    if shape == "cramped_room_65536":
+        sparse, _ = _long_launch_against_oracle(gpu, "cramped_room", 65536, flags_tiled8=True)
+    elif shape == "five_layout_mix_65536":
+        table, lid = _mix_table_and_ids(65536, 5)
+        sparse, _ = _long_launch_against_oracle(gpu, table, 65536, lid=lid, env_offset=5 * 65536, flags_tiled8=True)
+    else:
+        from overcooked_ai_amd.layout_gen import reference_generated_layouts
+        from overcooked_ai_amd.layouts import LayoutTable
+
+        n, K, rank = 131072, 4096, 3
+        lid = ((np.arange(n) + rank * n) % K).astype(np.uint16)
+        sparse, _ = _long_launch_against_oracle(gpu, LayoutTable(reference_generated_layouts(K)), n, lid=lid, env_offset=rank * n,
+                                                flags_tiled8=True)
+    assert sparse > 0
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+@pytest.mark.parametrize("layout", ["asymmetric_advantages", "coordination_ring", "forced_coordination", "counter_circuit", "mix5",
+                                    "generated_4096"])
+def test_mover_interact_split_against_oracle(layout, tiled, gpu):
+    """k_rollout4 MODE 3 (two wavefronts per 64 envs: a mover running ahead of an interact wavefront through a ring in LDS) on
+    every batch kind it serves — single two-player layouts, the 5-layout table in LDS, 4 096 generated terrains read through
+    L2 — against the oracle over episodes of 23 steps with DRAWN start states (so that every restart exercises the mover's own
+    draw of the start pose), tiled and [step][env] flags; then the same launch with OC_OPT_ONE_WAVEFRONT must agree as well."""
+    from overcooked_ai_amd.layout_gen import reference_generated_layouts
+    from overcooked_ai_amd.layouts import LayoutTable
+
+    n, rank = 4096, 2
+    if layout == "mix5":
+        table, lid = _mix_table_and_ids(n, rank)
+    elif layout == "generated_4096":
+        table, lid = LayoutTable(reference_generated_layouts(4096)), ((np.arange(n) * 5 + 1) % 4096).astype(np.uint16)
+    else:
+        table, lid = layout, None
+    kw = dict(lid=lid, env_offset=rank * n, seed=11, steps=96, horizon=23,
+              start={"random_start_pos": True, "rnd_obj_prob_thresh": 0.35}, random_start_pos=True, rnd_obj_prob_thresh=0.35)
+    a = _long_launch_against_oracle(gpu, table, n, flags_tiled8=tiled, **kw)
+    # (single layouts get the tiled flags from the split kernel only: their one-wavefront run writes [step][env] rows)
+    b = _long_launch_against_oracle(gpu, table, n, flags_tiled8=tiled and lid is not None, one_wavefront=True, **kw)
+    assert a == b
+    # standard start states, a launch that begins in the middle of an episode (t0 = 96 from the env's own counter)
+    _long_launch_against_oracle(gpu, table, n, lid=lid, env_offset=rank * n, seed=3, steps=416, horizon=HORIZON, flags_tiled8=tiled)
+
+
+@pytest.mark.parametrize("table_kind", ["generated_4096", "canonical_5"])
+def test_mover_interact_split_with_layouts_redrawn_at_every_restart(table_kind, gpu):
+    """MODE 3 with regen_layout: at a restart BOTH wavefronts of an env draw the next layout — the interact wavefront records
+    it and resets the grid, the mover takes its floor mask and start pose — from the same counter-based stream.  Whole
+    workgroups (16 384 envs), launches of whole 8-step blocks (32 + 40 + 48 steps), horizon 23: five boundaries, layout ids,
+    states, rewards, flags and returns against the oracle, standard and drawn start states, tiled and row flags."""
+    from oracle import oracle as O
+    from overcooked_ai_amd.layout_gen import reference_generated_layouts
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+    from overcooked_ai_amd.vec_env import VecOvercookedEnv
+
+    if table_kind == "generated_4096":
+        table = LayoutTable(reference_generated_layouts(4096))
+    else:
+        table = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+    K, n, horizon, seed, off = len(table), 16384, 23, 29, 7 * 16384
+    orc = _oracle(table.specs)
+    for start_kw in ({}, {"random_start_pos": True, "rnd_obj_prob_thresh": 0.3}):
+        lid = ((np.arange(n) * 11 + 5) % K).astype(np.uint16)
+        lid_o = lid.copy()
+        env = VecOvercookedEnv(table, n, horizon=horizon, device=gpu, auto_reset=True, seed=seed, env_offset=off, layout_id=lid,
+                               regen_layout=True, **start_kw)
+        st = env.get_packed_state().copy()
+        ep_o = np.zeros((n, 4), np.float32)
+        steps = 0
+        for T_, tiled in ((32, False), (40, True), (48, False)):
+            rew = torch.zeros((T_, n, 4), dtype=torch.float32, device=gpu)
+            fl = torch.zeros((T_ // 8, n, 8) if tiled else (T_, n), dtype=torch.uint8, device=gpu)
+            env.rollout_random(T_, rew, fl, flags_tiled8=tiled)
+            if tiled:
+                fl = VecOvercookedEnv.untile_flags(fl)
+            sp = O.start_spec(seed, off, 1 + steps, regen=(0, K), **start_kw)
+            rew_o, fl_o = orc.rollout_random(st, T_, horizon=horizon, options=1, seed=seed, env_offset=off, t0=steps,
+                                             layout_id=lid_o, ep_returns=ep_o, start=sp)
+            steps += T_
+            assert np.array_equal(env.layout_ids(), lid_o), "layout ids differ after %d steps" % steps
+            assert np.array_equal(fl.cpu().numpy(), fl_o) and np.array_equal(rew.cpu().numpy(), rew_o), steps
+            assert np.array_equal(env.get_packed_state(), st) and np.array_equal(env.ep_returns.cpu().numpy(), ep_o)
+        assert (lid_o != lid).mean() > 0.75
 
 
 def test_long_launch_with_drawn_start_states_131072(gpu):
