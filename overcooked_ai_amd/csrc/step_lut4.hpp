@@ -135,6 +135,17 @@ __device__ __forceinline__ void lds_wr64(uint32_t a, uint32_t x, uint32_t y) {
     const oc_u32x2 v = {x, y};
     *(OC_LDS oc_u32x2*)(uintptr_t)a = v;
 }
+// Progress counters between the two wavefronts of a MODE 3 pair.  poll: a fresh wave-uniform read (never a value the
+// compiler has kept in a register); post: lane 0 writes — the LDS executes a wavefront's instructions in order, so whatever
+// the wavefront wrote (or read) before is done when the other side sees the new count.
+__device__ __forceinline__ uint32_t lds_poll32(uint32_t a) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ void lds_post32(uint32_t a, uint32_t v) {
+    if ((threadIdx.x & 63u) == 0u) asm volatile("ds_write_b32 %0, %1" : : "v"(a), "v"(v) : "memory");
+}
 __device__ __forceinline__ void lds_wr16(uint32_t a, uint32_t v) { *(OC_LDS uint16_t*)(uintptr_t)a = (uint16_t)v; }
 __device__ __forceinline__ void lds_wr32(uint32_t a, uint32_t v) { *(OC_LDS uint32_t*)(uintptr_t)a = v; }
 __device__ __forceinline__ void lds_wr8(uint32_t a, uint32_t v) { *(OC_LDS uint8_t*)(uintptr_t)a = (uint8_t)v; }
@@ -415,7 +426,9 @@ struct Lds4 {
     // MODE 3: the ring the mover wavefronts feed the interact wavefronts through — three buffers of one 8-step block each,
     // [step in block][lane] records of two u32 (the LDS addresses of the two cell words the players act on in that step)
     static constexpr int RING_BUF = 8 * BLOCK * 8, RING_BYTES = MODE == 3 ? 3 * RING_BUF : 0;
-    static constexpr int RING = TABLE_FIRST ? CT + 32 : MVJ + MVJ_CAP;
+    // ... and the progress counters of the four mover / interact pairs of a workgroup: {blocks produced, blocks consumed} x 4
+    static constexpr int SYNC = TABLE_FIRST ? CT + 32 : MVJ + MVJ_CAP, SYNC_BYTES = MODE == 3 ? 64 : 0;
+    static constexpr int RING = SYNC + SYNC_BYTES;
     static constexpr int CELLS = RING + RING_BYTES;
     static_assert(MODE != 3 || (CW == 4 && RING % 8 == 0), "the ring goes with 32-bit cell words");
     static_assert(CW == 4 || MVJ_CAP + ACT_BYTES + LUT4_KEYS * 16 < 65536, "row / LUT addresses are u16 in the tables");
@@ -460,8 +473,9 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
 //   the flag bytes — is computed by a MOVER wavefront that runs up to two 8-step blocks ahead and leaves, per step and lane,
 //   the LDS addresses of the two cell words the players act on (the faced cell, or a spare "nothing to interact with" word
 //   when the action is not INTERACT: one LUT variant, no address select) in a ring in LDS; the INTERACT wavefront of the same
-//   64 envs runs look-up, interact, cell writes, env effects, rewards and the rare branch.  One s_barrier per 8-step
-//   block keeps the mover at most two blocks ahead; the two wavefronts of a SIMD fill each other's waits.
+//   64 envs runs look-up, interact, cell writes, env effects, rewards and the rare branch.  Two progress counters per
+//   pair in LDS (blocks produced / consumed, polled once per 8-step block) keep the mover at most three blocks ahead; no
+//   workgroup barrier in the loop, so a pair whose interact wavefront sits in its rare branch delays nobody else.
 // RU: every layout of the table has the same shaping rewards and dynamics flag (hint OC_BATCH_UNIFORM_SHAPING): one LUT
 //   variant whose entries carry the reward floats, as with a single layout
 // OLD: some layout of the table may use old dynamics (auto-start of full pots in the env effects)
@@ -514,6 +528,7 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
             s_lut[i] = ent;
         }
     }
+    if (MODE == 3 && threadIdx.x < 8) reinterpret_cast<uint32_t*>(s_dyn4 + M::SYNC)[threadIdx.x] = 0u;
     if (UNIFORM && threadIdx.x < 32) {
         const LayC Cs = load_consts<true>(L);
         s_dyn4[M::CT + threadIdx.x] = (uint8_t)cook_of(Cs, OC_O_SOUP | threadIdx.x);
@@ -968,8 +983,8 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
     //      Block n_steps / 8 (one past the launch) is a stub: record 0 = {nothing, nothing} for the last step's look-ahead
     //      and record 1 = the final pose, which the interact wavefront puts into the stored state.
     constexpr uint32_t RING_SLOT = (uint32_t)BLOCK * 8u;  // bytes of one step's records
-#define OC_DUO_BARRIER_MOVER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#define OC_DUO_BARRIER() asm volatile("s_barrier" ::: "memory")
+    // progress counters of this lane's mover / interact pair: {blocks the mover has finished, blocks the interact wavefront has finished}
+    const uint32_t sync_pair = (uint32_t)M::SYNC + (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * 8u;
     if (MODE == 3 && mover) {
         auto ahead = [&](uint32_t c, uint32_t d) __attribute__((always_inline)) {
             return c + (uint32_t)(int32_t)(int8_t)(uint8_t)__builtin_amdgcn_perm(0u, delta4, d);
@@ -1046,14 +1061,16 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
             }
             flg_k += 8 * n;
         };
-        produce(0, ring0);
-        produce(1, ring0 + (uint32_t)M::RING_BUF);
-        OC_DUO_BARRIER_MOVER();
-        uint32_t wbuf = 2u * (uint32_t)M::RING_BUF;  // (wave-uniform) offset of the buffer block b + 1 goes to
-        for (int b = 1; b < n_blocks; ++b) {
-            produce(b + 1, ring0 + wbuf);
+        // Block j goes to buffer j % 3, which held block j - 3: the interact wavefront must have finished block j - 3 (its
+        // count of finished blocks >= j - 2) — the mover runs at most three blocks ahead, and only ITS partner holds it back
+        // (a workgroup barrier per block, the first version, made every pair wait for the workgroup's slowest interact wavefront).
+        uint32_t wbuf = 0;  // (wave-uniform) offset of the buffer block j goes to
+        for (int j = 0; j <= n_blocks; ++j) {
+            if (j >= 3)
+                while (lds_poll32(sync_pair + 4u) + 2u < (uint32_t)j) __builtin_amdgcn_s_sleep(2);
+            produce(j, ring0 + wbuf);
             wbuf = wbuf == 2u * (uint32_t)M::RING_BUF ? 0u : wbuf + (uint32_t)M::RING_BUF;
-            OC_DUO_BARRIER_MOVER();
+            lds_post32(sync_pair, (uint32_t)j + 1u);
         }
         return;
     }
@@ -1233,11 +1250,10 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
     } else if (MODE == 3) {
         // The INTERACT wavefronts of MODE 3: the step of MODE 2 without its movement — the two cell words a step acts on come
         // out of the mover's ring (the next step's record is read while this step's look-ups are in flight, its cells right
-        // after this step's cell writes).  Block b's barrier: the mover has finished block b + 1 (whose first record step 7
-        // looks ahead to) and may go on to block b + 2, into the buffer this wavefront has just left.
+        // after this step's cell writes).
         const uint32_t ring0 = (uint32_t)M::RING + tid * 8u;
         const int n_blocks = n_steps >> 3;
-        OC_DUO_BARRIER();
+        while (lds_poll32(sync_pair) < 2u) __builtin_amdgcn_s_sleep(1);
         uint32_t fo0, fo1, c0, c1, pw[MAXP];
         {
             const uint2 rec = lds_rd64(ring0);
@@ -1257,13 +1273,16 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
         };
         uint32_t rbuf = 0;  // (wave-uniform) offset of the ring buffer that holds the block being run
         for (int b = 0; b < n_blocks; ++b) {
-            if (b) OC_DUO_BARRIER();
+            // block b needs its own records and the first one of block b + 1 (step 7 looks ahead): b + 2 blocks finished
+            // by the mover (the stub behind the launch counts as one)
+            if (b) while (lds_poll32(sync_pair) < (uint32_t)b + 2u) __builtin_amdgcn_s_sleep(1);
             const uint32_t cur = ring0 + rbuf;
             rbuf = rbuf == 2u * (uint32_t)M::RING_BUF ? 0u : rbuf + (uint32_t)M::RING_BUF;
 #pragma unroll
             for (int k8 = 0; k8 < 7; ++k8) dstep(k8, cur + (uint32_t)(k8 + 1) * RING_SLOT);
             dstep(7, ring0 + rbuf);
             advance_rows();
+            lds_post32(sync_pair + 4u, (uint32_t)b + 1u);
         }
         const uint32_t pose = lds_rd32(ring0 + rbuf + RING_SLOT);  // the stub block's second record: the pose after the last step
         s.pos0 = pose & 0xFFu; s.or0 = (pose >> 8) & 0xFFu; s.pos1 = (pose >> 16) & 0xFFu; s.or1 = pose >> 24;
@@ -1319,8 +1338,6 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
         }
     }
 #undef OC_JA_AT
-#undef OC_DUO_BARRIER
-#undef OC_DUO_BARRIER_MOVER
     store_env4<MAXP, CW>(C, L, st, n, e, n_obj, horizon, s, col);
     ep.z = epsh.x; ep.w = epsh.y;
     if (ep_returns) ep_returns[e] = ep;
