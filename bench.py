@@ -48,6 +48,7 @@ DEFAULT_FUSE = 10 * HORIZON
 LAUNCHES_PER_STEP = 400
 ENC_FUSE = 50                 # --config 3: transitions (+ observations) per oc_rollout_encode launch
 ENC_LAUNCHES_PER_STEP = 200   # ... 200 x 50 = 10 000 transitions + observations per bench step (~0.3 s)
+PMC_ENC_FUSE = 10             # --config 3: steps per launch inside the --pmc child passes (a 50-step launch wraps WRITE_SIZE)
 
 # SURVEY.md §8d algorithmic bytes.  S = minimal state of cramped_room (2 players x 3 B + 14 non-floor cells
 # + 1 pot tick + 2 B timestep -> 24 B), outputs 17 B per env-step, actions generated in-kernel (0 B).
@@ -253,16 +254,20 @@ def timed_launches(torch, dev, sharding, launch, n_launches):
     return time.perf_counter() - t0, tm.launch_ms()
 
 
-def measure_store_only(torch, dev, env, n, fuse, rew, fl, rate_per_gpu, launch_med_ms, reps=12):
+def measure_store_only(torch, dev, env, n, fuse, rew, fl, rate_per_gpu, launch_med_ms, reps=12, tiled8=False):
     """The ceiling of the output format: `reps` launches of oc_output_stores_only — per env-step one 16-byte reward quad and
-    one flag byte into the same [step][env] arrays the rollout writes, no state, no game — timed with HIP events."""
+    one flag byte into the same arrays the rollout writes, in the flags layout the rollout was timed in ([step][env] rows, or
+    the OC_OPT_FLAGS_TILED8 tiles: one 8-byte store per env and 8-step block), no state, no game — timed with HIP events."""
     import ctypes
+
+    from overcooked_ai_amd import _lib
 
     lib = env.lib
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    opt = _lib.OPT_FLAGS_TILED8 if tiled8 else 0
 
     def launch():
-        rc = lib.oc_output_stores_only(n, fuse, rew.data_ptr(), fl.data_ptr(), stream)
+        rc = lib.oc_output_stores_only(n, fuse, rew.data_ptr(), fl.data_ptr(), opt, stream)
         if rc:
             raise RuntimeError("oc_output_stores_only: rc %d" % rc)
 
@@ -279,7 +284,9 @@ def measure_store_only(torch, dev, env, n, fuse, rew, fl, rate_per_gpu, launch_m
     med = ms[len(ms) // 2]
     rate = n * fuse / (med * 1e-3)
     return {"what": "oc_output_stores_only: nothing but the rollout's output stores (16-byte quad + flag byte per env-step, same "
-                    "arrays, same launch shape), median of %d launches" % reps,
+                    "arrays, same launch shape, flags layout %s), median of %d launches"
+                    % ("[steps/8][envs][8] (OC_OPT_FLAGS_TILED8), as timed" if tiled8 else "[steps][envs], as timed", reps),
+            "flags_layout": "tiled8" if tiled8 else "step",
             "launch_ms": med, "env_steps_per_s": rate, "GBs": n * fuse * OUT_BYTES / (med * 1e-3) / 1e9,
             "frac_of_peak": n * fuse * OUT_BYTES / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "rollout_over_store_only": (n * fuse / (launch_med_ms * 1e-3)) / rate}
@@ -536,7 +543,19 @@ def flags_tiled8_ok(args, env, fuse, rew, fl):
 
 
 def pmc_child(args, torch, VecOvercookedEnv, dev):
-    """The process the --pmc passes wrap: the same batch, reset, then 3 launches of the timed shape and nothing else."""
+    """The process the --pmc passes wrap: the same batch, reset, then 3 launches of the timed shape and nothing else.
+    --config 3: launches of PMC_ENC_FUSE (10) steps instead of ENC_FUSE (50) — WRITE_SIZE wraps on the 7.7 GB a 50-step
+    launch writes; the kernel streams the same bytes per step whatever the launch length."""
+    if args.config == 3:
+        n, fuse = args.envs, PMC_ENC_FUSE
+        env = VecOvercookedEnv("asymmetric_advantages", n, horizon=HORIZON, device=dev, auto_reset=True, seed=0)
+        rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
+        fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
+        obs = torch.empty((fuse, n, 2, env.width, env.height, 26), dtype=torch.uint8, device=dev)
+        for _ in range(3):
+            env.rollout_encode(fuse, obs, rew, fl)
+        torch.cuda.synchronize(dev)
+        return
     wl = make_workload(args, 0)
     n, fuse = args.envs, max(1, args.fuse)
     env = rollout_workload_env(args, wl, n, 0, dev, VecOvercookedEnv)()
@@ -748,11 +767,26 @@ def run_single_process(args):
     wls = [make_workload(_ap.Namespace(config=args.config if args.config != 3 else 2, envs=n, layout=args.layout,
                                        terrains=args.terrains), r) for r in range(N)]
     lid = None if wls[0]["lid"] is None else np.concatenate([w["lid"] for w in wls])
-    env = ShardedVecOvercookedEnv(wls[0]["table"], N * n, devices=devices, layout_id=lid, horizon=HORIZON, auto_reset=True, seed=0)
-    rews, fls = env.alloc_outputs(fuse)
+    def make():
+        return ShardedVecOvercookedEnv(wls[0]["table"], N * n, devices=devices, layout_id=lid, horizon=HORIZON, auto_reset=True, seed=0)
+
+    # the flags layout, as the per-rank path decides it: tiled by 8 steps where the kernels that serve the shards write it
+    tiled8 = False
+    if args.flags_layout == "tiled8" and fuse % 8 == 0:
+        probe = make()
+        try:
+            pr, pf = probe.alloc_outputs(8, flags_tiled8=True)
+            probe.rollout_random(8, pr, pf, flags_tiled8=True)
+            probe.synchronize()
+            tiled8 = True
+        except Exception:
+            tiled8 = False
+        del probe
+    env = make()
+    rews, fls = env.alloc_outputs(fuse, flags_tiled8=tiled8)
 
     def launch():
-        env.rollout_random(fuse, rews, fls)
+        env.rollout_random(fuse, rews, fls, flags_tiled8=tiled8)
 
     for _ in range(max(1, args.warmup * lps)):
         launch()
@@ -769,25 +803,31 @@ def run_single_process(args):
         from oracle import oracle as O
 
         psteps = min(fuse, args.parity_steps or 400)
-        chk = ShardedVecOvercookedEnv(wls[0]["table"], N * n, devices=devices, layout_id=lid, horizon=HORIZON, auto_reset=True, seed=0)
-        chk.rollout_random(psteps, [r[:psteps] for r in rews], [f[:psteps] for f in fls])
+        psteps -= psteps % 8 if tiled8 else 0
+        chk = make()
+        fl_chk = [f[:psteps // 8] if tiled8 else f[:psteps] for f in fls]
+        chk.rollout_random(psteps, [r[:psteps] for r in rews], fl_chk, flags_tiled8=tiled8)
+        if tiled8:  # [steps / 8][envs][8] -> [steps][envs] for the comparison
+            fl_chk = [f.permute(0, 2, 1).reshape(psteps, f.shape[1]) for f in fl_chk]
         O.set_threads(usable_cores())
         orc = O.Oracle([O.mdp_from_layout_dict(sp.to_layout_dict()) for sp in wls[0]["specs"]])
         st = orc.reset(orc.new_state(N * n), layout_id=lid)
         ep = np.zeros((N * n, 4), np.float32)
         rew_o, fl_o = orc.rollout_random(st, psteps, horizon=HORIZON, options=1, seed=0, layout_id=lid, ep_returns=ep)
         O.set_threads(1)
-        bad = int(((chk.gather([r[:psteps] for r in rews], 1) != rew_o).any(axis=2) | (chk.gather([f[:psteps] for f in fls], 1) != fl_o)).sum())
+        bad = int(((chk.gather([r[:psteps] for r in rews], 1) != rew_o).any(axis=2) | (chk.gather(fl_chk, 1) != fl_o)).sum())
         bad += int((chk.get_packed_state() != st).any(axis=(0, 2)).sum()) + int((chk.ep_returns() != ep).any(axis=1).sum())
         parity = {"envs": N * n, "steps": psteps, "mismatches": bad,
                   "what": "one %d-step launch per shard from reset: rewards, flags, final states and episode returns of all "
                           "%d envs against oracle/overcooked_oracle.c" % (psteps, N * n)}
     emit({"metric": "env steps/sec (whole node), 65k parallel cramped_room envs" if args.config == 2 else "env steps/sec (whole node)",
-          "value": float(N) * n * transitions / wall, "unit": "env steps/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+          "value": float(N) * n * transitions / wall, "unit": "env steps/s", "n_gpus": len(set(devices)), "n_shards": N,
+          "steps": args.steps, "warmup": args.warmup,
           "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
           "data": "synthetic", "timed_region_s": wall, "timed_transitions_per_env": transitions,
           "ms_per_batched_transition": wall * 1e3 / transitions,
           "config": {"workload": wls[0]["workload"], "baseline_config": args.config, "envs_per_gpu": n,
+                     "flags_layout": "[steps/8][envs][8] (OC_OPT_FLAGS_TILED8)" if tiled8 else "[steps][envs]",
                      "fused_transitions_per_launch": fuse, "launches_per_step": lps,
                      "parallelism": "single process, ShardedVecOvercookedEnv, %d shards on %s" % (N, sorted(set(devices)))},
           "roofline": None, "parity_check": parity, "aggregate": dict(agg, reduced_over="host sum over shards")})
@@ -885,7 +925,7 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
     store_only = None
     if rank == 0 and not args.stub:
         try:
-            store_only = measure_store_only(torch, dev, env, n, fuse, rew, fl, value / world, launch_med)
+            store_only = measure_store_only(torch, dev, env, n, fuse, rew, fl, value / world, launch_med, tiled8=tiled8)
         except Exception as exc:  # an aid, never a reason to lose the line
             store_only = {"error": repr(exc)}
 
@@ -971,7 +1011,8 @@ def side_legs(args, torch, VecOvercookedEnv, sharding, dev):
         legs["3"] = {"error": repr(exc)[:300]}
     for cfg, envs in ((4, N_ENVS_PER_GPU), (5, 2 * N_ENVS_PER_GPU)):
         try:
-            a = argparse.Namespace(config=cfg, envs=envs, layout="cramped_room", terrains=4096, stub=False,
+            a = argparse.Namespace(config=cfg, envs=envs, layout="cramped_room", terrains=4096, stub=False, fuse=DEFAULT_FUSE,
+                                   lane_pair=False, predicate_interact=False, one_wavefront=getattr(args, "one_wavefront", False),
                                    flags_layout=getattr(args, "flags_layout", "step"))
             wl = make_workload(a, 0)
             make_env = rollout_workload_env(a, wl, envs, 0, dev, VecOvercookedEnv)
@@ -1005,10 +1046,31 @@ def side_legs(args, torch, VecOvercookedEnv, sharding, dev):
                                 "bytes_model": "n_envs*(2*S + 17*T), S=%d B (SURVEY 8d)" % wl["sbytes"]}}
             if not args.no_parity_check:
                 leg["parity_check"] = parity_check(torch, wl, make_env, envs, 0, 1200, rew, fl, usable_cores(), tiled8=tiled8)
-            legs[str(cfg)] = leg
             del env, rew, fl
+            if not getattr(args, "no_traffic", False):  # two --pmc child passes of this leg's launch shape (no nulls)
+                torch.cuda.empty_cache()
+                leg["roofline"]["traffic"], leg["roofline"]["traffic_source"] = measure_traffic(a, "k_rollout4", tiled8)
+            legs[str(cfg)] = leg
+            continue
         except Exception as exc:
             legs[str(cfg)] = {"error": repr(exc)[:300]}
+    try:  # config 3's traffic last (its 7.7 GB trajectory buffer is gone by now): 10-step launches in the child
+        if "roofline" in legs.get("3", {}) and not getattr(args, "no_traffic", False):
+            torch.cuda.empty_cache()
+            a3 = argparse.Namespace(config=3, envs=N_ENVS_PER_GPU, layout="asymmetric_advantages", terrains=4096, fuse=PMC_ENC_FUSE,
+                                    lane_pair=False, predicate_interact=False, one_wavefront=False)
+            t10, src = measure_traffic(a3, "k_rollout_encode", False)
+            rl = legs["3"]["roofline"]
+            if t10 is not None:
+                n, per_step = N_ENVS_PER_GPU, OUT_BYTES + 2 * 9 * 5 * 26
+                b10 = n * (2 * S_ASYM + per_step * PMC_ENC_FUSE)
+                src = dict(src, measured_on="launches of %d steps (a %d-step launch wraps WRITE_SIZE): %d bytes measured against %d "
+                                            "algorithmic; `traffic` = that ratio x bytes_per_launch" % (PMC_ENC_FUSE, ENC_FUSE, int(t10), b10),
+                           traffic_over_algorithmic=t10 / b10)
+                rl["traffic"] = rl["bytes_per_launch"] * t10 / b10
+            rl["traffic_source"] = src
+    except Exception as exc:
+        legs["3"]["roofline"]["traffic_source"] = {"how": "not collected", "why": repr(exc)[:200]}
     return legs
 
 

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define OC_ABI_VERSION 4
+#define OC_ABI_VERSION 5
 
 #define OC_MAX_CELLS 128
 #define OC_MAX_POTS 8
@@ -490,8 +490,11 @@ int oc_mailbox_close(OcMailbox* mailbox);
  * device at this batch size (MI355X, 65 536 envs: 370-375 G env-steps/s = 0.79-0.80 of the HBM peak on one box, and
  * sensitive to the loop around the stores: 352 G for tools/store_rate.hip's loop on the same box), i.e. the ceiling bench.py
  * reports next to the roofline.  d_flags may be NULL (quads only).  Leaves the arrays zeroed.
+ * options (ABI 5): 0, or OC_OPT_FLAGS_TILED8 — the flags array in the tiled layout ([n_steps / 8][n_envs][8]: per 8-step block
+ * one 8-byte store per lane into the block's tile row, as the kernels serving that layout write it; n_steps a multiple of 8,
+ * d_flags 8-byte aligned and not NULL), so that the ceiling is reported in the layout the rollout was timed in.
  */
-int oc_output_stores_only(int64_t n_envs, int n_steps, float* d_rewards, uint8_t* d_flags, void* stream);
+int oc_output_stores_only(int64_t n_envs, int n_steps, float* d_rewards, uint8_t* d_flags, uint32_t options, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,9 +15,9 @@ def __getattr__(name):  # lazy: these import torch
     if name == "VecOvercookedEnv":
         from .vec_env import VecOvercookedEnv
         return VecOvercookedEnv
-    if name == "ShardedVecOvercookedEnv":
-        from .sharded_env import ShardedVecOvercookedEnv
-        return ShardedVecOvercookedEnv
+    if name in ("ShardedVecOvercookedEnv", "ShardedVecOvercookedMultiAgent"):
+        from . import sharded_env
+        return getattr(sharded_env, name)
     if name in ("OvercookedGridworld", "EVENT_TYPES"):
         from . import mdp
         return getattr(mdp, name)

@@ -6,7 +6,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OC_AMD_LIB") or os.path.join(PKG, "liboc_amd.so")  # OC_AMD_LIB: developer override
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 F_DONE, F_BAD_ACTION, F_RESET = 0x01, 0x02, 0x04
 OPT_AUTO_RESET = 0x1
 OPT_LANE_PAIR = 0x4
@@ -132,7 +132,7 @@ def load():
     L.oc_mailbox_close.restype = i32
     L.oc_mailbox_close.argtypes = [vp]
     L.oc_output_stores_only.restype = i32
-    L.oc_output_stores_only.argtypes = [i64, i32, vp, vp, vp]
+    L.oc_output_stores_only.argtypes = [i64, i32, vp, vp, u32, vp]
     if L.oc_abi_version() != ABI_VERSION:
         raise OcAmdError("liboc_amd.so ABI version %d != expected %d; rebuild" % (L.oc_abi_version(), ABI_VERSION))
     if L.oc_layout_size() != 256:

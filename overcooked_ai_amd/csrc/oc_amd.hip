@@ -219,6 +219,24 @@ __global__ __launch_bounds__(BLOCK) void k_output_stores_only(float4* __restrict
         rew_k += n;
     }
 }
+// ... with the flags array tiled by 8 steps (OC_OPT_FLAGS_TILED8): per block of 8 steps eight reward rows and ONE 8-byte store
+// per lane into the block's tile row, as the kernels that serve that layout write it
+__global__ __launch_bounds__(BLOCK) void k_output_stores_only_tiled8(float4* __restrict__ rewards, uint2* __restrict__ flag_tiles,
+                                                                     int64_t n, int n_blocks) {
+    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= n) return;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* rew_k = rewards + (int64_t)blockIdx.x * BLOCK;
+    uint2* flg_k = flag_tiles + (int64_t)blockIdx.x * BLOCK;
+#pragma unroll 1
+    for (int b = 0; b < n_blocks; ++b) {
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) rew_k[(int64_t)k8 * n + threadIdx.x] = zero4;
+        flg_k[threadIdx.x] = make_uint2(0u, 0u);
+        rew_k += 8 * n;
+        flg_k += n;
+    }
+}
 
 }  // namespace
 
@@ -970,9 +988,18 @@ int oc_mailbox_step(OcMailbox* m) {
     return OC_OK;
 }
 
-int oc_output_stores_only(int64_t n_envs, int n_steps, float* d_rewards, uint8_t* d_flags, void* stream) {
+int oc_output_stores_only(int64_t n_envs, int n_steps, float* d_rewards, uint8_t* d_flags, uint32_t options, void* stream) {
     if (n_envs < 0 || n_steps < 0 || !d_rewards) return fail(OC_EINVAL, "oc_output_stores_only: negative sizes or no rewards array");
     if (((uintptr_t)d_rewards & 15u) != 0) return fail(OC_EINVAL, "oc_output_stores_only: d_rewards must be 16-byte aligned");
+    if (options & ~(uint32_t)OC_OPT_FLAGS_TILED8) return fail(OC_EINVAL, "oc_output_stores_only: the only option is OC_OPT_FLAGS_TILED8");
+    if (options & OC_OPT_FLAGS_TILED8) {
+        if (!d_flags || ((uintptr_t)d_flags & 7u) != 0 || (n_steps & 7) != 0)
+            return fail(OC_EINVAL, "oc_output_stores_only: OC_OPT_FLAGS_TILED8 needs an 8-byte aligned d_flags and n_steps a multiple of 8");
+        if (n_envs == 0 || n_steps == 0) return OC_OK;
+        hipLaunchKernelGGL(k_output_stores_only_tiled8, dim3(grid_for(n_envs)), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)d_rewards,
+                           (uint2*)d_flags, n_envs, n_steps / 8);
+        return check_launch("oc_output_stores_only");
+    }
     if (n_envs == 0 || n_steps == 0) return OC_OK;
     hipLaunchKernelGGL(k_output_stores_only, dim3(grid_for(n_envs)), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)d_rewards, d_flags,
                        n_envs, n_steps);

@@ -108,10 +108,22 @@ class ShardedVecOvercookedEnv:
             with torch.cuda.device(s.device):
                 torch.cuda.current_stream(s.device).wait_stream(s.stream)
 
-    def alloc_outputs(self, n_steps):
-        """Per-shard (rewards [n_steps, n, 4] f32, flags [n_steps, n] u8) buffers on the shards' devices."""
+    def alloc_outputs(self, n_steps, flags_tiled8=False):
+        """Per-shard (rewards [n_steps, n, 4] f32, flags [n_steps, n] u8) buffers on the shards' devices; flags_tiled8: the
+        flags as [n_steps // 8, n, 8] (OC_OPT_FLAGS_TILED8, see VecOvercookedEnv.rollout_random)."""
+        def fl(s, i):
+            n = s.stop - s.start
+            return torch.zeros((n_steps // 8, n, 8) if flags_tiled8 else (n_steps, n), dtype=torch.uint8, device=s.device)
         return (self._each(lambda s, i: torch.zeros((n_steps, s.stop - s.start, 4), dtype=torch.float32, device=s.device)),
-                self._each(lambda s, i: torch.zeros((n_steps, s.stop - s.start), dtype=torch.uint8, device=s.device)))
+                self._each(fl))
+
+    def alloc_observations(self, n_steps=None, dtype=torch.uint8):
+        """Per-shard observation buffers: [n, 2, W, H, 26] (n_steps None: one observation per env) or the trajectory form
+        [n_steps, n, 2, W, H, 26] of rollout_encode."""
+        def ob(s, i):
+            shape = (s.stop - s.start, 2, self.width, self.height, 26)
+            return torch.empty(shape if n_steps is None else (int(n_steps),) + shape, dtype=dtype, device=s.device)
+        return self._each(ob)
 
     def _split(self, t, per_env_dim=0):
         """A caller tensor over this object's envs -> per-shard tensors on the shards' devices (async copies)."""
@@ -126,7 +138,14 @@ class ShardedVecOvercookedEnv:
                 if t.is_cuda:  # (ordered after whatever produced `t` on its device's current stream)
                     s.stream.wait_stream(torch.cuda.current_stream(t.device))
                 with torch.cuda.stream(s.stream):
-                    out.append(t[tuple(sl)].to(s.device, non_blocking=True).contiguous())
+                    piece = t[tuple(sl)].to(s.device, non_blocking=True).contiguous()
+                if piece.is_cuda:
+                    # a view of the caller's tensor (same device, already contiguous: no copy was made), or a fresh copy made on
+                    # the shard's stream: either way the caching allocator must not hand the memory to somebody else on the
+                    # caller's stream while the shard's kernels still read it.  (Refilling `t` before join() / synchronize()
+                    # is still the caller's race: keep inputs untouched until then.)
+                    piece.record_stream(s.stream)
+                out.append(piece)
         return out
 
     # ------------------------------------------------------------------ env API (lists hold one entry per shard)
@@ -134,12 +153,38 @@ class ShardedVecOvercookedEnv:
         masks = None if mask is None else self._split(mask)
         self._each(lambda s, i: s.env.reset(None if masks is None else masks[i], **kw))
 
-    def rollout_random(self, n_steps, rewards_out=None, flags_out=None):
+    def rollout_random(self, n_steps, rewards_out=None, flags_out=None, events_out=None, flags_tiled8=False):
         """n_steps fused random-policy transitions on every shard (one oc_rollout_random launch per shard, all in flight
-        together).  rewards_out / flags_out: lists from alloc_outputs, or None."""
+        together).  rewards_out / flags_out (/ events_out: int64 [n_steps, n] masks): per-shard lists (alloc_outputs), or
+        None.  flags_tiled8: the OC_OPT_FLAGS_TILED8 flags layout on every shard (alloc_outputs(n_steps, flags_tiled8=True);
+        ValueError from the first shard whose batch / launch shape no tiled instance serves)."""
         self._each(lambda s, i: s.env.rollout_random(n_steps, None if rewards_out is None else rewards_out[i],
-                                                     None if flags_out is None else flags_out[i]))
+                                                     None if flags_out is None else flags_out[i],
+                                                     None if events_out is None else events_out[i], flags_tiled8=flags_tiled8))
         return rewards_out, flags_out
+
+    def rollout_encode(self, n_steps, obs_out, rewards_out=None, flags_out=None, actions=None, dtype=torch.uint8):
+        """n_steps transitions with the lossless observation after every step on every shard (VecOvercookedEnv.rollout_encode).
+        obs_out: per-shard list (alloc_observations(n_steps) for the trajectory, alloc_observations() for the last observation
+        only); actions: None (the random policy, the global Philox stream) or uint8 [n_steps, n_local, 2] / a per-shard list."""
+        acts = None if actions is None else self._split(actions, per_env_dim=1)
+        self._each(lambda s, i: s.env.rollout_encode(n_steps, obs_out[i], None if rewards_out is None else rewards_out[i],
+                                                     None if flags_out is None else flags_out[i],
+                                                     None if acts is None else acts[i], dtype=dtype))
+        return obs_out, rewards_out, flags_out
+
+    def step_encode(self, actions, dtype=torch.uint8, out=None):
+        """step(actions) + the lossless observation of the new states in one C call per shard (VecOvercookedEnv.step_encode).
+        Returns (rewards list, flags list, obs list)."""
+        acts = self._split(actions)
+        res = self._each(lambda s, i: s.env.step_encode(acts[i], dtype, out=None if out is None else out[i]))
+        return [r for r, _, _ in res], [f for _, f, _ in res], [o for _, _, o in res]
+
+    def event_stats(self, finished=False):
+        """{event name: per-shard list of int32 [n, 2] tensors} — the per-episode event counters of every shard (construct
+        with track_events=True); `gather(stats[name])` gives the [n_local, 2] host array."""
+        per = self._each(lambda s, i: s.env.event_stats(finished))
+        return {name: [d[name] for d in per] for name in per[0]}
 
     def step(self, actions):
         """actions: uint8 [n_local, 2] (any device / host; split and copied asynchronously) or a per-shard list.
@@ -213,3 +258,75 @@ class ShardedVecOvercookedEnv:
         names = ("ep_sparse_0", "ep_sparse_1", "ep_shaped_0", "ep_shaped_1", "sparse_in_buffers", "shaped_in_buffers",
                  "episodes_done_in_buffers", "env_steps")
         return dict(zip(names, (float(x) for x in total)))
+
+
+class ShardedVecOvercookedMultiAgent:
+    """VecOvercookedMultiAgent (the batched rllib.py:293-342 training env) over the same env-range shards: one
+    VecOvercookedMultiAgent per device on its own stream, `step` fans the actions out and returns per-shard lists of
+    (obs, shaped rewards, dones, infos) — device tensors that stay on their GPUs (a data-parallel learner consumes each
+    shard's where it lives).  Drawn start states are keyed by the global env index, so the shards reproduce the unsharded
+    batch."""
+
+    def __init__(self, layouts, n_global, devices=None, layout_id=None, env_offset=0, pad_to=None, ranks=None, **ma_kw):
+        from .multi_agent import VecOvercookedMultiAgent
+
+        self.table = as_layout_table(layouts, pad_to)
+        self.n_global, self.env_offset = int(n_global), int(env_offset)
+        if devices is None:
+            devices = ["cuda:%d" % i for i in range(max(1, torch.cuda.device_count()))]
+        devices = [torch.device(d) for d in devices]
+        if layout_id is not None:
+            layout_id = np.asarray(layout_id)
+            if layout_id.shape != (self.n_global,):
+                raise ValueError("layout_id must cover all %d global envs" % self.n_global)
+        rank, world = (0, 1) if ranks is None else (int(ranks[0]), int(ranks[1]))
+        self.shards = []
+        for dev, (start, stop) in zip(devices, shard_plan(self.n_global, len(devices), rank, world)):
+            with torch.cuda.device(dev):
+                stream = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(stream):
+                    ma = VecOvercookedMultiAgent(self.table, stop - start, device=dev, env_offset=self.env_offset + start,
+                                                 layout_id=None if layout_id is None else layout_id[start:stop], **ma_kw)
+            sh = _Shard(ma.venv, stream, start, stop)
+            self.shards.append((sh, ma))
+        self._fan = ShardedVecOvercookedEnv.__new__(ShardedVecOvercookedEnv)  # the fan-out helpers over the same shards
+        self._fan.shards = [sh for sh, _ in self.shards]
+
+    @classmethod
+    def from_process_group(cls, layouts, n_global, device=None, **kw):
+        rank, local_rank, world = sharding.dist_env()
+        return cls(layouts, n_global, devices=[device or "cuda:%d" % local_rank], ranks=(rank, world), **kw)
+
+    @property
+    def agents(self):
+        return [ma for _, ma in self.shards]
+
+    def reset(self):
+        """Per-shard observations of the first states."""
+        return self._fan._each(lambda s, i: self.shards[i][1].reset())
+
+    def step(self, actions):
+        """actions uint8 [n_local, 2] (or a per-shard list) -> per-shard lists (obs, shaped rewards, dones, infos)."""
+        acts = self._fan._split(actions)
+        res = self._fan._each(lambda s, i: self.shards[i][1].step(acts[i]))
+        return [r[0] for r in res], [r[1] for r in res], [r[2] for r in res], [r[3] for r in res]
+
+    def set_reward_shaping_factor(self, factor):
+        for _, ma in self.shards:
+            ma.set_reward_shaping_factor(factor)
+
+    def anneal_reward_shaping_factor(self, timesteps):
+        for _, ma in self.shards:
+            ma.anneal_reward_shaping_factor(timesteps)
+
+    def synchronize(self):
+        self._fan.synchronize()
+
+    def join(self):
+        self._fan.join()
+
+    def gather(self, per_shard, dim=0):
+        return self._fan.gather(per_shard, dim)
+
+    def get_packed_state(self):
+        return self._fan.get_packed_state()

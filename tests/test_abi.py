@@ -23,7 +23,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
     for s in syms:
         assert getattr(L, s) is not None
-    assert L.oc_abi_version() == 4
+    assert L.oc_abi_version() == 5
     assert L.oc_layout_size() == 256
     assert L.oc_state_planes(5, 4) == 3 and L.oc_state_planes(9, 5) == 4 and L.oc_state_planes(14, 9) == 9
 
@@ -110,9 +110,12 @@ def test_argument_validation_without_gpu():
     assert L.oc_rollout_random(br, 4096, 4096, 4096, None, 400, 0x45, 0, 0, 0, 16, None, None, None) == -1
     assert b"default kernel" in L.oc_last_error()
     # the measurement aid: argument checks before the launch, nothing to do for an empty job
-    assert L.oc_output_stores_only(64, 8, None, None, None) == -1 and b"no rewards array" in L.oc_last_error()
-    assert L.oc_output_stores_only(64, 8, 4100, None, None) == -1 and b"16-byte aligned" in L.oc_last_error()
-    assert L.oc_output_stores_only(0, 8, 4096, None, None) == 0 and L.oc_output_stores_only(64, 0, 4096, 4096, None) == 0
+    assert L.oc_output_stores_only(64, 8, None, None, 0, None) == -1 and b"no rewards array" in L.oc_last_error()
+    assert L.oc_output_stores_only(64, 8, 4100, None, 0, None) == -1 and b"16-byte aligned" in L.oc_last_error()
+    assert L.oc_output_stores_only(0, 8, 4096, None, 0, None) == 0 and L.oc_output_stores_only(64, 0, 4096, 4096, 0, None) == 0
+    assert L.oc_output_stores_only(64, 8, 4096, 4096, 0x1, None) == -1 and b"only option" in L.oc_last_error()
+    assert L.oc_output_stores_only(64, 12, 4096, 4096, 0x40, None) == -1 and b"multiple of 8" in L.oc_last_error()
+    assert L.oc_output_stores_only(64, 8, 4096, None, 0x40, None) == -1 and L.oc_output_stores_only(0, 8, 4096, 4096, 0x40, None) == 0
 
 
 def test_product_never_imports_the_oracle():

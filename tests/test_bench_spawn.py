@@ -88,3 +88,22 @@ def test_launcher_env_is_respected():
                 "127.0.0.1", "--master-port", "29631", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1",
                 "--stub", "--envs", "64", "--launches-per-step", "1", "--fuse", "400"])
     assert out["n_gpus"] == 2 and len(out["ms_per_step_by_rank"]) == 2
+
+
+def test_eight_stub_ranks_rehearse_the_scaling_run():
+    """The driver's N = 8 command on CPU: eight self-spawned stub ranks over gloo for the headline
+    config and for BASELINE configs[3] / [4] — per-rank layout-id slices of the GLOBAL env index, max-over-ranks timing, a
+    parity check on every rank, ONE JSON line.  A rehearsal of the plumbing, never a measurement: no 8-GPU run stands behind
+    the multi-GPU path in this repo's rounds."""
+    for cfg, envs, marker in ((2, 16, "cramped_room"), (4, 15, "5 canonical layouts"), (5, 24, "4096 LayoutGenerator")):
+        out = _run([sys.executable, "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", "--stub", "--envs", str(envs),
+                    "--config", str(cfg), "--fuse", "400", "--launches-per-step", "1"])
+        assert out["n_gpus"] == 8 and out["data"] == "stub" and out["scaling"] == "weak" and marker in out["config"]["workload"]
+        assert len(out["ms_per_step_by_rank"]) == 8 and all(x > 0 for x in out["ms_per_step_by_rank"])
+        # the timed region is the slowest rank's: ms_per_step x steps == timed_region_s >= every rank's own time
+        assert abs(out["ms_per_step"] * out["steps"] - out["timed_region_s"] * 1e3) < 1e-6 * out["timed_region_s"] * 1e3
+        assert max(out["ms_per_step_by_rank"]) <= out["ms_per_step"] * (1 + 1e-6)
+        assert abs(out["value"] - 8 * envs * out["timed_transitions_per_env"] / out["timed_region_s"]) < 1e-6 * out["value"]
+        pc = out["parity_check"]
+        assert pc["mismatches"] == 0 and pc["mismatches_by_rank"] == [0] * 8 and pc["envs"] == 8 * envs
+        assert out["aggregate"]["reduced_over"] == "gloo all-reduce"

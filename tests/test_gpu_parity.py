@@ -1297,12 +1297,22 @@ def test_output_stores_only_writes_every_output_of_a_rollout_shape(gpu):
         rew = torch.full((steps + 1, n, 4), 7.0, dtype=torch.float32, device=gpu)   # one guard row behind the arrays
         fl = torch.full((steps + 1, n), 9, dtype=torch.uint8, device=gpu)
         with torch.cuda.device(gpu):
-            rc = L.oc_output_stores_only(n, steps, rew.data_ptr(), fl.data_ptr() if with_flags else None,
+            rc = L.oc_output_stores_only(n, steps, rew.data_ptr(), fl.data_ptr() if with_flags else None, 0,
                                          ctypes.c_void_p(torch.cuda.current_stream(gpu).cuda_stream))
         assert rc == 0
         torch.cuda.synchronize(gpu)
         assert float(rew[:steps].abs().sum()) == 0.0 and bool((rew[steps] == 7.0).all())
         assert bool((fl[steps] == 9).all()) and bool((fl[:steps] == (0 if with_flags else 9)).all())
+    for n, steps in ((1000, 40), (256, 8)):  # the tiled flags layout: [steps / 8][envs][8], one guard tile row behind
+        rew = torch.full((steps + 1, n, 4), 7.0, dtype=torch.float32, device=gpu)
+        fl = torch.full((steps // 8 + 1, n, 8), 9, dtype=torch.uint8, device=gpu)
+        with torch.cuda.device(gpu):
+            rc = L.oc_output_stores_only(n, steps, rew.data_ptr(), fl.data_ptr(), _lib.OPT_FLAGS_TILED8,
+                                         ctypes.c_void_p(torch.cuda.current_stream(gpu).cuda_stream))
+        assert rc == 0
+        torch.cuda.synchronize(gpu)
+        assert float(rew[:steps].abs().sum()) == 0.0 and bool((rew[steps] == 7.0).all())
+        assert bool((fl[steps // 8] == 9).all()) and bool((fl[:steps // 8] == 0).all())
 
 
 @pytest.mark.gpu
