@@ -738,7 +738,9 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
         if (PW) {
             uint32_t ub = 0;
 #pragma unroll
-            for (int k = 0; k < MAXP; ++k) ub |= USEFUL_CLASSES >> (cw_kb<CW>(pw[k]) - KB_POT);  // (every slot reads a pot word: nopot_off)
+            // (every slot reads a pot word — nopot_off — so the key byte is in the pot range; the & 31 only keeps a foreign
+            //  key byte from being an undefined C++ shift: the hardware shift takes the low five bits anyway, no instruction)
+            for (int k = 0; k < MAXP; ++k) ub |= USEFUL_CLASSES >> ((cw_kb<CW>(pw[k]) - KB_POT) & 31u);
             take &= ub;
         }
         uint32_t gate = (uint32_t)F4_SERVE;

@@ -95,12 +95,13 @@ class _SingleEnvPort:
     step instead of a launch and a stream wait.  Grids above 64 cells (which the mailbox kernel does not serve) take the
     round-3 form: `oc_step` launched on pointers into a pinned buffer, one stream wait per call."""
 
+    MAILBOX_AFTER = 2  # single-state calls served by plain launches before the resident kernel is brought up
+
     def __init__(self, mdp):
         import ctypes
 
         import torch
 
-        from . import _lib
         from .state import SingleStateCodec
 
         self.env = mdp._env(1)  # owns the device copy of the layout table and the OcBatch
@@ -109,37 +110,61 @@ class _SingleEnvPort:
         self.n_state = env.n_planes * 16
         self.codec = SingleStateCodec(mdp.spec, env.n_planes)
         self.device, self.dev_index, self.torch, self.num_players = env.device, env._dev_index, torch, mdp.num_players
-        self.mailbox = None
-        if env.n_planes <= 5 and not os.environ.get("OC_AMD_NO_MAILBOX"):
-            mb = ctypes.c_void_p()
-            with torch.cuda.device(env.device):
-                _lib.check(self.lib.oc_mailbox_open(self.bref, 65535, ctypes.byref(mb)), "oc_mailbox_open")
-            self.mailbox = mb
-            buf = (ctypes.c_uint8 * _lib.MB_BYTES).from_address(self.lib.oc_mailbox_buffer(mb))
-            self.np = np.frombuffer(buf, dtype=np.uint8)
-            self.o_in, self.o_act, self.o_out = _lib.MB_STATE_IN, _lib.MB_ACTIONS, _lib.MB_STATE_OUT
-            self.o_rew, self.o_flag, self.o_ev = _lib.MB_REWARDS, _lib.MB_FLAGS, _lib.MB_EVENTS
-            self._step = self.lib.oc_mailbox_step
-            import weakref
+        self.mailbox, self._finalizer, self.calls = None, None, 0
+        # The mailbox (pinned mapped memory, a HIP stream, a resident polling kernel) is opened LAZILY, by the third
+        # single-state call: an mdp that is constructed and asked for one or two transitions — a layout generator's
+        # regen_mdp, a test fixture — never holds one.  OC_AMD_NO_MAILBOX keeps every call on the launch path.
+        self.mailbox_ok = env.n_planes <= 5 and not os.environ.get("OC_AMD_NO_MAILBOX")
+        off = lambda x: (x + 15) & ~15
+        o_act = off(self.n_state)
+        o_out = o_act + 16
+        o_rew = o_out + off(self.n_state)
+        self.pinned = torch.zeros((o_rew + 48,), dtype=torch.uint8).pin_memory()
+        base = self.pinned.data_ptr()
+        self.ptrs = tuple(ctypes.c_void_p(base + o) for o in (0, o_out, o_act, o_rew, o_rew + 16, o_rew + 32))
+        self.stream = torch.cuda.Stream(device=env.device)
+        self.stream_ptr = ctypes.c_void_p(self.stream.cuda_stream)
+        self._bind(self.pinned.numpy(), 0, o_act, o_out, o_rew, o_rew + 16, o_rew + 32)
 
-            weakref.finalize(self, self.lib.oc_mailbox_close, mb)  # (also runs at interpreter exit: the kernel is told to leave)
-        else:
-            off = lambda x: (x + 15) & ~15
-            self.o_in, self.o_act = 0, off(self.n_state)
-            self.o_out = self.o_act + 16
-            self.o_rew = self.o_out + off(self.n_state)
-            self.o_flag, self.o_ev = self.o_rew + 16, self.o_rew + 32
-            self.pinned = torch.zeros((self.o_ev + 16,), dtype=torch.uint8).pin_memory()
-            self.np = self.pinned.numpy()
-            base = self.pinned.data_ptr()
-            self.ptrs = tuple(ctypes.c_void_p(base + o) for o in (self.o_in, self.o_out, self.o_act, self.o_rew, self.o_flag, self.o_ev))
-            self.stream = torch.cuda.Stream(device=env.device)
-            self.stream_ptr = ctypes.c_void_p(self.stream.cuda_stream)
+    def _bind(self, arr, o_in, o_act, o_out, o_rew, o_flag, o_ev):
+        """Point the pack / unpack views at a request / response buffer (the pinned launch buffer, or the mailbox)."""
+        self.np = arr
+        self.o_in, self.o_act, self.o_out, self.o_rew, self.o_flag, self.o_ev = o_in, o_act, o_out, o_rew, o_flag, o_ev
         self.mv = memoryview(self.np)
         self.mv_in = self.mv[self.o_in:self.o_in + self.n_state]
         self.mv_out = self.mv[self.o_out:self.o_out + self.n_state]
         self.rew = self.np[self.o_rew:self.o_rew + 16].view(np.float32)
         self.ev = self.np[self.o_ev:self.o_ev + 8].view(np.uint64)
+
+    def _open_mailbox(self):
+        import ctypes
+        import weakref
+
+        from . import _lib
+
+        mb = ctypes.c_void_p()
+        with self.torch.cuda.device(self.device):
+            _lib.check(self.lib.oc_mailbox_open(self.bref, 65535, ctypes.byref(mb)), "oc_mailbox_open")
+        buf = (ctypes.c_uint8 * _lib.MB_BYTES).from_address(self.lib.oc_mailbox_buffer(mb))
+        request = bytes(self.mv[self.o_in:self.o_in + self.n_state]), self.mv[self.o_act], self.mv[self.o_act + 1]
+        self._bind(np.frombuffer(buf, dtype=np.uint8), _lib.MB_STATE_IN, _lib.MB_ACTIONS, _lib.MB_STATE_OUT, _lib.MB_REWARDS,
+                   _lib.MB_FLAGS, _lib.MB_EVENTS)
+        self.mv_in[:] = request[0]  # (the call that opens the mailbox has already packed its request)
+        self.mv[self.o_act], self.mv[self.o_act + 1] = request[1], request[2]
+        self._step = self.lib.oc_mailbox_step
+        self.mailbox = mb
+        # (the finalizer also runs at interpreter exit: the kernel is told to leave)
+        self._finalizer = weakref.finalize(self, self.lib.oc_mailbox_close, mb)
+
+    def close(self):
+        """Give the mailbox back now (the resident kernel leaves, the stream and the pinned pages are freed) instead of at
+        garbage collection; the port keeps working on the launch path and re-opens a mailbox after MAILBOX_AFTER further calls."""
+        if self.mailbox is not None:
+            self._finalizer.detach()
+            self.lib.oc_mailbox_close(self.mailbox)
+            self.mailbox, self._finalizer, self.calls = None, None, 0
+            o = [p.value - self.pinned.data_ptr() for p in self.ptrs]
+            self._bind(self.pinned.numpy(), o[0], o[2], o[1], o[3], o[4], o[5])
 
     def transition(self, state, a0, a1):
         """(next_state, rewards float32[4], event mask int) or None when the state needs the general path."""
@@ -148,6 +173,10 @@ class _SingleEnvPort:
         mv = self.mv
         mv[self.o_act] = a0
         mv[self.o_act + 1] = a1
+        if self.mailbox is None and self.mailbox_ok:
+            self.calls += 1
+            if self.calls > self.MAILBOX_AFTER:
+                self._open_mailbox()
         if self.mailbox is not None:
             rc = self._step(self.mailbox)
             if rc:
@@ -367,6 +396,21 @@ class OvercookedGridworld:
         if self._single is None:
             self._single = _SingleEnvPort(self)
         return self._single
+
+    def close(self):
+        """Release the single-state port's mailbox (resident polling kernel, HIP stream, pinned pages) now rather than at
+        garbage collection — for code that builds many mdps (layout generators, regen_mdp) or interleaves env.step with
+        device-wide synchronisations.  The mdp stays usable: the next single-state calls go through plain launches and a
+        mailbox is opened again after a few of them.  Also the exit of `with OvercookedGridworld...(...) as mdp:`."""
+        if self._single is not None:
+            self._single.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def _fast_transition(self, state, joint_action):
         """One env through the pinned-buffer port; None -> the general batched path (which also raises the reference's

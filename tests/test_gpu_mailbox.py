@@ -111,11 +111,18 @@ def test_drop_in_env_runs_on_the_mailbox_and_matches_the_launch_path(gpu, monkey
             monkeypatch.setenv("OC_AMD_NO_MAILBOX", "1")
         mdp = OvercookedGridworld.from_layout_name("asymmetric_advantages")
         env = OvercookedEnv.from_mdp(mdp, horizon=150, info_level=0)
-        assert (mdp._port().mailbox is None) == no_mailbox
+        assert mdp._port().mailbox is None  # opened lazily: the first calls are plain launches
         trace = []
-        for a0, a1 in plan:
+        for k, (a0, a1) in enumerate(plan):
             s, r, done, info = env.step((Action.INDEX_TO_ACTION[a0], Action.INDEX_TO_ACTION[a1]))
             trace.append((S.canonical_state_dict(s), r, done, list(info["shaped_r_by_agent"])))
+            if k == 5:
+                assert (mdp._port().mailbox is None) == no_mailbox  # the resident kernel is up by the third call
+            if k == 60 and not no_mailbox:  # an explicit close in the middle of an episode: launches again, then a new mailbox
+                mdp.close()
+                assert mdp._port().mailbox is None
+            if k == 70:
+                assert (mdp._port().mailbox is None) == no_mailbox
         trace.append(info["episode"]["ep_game_stats"])
         runs.append(trace)
     assert runs[0][:-1] == runs[1][:-1]

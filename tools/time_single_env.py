@@ -28,7 +28,7 @@ t0 = time.perf_counter()
 for _ in range(3):
     episode()
 print("OvercookedEnv.step: %.1f us per step" % ((time.perf_counter() - t0) / 1200 * 1e6))
-port = mdp._port()
+port = mdp._port()  # (the episodes above have brought the mailbox up: it opens with the third single-state call)
 state = mdp.get_standard_start_state()
 N = 2000
 t0 = time.perf_counter()
