@@ -430,12 +430,13 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         // MODE 3 (step_lut4.hpp): the per-env-terrain step split between mover and interact wavefronts — whole workgroups of
         // envs (every wavefront meets every barrier), whole 8-step blocks, and no more workgroups than CUs (a workgroup's
         // ~127 KB of LDS leave room for one per CU: a second round of workgroups would run behind the first)
-        c.duo = mode2 && !(options & OC_OPT_ONE_WAVEFRONT) && b->n_envs % BLOCK == 0 && b->n_envs <= (simd_count() / 4) * BLOCK &&
-                (t0 & 7) == 0 && (n_steps & 7) == 0;
+        const bool joint_duo = c.joint && b->width * b->height <= 64 && (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0;  // (MODE 4)
+        c.duo = (mode2 || joint_duo) && !(options & OC_OPT_ONE_WAVEFRONT) && b->n_envs % BLOCK == 0 &&
+                b->n_envs <= (simd_count() / 4) * BLOCK && (t0 & 7) == 0 && (n_steps & 7) == 0;
         c.tiled8 = tiled8;
         if (tiled8) {  // which instances write the tiled flags array: the pipelined joint-table one, the per-env-terrain ones of
                        // mixed tables in LDS (pipelined) and of one-pot tables in HBM
-            const bool by_joint = c.joint && c.pipe && b->width * b->height <= 64 && (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0;
+            const bool by_joint = c.joint && (c.pipe || c.duo) && b->width * b->height <= 64 && (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0;
             const bool by_mode2 = mode2 && (c.duo || (!uniform && ((lds && c.pipe) || (!lds && b->max_pots == 1))));
             if (!(by_joint || by_mode2) || b->n_envs >= ((int64_t)1 << 24))
                 return fail(OC_EINVAL, "oc_rollout_random: OC_OPT_FLAGS_TILED8 is served by the pipelined joint-table kernel (one two-player, "

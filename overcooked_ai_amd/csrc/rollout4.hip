@@ -49,6 +49,17 @@ constexpr size_t lds4_bytes(size_t cell_rows) {
                            (uint32_t)c.seed, (uint32_t)(c.seed >> 32), c.env_offset, c.t0, c.n_steps, c.sa, c.ea);  \
     } while (0)
 
+// MODE 4: the joint-table kernel (one cramped_room-like layout) with the same split — the mover reads the joint move table
+#define GO4J(FT8F)                                                                                                  \
+    do {                                                                                                            \
+        const size_t smem4 = lds4_bytes<true, 1, true, 4, true, false, 6, false, true, false, 4, true, FT8F>(cell_rows + 1); \
+        if (!want_lds(k_rollout4<true, 1, true, 4, true, false, 6, false, true, false, 4, true, FT8F>, smem4)) break; \
+        hipLaunchKernelGGL((k_rollout4<true, 1, true, 4, true, false, 6, false, true, false, 4, true, FT8F>), grid4, dim3(2 * BLOCK), smem4, c.stream, \
+                           b->d_layouts, b->n_layouts, b->d_layout_id, (uint4*)c.d_state, (float4*)c.d_rewards, c.d_flags, \
+                           (float4*)c.d_ep_returns, b->n_envs, b->width, c.n_obj, c.horizon, c.options,             \
+                           (uint32_t)c.seed, (uint32_t)(c.seed >> 32), c.env_offset, c.t0, c.n_steps, c.sa, c.ea);  \
+    } while (0)
+
 #define OC_R4_PROLOGUE                                                       \
     const OcBatch* b = c.b;                                                  \
     const size_t cell_rows = (size_t)c.n_obj * 16 + 2; /* + two spare words per lane (nopot_off) */ \
@@ -71,6 +82,10 @@ void launch_rollout4_joint_events(const Rollout4Call& c) {
     // (cramped_room): 32-bit cell words and the faced cells read a step ahead; else (big batches, shared faced cells, grids
     // above 64 cells) 16-bit words without the one-step-ahead reads (see PIPE in step_lut4.hpp)
     const bool noconf = (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0;
+    if (c.duo) {  // (oc_rollout_random: a joint-table batch on a grid of at most 64 cells without shared faced cells, whole workgroups and blocks)
+        if (c.tiled8) GO4J(true); else GO4J(false);
+        return;
+    }
     if (c.tiled8) {  // (oc_rollout_random has checked that this instance serves the batch and the launch)
         GO4(true, 1, true, 1, true, false, 6, false, true, false, 4, true, true);
         return;

@@ -311,9 +311,12 @@ template <int CW> struct Mvj {
 // the single-player moves SP[pose][action] = (cell, pose) after _move_if_direction by 168 lanes, and a joint row then
 // only combines two of them per entry (collision test + index arithmetic).  `sp` = 2 * 28 * 6 bytes of scratch LDS.
 // `mvj` = the table, `mvj_addr` = its LDS address (rows hold LDS addresses of rows).
-template <int CW>
+// FACE_STRIDE: bytes between two cells' words in a lane's column (the faced-cell offsets are multiples of it) — BLOCK * CW;
+// MODE 4 keeps the compact 16-bit rows (CW = 2 here) next to 32-bit cell words: faces = cell * 1024 still fit 16 bits.
+template <int CW, int FACE_STRIDE = BLOCK * CW>
 __device__ __forceinline__ void build_joint_table(const Lay L, int W, uint8_t* mvj, uint32_t mvj_addr, uint8_t* s_fl, uint8_t* s_fi,
                                                   uint8_t* sp) {
+    static_assert(CW == 4 || 63 * FACE_STRIDE < 65536, "16-bit faced-cell offsets");
     const int nc = (int)L.u8(L_NCELLS);
     if (threadIdx.x < 64) {  // free cells in row-major order: s_fi[cell] = rank (0xFF: not free / beyond the table), s_fl[rank] = cell
         int base = 0;
@@ -349,7 +352,7 @@ __device__ __forceinline__ void build_joint_table(const Lay L, int W, uint8_t* m
         uint16_t* row16 = reinterpret_cast<uint16_t*>(mvj + J * Mvj<CW>::ROW_BYTES);
         uint32_t* row32 = reinterpret_cast<uint32_t*>(mvj + J * Mvj<CW>::ROW_BYTES);
         *reinterpret_cast<uint32_t*>(mvj + J * Mvj<CW>::ROW_BYTES + Mvj<CW>::FACES) =
-            (uint32_t)(ahead(c0, P0 & 3) * (BLOCK * CW)) | ((uint32_t)(ahead(c1, P1 & 3) * (BLOCK * CW)) << 16);
+            (uint32_t)(ahead(c0, P0 & 3) * FACE_STRIDE) | ((uint32_t)(ahead(c1, P1 & 3) * FACE_STRIDE) << 16);
         int q1[6], p1[6];
 #pragma unroll
         for (int a = 0; a < 6; ++a) { q1[a] = sp[2 * (P1 * 6 + a)]; p1[a] = sp[2 * (P1 * 6 + a) + 1]; }
@@ -416,21 +419,27 @@ __device__ __forceinline__ uint32_t joint_action_of(uint32_t w0, uint32_t w1, ui
 // 64 KiB and fold into the 16-bit offset field of the DS instructions.
 template <bool UNIFORM, bool LAY_LDS, int MODE, int NF, bool ONE_LUT = UNIFORM, int CW = 2>
 struct Lds4 {
-    static constexpr int MVJ_CAP = MODE == 1 ? ((16 * NF * NF * Mvj<CW>::ROW_BYTES + 15) & ~15) : 0;
+    static constexpr bool DUO = MODE == 3 || MODE == 4;  // mover + interact wavefronts
+    // MODE 4 (the joint table read by a mover wavefront): compact rows of u16 whatever the cell words' width
+    static constexpr int MVJ_ROW = MODE == 4 ? Mvj<2>::ROW_BYTES : Mvj<CW>::ROW_BYTES;
+    static constexpr int MVJ_CAP = (MODE == 1 || MODE == 4) ? ((16 * NF * NF * MVJ_ROW + 15) & ~15) : 0;
     static constexpr bool TABLE_FIRST = CW == 2;
-    static constexpr int ACT = TABLE_FIRST ? MVJ_CAP : 0, ACT_P1 = 40 * CW, ACT_BYTES = MODE == 1 ? 2 * ACT_P1 : 0;  // [player][40] u16 / u32
+    // MODE 1: [player][40] u16 / u32 LUT addresses; MODE 4: [40] x {mask of player 0, mask of player 1}: all ones when the
+    // joint action has that player INTERACT (the mover then records the faced cell), zero otherwise (the "nothing" word)
+    static constexpr int ACT = TABLE_FIRST ? MVJ_CAP : 0, ACT_P1 = 40 * CW, ACT_BYTES = MODE == 1 ? 2 * ACT_P1 : MODE == 4 ? 40 * 8 : 0;
     static constexpr int LUT = ACT + ACT_BYTES, LUT_BYTES = ONE_LUT ? LUT4_BYTES : 2 * LUT4_BYTES;
     static constexpr int LAY = LUT + LUT_BYTES, LAY_BYTES = LAY_LDS ? (UNIFORM ? 256 : LDS_LAYOUT_MAX * 256) : 16;
-    static constexpr int FL = LAY + LAY_BYTES, FI = FL + 16, CT = FI + (MODE == 1 ? OC_MAX_CELLS : 0);
+    static constexpr int FL = LAY + LAY_BYTES, FI = FL + 16, CT = FI + ((MODE == 1 || MODE == 4) ? OC_MAX_CELLS : 0);
     static constexpr int MVJ = TABLE_FIRST ? 0 : CT + 32;  // LDS address of the move table
     // MODE 3: the ring the mover wavefronts feed the interact wavefronts through — three buffers of one 8-step block each,
     // [step in block][lane] records of two u32 (the LDS addresses of the two cell words the players act on in that step)
-    static constexpr int RING_BUF = 8 * BLOCK * 8, RING_BYTES = MODE == 3 ? 3 * RING_BUF : 0;
+    static constexpr int RING_BUF = 8 * BLOCK * 8, RING_BYTES = DUO ? 3 * RING_BUF : 0;
     // ... and the progress counters of the four mover / interact pairs of a workgroup: {blocks produced, blocks consumed} x 4
-    static constexpr int SYNC = TABLE_FIRST ? CT + 32 : MVJ + MVJ_CAP, SYNC_BYTES = MODE == 3 ? 64 : 0;
+    static constexpr int SYNC = TABLE_FIRST ? CT + 32 : MVJ + MVJ_CAP, SYNC_BYTES = DUO ? 64 : 0;
     static constexpr int RING = SYNC + SYNC_BYTES;
     static constexpr int CELLS = RING + RING_BYTES;
-    static_assert(MODE != 3 || (CW == 4 && RING % 8 == 0), "the ring goes with 32-bit cell words");
+    static_assert(!DUO || (CW == 4 && RING % 8 == 0), "the ring goes with 32-bit cell words");
+    static_assert(MODE != 4 || MVJ + MVJ_CAP < 65536, "MODE 4: row addresses are u16");
     static_assert(CW == 4 || MVJ_CAP + ACT_BYTES + LUT4_KEYS * 16 < 65536, "row / LUT addresses are u16 in the tables");
     static_assert(CW == 2 || CT + 32 < 65536, "the small tables' addresses must fit the DS offset field");
 };
@@ -495,7 +504,7 @@ template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, in
 #ifndef OC_R4_WAVES_MAX
 #define OC_R4_WAVES_MAX 4
 #endif
-__global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_WAVES_MAX))) void k_rollout4(const OcLayout* __restrict__ g_layouts, int n_layouts,
+__global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_WAVES_MAX))) void k_rollout4(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                     const uint16_t* layout_id, uint4* st,
                                                     float4* __restrict__ rewards, uint8_t* __restrict__ flags,
                                                     float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,
@@ -510,13 +519,16 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
     uint4* const s_lut = reinterpret_cast<uint4*>(s_dyn4 + M::LUT);
     uint8_t* const s_fl = s_dyn4 + M::FL;
     uint8_t* const s_fi = s_dyn4 + M::FI;
-    // MODE 3: lanes tid of the two halves of the workgroup share env e — threads 0..BLOCK-1 interact, the others move
+    // MODE 3 / 4: lanes tid of the two halves of the workgroup share env e — threads 0..BLOCK-1 interact, the others move
+    constexpr bool DUO = MODE == 3 || MODE == 4;
     static_assert(MODE != 3 || (MAXP <= 2 && OUT && !OLD && !EV && PIPE && (UNIFORM || RU) && CW == 4 && !NOCONF),
                   "MODE 3 = the pipelined MODE 2 instance, split");
-    const uint32_t tid = MODE == 3 ? (threadIdx.x & (uint32_t)(BLOCK - 1)) : threadIdx.x;
-    const bool mover = MODE == 3 && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
+    static_assert(MODE != 4 || (UNIFORM && MAXP == 1 && LAY_LDS && OUT && !OLD && !EV && PIPE && CW == 4 && NOCONF),
+                  "MODE 4 = the pipelined joint-table instance (MODE 1), split");
+    const uint32_t tid = DUO ? (threadIdx.x & (uint32_t)(BLOCK - 1)) : threadIdx.x;
+    const bool mover = DUO && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
     const int64_t e = (int64_t)blockIdx.x * BLOCK + tid;
-    const bool active = e < n;  // (MODE 3: the host launches whole workgroups only — every wavefront meets every barrier)
+    const bool active = e < n;  // (MODE 3 / 4: the host launches whole workgroups only — every wavefront runs to the end)
     Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains a barrier
     {
         const uint4* src = reinterpret_cast<const uint4*>(&g_lut4);
@@ -528,7 +540,7 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
             s_lut[i] = ent;
         }
     }
-    if (MODE == 3 && threadIdx.x < 8) reinterpret_cast<uint32_t*>(s_dyn4 + M::SYNC)[threadIdx.x] = 0u;
+    if (DUO && threadIdx.x < 8) reinterpret_cast<uint32_t*>(s_dyn4 + M::SYNC)[threadIdx.x] = 0u;
     if (UNIFORM && threadIdx.x < 32) {
         const LayC Cs = load_consts<true>(L);
         s_dyn4[M::CT + threadIdx.x] = (uint8_t)cook_of(Cs, OC_O_SOUP | threadIdx.x);
@@ -547,8 +559,15 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
         }
         build_joint_table<CW>(L, W, s_dyn4 + M::MVJ, (uint32_t)M::MVJ, s_fl, s_fi, s_dyn4 + M::CELLS);  // (scratch: the cell words come later)
     }
+    if (MODE == 4) {  // the mover's tables: who interacts under each joint action, and the joint move table in its compact form
+        if (threadIdx.x < 36) {
+            uint2* sel = reinterpret_cast<uint2*>(s_dyn4 + M::ACT);
+            sel[threadIdx.x] = make_uint2(threadIdx.x / 6 == 5 ? 0xFFFFFFFFu : 0u, threadIdx.x % 6 == 5 ? 0xFFFFFFFFu : 0u);
+        }
+        build_joint_table<2, BLOCK * CW>(L, W, s_dyn4 + M::MVJ, (uint32_t)M::MVJ, s_fl, s_fi, s_dyn4 + M::CELLS);
+    }
     __syncthreads();
-    if (MODE != 3 && !active) return;
+    if (!DUO && !active) return;
     const uint32_t col = (uint32_t)M::CELLS + tid * (uint32_t)CW;  // LDS address of this lane's column of cell words
     // (L, C, lut_var, two and MODE 2's floor mask change when a restart moves the env to another layout: StartArgs.regen_count)
     LayC C = load_consts<UNIFORM>(L);
@@ -556,8 +575,8 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
     const uint32_t delta4 = make_delta4(W);
     Env4<MAXP> s;
     if (!mover) load_env4<MAXP, CW>(C, L, st, n, e, n_obj, horizon, s, col);
-    if (MODE == 3 && !mover) cw_wr<CW>(col + noact_off<CW>(n_obj), cw_make<CW>(0u, KB_NOTHING));
-    bool two = MODE == 1 || MODE == 2 || MODE == 3 || s.pos1 != 0xFFu;
+    if (DUO && !mover) cw_wr<CW>(col + noact_off<CW>(n_obj), cw_make<CW>(0u, KB_NOTHING));
+    bool two = MODE == 1 || MODE == 2 || DUO || s.pos1 != 0xFFu;
     uint64_t fm = 0;  // MODE 2: bit c = cell c is floor (static per layout)
     auto floor_mask_of = [&](const Lay Lx) __attribute__((always_inline)) {
         uint64_t m = 0;
@@ -569,7 +588,7 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
         }
         return m;
     };
-    if (MODE == 2 || (MODE == 3 && mover)) fm = floor_mask_of(L);
+    if (MODE == 2 || (MODE == 3 && mover)) fm = floor_mask_of(L);  // (MODE 4's mover reads the joint move table instead)
     auto joint_row = [&]() {  // LDS address of the row of the joint pose (pos0, or0, pos1, or1)
         const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR];
         return (uint32_t)M::MVJ + ((s_fi[s.pos0] * 4u + s.or0) * NP + (s_fi[s.pos1] * 4u + s.or1)) * (uint32_t)Mvj<CW>::ROW_BYTES;
@@ -586,7 +605,7 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
     const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
     float4* rew_k = rewards ? rewards + (int64_t)blockIdx.x * BLOCK : nullptr;  // wave-uniform row pointers
     const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u));  // first lane of this wavefront
-    static_assert(!FT8 || ((MODE == 1 || MODE == 2 || MODE == 3) && OUT && !EV), "the tiled flags array is served by joint-table and per-env-terrain instances");
+    static_assert(!FT8 || ((MODE == 1 || MODE == 2 || DUO) && OUT && !EV), "the tiled flags array is served by joint-table and per-env-terrain instances");
     uint8_t* flg_k = flags ? flags + ((int64_t)blockIdx.x * BLOCK + wave_base) * (FT8 ? 8 : 1) : nullptr;  // (FT8: the tile row of 8 steps)
     uint32_t flt_lo = 0, flt_hi = 0;  // FT8: the flag bytes of the block's steps 0..3 / 4..7
     const uint32_t lane = tid & 63u;
@@ -662,7 +681,7 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
         // may be rewritten: the two instructions behind it.
         typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
         const u64x2 q = {p.lo, p.hi};
-        if (FT8 || MODE == 3) {  // (the flag byte has gone into the block's tile — MODE 3: the mover stores the flags; the second wait state is a no-op)
+        if (FT8 || DUO) {  // (the flag byte has gone into the block's tile — MODE 3 / 4: the mover stores the flags; the second wait state is a no-op)
             asm volatile("global_store_dwordx4 %1, %2, %4\n\tv_pk_add_f32 %0, %0, %3\n\ts_nop 0"
                          : "+v"(epsh) : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k) : "memory");
         } else {
@@ -712,7 +731,7 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
             nf0 = col + (m1 & 0xFFFFu);
             nf1 = col + (m1 >> 16);
         }
-        if ((MODE == 1 || MODE == 2 || MODE == 3) && PIPE) {  // the next step's cells: everything this step writes to the grid has been issued
+        if ((MODE == 1 || MODE == 2 || DUO) && PIPE) {  // the next step's cells: everything this step writes to the grid has been issued
             nc0 = cw_rd<CW>(nf0);
             nc1 = cw_rd<CW>(nf1);
             rd_pots(npw);
@@ -879,7 +898,7 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
                         m0 = joint_row();
                         m1 = lds_rd32(m0 + (uint32_t)Mvj<CW>::FACES);
                         m2 = CW == 2 ? lds_rd16(m0 + ja2n) : lds_rd32(m0 + ja2n);
-                    } else if (MODE == 3) {
+                    } else if (DUO) {
                         // (the mover has seen the same horizon: its record of the next step already faces from the start pose)
                     } else if (MODE == 2) {
                         m0 = s.pos0; m2 = s.pos1; m3 = s.or0; m4 = s.or1;
@@ -897,7 +916,7 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
                 nf0 = col + (m1 & 0xFFFFu);
                 nf1 = col + (m1 >> 16);
             }
-            if ((MODE == 1 || MODE == 2 || MODE == 3) && PIPE && grid_changed) {  // read the next step's cells again
+            if ((MODE == 1 || MODE == 2 || DUO) && PIPE && grid_changed) {  // read the next step's cells again
                 nc0 = cw_rd<CW>(nf0);
                 nc1 = cw_rd<CW>(nf1);
                 rd_pots(npw);
@@ -942,7 +961,7 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
             if (ea.events) ea.events[(int64_t)step_k * n + e] = ev;
             count_events(ea, e, ev, done, (options & OC_OPT_AUTO_RESET) != 0u);
         }
-        if (FT8 && MODE != 3 && k8 >= 0) {  // this step's byte of the block's flag tile (k8 is a constant of the unrolled step)
+        if (FT8 && !DUO && k8 >= 0) {  // this step's byte of the block's flag tile (k8 is a constant of the unrolled step)
             uint32_t& half = (k8 & 4) ? flt_hi : flt_lo;
             half = (k8 & 3) == 0 ? fl : (half | (fl << (8 * (k8 & 3))));
         }
@@ -968,7 +987,7 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
     // after the eight steps of an unrolled block (FT8: first the block's flag tile — 8 bytes per env, 512 contiguous bytes
     // per wavefront)
     auto advance_rows = [&]() __attribute__((always_inline)) {
-        if (FT8 && MODE != 3) {
+        if (FT8 && !DUO) {
             const uint64_t tile = ((uint64_t)flt_hi << 32) | flt_lo;
             asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lane * 8u), "v"(tile), "s"(flg_k) : "memory");
         }
@@ -987,12 +1006,19 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
     constexpr uint32_t RING_SLOT = (uint32_t)BLOCK * 8u;  // bytes of one step's records
     // progress counters of this lane's mover / interact pair: {blocks the mover has finished, blocks the interact wavefront has finished}
     const uint32_t sync_pair = (uint32_t)M::SYNC + (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * 8u;
-    if (MODE == 3 && mover) {
+    if (DUO && mover) {
         auto ahead = [&](uint32_t c, uint32_t d) __attribute__((always_inline)) {
             return c + (uint32_t)(int32_t)(int8_t)(uint8_t)__builtin_amdgcn_perm(0u, delta4, d);
         };
         const uint4 h = st[e];
         uint32_t P0 = h.x & 0xFFu, O0 = (h.x >> 8) & 0xFFu, P1 = h.x >> 24, O1 = h.y & 0xFFu;
+        // MODE 4: the pose is a ROW of the joint move table (compact form: u16 entries, 76 bytes per row)
+        constexpr uint32_t ROW4 = (uint32_t)Mvj<2>::ROW_BYTES, FACES4 = (uint32_t)Mvj<2>::FACES;
+        auto row_of = [&](uint32_t p0, uint32_t o0, uint32_t p1, uint32_t o1) __attribute__((always_inline)) {
+            const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR];
+            return (uint32_t)M::MVJ + ((s_fi[p0] * 4u + o0) * NP + (s_fi[p1] * 4u + o1)) * ROW4;
+        };
+        uint32_t J = MODE == 4 ? row_of(P0, O0, P1, O1) : 0u;
         const uint32_t t_in = h.y >> 16;
         uint32_t tleft = t_in < (uint32_t)horizon ? (uint32_t)horizon - 1u - t_in : 0u;
         const uint32_t noact = col + noact_off<CW>(n_obj);
@@ -1000,6 +1026,10 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
         const int n_blocks = n_steps >> 3;
         auto produce = [&](int b, uint32_t ring) __attribute__((always_inline)) {
             if (b >= n_blocks) {  // the stub block
+                if (MODE == 4) {  // joint pose -> cells / orientations
+                    const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR], Jidx = (J - (uint32_t)M::MVJ) / ROW4, I0 = Jidx / NP, I1 = Jidx - I0 * NP;
+                    P0 = s_fl[I0 >> 2]; O0 = I0 & 3u; P1 = s_fl[I1 >> 2]; O1 = I1 & 3u;
+                }
                 lds_wr64(ring, noact, noact);
                 lds_wr64(ring + RING_SLOT, P0 | (O0 << 8) | (P1 << 16) | (O1 << 24), 0u);
                 return;
@@ -1011,6 +1041,18 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
                 // the actions of this step: the base-6 digits of the block's word k8 / 2 (second pair of digits: 36 x)
                 uint32_t x = (k8 >> 1) == 0 ? wb.w0 : (k8 >> 1) == 1 ? wb.w1 : (k8 >> 1) == 2 ? wb.w2 : wb.w3;
                 if (k8 & 1) x *= 36u;
+                if (MODE == 4) {
+                    // the joint action as a byte offset into a row of u16 (2 x the top base-36 digit of x); three look-ups:
+                    // the faced cells of this pose, who interacts under this joint action, the row of the next pose
+                    // (resolve_movement with both collision rules is that one table read, as in MODE 1)
+                    const uint32_t ja2 = __umulhi(x, 72u) & ~1u;
+                    const uint32_t fa = lds_rd32(J + FACES4);
+                    const uint2 sel = lds_rd64((uint32_t)M::ACT + 4u * ja2);
+                    const uint32_t Jn = lds_rd16(J + ja2);
+                    const uint32_t f0 = col + (fa & 0xFFFFu), f1 = col + (fa >> 16);
+                    lds_wr64(ring + (uint32_t)k8 * RING_SLOT, (f0 & sel.x) | (noact & ~sel.x), (f1 & sel.y) | (noact & ~sel.y));
+                    J = Jn;
+                } else {
                 const uint32_t a0 = __umulhi(x, 6u), a1 = __umulhi(x * 6u, 6u);
                 const uint32_t f0 = col + ahead(P0, O0) * (BLOCK * CW), f1 = col + ahead(P1, O1) * (BLOCK * CW);
                 lds_wr64(ring + (uint32_t)k8 * RING_SLOT, a0 == 5u ? f0 : noact, a1 == 5u ? f1 : noact);
@@ -1024,6 +1066,7 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
                 const uint32_t q0 = collide ? P0 : np0, q1 = collide ? P1 : np1;
                 O0 = a0 < 4u ? a0 : O0; O1 = a1 < 4u ? a1 : O1;
                 P0 = q0; P1 = q1;
+                }
                 // OvercookedEnv.step at the horizon (env.py:266-267, 321-325): the flag byte; a restart moves the players
                 uint32_t fl = 0;
                 const bool done = tleft == 0u;
@@ -1048,6 +1091,7 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
                             P0 = L.u8(L_START_POS); P1 = L.u8(L_START_POS + 1);
                         }
                         O0 = L.u8(L_START_OR); O1 = L.u8(L_START_OR + 1);
+                        if (MODE == 4) J = row_of(P0, O0, P1, O1);
                     }
                 }
                 if (FT8) {
@@ -1249,8 +1293,8 @@ __global__ __launch_bounds__(MODE == 3 ? 2 * BLOCK : BLOCK) __attribute__((amdgp
             }
         }
         s.pos0 = P0; s.or0 = O0; s.pos1 = P1; s.or1 = O1;
-    } else if (MODE == 3) {
-        // The INTERACT wavefronts of MODE 3: the step of MODE 2 without its movement — the two cell words a step acts on come
+    } else if (DUO) {
+        // The INTERACT wavefronts of MODE 3 / 4: the step of MODE 2 without its movement — the two cell words a step acts on come
         // out of the mover's ring (the next step's record is read while this step's look-ups are in flight, its cells right
         // after this step's cell writes).
         const uint32_t ring0 = (uint32_t)M::RING + tid * 8u;

@@ -138,12 +138,12 @@ def test_tiled_flags_launch_shapes_against_oracle(shape, gpu):
 
 
 @pytest.mark.parametrize("tiled", [False, True])
-@pytest.mark.parametrize("layout", ["asymmetric_advantages", "coordination_ring", "forced_coordination", "counter_circuit", "mix5",
-                                    "generated_4096"])
+@pytest.mark.parametrize("layout", ["cramped_room", "asymmetric_advantages", "coordination_ring", "forced_coordination",
+                                    "counter_circuit", "mix5", "generated_4096"])
 def test_mover_interact_split_against_oracle(layout, tiled, gpu):
-    """k_rollout4 MODE 3 (two wavefronts per 64 envs: a mover running ahead of an interact wavefront through a ring in LDS) on
-    every batch kind it serves — single two-player layouts, the 5-layout table in LDS, 4 096 generated terrains read through
-    L2 — against the oracle over episodes of 23 steps with DRAWN start states (so that every restart exercises the mover's own
+    """k_rollout4 MODE 3 / 4 (two wavefronts per 64 envs: a mover running ahead of an interact wavefront through a ring in LDS) on
+    every batch kind it serves — cramped_room (MODE 4: the mover reads the joint move table), single two-player layouts, the
+    5-layout table in LDS, 4 096 generated terrains read through L2 (MODE 3: the mover moves on a floor mask) — against the oracle over episodes of 23 steps with DRAWN start states (so that every restart exercises the mover's own
     draw of the start pose), tiled and [step][env] flags; then the same launch with OC_OPT_ONE_WAVEFRONT must agree as well."""
     from overcooked_ai_amd.layout_gen import reference_generated_layouts
     from overcooked_ai_amd.layouts import LayoutTable
