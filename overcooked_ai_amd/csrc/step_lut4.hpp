@@ -131,6 +131,19 @@ __device__ __forceinline__ uint2 lds_rd64(uint32_t a) {
     const oc_u32x2 v = *(const OC_LDS oc_u32x2*)(uintptr_t)a;
     return make_uint2(v.x, v.y);
 }
+// 12-byte records at a 12-byte stride (ds_read_b96 / ds_write_b96: gfx950 takes them at 4-byte alignment)
+typedef uint32_t oc_u32x3 __attribute__((ext_vector_type(3)));
+struct oc_rec3 { uint32_t x, y, z; };
+__device__ __forceinline__ oc_rec3 lds_rd96(uint32_t a) {
+    typedef oc_u32x3 __attribute__((aligned(4))) u32x3_a4;
+    const oc_u32x3 v = *(const OC_LDS u32x3_a4*)(uintptr_t)a;
+    return oc_rec3{v.x, v.y, v.z};
+}
+__device__ __forceinline__ void lds_wr96(uint32_t a, uint32_t x, uint32_t y, uint32_t z) {
+    typedef oc_u32x3 __attribute__((aligned(4))) u32x3_a4;
+    const oc_u32x3 v = {x, y, z};
+    *(OC_LDS u32x3_a4*)(uintptr_t)a = v;
+}
 __device__ __forceinline__ void lds_wr64(uint32_t a, uint32_t x, uint32_t y) {
     const oc_u32x2 v = {x, y};
     *(OC_LDS oc_u32x2*)(uintptr_t)a = v;
@@ -412,7 +425,7 @@ __device__ __forceinline__ uint32_t joint_action_of(uint32_t w0, uint32_t w1, ui
 //    LAY               staged layout records
 //    FL / FI           free-cell list / cell -> free-cell index (MODE 1)
 //    CT                [32] cook time by the low five bits of the soup code (one layout)
-//    RING              MODE 3 only: mover -> interact records, [3][8][BLOCK] x 8 bytes
+//    SYNC / RING       MODE 3 / 4 only: progress counters of the pairs; mover -> interact records, [3][8][BLOCK] x 12 bytes
 //    CELLS             cell words u16 / u32 [n_obj * 16 + 2 (+ 1 with MODE 3)][BLOCK]
 // With u16 table entries (CW = 2) the move table comes first, so that row addresses and the LUT addresses in ACT fit 16 bits;
 // with u32 entries (CW = 4, an 85 KB move table) the small tables come first instead, so that THEIR addresses stay below
@@ -431,14 +444,18 @@ struct Lds4 {
     static constexpr int LAY = LUT + LUT_BYTES, LAY_BYTES = LAY_LDS ? (UNIFORM ? 256 : LDS_LAYOUT_MAX * 256) : 16;
     static constexpr int FL = LAY + LAY_BYTES, FI = FL + 16, CT = FI + ((MODE == 1 || MODE == 4) ? OC_MAX_CELLS : 0);
     static constexpr int MVJ = TABLE_FIRST ? 0 : CT + 32;  // LDS address of the move table
-    // MODE 3: the ring the mover wavefronts feed the interact wavefronts through — three buffers of one 8-step block each,
-    // [step in block][lane] records of two u32 (the LDS addresses of the two cell words the players act on in that step)
-    static constexpr int RING_BUF = 8 * BLOCK * 8, RING_BYTES = DUO ? 3 * RING_BUF : 0;
+    // MODE 3 / 4: the ring the mover wavefronts feed the interact wavefronts through — three buffers of one 8-step block
+    // each, [step in block][lane] records of three u32: the LDS addresses of the two cell words the players act on in that
+    // step, and a flag word — bit 31: the episode ends with this step (the horizon), F4_CHG: both players interact with the
+    // same cell, so player 1 must redo its interact if player 0 changes the cell.  (Measured: with TWO buffers — 16-byte
+    // records would leave room for no more — the mover cannot build a lead, every block the interact wavefront waits for
+    // the record it looks ahead to: counter_circuit 330 -> 283 G, the 5-layout mix 269 -> 258 G.)
+    static constexpr int RING_REC = 12, RING_BUF = 8 * BLOCK * RING_REC, RING_BYTES = DUO ? 3 * RING_BUF : 0;
     // ... and the progress counters of the four mover / interact pairs of a workgroup: {blocks produced, blocks consumed} x 4
     static constexpr int SYNC = TABLE_FIRST ? CT + 32 : MVJ + MVJ_CAP, SYNC_BYTES = DUO ? 64 : 0;
     static constexpr int RING = SYNC + SYNC_BYTES;
     static constexpr int CELLS = RING + RING_BYTES;
-    static_assert(!DUO || (CW == 4 && RING % 8 == 0), "the ring goes with 32-bit cell words");
+    static_assert(!DUO || (CW == 4 && RING % 4 == 0), "the ring goes with 32-bit cell words");
     static_assert(MODE != 4 || MVJ + MVJ_CAP < 65536, "MODE 4: row addresses are u16");
     static_assert(CW == 4 || MVJ_CAP + ACT_BYTES + LUT4_KEYS * 16 < 65536, "row / LUT addresses are u16 in the tables");
     static_assert(CW == 2 || CT + 32 < 65536, "the small tables' addresses must fit the DS offset field");
@@ -745,8 +762,10 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
         };
         const float sh0 = shaped_of(e0.w);
         float sh1 = shaped_of(e1.w);
-        const bool done = s.tleft == 0u;
-        const bool conflict = NOCONF ? false : (fo0 == fo1) & ((r0 & F4_CHG) != 0u);
+        // (MODE 3 / 4: m0 carries the record's flag word of this step: bit 31 = the horizon, F4_CHG = the players share a cell)
+        const uint32_t f_rec = DUO ? m0 : 0u;
+        const bool done = DUO ? (f_rec & 0x80000000u) != 0u : s.tleft == 0u;
+        const bool conflict = NOCONF ? false : DUO ? (r0 & f_rec & F4_CHG) != 0u : (fo0 == fo1) & ((r0 & F4_CHG) != 0u);
         // ---- ONE branch for everything rare; its test is integer arithmetic up to one compare (no SGPR hand-offs) ----
         // bit 0 (= F4_TAKE_DISH) of `take`: a dish taken from the dispenser may be "useful" — some pot was (pot_states
         // before the interacts: class idle 1, idle 2, cooking or ready) and no dish lay on a counter, before or after
@@ -766,11 +785,18 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
         if (!FAST_START) gate |= F4_START;
         else gate |= zero_cook ? (uint32_t)F4_START : 0u;
         if (OLD) gate |= C.old_dyn ? (uint32_t)F4_PLACE : 0u;  // old dynamics: the third item starts the pot (Q11)
-        const uint32_t tleft_new = s.tleft - 1u;               // the horizon: the sign bit (tleft < 2^31)
-        s.tleft = tleft_new;
-        uint32_t rare_bits = ((r0 | r1) & (take | gate)) | (tleft_new & 0x80000000u);
-        if (OLD) rare_bits |= s.pending;
-        bool rare = (rare_bits != 0u) | conflict;
+        uint32_t rare_bits;
+        bool rare;
+        if (DUO) {  // the mover has decided the horizon and seen whether the players share a cell: two and-or's and one compare
+            rare_bits = NOCONF ? (((r0 | r1) & (take | gate)) | f_rec) : (((r0 | r1) & (take | gate)) | ((r0 | 0x80000000u) & f_rec));
+            rare = rare_bits != 0u;
+        } else {
+            const uint32_t tleft_new = s.tleft - 1u;               // the horizon: the sign bit (tleft < 2^31)
+            s.tleft = tleft_new;
+            rare_bits = ((r0 | r1) & (take | gate)) | (tleft_new & 0x80000000u);
+            if (OLD) rare_bits |= s.pending;
+            rare = (rare_bits != 0u) | conflict;
+        }
         uint32_t nh0 = r0, nh1 = r1;  // the hands after the step
         float4 rw = make_float4(0.f, 0.f, sh0, sh1);  // this step's reward quad and flag byte: stored ONCE, after the branch
         uint64_t q_lo = 0, q_hi = 0;  // the same quad as two register pairs (what the unrolled blocks store; the rare branch rewrites both whole)
@@ -1003,7 +1029,7 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
     //      counter-based draws as the interact wavefront's env_reset4_draw, keyed by (seed, global env, epoch)).
     //      Block n_steps / 8 (one past the launch) is a stub: record 0 = {nothing, nothing} for the last step's look-ahead
     //      and record 1 = the final pose, which the interact wavefront puts into the stored state.
-    constexpr uint32_t RING_SLOT = (uint32_t)BLOCK * 8u;  // bytes of one step's records
+    constexpr uint32_t RING_SLOT = (uint32_t)BLOCK * (uint32_t)M::RING_REC;  // bytes of one step's records
     // progress counters of this lane's mover / interact pair: {blocks the mover has finished, blocks the interact wavefront has finished}
     const uint32_t sync_pair = (uint32_t)M::SYNC + (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * 8u;
     if (DUO && mover) {
@@ -1021,8 +1047,9 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
         uint32_t J = MODE == 4 ? row_of(P0, O0, P1, O1) : 0u;
         const uint32_t t_in = h.y >> 16;
         uint32_t tleft = t_in < (uint32_t)horizon ? (uint32_t)horizon - 1u - t_in : 0u;
+        uint32_t over = t_in < (uint32_t)horizon ? 0u : t_in - ((uint32_t)horizon - 1u);  // (as Env4: steps run past the horizon)
         const uint32_t noact = col + noact_off<CW>(n_obj);
-        const uint32_t ring0 = (uint32_t)M::RING + tid * 8u;
+        const uint32_t ring0 = (uint32_t)M::RING + tid * (uint32_t)M::RING_REC;
         const int n_blocks = n_steps >> 3;
         auto produce = [&](int b, uint32_t ring) __attribute__((always_inline)) {
             if (b >= n_blocks) {  // the stub block
@@ -1030,8 +1057,8 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
                     const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR], Jidx = (J - (uint32_t)M::MVJ) / ROW4, I0 = Jidx / NP, I1 = Jidx - I0 * NP;
                     P0 = s_fl[I0 >> 2]; O0 = I0 & 3u; P1 = s_fl[I1 >> 2]; O1 = I1 & 3u;
                 }
-                lds_wr64(ring, noact, noact);
-                lds_wr64(ring + RING_SLOT, P0 | (O0 << 8) | (P1 << 16) | (O1 << 24), 0u);
+                lds_wr96(ring, noact, noact, 0u);
+                lds_wr96(ring + RING_SLOT, P0 | (O0 << 8) | (P1 << 16) | (O1 << 24), tleft, over);
                 return;
             }
             const Phx4 wb = philox_words(((uint64_t)t0 >> 3) + (uint64_t)b, g_lo, g_hi, seed_lo, seed_hi);
@@ -1041,6 +1068,7 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
                 // the actions of this step: the base-6 digits of the block's word k8 / 2 (second pair of digits: 36 x)
                 uint32_t x = (k8 >> 1) == 0 ? wb.w0 : (k8 >> 1) == 1 ? wb.w1 : (k8 >> 1) == 2 ? wb.w2 : wb.w3;
                 if (k8 & 1) x *= 36u;
+                uint32_t rec0, rec1, f_same = 0u;
                 if (MODE == 4) {
                     // the joint action as a byte offset into a row of u16 (2 x the top base-36 digit of x); three look-ups:
                     // the faced cells of this pose, who interacts under this joint action, the row of the next pose
@@ -1050,12 +1078,15 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
                     const uint2 sel = lds_rd64((uint32_t)M::ACT + 4u * ja2);
                     const uint32_t Jn = lds_rd16(J + ja2);
                     const uint32_t f0 = col + (fa & 0xFFFFu), f1 = col + (fa >> 16);
-                    lds_wr64(ring + (uint32_t)k8 * RING_SLOT, (f0 & sel.x) | (noact & ~sel.x), (f1 & sel.y) | (noact & ~sel.y));
-                    J = Jn;
+                    rec0 = (f0 & sel.x) | (noact & ~sel.x);
+                    rec1 = (f1 & sel.y) | (noact & ~sel.y);
+                    J = Jn;  // (NOCONF: two players never face the same cell on this layout — no shared-cell flag)
                 } else {
                 const uint32_t a0 = __umulhi(x, 6u), a1 = __umulhi(x * 6u, 6u);
                 const uint32_t f0 = col + ahead(P0, O0) * (BLOCK * CW), f1 = col + ahead(P1, O1) * (BLOCK * CW);
-                lds_wr64(ring + (uint32_t)k8 * RING_SLOT, a0 == 5u ? f0 : noact, a1 == 5u ? f1 : noact);
+                rec0 = a0 == 5u ? f0 : noact;
+                rec1 = a1 == 5u ? f1 : noact;
+                f_same = rec0 == rec1 ? (a0 == 5u ? (uint32_t)F4_CHG : 0u) : 0u;  // both interact with the same cell
                 // the pose of the next step, on the static terrain (as MODE 2)
                 const uint32_t t0_ = ahead(P0, a0), t1_ = ahead(P1, a1);
                 uint32_t fb0 = (uint32_t)(fm >> t0_), fb1 = (uint32_t)(fm >> t1_);
@@ -1071,10 +1102,13 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
                 uint32_t fl = 0;
                 const bool done = tleft == 0u;
                 tleft -= 1u;
+                lds_wr96(ring + (uint32_t)k8 * RING_SLOT, rec0, rec1, f_same | (done ? 0x80000000u : 0u));
                 if (__builtin_expect(done, 0)) {
                     fl = OC_F_DONE;
                     tleft = 0u;
+                    over += 1u;
                     if (options & OC_OPT_AUTO_RESET) {
+                        over = 0u;
                         fl |= OC_F_RESET;
                         tleft = (uint32_t)horizon - 1u;
                         const uint32_t ep_k = sa.epoch + (uint32_t)(b * 8 + k8);
@@ -1297,41 +1331,48 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
         // The INTERACT wavefronts of MODE 3 / 4: the step of MODE 2 without its movement — the two cell words a step acts on come
         // out of the mover's ring (the next step's record is read while this step's look-ups are in flight, its cells right
         // after this step's cell writes).
-        const uint32_t ring0 = (uint32_t)M::RING + tid * 8u;
+        const uint32_t ring0 = (uint32_t)M::RING + tid * (uint32_t)M::RING_REC;
         const int n_blocks = n_steps >> 3;
-        while (lds_poll32(sync_pair) < 2u) __builtin_amdgcn_s_sleep(1);
-        uint32_t fo0, fo1, c0, c1, pw[MAXP];
+        while (lds_poll32(sync_pair) < 1u) __builtin_amdgcn_s_sleep(1);
+        uint32_t fo0, fo1, f_rec, c0, c1, pw[MAXP];
         {
-            const uint2 rec = lds_rd64(ring0);
-            fo0 = rec.x; fo1 = rec.y;
+            const oc_rec3 rec = lds_rd96(ring0);
+            fo0 = rec.x; fo1 = rec.y; f_rec = rec.z;
         }
         c0 = cw_rd<CW>(fo0);
         c1 = cw_rd<CW>(fo1);
         rd_pots(pw);
         auto dstep = [&](int k8, uint32_t next_rec) __attribute__((always_inline)) {
             const Looked looked = look_up(lut_var, lut_var, c0, c1, pw);
-            const uint2 nrec = lds_rd64(next_rec);
-            uint32_t u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0, nf0 = nrec.x, nf1 = nrec.y, nc0 = 0, nc1 = 0, npw[MAXP];
+            const oc_rec3 nrec = lds_rd96(next_rec);
+            uint32_t u0 = f_rec, u1 = 0, u2 = 0, u3 = 0, u4 = 0, nf0 = nrec.x, nf1 = nrec.y, nc0 = 0, nc1 = 0, npw[MAXP];
             core(fo0, fo1, lut_var, lut_var, c0, c1, 0u, pw, u0, u1, u2, u3, u4, nf0, nf1, nc0, nc1, npw, k8, looked);
-            fo0 = nf0; fo1 = nf1; c0 = nc0; c1 = nc1;
+            fo0 = nf0; fo1 = nf1; c0 = nc0; c1 = nc1; f_rec = nrec.z;
 #pragma unroll
             for (int k = 0; k < MAXP; ++k) pw[k] = npw[k];
         };
         uint32_t rbuf = 0;  // (wave-uniform) offset of the ring buffer that holds the block being run
         for (int b = 0; b < n_blocks; ++b) {
-            // block b needs its own records and the first one of block b + 1 (step 7 looks ahead): b + 2 blocks finished
-            // by the mover (the stub behind the launch counts as one)
-            if (b) while (lds_poll32(sync_pair) < (uint32_t)b + 2u) __builtin_amdgcn_s_sleep(1);
+            // Block b's own records are there (checked by block b - 1's step 7); step 7 looks ahead to the first record of
+            // block b + 1: the mover must have finished b + 2 blocks by then (the stub behind the launch counts as one).
+            // The count is read before step 6 and looked at after it, so that the read's latency is not the loop's.
             const uint32_t cur = ring0 + rbuf;
             rbuf = rbuf == 2u * (uint32_t)M::RING_BUF ? 0u : rbuf + (uint32_t)M::RING_BUF;
 #pragma unroll
-            for (int k8 = 0; k8 < 7; ++k8) dstep(k8, cur + (uint32_t)(k8 + 1) * RING_SLOT);
+            for (int k8 = 0; k8 < 6; ++k8) dstep(k8, cur + (uint32_t)(k8 + 1) * RING_SLOT);
+            const uint32_t produced = *(const volatile OC_LDS uint32_t*)(uintptr_t)sync_pair;
+            dstep(6, cur + 7u * RING_SLOT);
+            if (__builtin_amdgcn_readfirstlane((int)produced) < b + 2)
+                while (lds_poll32(sync_pair) < (uint32_t)b + 2u) __builtin_amdgcn_s_sleep(1);
             dstep(7, ring0 + rbuf);
             advance_rows();
             lds_post32(sync_pair + 4u, (uint32_t)b + 1u);
         }
-        const uint32_t pose = lds_rd32(ring0 + rbuf + RING_SLOT);  // the stub block's second record: the pose after the last step
-        s.pos0 = pose & 0xFFu; s.or0 = (pose >> 8) & 0xFFu; s.pos1 = (pose >> 16) & 0xFFu; s.or1 = pose >> 24;
+        {   // the stub block's second record: the pose after the last step and where the episode clock stands
+            const oc_rec3 fin = lds_rd96(ring0 + rbuf + RING_SLOT);
+            s.pos0 = fin.x & 0xFFu; s.or0 = (fin.x >> 8) & 0xFFu; s.pos1 = (fin.x >> 16) & 0xFFu; s.or1 = fin.x >> 24;
+            s.tleft = fin.y; s.over = fin.z;
+        }
     } else {
         auto astep = [&](uint32_t a0, uint32_t a1) __attribute__((always_inline)) {
             const uint32_t f0 = step_cell(s.pos0, s.or0, delta4), f1 = two ? step_cell(s.pos1, s.or1, delta4) : f0;
