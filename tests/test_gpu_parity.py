@@ -1278,10 +1278,19 @@ def test_rollout_random_with_flags_tiled_by_8_steps(gpu):
     a.rollout_random(4, rew[:4], fl.view(-1)[:4 * 256].view(4, 256))  # step counter -> 4
     with pytest.raises((_lib.OcAmdError, ValueError)):
         a.rollout_random(16, rew, fl, flags_tiled8=True)
+    # one two-pot layout: whole workgroups of envs run the mover / interact instance (round 5), which writes the tiled array;
+    # a ragged batch of the same layout is served by an instance that does not
     t2 = LayoutTable([spec_from_name("asymmetric_advantages")])
     c = make_env(t2, 256, gpu, horizon=400, auto_reset=True, seed=1)
+    d = make_env(t2, 256, gpu, horizon=400, auto_reset=True, seed=1)
+    rew_d, fl_d = torch.zeros_like(rew), torch.zeros((16, 256), dtype=torch.uint8, device=gpu)
+    c.rollout_random(16, rew, fl, flags_tiled8=True)
+    d.rollout_random(16, rew_d, fl_d)
+    assert torch.equal(VecOvercookedEnv.untile_flags(fl), fl_d) and torch.equal(rew, rew_d) and torch.equal(c.state, d.state)
+    c = make_env(t2, 300, gpu, horizon=400, auto_reset=True, seed=1)
     with pytest.raises((_lib.OcAmdError, ValueError)):
-        c.rollout_random(16, rew, fl, flags_tiled8=True)
+        c.rollout_random(16, torch.zeros((16, 300, 4), dtype=torch.float32, device=gpu),
+                         torch.zeros((2, 300, 8), dtype=torch.uint8, device=gpu), flags_tiled8=True)
 
 
 @pytest.mark.gpu
