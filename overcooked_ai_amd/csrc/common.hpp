@@ -11,6 +11,24 @@ constexpr int L_NCELLS = 2, L_NPOTS = 3, L_NPLAYERS = 4, L_OLDDYN = 5, L_START_P
               L_PCLASS = 24, L_REW = 32, L_COOK = 48, L_VALUE = 64, L_TERRAIN = 128;
 static_assert(sizeof(OcLayout) == 256, "OcLayout must be 256 bytes");
 
+// ------------------------------------------------------------------------------------------
+// Workgroup id -> block of work.  The dispatcher deals workgroup b to XCD b % 8 (MI355X: 8 XCDs, each with its own L2).
+// With block = workgroup id, neighbouring pieces of every output array belong to eight different L2s; measured with
+// tools/store_front.hip / store_rollout.hip (profiles/r05_store_front.txt): a streaming write of 64 KiB pieces reaches 5.5 TB/s
+// that way and 6.3 TB/s when each XCD owns one contiguous eighth of the buffer (16 KiB pieces: 6.0 -> 6.6; the rollout's rows at
+// two workgroups per CU: 5.3 -> 5.6).  xcd_block() is that mapping: XCD x takes blocks [x * g / 8, (x + 1) * g / 8) of a grid of
+// g workgroups (grids that are not a multiple of 8 keep the identity).  Envs are independent and every random stream is keyed
+// by the env's global index, so which workgroup steps which envs changes no result.  (-DOC_NO_XCD_REMAP: the identity, for A/B.)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t xcd_block() {
+#ifdef OC_NO_XCD_REMAP
+    return blockIdx.x;
+#else
+    const uint32_t b = blockIdx.x, g = gridDim.x;
+    return (g & 7u) ? b : (b & 7u) * (g >> 3) + (b >> 3);
+#endif
+}
+
 using oc_detail::g_err;
 using oc_detail::g_lds_refused;
 using oc_detail::StartArgs;

@@ -208,7 +208,18 @@ __global__ __launch_bounds__(BLOCK) void k_encode_uniform(const OcLayout* __rest
 
     const int64_t n_groups = (n + epg - 1) / epg;
     const int obj_dwords = (n_planes - 1) * 4;
-    for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    // which groups this workgroup encodes: with a grid that is a multiple of 8, XCD x (= workgroup id % 8) owns the x-th
+    // contiguous eighth of the groups and its workgroups stride through it (xcd_block, common.hpp); else a plain grid stride
+#ifdef OC_NO_XCD_REMAP
+    const bool by_xcd = false;
+#else
+    const bool by_xcd = (gridDim.x & 7u) == 0u;
+#endif
+    const int64_t per_xcd = by_xcd ? (n_groups + 7) / 8 : n_groups;
+    const int64_t g_first = by_xcd ? (int64_t)(blockIdx.x & 7u) * per_xcd : 0;
+    const int64_t g_end = min(n_groups, g_first + per_xcd);
+    const int64_t g_stride = by_xcd ? (int64_t)(gridDim.x >> 3) : (int64_t)gridDim.x;
+    for (int64_t g = g_first + (by_xcd ? (int64_t)(blockIdx.x >> 3) : (int64_t)blockIdx.x); g < g_end; g += g_stride) {
         const int64_t e0 = g * epg;
         const int ne = (int)min((int64_t)epg, n - e0);
         // state planes of the group (issued first, parked after the template copy)
@@ -287,3 +298,4 @@ __global__ __launch_bounds__(BLOCK) void k_encode_uniform(const OcLayout* __rest
         __syncthreads();
     }
 }
+

@@ -35,6 +35,13 @@ constexpr int MB_REQ = 0, MB_ALIVE = 128, MB_IN = 256 /* 5 planes x 16 B */, MB_
 constexpr int MB_RSP_BYTES = 80 + 16 + 4 + 8, MB_RSP_GRANULES = (MB_RSP_BYTES + 11) / 12;  // 9
 
 typedef uint32_t mb_u32x4 __attribute__((ext_vector_type(4)));
+#ifdef OC_AMD_TUNING
+__device__ __forceinline__ uint64_t mb_now() {  // the 100 MHz clock, read where the program says (the builtin may be merged with its neighbours)
+    uint64_t t;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+#endif
 __device__ __forceinline__ uint32_t mb_load(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -85,6 +92,9 @@ __global__ __launch_bounds__(64) void k_mailbox(const OcLayout* __restrict__ g_l
     uint32_t served = mb_load(reinterpret_cast<const uint32_t*>(mb + MB_RSPG + 12));  // the last request answered (by an earlier incarnation)
     const uint64_t born = wall_clock64();
     uint64_t last = born;
+#ifdef OC_AMD_TUNING
+    uint64_t tm_prev = 0;
+#endif
     for (;;) {
         const uint32_t tag = mb_load(req);
         if (tag == MB_STOP) break;
@@ -94,6 +104,9 @@ __global__ __launch_bounds__(64) void k_mailbox(const OcLayout* __restrict__ g_l
             __builtin_amdgcn_s_sleep(4);
             continue;
         }
+#ifdef OC_AMD_TUNING
+        const uint64_t tm0 = mb_now();  // tuning builds: where a served request's time goes, in 10 ns ticks, left in the spare granule 8
+#endif
         __atomic_thread_fence(__ATOMIC_ACQUIRE);  // the payload was written before the request word; drop cached copies of it
         // ---- the request: header, object planes, the two action bytes
         OneIn q_in;
@@ -105,6 +118,9 @@ __global__ __launch_bounds__(64) void k_mailbox(const OcLayout* __restrict__ g_l
 #pragma unroll
         for (int p = 0; p < STEP1_MAX_PLANES; ++p)
             if (p < n_obj) s_rows[p * BLOCK] = q_in.v[p];
+#ifdef OC_AMD_TUNING
+        const uint64_t tm1 = mb_now();
+#endif
         const uint8_t* row = reinterpret_cast<const uint8_t*>(s_rows);
         One<MAXP> q;
         one_decode<MAXP>(C, L, q_in.h, row, q);
@@ -138,6 +154,13 @@ __global__ __launch_bounds__(64) void k_mailbox(const OcLayout* __restrict__ g_l
         mb_u32x4 gr[MB_RSP_GRANULES];
 #pragma unroll
         for (int g = 0; g < MB_RSP_GRANULES; ++g) gr[g] = g < n_rsp ? mb_u32x4{r[3 * g], r[3 * g + 1], r[3 * g + 2], tag} : mb_u32x4{0u, 0u, 0u, 0u};
+#ifdef OC_AMD_TUNING
+        if (n_rsp < MB_RSP_GRANULES) {
+            const uint64_t tm2 = mb_now();
+            gr[MB_RSP_GRANULES - 1] = mb_u32x4{(uint32_t)(tm1 - tm0), (uint32_t)(tm2 - tm1), (uint32_t)(tm0 - tm_prev), tag};
+            tm_prev = tm2;
+        }
+#endif
         mb_store_granules(mb + MB_RSPG, gr);
         served = tag;
         last = wall_clock64();

@@ -207,11 +207,12 @@ void launch_step(const OcBatch* b, int n_obj, const void* d_state_in, void* d_st
 // in step order, through (row pointer of the step, lane offset) exactly as k_rollout4 addresses its rows
 __global__ __launch_bounds__(BLOCK) void k_output_stores_only(float4* __restrict__ rewards, uint8_t* __restrict__ flags, int64_t n,
                                                               int n_steps) {
-    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t blk = xcd_block();  // (as k_rollout4: each XCD owns a contiguous eighth of the envs)
+    const int64_t e = (int64_t)blk * BLOCK + threadIdx.x;
     if (e >= n) return;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4* rew_k = rewards + (int64_t)blockIdx.x * BLOCK;                      // wave-uniform row pointers
-    uint8_t* flg_k = flags ? flags + (int64_t)blockIdx.x * BLOCK : nullptr;
+    float4* rew_k = rewards + (int64_t)blk * BLOCK;                      // wave-uniform row pointers
+    uint8_t* flg_k = flags ? flags + (int64_t)blk * BLOCK : nullptr;
 #pragma unroll 1
     for (int k = 0; k < n_steps; ++k) {
         rew_k[threadIdx.x] = zero4;
@@ -223,11 +224,12 @@ __global__ __launch_bounds__(BLOCK) void k_output_stores_only(float4* __restrict
 // per lane into the block's tile row, as the kernels that serve that layout write it
 __global__ __launch_bounds__(BLOCK) void k_output_stores_only_tiled8(float4* __restrict__ rewards, uint2* __restrict__ flag_tiles,
                                                                      int64_t n, int n_blocks) {
-    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t blk = xcd_block();
+    const int64_t e = (int64_t)blk * BLOCK + threadIdx.x;
     if (e >= n) return;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4* rew_k = rewards + (int64_t)blockIdx.x * BLOCK;
-    uint2* flg_k = flag_tiles + (int64_t)blockIdx.x * BLOCK;
+    float4* rew_k = rewards + (int64_t)blk * BLOCK;
+    uint2* flg_k = flag_tiles + (int64_t)blk * BLOCK;
 #pragma unroll 1
     for (int b = 0; b < n_blocks; ++b) {
 #pragma unroll

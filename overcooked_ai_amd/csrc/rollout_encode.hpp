@@ -73,7 +73,8 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_encode(const OcLayout* __re
     // of owner wavefront w's envs (between two workgroup barriers per step), halving what a wavefront does per step.
     const bool owner = NW == 4 || threadIdx.x < BLOCK;
     const int ow = wave & 3, part = wave >> 2;
-    const int64_t e = (int64_t)blockIdx.x * BLOCK + (threadIdx.x & (BLOCK - 1));
+    const uint32_t blk = xcd_block();  // (common.hpp: each XCD owns a contiguous eighth of the envs — and of every step's observations)
+    const int64_t e = (int64_t)blk * BLOCK + (threadIdx.x & (BLOCK - 1));
     const bool active = owner && e < n;
     // caller actions: the first step's are requested before the tables are staged, step k + 1's while step k is encoded
     uint32_t a01_next = (actions && active && n_steps > 0) ? reinterpret_cast<const uint16_t*>(actions)[e] : 0u;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(NW * 64) void k_rollout_encode(const OcLayout* __re
         }
     }
     __syncthreads();  // NW = 4: the last workgroup barrier, from here on every wavefront runs by itself
-    const int64_t wave_e0 = (int64_t)blockIdx.x * BLOCK + (int64_t)ow * 64;
+    const int64_t wave_e0 = (int64_t)blk * BLOCK + (int64_t)ow * 64;
     const int n_wave = (int)max((int64_t)0, min((int64_t)64, n - wave_e0));  // envs of the owner wavefront
     if (NW == 4 && n_wave == 0) return;
 

@@ -544,7 +544,8 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
                   "MODE 4 = the pipelined joint-table instance (MODE 1), split");
     const uint32_t tid = DUO ? (threadIdx.x & (uint32_t)(BLOCK - 1)) : threadIdx.x;
     const bool mover = DUO && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
-    const int64_t e = (int64_t)blockIdx.x * BLOCK + tid;
+    const uint32_t blk = xcd_block();  // (common.hpp: each XCD owns a contiguous eighth of the envs)
+    const int64_t e = (int64_t)blk * BLOCK + tid;
     const bool active = e < n;  // (MODE 3 / 4: the host launches whole workgroups only — every wavefront runs to the end)
     Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains a barrier
     {
@@ -620,10 +621,10 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
     f32x2 epsh = {ep.z, ep.w};
     const uint64_t g = (uint64_t)(env_offset + e);
     const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
-    float4* rew_k = rewards ? rewards + (int64_t)blockIdx.x * BLOCK : nullptr;  // wave-uniform row pointers
+    float4* rew_k = rewards ? rewards + (int64_t)blk * BLOCK : nullptr;  // wave-uniform row pointers
     const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u));  // first lane of this wavefront
     static_assert(!FT8 || ((MODE == 1 || MODE == 2 || DUO) && OUT && !EV), "the tiled flags array is served by joint-table and per-env-terrain instances");
-    uint8_t* flg_k = flags ? flags + ((int64_t)blockIdx.x * BLOCK + wave_base) * (FT8 ? 8 : 1) : nullptr;  // (FT8: the tile row of 8 steps)
+    uint8_t* flg_k = flags ? flags + ((int64_t)blk * BLOCK + wave_base) * (FT8 ? 8 : 1) : nullptr;  // (FT8: the tile row of 8 steps)
     uint32_t flt_lo = 0, flt_hi = 0;  // FT8: the flag bytes of the block's steps 0..3 / 4..7
     const uint32_t lane = tid & 63u;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -480,7 +480,8 @@ __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_
     extern __shared__ __attribute__((aligned(16))) uint16_t s_cells3[];  // [n_obj * 16][BLOCK]
     __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];  // one 256-byte record when the batch has one layout
     __shared__ uint2 s_lut[2 * LUT_ENTRIES];
-    const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t blk = xcd_block();  // (common.hpp)
+    const int64_t e = (int64_t)blk * BLOCK + threadIdx.x;
     const bool active = e < n;
     for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
     Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains the barrier
@@ -496,9 +497,9 @@ __global__ __launch_bounds__(BLOCK) void k_step3(const OcLayout* __restrict__ g_
     float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     // n_steps transitions with the caller's actions [n_steps][n][2] (oc_step: one; oc_step_many: K in one launch, the
     // env staying on chip in between).  The next step's actions are fetched while the current step runs.
-    const uint16_t* act_k = reinterpret_cast<const uint16_t*>(actions) + (int64_t)blockIdx.x * BLOCK;  // wave-uniform rows
-    float4* rew_k = rewards + (int64_t)blockIdx.x * BLOCK;
-    uint8_t* flg_k = flags + (int64_t)blockIdx.x * BLOCK;
+    const uint16_t* act_k = reinterpret_cast<const uint16_t*>(actions) + (int64_t)blk * BLOCK;  // wave-uniform rows
+    float4* rew_k = rewards + (int64_t)blk * BLOCK;
+    uint8_t* flg_k = flags + (int64_t)blk * BLOCK;
     // The actions of eight steps are fetched together into a 128-bit queue: s_waitcnt vmcnt counts loads AND stores in
     // issue order, so a per-step look-ahead load makes every step wait for the previous step's output stores as well
     // (~1 us per step; measured on oc_step_many).  One such wait per eight steps instead.

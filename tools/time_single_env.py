@@ -43,6 +43,15 @@ if port.mailbox is not None:  # the resident kernel: post + spin, no launch
     for _ in range(N):
         port._step(port.mailbox)
     t3 = time.perf_counter()
+    if "tuning" in os.environ.get("OC_AMD_LIB", ""):  # a -DOC_AMD_TUNING build leaves the kernel's own phase times (10 ns ticks) in granule 8
+        from overcooked_ai_amd import _lib
+        ph = np.zeros(3)
+        for _ in range(200):
+            port._step(port.mailbox)
+            ph += port.np[2048 + 16 * 8:2048 + 16 * 8 + 12].view(np.uint32)
+        print("inside k_mailbox: request seen -> payload loaded %.2f us, -> transition computed %.2f us; previous answer -> this request seen %.2f us"
+              % tuple(ph / 200 * 0.01))
+        t3 = time.perf_counter()
     for _ in range(N):
         port.transition(state, 4, 4)
     t6 = time.perf_counter()
