@@ -896,6 +896,21 @@ namespace {
 static_assert(OC_MB_STATE_IN == MB_IN && OC_MB_ACTIONS == MB_ACT && OC_MB_STATE_OUT == MB_OUT && OC_MB_REWARDS == MB_REW &&
               OC_MB_FLAGS == MB_FLAGS && OC_MB_EVENTS == MB_EV, "mailbox offsets of include/oc_amd.h");
 
+// the request granules of `tag`: payload = n_state bytes of MB_IN + the two bytes of MB_ACT
+void mailbox_post(OcMailbox* m, uint32_t tag, int n_state) {
+    alignas(16) uint8_t pay[12 * MB_REQ_MAX + 4] = {0};
+    memcpy(pay, m->h + MB_IN, (size_t)n_state);
+    memcpy(pay + n_state, m->h + MB_ACT, 2);
+    const int n_req = (n_state + 2 + 11) / 12;
+    for (int g = 0; g < n_req; ++g) {
+        alignas(16) uint32_t q[4];
+        memcpy(q, pay + 12 * g, 12);
+        q[3] = tag;
+        typedef long long mb_i64x2 __attribute__((vector_size(16), aligned(16)));
+        *reinterpret_cast<volatile mb_i64x2*>(m->h + MB_REQG + 16 * g) = *reinterpret_cast<const mb_i64x2*>(q);  // one movaps
+    }
+}
+
 int mailbox_launch(OcMailbox* m) {
     *reinterpret_cast<volatile uint32_t*>(m->h + MB_ALIVE) = 1u;
     DISPATCH_NOBJ(m->n_obj, {
@@ -955,17 +970,18 @@ int oc_mailbox_step(OcMailbox* m) {
     if (seq == MB_STOP || seq == 0u) seq = 1u;
     m->seq = seq;
     const int n_state = 16 * (1 + m->n_obj);
-    const int n_rsp = (n_state + 28 + 11) / 12;
-    // ---- the request: the payload is where the caller wrote it (MB_IN, MB_ACT); publish it
-    __atomic_store_n(reinterpret_cast<uint32_t*>(m->h + MB_REQ), seq, __ATOMIC_RELEASE);
-    // ---- the response: every granule carries the tag once the kernel has answered
+    const int n_words = (n_state + 28) / 4;  // payload dwords of the response
+    // ---- the request: the caller's plain views (MB_IN, MB_ACT) as granules of {12 payload bytes, tag}, one aligned 16-byte
+    //      store each (the kernel's lanes read one granule each with a single 16-byte load: payload and tag arrive together)
+    mailbox_post(m, seq, n_state);
+    // ---- the response: two 64-byte lines of {15 payload dwords, tag}
     volatile uint32_t* alive = reinterpret_cast<volatile uint32_t*>(m->h + MB_ALIVE);
     uint32_t spins = 0;
     struct timespec t0 = {0, 0};
     for (;;) {
-        int ok = 1;
-        for (int g = n_rsp - 1; g >= 0 && ok; --g)
-            ok = __atomic_load_n(reinterpret_cast<uint32_t*>(m->h + MB_RSPG + 16 * g + 12), __ATOMIC_ACQUIRE) == seq;
+        // the last dword of each response line carries the tag once the line has arrived (line 1 only when the payload needs it)
+        int ok = __atomic_load_n(reinterpret_cast<uint32_t*>(m->h + MB_RSPG + 60), __ATOMIC_ACQUIRE) == seq;
+        if (ok && n_words > 15) ok = __atomic_load_n(reinterpret_cast<uint32_t*>(m->h + MB_RSPG + 124), __ATOMIC_ACQUIRE) == seq;
         if (ok) break;
         __builtin_ia32_pause();
         if ((++spins & 0x3FFu) != 0u) continue;
@@ -982,14 +998,27 @@ int oc_mailbox_step(OcMailbox* m) {
         if (t0.tv_sec == 0 && t0.tv_nsec == 0) t0 = now;
         else if ((now.tv_sec - t0.tv_sec) > 5) return fail(OC_ELAUNCH, "oc_mailbox_step: no answer from the resident kernel within 5 s");
     }
-    uint8_t rsp[12 * MB_RSP_GRANULES];
-    for (int g = 0; g < n_rsp; ++g) memcpy(rsp + 12 * g, m->h + MB_RSPG + 16 * g, 12);
+    uint8_t rsp[120];
+    memcpy(rsp, m->h + MB_RSPG, 60);
+    memcpy(rsp + 60, m->h + MB_RSPG + 64, 60);
     memcpy(m->h + MB_OUT, rsp, (size_t)n_state);
     memcpy(m->h + MB_REW, rsp + n_state, 16);
     memcpy(m->h + MB_FLAGS, rsp + n_state + 16, 4);
     memcpy(m->h + MB_EV, rsp + n_state + 20, 8);
     return OC_OK;
 }
+
+#ifdef OC_AMD_TUNING
+// tuning builds: n back-to-back oc_mailbox_step calls from C (no Python / ctypes between them) -> microseconds per call
+double oc_mailbox_bench(OcMailbox* m, int n) {
+    struct timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    for (int i = 0; i < n; ++i)
+        if (oc_mailbox_step(m)) return -1.0;
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    return ((b.tv_sec - a.tv_sec) * 1e9 + (b.tv_nsec - a.tv_nsec)) / n * 1e-3;
+}
+#endif
 
 int oc_output_stores_only(int64_t n_envs, int n_steps, float* d_rewards, uint8_t* d_flags, uint32_t options, void* stream) {
     if (n_envs < 0 || n_steps < 0 || !d_rewards) return fail(OC_EINVAL, "oc_output_stores_only: negative sizes or no rewards array");
@@ -1011,7 +1040,7 @@ int oc_output_stores_only(int64_t n_envs, int n_steps, float* d_rewards, uint8_t
 
 int oc_mailbox_close(OcMailbox* m) {
     if (!m) return OC_OK;
-    __atomic_store_n(reinterpret_cast<uint32_t*>(m->h + MB_REQ), MB_STOP, __ATOMIC_RELEASE);
+    mailbox_post(m, MB_STOP, 16 * (1 + m->n_obj));
     (void)hipStreamSynchronize(m->stream);
     (void)hipStreamDestroy(m->stream);
     (void)hipHostFree(m->h);

@@ -90,19 +90,40 @@ class OvercookedEnv:
     # ---------------------------------------------------------------- stepping (API of env.py:244-325)
     def step(self, joint_action, joint_agent_action_info=None, display_phi=False):
         """One joint action -> (next_state, summed sparse reward, done, env_info); refuses to step a finished env."""
-        assert not self.is_done()
-        if self.state.timestep >= MAX_TIMESTEP:
-            raise ValueError("timestep %d: the packed state counts steps in 16 bits; use a horizon <= %d"
-                             % (self.state.timestep, MAX_TIMESTEP))
+        state, mdp = self.state, self.mdp
+        t = state.timestep
+        assert t < self.horizon and not mdp.is_terminal(state)  # = not self.is_done()
+        if t >= MAX_TIMESTEP:
+            raise ValueError("timestep %d: the packed state counts steps in 16 bits; use a horizon <= %d" % (t, MAX_TIMESTEP))
         agent_infos = joint_agent_action_info if joint_agent_action_info is not None else [{}, {}]
-        next_state, mdp_infos = self.mdp.get_state_transition(self.state, joint_action, display_phi)
-        self._update_game_stats(mdp_infos)  # events are stamped with the pre-step timestep (env.py:385)
+        fast = None if display_phi else mdp._fast_step(state, joint_action)
+        if fast is not None:
+            # the single-state port: rewards and the kernel's event mask as plain values, no infos dict in between
+            next_state, sparse, shaped, mask = fast
+            phi_s = phi_s_prime = None
+            if mask or sparse[0] or shaped[0] or (len(sparse) > 1 and (sparse[1] or shaped[1])):  # (most steps: nothing happened)
+                gs = self.game_stats
+                if any(sparse):
+                    gs["cumulative_sparse_rewards_by_agent"] = gs["cumulative_sparse_rewards_by_agent"] + np.asarray(sparse)
+                if any(shaped):
+                    gs["cumulative_shaped_rewards_by_agent"] = gs["cumulative_shaped_rewards_by_agent"] + np.asarray(shaped)
+                while mask:  # events are stamped with the pre-step timestep (env.py:385); bit 2 * event + agent
+                    low = mask & -mask
+                    k = low.bit_length() - 1
+                    gs[EVENT_TYPES[k >> 1]][k & 1].append(t)
+                    mask ^= low
+        else:
+            next_state, mdp_infos = mdp.get_state_transition(state, joint_action, display_phi)
+            self._update_game_stats(mdp_infos)  # events are stamped with the pre-step timestep (env.py:385)
+            sparse, shaped = mdp_infos["sparse_reward_by_agent"], mdp_infos["shaped_reward_by_agent"]
+            phi_s, phi_s_prime = mdp_infos.get("phi_s"), mdp_infos.get("phi_s_prime")
         self.state = next_state
-        done = self.is_done()
-        env_info = self._prepare_info_dict(agent_infos, mdp_infos)
+        done = next_state.timestep >= self.horizon or mdp.is_terminal(next_state)  # = self.is_done()
+        env_info = {"agent_infos": list(agent_infos[:mdp.num_players]), "sparse_r_by_agent": sparse,
+                    "shaped_r_by_agent": shaped, "phi_s": phi_s, "phi_s_prime": phi_s_prime}  # the keys of env.py:339-361
         if done:
             self._add_episode_info(env_info)
-        return next_state, sum(mdp_infos["sparse_reward_by_agent"]), done, env_info
+        return next_state, sum(sparse), done, env_info
 
     def lossless_state_encoding_mdp(self, state):
         return self.mdp.lossless_state_encoding(state, self.horizon)

@@ -135,6 +135,9 @@ class _SingleEnvPort:
         self.mv_out = self.mv[self.o_out:self.o_out + self.n_state]
         self.rew = self.np[self.o_rew:self.o_rew + 16].view(np.float32)
         self.ev = self.np[self.o_ev:self.o_ev + 8].view(np.uint64)
+        import struct
+        # (sparse0, sparse1, shaped0, shaped1, event mask) in one call: four floats at o_rew, the u64 mask at o_ev
+        self._outputs = struct.Struct("<4f%dxQ" % (self.o_ev - self.o_rew - 16)).unpack_from
 
     def _open_mailbox(self):
         import ctypes
@@ -167,7 +170,8 @@ class _SingleEnvPort:
             self._bind(self.pinned.numpy(), o[0], o[2], o[1], o[3], o[4], o[5])
 
     def transition(self, state, a0, a1):
-        """(next_state, rewards float32[4], event mask int) or None when the state needs the general path."""
+        """(next_state, (sparse0, sparse1, shaped0, shaped1, event mask)) or None when the state needs the general path.
+        The state comes back as a state._LazyState: its players / objects are built when somebody looks at them."""
         if not self.codec.pack(state, self.mv_in):
             return None
         mv = self.mv
@@ -182,7 +186,7 @@ class _SingleEnvPort:
             if rc:
                 from . import _lib
                 _lib.check(rc, "oc_mailbox_step")
-            return self.codec.unpack(self.mv_out), self.rew, int(self.ev[0])
+            return self.codec.unpack_lazy(self.mv_out), self._outputs(self.mv, self.o_rew)
         p = self.ptrs
         if self.torch.cuda.current_device() == self.dev_index:
             rc = self.lib.oc_step(self.bref, p[0], p[1], p[2], p[3], p[4], None, p[5], 65535, 0, None, None, self.stream_ptr)
@@ -193,7 +197,7 @@ class _SingleEnvPort:
             from . import _lib
             _lib.check(rc, "oc_step")
         self.stream.synchronize()
-        return self.codec.unpack(self.mv_out), self.rew, int(self.ev[0])
+        return self.codec.unpack_lazy(self.mv_out), self._outputs(self.mv, self.o_rew)
 
 
 class OvercookedGridworld:
@@ -412,9 +416,9 @@ class OvercookedGridworld:
         self.close()
         return False
 
-    def _fast_transition(self, state, joint_action):
-        """One env through the pinned-buffer port; None -> the general batched path (which also raises the reference's
-        errors for illegal actions / invalid states)."""
+    def _fast_step(self, state, joint_action):
+        """One env through the single-state port: (next_state, sparse rewards, shaped rewards, event mask), or None -> the
+        general batched path (which also raises the reference's errors for illegal actions / invalid states)."""
         if len(joint_action) != self.num_players:
             return None
         try:
@@ -425,12 +429,21 @@ class OvercookedGridworld:
         out = self._port().transition(state, a0, a1)
         if out is None:
             return None
-        nxt, rew, mask = out
+        nxt, (r0, r1, r2, r3, mask) = out
         n = self.num_players
-        r = rew.tolist()  # four Python floats; all-zero on most steps
-        infos = _Infos(sparse_reward_by_agent=[0] * n if not (r[0] or r[1]) else [_num(v) for v in r[0:n]],
-                       shaped_reward_by_agent=[0] * n if not (r[2] or r[3]) else [_num(v) for v in r[2:2 + n]])
-        infos.event_mask, infos.num_players = mask, n
+        # (rewards are Python floats; all-zero on most steps; the reference returns ints for integer-valued configs)
+        sparse = [0] * n if not (r0 or r1) else [_num(v) for v in (r0, r1)[:n]]
+        shaped = [0] * n if not (r2 or r3) else [_num(v) for v in (r2, r3)[:n]]
+        return nxt, sparse, shaped, mask
+
+    def _fast_transition(self, state, joint_action):
+        """get_state_transition through the port: (next_state, infos) or None."""
+        out = self._fast_step(state, joint_action)
+        if out is None:
+            return None
+        nxt, sparse, shaped, mask = out
+        infos = _Infos(sparse_reward_by_agent=sparse, shaped_reward_by_agent=shaped)
+        infos.event_mask, infos.num_players = mask, self.num_players
         return nxt, infos
 
     def get_state_transition(self, state, joint_action, display_phi=False, motion_planner=None):

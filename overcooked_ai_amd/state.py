@@ -337,6 +337,36 @@ class OvercookedState:
                                all_orders=d.get("all_orders") or [], timestep=d.get("timestep", 0))
 
 
+class _LazyState(OvercookedState):
+    """The state the single-state port (mdp._SingleEnvPort) hands back: an OvercookedState that still IS the packed bytes the
+    kernel wrote.  `players` and `objects` are built from them the first time anything looks at them — `OvercookedEnv.step`
+    itself never does — and from then on the object is a plain OvercookedState (its class is switched back, the bytes are
+    dropped: whoever has seen the player / object instances may have changed them).  A state nobody looked at goes back into
+    the next `get_state_transition` as a 48-80 byte copy instead of a walk over its objects; `timestep`, a plain attribute
+    from the start, is always taken from the object.  (The reference's own timing loop, SURVEY 8d-1, never reads the states.)"""
+
+    def __init__(self, *args, **kwargs):
+        raise TypeError("_LazyState is built by SingleStateCodec.unpack_lazy")
+
+    def __getattr__(self, name):  # (only reached when normal lookup fails: before the first look at players / objects)
+        if name == "players" or name == "objects":
+            d = self.__dict__
+            if "_packed" in d:
+                codec, packed = d.pop("_codec"), d.pop("_packed")
+                self.__class__ = OvercookedState
+                codec.fill(self, packed)
+                return d[name]
+        raise AttributeError(name)
+
+    def __getstate__(self):  # pickle / copy: as a plain state
+        self.players
+        return self.__dict__
+
+    def __reduce_ex__(self, protocol):
+        self.players
+        return object.__reduce_ex__(self, protocol)
+
+
 # ------------------------------------------------------------------------------------------------
 # wire format
 # ------------------------------------------------------------------------------------------------
@@ -612,6 +642,15 @@ class SingleStateCodec:
     def pack(self, state, buf):
         """Write `state` (an OvercookedState of this package) into the 16 * n_planes bytes of `buf`; False = use the
         general path (unknown types, anything invalid: it raises the proper error)."""
+        if type(state) is _LazyState:  # nobody has looked at it since the kernel wrote it: the bytes are the state
+            d = state.__dict__
+            if d.get("_codec") is self:
+                t = d["timestep"]
+                if type(t) is int and 0 <= t < 65536:
+                    buf[:] = d["_packed"]
+                    buf[6], buf[7] = t & 0xFF, t >> 8
+                    return True
+            state.players  # (another layout's codec, an odd timestep: as a plain state)
         if type(state) is not OvercookedState or len(state.players) != self.num_players:
             return False
         W, terrain = self.W, self.terrain
@@ -676,7 +715,24 @@ class SingleStateCodec:
         o._ingredients, o._cooking_tick, o._cook_time = list(ings), tick, (None if tick < 0 else ct)
         return o
 
+    def unpack_lazy(self, buf):
+        """The state of `buf` (16 * n_planes bytes) as a _LazyState: built when somebody looks."""
+        st = _LazyState.__new__(_LazyState)
+        d = st.__dict__
+        d["_packed"] = bytes(buf)
+        d["_codec"] = self
+        d["_bonus_orders"], d["_all_orders"] = self.bonus_orders, self.all_orders
+        d["timestep"] = buf[6] | (buf[7] << 8)
+        return st
+
     def unpack(self, buf):
+        st = OvercookedState.__new__(OvercookedState)
+        st._bonus_orders, st._all_orders = self.bonus_orders, self.all_orders
+        st.timestep = buf[6] | (buf[7] << 8)
+        return self.fill(st, buf)
+
+    def fill(self, st, buf):
+        """players / objects of `st` from the packed bytes (timestep and orders are the caller's)."""
         xy = self.xy
         players = []
         for p in range(self.num_players):
@@ -693,8 +749,5 @@ class SingleStateCodec:
                 if code:
                     tick = buf[8 + self.pot_slot[c]] - 1 if c in self.pot_slot else None
                     objects[xy[c]] = self._obj(code, xy[c], tick)
-        st = OvercookedState.__new__(OvercookedState)
         st.players, st.objects = tuple(players), objects
-        st._bonus_orders, st._all_orders = self.bonus_orders, self.all_orders
-        st.timestep = buf[6] | (buf[7] << 8)
         return st

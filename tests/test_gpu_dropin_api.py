@@ -505,3 +505,50 @@ def test_one_player_env_fixed_plan():
     env4 = OvercookedEnv.from_mdp(OvercookedGridworld.from_layout_name("multiplayer_schelling"), horizon=4, info_level=0)
     with pytest.raises(ValueError, match="1- and 2-player"):  # four players: outside the packed format, refused loudly
         env4.step((stay,) * 4)
+
+
+def test_lazy_states_become_plain_states_the_moment_somebody_looks(episodes):
+    """OvercookedEnv.step hands back state._LazyState objects (the kernel's packed bytes; players / objects are built on the
+    first look).  An env whose states nobody looks at and an env whose states are read — and changed — every step give the
+    same trajectory as the reference's; a timestep written into a state nobody has looked at is honoured as well."""
+    import copy
+
+    from overcooked_ai_amd import Action, OvercookedEnv, OvercookedGridworld
+    from overcooked_ai_amd import state as S
+    from overcooked_ai_amd.layouts import LayoutSpec
+
+    name, ep = sorted(episodes.items())[0]
+    mdp = OvercookedGridworld.from_spec(LayoutSpec(ep["layout"]))
+    blind = OvercookedEnv.from_mdp(mdp, horizon=ep["horizon"], info_level=0)
+    seeing = OvercookedEnv.from_mdp(mdp, horizon=ep["horizon"], info_level=0)
+    n_lazy = 0
+    for t, step in enumerate(ep["steps"]):
+        ja = [Action.INDEX_TO_ACTION[a] for a in step["actions"]]
+        s_b, r_b, d_b, _ = blind.step(ja)
+        s_s, r_s, d_s, _ = seeing.step(ja)
+        n_lazy += type(s_b) is S._LazyState
+        assert isinstance(s_b, S.OvercookedState) and s_b.timestep == t + 1
+        assert s_s.players is not None and type(s_s) is S.OvercookedState  # the look makes it a plain state
+        assert (r_b, d_b) == (r_s, d_s) == (step["reward"], step["done"]), (name, t)
+        if t % 5 == 0:  # rebuild the seen state from its dict: the next step then packs objects nobody got from the kernel
+            seeing.state = S.OvercookedState.from_dict(copy.deepcopy(seeing.state.to_dict()))
+    assert n_lazy >= len(ep["steps"]) - 3  # (the first calls go through plain launches before the mailbox opens: lazy as well)
+    assert S.canonical_state_dict(blind.state) == S.canonical_state_dict(ep["final_state"])
+    assert S.canonical_state_dict(seeing.state) == S.canonical_state_dict(ep["final_state"])
+    # a state nobody looked at, with its clock changed: the transition starts from that clock
+    mdp2 = OvercookedGridworld.from_spec(LayoutSpec(ep["layout"]))
+    env = OvercookedEnv.from_mdp(mdp2, horizon=400, info_level=0)
+    for _ in range(4):
+        s, *_ = env.step((Action.STAY, Action.STAY))
+    assert type(s) is S._LazyState
+    s.timestep = 100
+    nxt, _ = mdp2.get_state_transition(s, (Action.STAY, Action.INTERACT))
+    assert nxt.timestep == 101 and type(s) is S._LazyState
+    # ... and one somebody changed after looking: the change is what the kernel steps
+    p0 = s.players[0]
+    assert type(s) is S.OvercookedState
+    free = [c for c in mdp2.get_valid_player_positions() if c not in s.player_positions][0]
+    p0.position = free
+    nxt2, _ = mdp2.get_state_transition(s, (Action.STAY, Action.STAY))
+    assert nxt2.players[0].position == free and nxt2.timestep == 101
+    assert copy.deepcopy(nxt2) == nxt2 and hash(copy.deepcopy(nxt2)) == hash(nxt2)

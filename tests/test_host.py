@@ -445,3 +445,37 @@ def test_untile_flags_is_the_inverse_of_the_tiled_layout():
         tiled[k // 8, :, k % 8] = ref[k]
     assert torch.equal(VecOvercookedEnv.untile_flags(tiled), ref)
 
+
+
+def test_lazy_single_state_is_a_plain_state_after_the_first_look():
+    """state._LazyState (what the single-state port hands back): packs back from its bytes while nobody has looked, takes its
+    timestep from the attribute, and is an ordinary OvercookedState — class included — after the first look, a copy or a pickle."""
+    import copy
+    import pickle
+
+    from overcooked_ai_amd import OvercookedGridworld
+    from overcooked_ai_amd.layouts import spec_from_name
+    from overcooked_ai_amd.state import OvercookedState, SingleStateCodec, _LazyState
+
+    spec = spec_from_name("cramped_room")
+    codec = SingleStateCodec(spec, 3)
+    s0 = OvercookedGridworld.from_layout_name("cramped_room", device="cpu").get_standard_start_state()
+    buf = bytearray(48)
+    assert codec.pack(s0, memoryview(buf))
+    lazy = codec.unpack_lazy(buf)
+    assert type(lazy) is _LazyState and isinstance(lazy, OvercookedState) and lazy.timestep == 0
+    again = bytearray(48)
+    assert codec.pack(lazy, memoryview(again)) and again == buf and type(lazy) is _LazyState
+    lazy.timestep = 7
+    assert codec.pack(lazy, memoryview(again)) and again[6] == 7 and again[:6] == buf[:6]
+    other = SingleStateCodec(spec, 3)  # another codec (another mdp of the same layout): packs it as a plain state
+    assert other.pack(codec.unpack_lazy(buf), memoryview(again)) and again == buf
+    dup = copy.deepcopy(lazy)
+    assert type(dup) is OvercookedState and dup.timestep == 7 and type(lazy) is OvercookedState and "_packed" not in lazy.__dict__
+    assert codec.unpack_lazy(buf) == s0 and hash(codec.unpack_lazy(buf)) == hash(s0)
+    assert pickle.loads(pickle.dumps(codec.unpack_lazy(buf))) == s0
+    assert str(codec.unpack_lazy(buf)) == str(s0) and codec.unpack_lazy(buf).to_dict() == s0.to_dict()
+    with pytest.raises(AttributeError):
+        codec.unpack_lazy(buf).no_such_attribute
+    with pytest.raises(TypeError):
+        _LazyState()

@@ -43,12 +43,16 @@ if port.mailbox is not None:  # the resident kernel: post + spin, no launch
     for _ in range(N):
         port._step(port.mailbox)
     t3 = time.perf_counter()
-    if "tuning" in os.environ.get("OC_AMD_LIB", ""):  # a -DOC_AMD_TUNING build leaves the kernel's own phase times (10 ns ticks) in granule 8
+    if "tuning" in os.environ.get("OC_AMD_LIB", ""):  # a -DOC_AMD_TUNING build leaves the kernel's own phase times (10 ns ticks) in the spare payload dwords 27..29 of the response
         from overcooked_ai_amd import _lib
         ph = np.zeros(3)
         for _ in range(200):
             port._step(port.mailbox)
-            ph += port.np[2048 + 16 * 8:2048 + 16 * 8 + 12].view(np.uint32)
+            ph += port.np[2048 + 64 + 48:2048 + 64 + 60].view(np.uint32)  # payload dwords 27..29 = words 12..14 of response line 1
+        import ctypes
+        port.lib.oc_mailbox_bench.restype = ctypes.c_double
+        port.lib.oc_mailbox_bench.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        print("oc_mailbox_step called from C, back to back: %.2f us per call" % port.lib.oc_mailbox_bench(port.mailbox, 5000))
         print("inside k_mailbox: request seen -> payload loaded %.2f us, -> transition computed %.2f us; previous answer -> this request seen %.2f us"
               % tuple(ph / 200 * 0.01))
         t3 = time.perf_counter()
