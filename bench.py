@@ -929,6 +929,27 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
         except Exception as exc:  # an aid, never a reason to lose the line
             store_only = {"error": repr(exc)}
 
+    # the same launches with flags[step][env] (what a caller that does not ask for the tiled layout gets), next to the headline
+    step_layout = None
+    if rank == 0 and world == 1 and not args.stub and tiled8 and not args.no_extras:
+        try:
+            for _ in range(3):
+                env.rollout_random(fuse, rew, fl)
+            tm = _Timer(torch, dev, reserve=41)
+            tm.sync()
+            for _ in range(40):
+                tm.mark()
+                env.rollout_random(fuse, rew, fl)
+            tm.mark()
+            tm.sync()
+            ms = sorted(tm.launch_ms())
+            med = ms[len(ms) // 2]
+            step_layout = {"flags_layout": "[steps][envs]", "launch_ms": med, "env_steps_per_s": n * fuse / (med * 1e-3),
+                           "frac": bytes_per_launch / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "note": "40 launches of the headline shape with the flags as [steps][envs] rows (no OC_OPT_FLAGS_TILED8), median, HIP events"}
+        except Exception as exc:
+            step_layout = {"error": repr(exc)}
+
     out = {
         "metric": "env steps/sec (whole node), 65k parallel cramped_room envs" if args.config == 2 else "env steps/sec (whole node)",
         "value": value, "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -956,7 +977,7 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
                      "launch_ms_mean": dev_ms / max(1, launches), "launch_timing": "per-launch HIP events on the launch stream, median",
                      "bytes_model": "n_envs*(2*S + 17*T): S=%d B state in+out once per launch, 17 B outputs per env-step, actions in-kernel" % state_bytes,
                      "survey_8d_per_step_model_GBs": n * (2 * state_bytes + OUT_BYTES) * fuse / (launch_med * 1e-3) / 1e9,
-                     "issue_bound": issue, "store_only": store_only},
+                     "issue_bound": issue, "store_only": store_only, "step_layout": step_layout},
         "parity_check": parity,
         "device_ms_timed_region": dev_ms,
         "aggregate": {"sparse_return_last_launch": float(metrics[0]), "shaped_return_last_launch": float(metrics[1]),
