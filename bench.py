@@ -1366,8 +1366,13 @@ def bench_training_env(dev, torch, iters=300):
                 out[name]["graph_replay_us_per_batched_step"] = wall_g / (16 * reps) * 1e6
             except Exception as exc:
                 out[name]["graph_replay_error"] = repr(exc)[:200]
-    out["note"] = ("per batched step: one oc_multi_agent_step call = k_train_step1 (step + phi + shaped rewards + restart, fused, on the "
-                   "wire format) + k_encode; graph_replay: 16 such calls captured in one HIP graph")
+    for name, dt in (("obs_u8", torch.uint8),):  # roofline of the u8 leg: the bytes one call must move / its wall time
+        nbytes = n * (2 * 24 + 2 + 17 + 16 + 1 + 16 + 2 * 5 * 4 * 26)  # state in+out, actions, outputs, shaped, done, phi, observation
+        us = out[name]["us_per_batched_step"]
+        out[name].update({"bytes_per_step": nbytes, "achieved_GBs": nbytes / us / 1e3, "frac": nbytes / us / 1e3 / HBM_PEAK_GBS})
+    out["note"] = ("per batched step: one oc_multi_agent_step call = ONE kernel since round 5 (k_train_step_obs: transition on the wire "
+                   "format + phi + shaped rewards + restart + the lossless observation; rounds 2-4: k_train_step1 then k_encode); "
+                   "wall clock of back-to-back calls from Python; graph_replay: 16 such calls captured in one HIP graph")
     return out
 
 

@@ -389,6 +389,11 @@ int oc_shape_rewards(const OcBatch* batch, const float* d_rewards, const uint8_t
  * (when d_obs != NULL).  Arguments as in those entry points; d_done is required.  Two-player tables with at most two
  * pots run everything before the encoding as one kernel (k_train_step) with identical results.  With `start`, finished
  * envs restart from drawn start states and d_phi_cur receives the potential of those.
+ * ABI 5, round 5: with d_obs, ONE layout on a grid of at most 64 cells, no event sink and a batch that gives at least half
+ * of the CUs a workgroup (>= 32 768 envs on MI355X) the whole call is ONE kernel (k_train_step_obs, csrc/train_obs.hpp: eight
+ * wavefronts per 256 envs — four step and restart, four compute phi and the shaped rewards, all eight encode and stream the
+ * observations): 65 536 cramped_room envs with u8 observations 26.2 -> 20.3 us per call, asymmetric_advantages 37.6 -> 30.7 us
+ * (profiles/r05_train_step_obs.txt); same results bit for bit.
  */
 int oc_multi_agent_step(const OcBatch* batch, void* d_state, const uint8_t* d_actions, float* d_rewards,
                         uint8_t* d_flags, float* d_ep_returns, float* d_ep_returns_out, const uint8_t* d_plan_blob,

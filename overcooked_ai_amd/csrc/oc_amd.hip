@@ -51,6 +51,7 @@ namespace {
 #include "featurize.hpp"
 #include "potential.hpp"
 #include "shaping.hpp"
+#include "train_obs.hpp"
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -584,6 +585,46 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
 #else
                 constexpr bool no_lean = false;
 #endif
+                // Round 5: the step AND its observation in one kernel (train_obs.hpp) for single-layout batches that give at
+                // least half of the CUs a workgroup of 256 envs (smaller batches: the observation kernel below spreads over all CUs)
+#ifdef OC_AMD_TUNING
+                static const bool no_fused_obs = getenv("OC_TRAIN_NO_FUSED_OBS") != nullptr;
+#else
+                constexpr bool no_fused_obs = false;
+#endif
+                if (d_obs && uniform && fast && !ev_on(ea) && n_obj <= STEP1_MAX_PLANES && !no_lean && !no_fused_obs &&
+                    (obs_dtype == OC_OBS_U8 || obs_dtype == OC_OBS_F32) && ((uintptr_t)d_obs & 15u) == 0 &&
+                    b->n_envs >= (simd_count() / 8) * BLOCK) {
+                    const size_t elem = obs_dtype == OC_OBS_U8 ? 1 : 4;
+                    const size_t env_bytes = (size_t)2 * b->width * b->height * OC_NUM_LAYERS * elem;
+                    int unit = 1;
+                    while (((env_bytes * unit) & 15u) != 0) unit *= 2;  // 1, 2 or 4 envs per template
+                    const size_t fixed = (size_t)n_obj * BLOCK * 16 + env_bytes * unit + (size_t)4 * BLOCK * 16;
+                    const size_t budget = 150 * 1024;
+                    int gmax = fixed < budget ? (int)((budget - fixed) / (8 * env_bytes)) : 0;
+                    if (gmax > 64) gmax = 64;
+#ifdef OC_AMD_TUNING
+                    static const int forced_g = []() { const char* e = getenv("OC_TRAIN_OBS_G"); return e ? atoi(e) : 0; }();
+                    if (forced_g > 0 && forced_g < gmax) gmax = forced_g;
+#endif
+                    gmax -= gmax % unit;
+                    if (gmax >= unit && gmax >= 2) {  // (one env per image — 9x5 f32 — measured slower than the two kernels: 123-127 vs 116-122 us)
+                        const size_t smem_o = fixed + (size_t)8 * gmax * env_bytes;
+#define GOTO(MP, T)                                                                                                     \
+    do {                                                                                                                \
+        if (!want_lds(k_train_step_obs<MP, T>, smem_o)) break;                                                          \
+        hipLaunchKernelGGL((k_train_step_obs<MP, T>), grid, dim3(2 * BLOCK), smem_o, (hipStream_t)stream, b->d_layouts, \
+                           (uint4*)d_state, d_actions, (float4*)d_rewards, d_flags, (float4*)d_ep_returns,              \
+                           (float4*)d_ep_returns_out, d_plan_blob, d_plan_off, d_phi_tables, d_phi_next, d_phi_cur,     \
+                           d_phi_start, reward_shaping_factor, d_shaped, d_done, (uint8_t*)d_obs, b->n_envs, b->width,  \
+                           b->height, n_obj, horizon, unit, gmax, sa);                                                  \
+    } while (0)
+                        if (obs_dtype == OC_OBS_U8) { if (b->max_pots == 1) GOTO(1, uint8_t); else GOTO(2, uint8_t); }
+                        else { if (b->max_pots == 1) GOTO(1, float); else GOTO(2, float); }
+#undef GOTO
+                        return check_launch("oc_multi_agent_step");
+                    }
+                }
                 if (!ev_on(ea) && n_obj <= STEP1_MAX_PLANES && !no_lean) {  // the transition on the wire format itself (step_one.hpp)
                     const size_t smem1 = (size_t)n_obj * BLOCK * sizeof(uint4);
 #define GOT1(U, MP, LL)                                                                                                \

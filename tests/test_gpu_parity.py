@@ -777,6 +777,49 @@ def test_fused_training_step_equals_the_kernel_sequence(gpu):
             assert int(env.done.sum()) >= 0 and (env.venv.flags & 2).any()
 
 
+def test_training_step_with_its_observation_in_one_kernel(gpu):
+    """Single-layout batches of >= 32 768 envs run oc_multi_agent_step as ONE kernel (k_train_step_obs: transition, phi,
+    shaped rewards, restart AND the lossless observation).  The same envs over a table that holds the layout TWICE (a mixed
+    table: k_train_step1's per-env-layout instance + the generic observation kernel) must give identical states, rewards,
+    flags, episode returns, potentials, shaped rewards, done masks and observations — u8 and f32, one and two pots, with
+    and without use_phi, standard and drawn restarts, across episode ends, illegal actions and a ragged last workgroup."""
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+    from overcooked_ai_amd.multi_agent import VecOvercookedMultiAgent
+
+    rng = np.random.default_rng(21)
+    n = 128 * 256 + 232  # at least half of the CUs get a workgroup; the last workgroup is ragged
+    cases = [("cramped_room", torch.uint8, True, True), ("cramped_room", torch.float32, False, False),
+             ("coordination_ring", torch.uint8, True, False), ("asymmetric_advantages", torch.uint8, False, True),
+             ("asymmetric_advantages", torch.float32, True, True)]
+    for name, dt, use_phi, random_starts in cases:
+        spec = spec_from_name(name)
+        kw = dict(horizon=11, reward_shaping_factor=0.37, use_phi=use_phi, device=gpu, obs_dtype=dt, seed=5,
+                  random_start_pos=random_starts, rnd_obj_prob_thresh=0.4 if random_starts else 0.0)
+        one = VecOvercookedMultiAgent(spec, n, **kw)
+        two = VecOvercookedMultiAgent(LayoutTable([spec, spec]), n, layout_id=(np.arange(n) % 2).astype(np.uint16), **kw)
+        one.venv.reset(random_start_pos=True, rnd_obj_prob_thresh=0.5)
+        two.venv.set_packed_state(one.venv.get_packed_state())
+        if use_phi:
+            one.phi_cur.copy_(one.venv.potential(0.99))
+            two.phi_cur.copy_(one.phi_cur)
+        two.venv._epoch = one.venv._epoch  # (the restart draws are keyed by (seed, env, epoch))
+        for t in range(25):
+            a = rng.integers(0, 6, size=(n, 2)).astype(np.uint8)
+            a[rng.integers(0, n, size=7), rng.integers(0, 2, size=7)] = 9  # illegal actions: env untouched, flagged
+            acts = torch.from_numpy(a).to(gpu)
+            obs1 = one.step(acts)[0]
+            obs2 = two.step(acts)[0]
+            for what, x, y in (("state", one.venv.state, two.venv.state), ("rewards", one.venv.rewards, two.venv.rewards),
+                               ("flags", one.venv.flags, two.venv.flags), ("ep", one.venv.ep_returns, two.venv.ep_returns),
+                               ("ep_out", one.ep_returns, two.ep_returns), ("shaped", one.shaped, two.shaped),
+                               ("done", one.done, two.done), ("phi_next", one.phi_next, two.phi_next),
+                               ("phi_cur", one.phi_cur, two.phi_cur), ("obs", obs1, obs2)):
+                assert torch.equal(x, y), (name, dt, use_phi, random_starts, t, what)
+        assert int(one.done.sum()) >= 0 and (one.venv.flags & 2).any()
+        # ... and the observation is the encoding of the stored state
+        assert torch.equal(obs1, one.venv.encode_lossless(dt))
+
+
 def test_no_out_of_bounds_writes_with_ragged_batches(gpu):
     """Every caller-owned buffer sits between two guard regions; after all kernels ran on ragged batch sizes (not a
     multiple of the 256-lane workgroup, of the encode group or of the 128-env featurize block) the guards are intact."""
