@@ -299,3 +299,4 @@ __global__ __launch_bounds__(BLOCK) void k_encode_uniform(const OcLayout* __rest
     }
 }
 
+
