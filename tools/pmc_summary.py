@@ -26,8 +26,12 @@ for kern in kerns:
         for d in dirs:
             for f in glob.glob(d + "/*.db"):
                 names |= {r[0] for r in sqlite3.connect(f).execute("select distinct name from pmc_events where name like ?", ("%" + kern + "%",))}
-        per = lambda k: round(vals.get(k, 0.0) / w / steps, 2)
         import os
+
+        # per env-step of a 64-env group: one wavefront per group in the one-wavefront kernels, a mover + an interact wavefront in
+        # k_rollout4's MODE 3 / 4 (their counters add up)
+        groups = float(os.environ.get("ENVS", "65536")) / 64.0
+        per = lambda k: round(vals.get(k, 0.0) / groups / steps, 2)
 
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from overcooked_ai_amd import build
@@ -35,11 +39,13 @@ for kern in kerns:
         json.dump({
             "kernel_source_sha": build.source_hash(),
             "_note": "rocprofv3 --pmc SQ_* passes of tools/prof_rollout.py (tools/pmc_rollout.sh), 65 536 cramped_room envs, %d fused "
-                     "steps per launch; per wavefront and env-step (the launch prologue, e.g. the joint move table build, is included)" % steps,
+                     "steps per launch; per 64-env group and env-step — with MODE 3 / 4 the mover's and the interact wavefront's instructions "
+                     "together (wavefronts_per_64_envs = 2) — the launch prologue (e.g. the joint move table build) included; "
+                     "wave_clk_per_env_step = clocks of ONE wavefront per step (mean over movers and interact wavefronts)" % steps,
             "kernel": sorted(n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] for n in names)[0] if names else kern,
             "valu_per_env_step": per("SQ_INSTS_VALU"), "salu_per_env_step": per("SQ_INSTS_SALU"),
             "lds_per_env_step": per("SQ_INSTS_LDS"), "vmem_wr_per_env_step": per("SQ_INSTS_VMEM_WR"),
-            "branches_per_env_step": per("SQ_INSTS_BRANCH"),
+            "branches_per_env_step": per("SQ_INSTS_BRANCH"), "wavefronts_per_64_envs": round(w / groups, 2),
             "wave_clk_per_env_step": round(4 * wc / w / steps, 1),
             "valu_busy_frac": round(vals.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 3),
             "wait_any_frac": round(vals.get("SQ_WAIT_ANY", 0.0) / wc, 3),
