@@ -667,11 +667,14 @@ def issue_counters(kernel, n, layout):
     return {"valu_per_env_step": sq["valu_per_env_step"], "salu_per_env_step": sq["salu_per_env_step"],
             "lds_per_env_step": sq["lds_per_env_step"], "valu_busy_frac": sq["valu_busy_frac"],
             "wait_frac": sq["wait_any_frac"], "wave_clk_per_env_step": sq.get("wave_clk_per_env_step"),
+            "wavefronts_per_64_envs": sq.get("wavefronts_per_64_envs", 1),
             "source": "replayed from profiles/sq_counters.json (rocprofv3 --pmc SQ_* passes of tools/pmc_rollout.sh on the same "
                       "kernel sources, sha %s), NOT measured in this run" % sq.get("kernel_source_sha"),
-            "note": "one wavefront per SIMD at 65 536 envs: every instruction of the wavefront issues in turn (~4 clk "
-                    "each), so (VALU + SALU + LDS + VMEM per env-step) * 4 clk is the floor of a batched step "
-                    "whatever the bytes moved"}
+            "note": "instructions per env-step of a 64-env group; since round 5 two wavefronts share them (k_rollout4 MODE 4: a mover "
+                    "and an interact wavefront per 64 envs, two wavefronts per SIMD at 65 536 envs), so a batched step costs about "
+                    "max(mover, interact) instructions x the ~4-8 clk a lone dependent instruction stream needs per instruction — "
+                    "wave_clk_per_env_step is what one wavefront measured — whatever the bytes moved; the launch sits at the "
+                    "store-only ceiling of its output format (roofline.store_only)"}
 
 
 def main():

@@ -699,8 +699,22 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
         // may be rewritten: the two instructions behind it.
         typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
         const u64x2 q = {p.lo, p.hi};
-        if (FT8 || DUO) {  // (the flag byte has gone into the block's tile — MODE 3 / 4: the mover stores the flags; the second wait state is a no-op)
+        // Two or more wavefronts per SIMD (the one-wavefront-per-env-group instances on big batches: BASELINE configs[4] at
+        // 131 072 envs per GPU) store the quads with `sc1 nt` — streaming, written through: a step's row is written once and read by
+        // nobody on this GPU before the launch ends.  Measured: 304 -> 315 G env-steps/s there (tools/store_rollout.hip: the store
+        // path alone 5.36 -> 5.52 TB/s; the same bits on the flag tiles cost it all again).  The mover / interact instances at one
+        // workgroup per CU lose 1 % with it (they sit at the plain stores' ceiling) and keep plain stores.
+        // -DOC_R4_PLAIN_QUADS: plain stores everywhere, for A/B.
+#ifdef OC_R4_PLAIN_QUADS
+#define OC_R4_QUAD_POLICY ""
+#else
+#define OC_R4_QUAD_POLICY " sc1 nt"
+#endif
+        if (DUO) {  // (MODE 3 / 4: the mover stores the flags; the second wait state behind the store is a no-op)
             asm volatile("global_store_dwordx4 %1, %2, %4\n\tv_pk_add_f32 %0, %0, %3\n\ts_nop 0"
+                         : "+v"(epsh) : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k) : "memory");
+        } else if (FT8) {  // (the flag byte has gone into the block's tile)
+            asm volatile("global_store_dwordx4 %1, %2, %4" OC_R4_QUAD_POLICY "\n\tv_pk_add_f32 %0, %0, %3\n\ts_nop 0"
                          : "+v"(epsh) : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k) : "memory");
         } else {
             asm volatile("global_store_dwordx4 %1, %2, %4\n\tglobal_store_byte %5, %6, %7\n\t"

@@ -109,7 +109,59 @@ __global__ __launch_bounds__(256) void k_tiles(float4* __restrict__ rew, uint8_t
     }
 }
 
+// POL: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc0 — the reward-quad store's cache policy bits (flags tiled by 8, plain)
+template <int POL>
+__global__ __launch_bounds__(256) void k_pol(float4* __restrict__ rew, uint8_t* __restrict__ fl, int n_steps) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)gridDim.x * 256;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 v = {0.f, 0.f, (float)(threadIdx.x & 63), 1.f};
+    uint32_t acc = threadIdx.x;
+    for (int k = 0; k < n_steps; ++k) {
+        float4* p = rew + (size_t)k * n + e;
+        if (POL == 0) asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+        if (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+        if (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+        if (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+        if (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0" : : "v"(p), "v"(v) : "memory");
+        if (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(v) : "memory");
+        if (POL == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(v) : "memory");
+        if (POL == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" : : "v"(p), "v"(v) : "memory");
+        if (POL >= 8) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(v) : "memory");
+        if ((k & 7) == 7) {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 t = {acc, (uint32_t)k};
+            uint8_t* q = fl + ((size_t)(k >> 3) * n + e) * 8;
+            if (POL == 8) asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(q), "v"(t) : "memory");
+            else if (POL == 9) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" : : "v"(q), "v"(t) : "memory");
+            else *reinterpret_cast<uint2*>(q) = make_uint2(acc, k);
+        }
+        acc = acc * 1664525u + 1013904223u;
+        v.w = (float)(acc >> 31);
+    }
+}
+
 static hipEvent_t e0, e1;
+template <int POL>
+void run_pol(const char* name, void* d, int n_wg, int n_steps) {
+    const size_t n = (size_t)n_wg * 256;
+    float4* rew = (float4*)d;
+    uint8_t* fl = (uint8_t*)d + (size_t)n_steps * n * 16;
+    double sum = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipLaunchKernelGGL((k_pol<POL>), dim3(n_wg), dim3(256), 0, 0, rew, fl, n_steps);
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0);
+        for (int r = 0; r < 6; ++r) hipLaunchKernelGGL((k_pol<POL>), dim3(n_wg), dim3(256), 0, 0, rew, fl, n_steps);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        sum += 6.0 * 17.0 * (double)n * n_steps / (ms * 1e-3) / 1e12;
+    }
+    printf("quads + flags tiled by 8, quad store %-12s %7zu envs x %d steps: mean %5.2f TB/s = %.3f of 8; %6.1f G env-steps/s\n", name, n, n_steps, sum / 3, sum / 3 / 8, sum / 3 * 1e12 / 17.0 / 1e9);
+}
+
 template <int TS, int FL64>
 void run_tiles(const char* name, void* d, int n_wg, int n_steps, int remap) {
     const size_t n = (size_t)n_wg * 256;
@@ -165,6 +217,20 @@ int main() {
         run<8, 4>("quads + flags tiled by 8", d, 256, 3808, remap);
         run<16, 4>("quads + flags tiled by 16", d, 256, 3808, remap);
     }
+    run_pol<0>("plain", d, 256, 3808);
+    run_pol<1>("nt", d, 256, 3808);
+    run_pol<2>("sc1", d, 256, 3808);
+    run_pol<3>("sc0 sc1", d, 256, 3808);
+    run_pol<4>("sc0", d, 256, 3808);
+    run_pol<5>("sc0 sc1 nt", d, 256, 3808);
+    run_pol<6>("sc1 nt", d, 256, 3808);
+    run_pol<7>("sc0 nt", d, 256, 3808);
+    run_pol<8>("sc0sc1nt, fl nt", d, 256, 3808);
+    run_pol<9>("all sc0sc1nt", d, 256, 3808);
+    run_pol<0>("plain", d, 256, 3808);
+    run_pol<5>("sc0 sc1 nt", d, 512, 1904);
+    run_pol<0>("plain", d, 512, 1904);
+    return 0;
     for (int remap = 0; remap < 2; ++remap) {
         run_tiles<4, 0>("wave tiles of 4 steps, flags tiled 16", d, 256, 3840, remap);
         run_tiles<4, 1>("wave tiles of 4 steps, flag tiles of 64 steps", d, 256, 3840, remap);
