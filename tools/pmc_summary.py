@@ -30,8 +30,12 @@ for kern in kerns:
 
         # per env-step of a 64-env group: one wavefront per group in the one-wavefront kernels, a mover + an interact wavefront in
         # k_rollout4's MODE 3 / 4 (their counters add up)
-        groups = float(os.environ.get("ENVS", "65536")) / 64.0
-        per = lambda k: round(vals.get(k, 0.0) / groups / steps, 2)
+        # (the database holds one row per counter instance — XCD x shader engine —, so only RATIOS of its means are meaningful:
+        #  per wavefront = counter / SQ_WAVES; wavefronts per group from the kernel's MODE template argument)
+        kname = sorted(n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] for n in names)[0] if names else kern
+        targs = kname.split("<", 1)[1].split(",") if "<" in kname else []
+        wpg = 2 if kname.startswith("k_rollout4") and len(targs) > 3 and targs[3].strip() in ("3", "4") else 1
+        per = lambda k: round(vals.get(k, 0.0) / w / steps * wpg, 2)
 
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from overcooked_ai_amd import build
@@ -45,7 +49,7 @@ for kern in kerns:
             "kernel": sorted(n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] for n in names)[0] if names else kern,
             "valu_per_env_step": per("SQ_INSTS_VALU"), "salu_per_env_step": per("SQ_INSTS_SALU"),
             "lds_per_env_step": per("SQ_INSTS_LDS"), "vmem_wr_per_env_step": per("SQ_INSTS_VMEM_WR"),
-            "branches_per_env_step": per("SQ_INSTS_BRANCH"), "wavefronts_per_64_envs": round(w / groups, 2),
+            "branches_per_env_step": per("SQ_INSTS_BRANCH"), "wavefronts_per_64_envs": wpg,
             "wave_clk_per_env_step": round(4 * wc / w / steps, 1),
             "valu_busy_frac": round(vals.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 3),
             "wait_any_frac": round(vals.get("SQ_WAIT_ANY", 0.0) / wc, 3),
