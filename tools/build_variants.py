@@ -1,4 +1,4 @@
-"""Variant libraries for same-box A/B runs (tools/gpu_ab5.sh, tools/gpu_ab8.sh): python tools/build_variants.py name=-DFLAG1,-DFLAG2 ...
+"""Variant libraries for same-box A/B runs (tools/gpu_ab5.sh, tools/gpu_ab8.sh, tools/gpu_r5_xcd.sh, tools/gpu_r5_ab2.sh): python tools/build_variants.py name=-DFLAG1,-DFLAG2 ...
 builds overcooked_ai_amd/<name>.so with the given extra defines next to the default library (OC_AMD_LIB selects one)."""
 import os
 import sys
