@@ -348,22 +348,27 @@ class _LazyState(OvercookedState):
     def __init__(self, *args, **kwargs):
         raise TypeError("_LazyState is built by SingleStateCodec.unpack_lazy")
 
+    def _materialize(self):
+        """Build players / objects from the bytes and become a plain OvercookedState."""
+        d = self.__dict__
+        codec, packed = d.pop("_codec"), d.pop("_packed")
+        self.__class__ = OvercookedState
+        keep = {k: d[k] for k in ("players", "objects") if k in d}  # (one of the two assigned without a look: it stands)
+        codec.fill(self, packed)
+        d.update(keep)
+
     def __getattr__(self, name):  # (only reached when normal lookup fails: before the first look at players / objects)
-        if name == "players" or name == "objects":
-            d = self.__dict__
-            if "_packed" in d:
-                codec, packed = d.pop("_codec"), d.pop("_packed")
-                self.__class__ = OvercookedState
-                codec.fill(self, packed)
-                return d[name]
+        if (name == "players" or name == "objects") and "_packed" in self.__dict__:
+            self._materialize()
+            return self.__dict__[name]
         raise AttributeError(name)
 
     def __getstate__(self):  # pickle / copy: as a plain state
-        self.players
+        self._materialize()
         return self.__dict__
 
     def __reduce_ex__(self, protocol):
-        self.players
+        self._materialize()
         return object.__reduce_ex__(self, protocol)
 
 
@@ -644,13 +649,13 @@ class SingleStateCodec:
         general path (unknown types, anything invalid: it raises the proper error)."""
         if type(state) is _LazyState:  # nobody has looked at it since the kernel wrote it: the bytes are the state
             d = state.__dict__
-            if d.get("_codec") is self:
+            if d.get("_codec") is self and "players" not in d and "objects" not in d:  # (an attribute assigned without a look: the slow way)
                 t = d["timestep"]
                 if type(t) is int and 0 <= t < 65536:
                     buf[:] = d["_packed"]
                     buf[6], buf[7] = t & 0xFF, t >> 8
                     return True
-            state.players  # (another layout's codec, an odd timestep: as a plain state)
+            state._materialize()  # (another layout's codec, an odd timestep, an assigned attribute: as a plain state)
         if type(state) is not OvercookedState or len(state.players) != self.num_players:
             return False
         W, terrain = self.W, self.terrain

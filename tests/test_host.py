@@ -475,6 +475,12 @@ def test_lazy_single_state_is_a_plain_state_after_the_first_look():
     assert codec.unpack_lazy(buf) == s0 and hash(codec.unpack_lazy(buf)) == hash(s0)
     assert pickle.loads(pickle.dumps(codec.unpack_lazy(buf))) == s0
     assert str(codec.unpack_lazy(buf)) == str(s0) and codec.unpack_lazy(buf).to_dict() == s0.to_dict()
+    # an attribute assigned WITHOUT a look stands: the bytes are no longer the state
+    lazy = codec.unpack_lazy(buf)
+    swapped = tuple(reversed(s0.deepcopy().players))
+    lazy.players = swapped
+    assert codec.pack(lazy, memoryview(again)) and again != buf and type(lazy) is OvercookedState
+    assert lazy.players is swapped and lazy.objects == s0.objects and again[0] == buf[3] and again[3] == buf[0]
     with pytest.raises(AttributeError):
         codec.unpack_lazy(buf).no_such_attribute
     with pytest.raises(TypeError):
