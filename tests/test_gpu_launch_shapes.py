@@ -287,3 +287,46 @@ def test_layout_redrawn_every_episode_inside_the_fused_auto_reset(table_kind, gp
         # the object view follows the moved layouts
         some = env.get_states()[:5]
         assert [s.timestep for s in some] == [int(st[0, e, 6]) for e in range(5)]
+
+
+@pytest.mark.parametrize("n", [8 * 256 - 48, 16 * 256 - 1, 24 * 256])
+def test_xcd_contiguous_block_mapping_on_ragged_batches(n, gpu):
+    """xcd_block() (round 5): grids that are a multiple of 8 workgroups deal block (b % 8) * grid / 8 + b / 8 to workgroup b, so
+    the ragged last block of a batch is no longer the last workgroup.  Every kernel that takes the mapping, on batches whose
+    grid is 8, 16 and 24 workgroups with a ragged or a full last block: the rollout (one layout: joint-table instances; the
+    5-layout mix: per-env terrain; with and without whole workgroups, i.e. mover / interact or one wavefront), K caller-action
+    steps (k_step3) and the rollout with observations (k_rollout_encode), against the C oracle."""
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+    from overcooked_ai_amd.vec_env import VecOvercookedEnv
+
+    steps = 48
+    _long_launch_against_oracle(gpu, LayoutTable([spec_from_name("cramped_room")]), n, steps=steps, horizon=20, seed=3)
+    mix = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+    lid = (np.arange(n) % 5).astype(np.uint16)
+    _long_launch_against_oracle(gpu, mix, n, lid=lid, steps=steps, horizon=20, seed=4)
+    if n % 256 == 0:
+        _long_launch_against_oracle(gpu, mix, n, lid=lid, steps=steps, horizon=20, seed=4, flags_tiled8=True)
+    # K caller-action steps in one launch + the rollout with the observation of every step, one layout
+    rng = np.random.default_rng(n)
+    for name in ("cramped_room", "asymmetric_advantages"):
+        spec = spec_from_name(name)
+        env = VecOvercookedEnv(spec, n, horizon=9, device=gpu, auto_reset=True, seed=2)
+        orc = _oracle(env.table.specs)
+        st = orc.reset(orc.new_state(n))
+        K = 12
+        acts = rng.integers(0, 6, size=(K, n, 2)).astype(np.uint8)
+        rew = torch.zeros((K, n, 4), dtype=torch.float32, device=gpu)
+        fl = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
+        env.step_many(torch.from_numpy(acts).to(gpu), rew, fl)
+        for k in range(K):
+            st, r_o, f_o = orc.step(st, acts[k], horizon=9, options=1)
+            assert np.array_equal(rew[k].cpu().numpy(), r_o) and np.array_equal(fl[k].cpu().numpy(), f_o), (name, n, k)
+        assert np.array_equal(env.get_packed_state(), st), (name, n)
+        env.one_kernel = True
+        obs = torch.zeros((K, n, 2, env.width, env.height, 26), dtype=torch.uint8, device=gpu)
+        env.rollout_encode(K, obs, rew, fl)
+        for k in range(K):
+            r_o, f_o = orc.rollout_random(st, 1, horizon=9, options=1, seed=2, t0=k)  # (the Philox clock counts random-policy steps only)
+            assert np.array_equal(rew[k].cpu().numpy(), r_o[0]) and np.array_equal(fl[k].cpu().numpy(), f_o[0]), (name, n, k)
+            assert np.array_equal(obs[k].cpu().numpy().astype(np.int32), orc.encode_lossless(st, horizon=9)), (name, n, k)
+        assert np.array_equal(env.get_packed_state(), st), (name, n)
