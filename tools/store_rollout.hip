@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <string.h>
 
 // FLAGS: 0 none; 1 one byte per env-step, [step][env]; 8 tiled by 8 steps ([steps/8][env][8]: 512 B per wavefront per 8 steps);
 // 16 tiled by 16 steps ([steps/16][env][16]: 1 KiB per wavefront, an aligned 4 KiB per workgroup, per 16 steps)
@@ -206,83 +207,102 @@ void run(const char* name, void* d, int n_wg, int n_steps, int remap) {
            n_steps, WAVES, sum / 3, sum / 3 / 8, best, sum / 3 * 1e12 / (FLAGS ? 17.0 : 16.0) / 1e9);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    // sections (any number of them as arguments; none = all): formats stride policy tiles barriers (barrier periods, jitter, drift bounds) barriers2 (barrier per step x formats, tiled quads, 131 072 envs)
+    auto want = [&](const char* name) {
+        if (argc < 2) return true;
+        for (int i = 1; i < argc; ++i) if (!strcmp(argv[i], name)) return true;
+        return false;
+    };
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     void* d;
     (void)hipMalloc(&d, (size_t)5 << 30);
-    for (int remap = 0; remap < 2; ++remap) {
-        run<0, 4>("quads only", d, 256, 3808, remap);
-        run<1, 4>("quads + flag byte [step][env]", d, 256, 3808, remap);
-        run<8, 4>("quads + flags tiled by 8", d, 256, 3808, remap);
-        run<16, 4>("quads + flags tiled by 16", d, 256, 3808, remap);
+    if (want("formats")) {
+        for (int remap = 0; remap < 2; ++remap) {
+            run<0, 4>("quads only", d, 256, 3808, remap);
+            run<1, 4>("quads + flag byte [step][env]", d, 256, 3808, remap);
+            run<8, 4>("quads + flags tiled by 8", d, 256, 3808, remap);
+            run<16, 4>("quads + flags tiled by 16", d, 256, 3808, remap);
+        }
+        // row stride: 256 workgroups = rows of exactly 1 MiB (quads) — is the power of two special?
+        for (int wg : {256, 255, 257, 248, 264, 240, 272}) {
+            char nm[64];
+            snprintf(nm, sizeof nm, "quads + flags tiled 8, %d workgroups", wg);
+            run<8, 4>(nm, d, wg, 3808, 0);
+        }
     }
-    run_pol<0>("plain", d, 256, 3808);
-    run_pol<1>("nt", d, 256, 3808);
-    run_pol<2>("sc1", d, 256, 3808);
-    run_pol<3>("sc0 sc1", d, 256, 3808);
-    run_pol<4>("sc0", d, 256, 3808);
-    run_pol<5>("sc0 sc1 nt", d, 256, 3808);
-    run_pol<6>("sc1 nt", d, 256, 3808);
-    run_pol<7>("sc0 nt", d, 256, 3808);
-    run_pol<8>("sc0sc1nt, fl nt", d, 256, 3808);
-    run_pol<9>("all sc0sc1nt", d, 256, 3808);
-    run_pol<0>("plain", d, 256, 3808);
-    run_pol<5>("sc0 sc1 nt", d, 512, 1904);
-    run_pol<0>("plain", d, 512, 1904);
-    return 0;
-    for (int remap = 0; remap < 2; ++remap) {
-        run_tiles<4, 0>("wave tiles of 4 steps, flags tiled 16", d, 256, 3840, remap);
-        run_tiles<4, 1>("wave tiles of 4 steps, flag tiles of 64 steps", d, 256, 3840, remap);
-        run_tiles<8, 1>("wave tiles of 8 steps, flag tiles of 64 steps", d, 256, 3840, remap);
-        run_tiles<2, 1>("wave tiles of 2 steps, flag tiles of 64 steps", d, 256, 3840, remap);
-        run_tiles<1, 1>("wave rows (1 step), flag tiles of 64 steps", d, 256, 3840, remap);
-        run_tiles<4, 1>("131 072 envs: tiles of 4, flag tiles of 64", d, 512, 1920, remap);
+    if (want("stride")) {
+        run_pol<0>("plain", d, 256, 3808);
+        run_pol<1>("nt", d, 256, 3808);
+        run_pol<2>("sc1", d, 256, 3808);
+        run_pol<3>("sc0 sc1", d, 256, 3808);
+        run_pol<4>("sc0", d, 256, 3808);
+        run_pol<5>("sc0 sc1 nt", d, 256, 3808);
+        run_pol<6>("sc1 nt", d, 256, 3808);
+        run_pol<7>("sc0 nt", d, 256, 3808);
+        run_pol<8>("sc0sc1nt, fl nt", d, 256, 3808);
+        run_pol<9>("all sc0sc1nt", d, 256, 3808);
+        run_pol<0>("plain", d, 256, 3808);
+        run_pol<5>("sc0 sc1 nt", d, 512, 1904);
+        run_pol<0>("plain", d, 512, 1904);
     }
-    run<16, 4, 0>("tiled 16, no barrier (control)", d, 256, 3808, 0);
-    run<8, 4, 0>("tiled 8, no barrier (control)", d, 256, 3808, 0);
-    return 0;
-    run<16, 4, 1>("tiled 16, barrier every step", d, 256, 3808, 0);
-    run<16, 4, 12>("tiled 16, barrier every 2 steps", d, 256, 3808, 0);
-    run<16, 4, 14>("tiled 16, barrier every 4 steps", d, 256, 3808, 0);
-    run<16, 4, 18>("tiled 16, barrier every 8 steps", d, 256, 3808, 0);
-    run<16, 4, 26>("tiled 16, barrier every 16 steps", d, 256, 3808, 0);
-    run<16, 4, 74>("tiled 16, barrier every 64 steps", d, 256, 3808, 0);
-    run<16, 4, 0>("tiled 16, no barrier", d, 256, 3808, 0);
-    run<16, 4, 200>("tiled 16, jitter, no barrier", d, 256, 3808, 0);
-    run<16, 4, 201>("tiled 16, jitter, barrier every step", d, 256, 3808, 0);
-    run<16, 4, 202>("tiled 16, jitter, barrier every 2", d, 256, 3808, 0);
-    run<16, 4, 204>("tiled 16, jitter, barrier every 4", d, 256, 3808, 0);
-    run<16, 4, 208>("tiled 16, jitter, barrier every 8", d, 256, 3808, 0);
-    run<16, 4, 216>("tiled 16, jitter, barrier every 16", d, 256, 3808, 0);
-    run<8, 4, 200>("tiled 8, jitter, no barrier", d, 256, 3808, 0);
-    run<8, 4, 208>("tiled 8, jitter, barrier every 8", d, 256, 3808, 0);
-    run<16, 4, 100>("tiled 16, drift bound 0 blocks", d, 256, 3808, 0);
-    run<16, 4, 101>("tiled 16, drift bound 1 block", d, 256, 3808, 0);
-    run<16, 4, 102>("tiled 16, drift bound 2 blocks", d, 256, 3808, 0);
-    run<16, 4, 104>("tiled 16, drift bound 4 blocks", d, 256, 3808, 0);
-    run<16, 4, 108>("tiled 16, drift bound 8 blocks", d, 256, 3808, 0);
-    run<8, 4, 101>("tiled 8, drift bound 1 block", d, 256, 3808, 0);
-    run<8, 4, 1>("tiled 8, barrier every step", d, 256, 3808, 0);
-    run<8, 4, 18>("tiled 8, barrier every 8 steps", d, 256, 3808, 0);
-    run<8, 4, 0>("tiled 8, no barrier", d, 256, 3808, 0);
-    run<16, 4, 1>("131 072 envs tiled 16, barrier every step", d, 512, 1904, 1);
-    run<16, 4, 18>("131 072 envs tiled 16, barrier every 8", d, 512, 1904, 1);
-    run<16, 4, 0>("131 072 envs tiled 16, no barrier", d, 512, 1904, 1);
-    return 0;
-    for (int remap = 0; remap < 2; ++remap) {
-        run<0, 4, 1>("quads only, barrier per step", d, 256, 3808, remap);
-        run<8, 4, 1>("quads + tiled 8, barrier per step", d, 256, 3808, remap);
-        run<16, 4, 1>("quads + tiled 16, barrier per step", d, 256, 3808, remap);
-        run<0, 4, 2>("quads tiled by 4 steps, no flags", d, 256, 3808, remap);
-        run<16, 4, 2>("quads tiled by 4 + flags tiled 16", d, 256, 3808, remap);
-        run<16, 4, 3>("same, contiguous store instrs", d, 256, 3808, remap);
-        run<0, 4, 0>("quads only (again)", d, 256, 3808, remap);
+    if (want("policy")) {
+        for (int remap = 0; remap < 2; ++remap) {
+            run_tiles<4, 0>("wave tiles of 4 steps, flags tiled 16", d, 256, 3840, remap);
+            run_tiles<4, 1>("wave tiles of 4 steps, flag tiles of 64 steps", d, 256, 3840, remap);
+            run_tiles<8, 1>("wave tiles of 8 steps, flag tiles of 64 steps", d, 256, 3840, remap);
+            run_tiles<2, 1>("wave tiles of 2 steps, flag tiles of 64 steps", d, 256, 3840, remap);
+            run_tiles<1, 1>("wave rows (1 step), flag tiles of 64 steps", d, 256, 3840, remap);
+            run_tiles<4, 1>("131 072 envs: tiles of 4, flag tiles of 64", d, 512, 1920, remap);
+        }
+        run<16, 4, 0>("tiled 16, no barrier (control)", d, 256, 3808, 0);
+        run<8, 4, 0>("tiled 8, no barrier (control)", d, 256, 3808, 0);
     }
-    // two wavefronts per SIMD (BASELINE configs[4]'s 131 072 envs per GPU) and the 5-layout mix's shape
-    for (int remap = 0; remap < 2; ++remap) {
-        run<8, 4>("131 072 envs, flags tiled by 8", d, 512, 1904, remap);
-        run<16, 4>("131 072 envs, flags tiled by 16", d, 512, 1904, remap);
+    if (want("tiles")) {
+        run<16, 4, 1>("tiled 16, barrier every step", d, 256, 3808, 0);
+        run<16, 4, 12>("tiled 16, barrier every 2 steps", d, 256, 3808, 0);
+        run<16, 4, 14>("tiled 16, barrier every 4 steps", d, 256, 3808, 0);
+        run<16, 4, 18>("tiled 16, barrier every 8 steps", d, 256, 3808, 0);
+        run<16, 4, 26>("tiled 16, barrier every 16 steps", d, 256, 3808, 0);
+        run<16, 4, 74>("tiled 16, barrier every 64 steps", d, 256, 3808, 0);
+        run<16, 4, 0>("tiled 16, no barrier", d, 256, 3808, 0);
+        run<16, 4, 200>("tiled 16, jitter, no barrier", d, 256, 3808, 0);
+        run<16, 4, 201>("tiled 16, jitter, barrier every step", d, 256, 3808, 0);
+        run<16, 4, 202>("tiled 16, jitter, barrier every 2", d, 256, 3808, 0);
+        run<16, 4, 204>("tiled 16, jitter, barrier every 4", d, 256, 3808, 0);
+        run<16, 4, 208>("tiled 16, jitter, barrier every 8", d, 256, 3808, 0);
+        run<16, 4, 216>("tiled 16, jitter, barrier every 16", d, 256, 3808, 0);
+        run<8, 4, 200>("tiled 8, jitter, no barrier", d, 256, 3808, 0);
+        run<8, 4, 208>("tiled 8, jitter, barrier every 8", d, 256, 3808, 0);
+        run<16, 4, 100>("tiled 16, drift bound 0 blocks", d, 256, 3808, 0);
+        run<16, 4, 101>("tiled 16, drift bound 1 block", d, 256, 3808, 0);
+        run<16, 4, 102>("tiled 16, drift bound 2 blocks", d, 256, 3808, 0);
+        run<16, 4, 104>("tiled 16, drift bound 4 blocks", d, 256, 3808, 0);
+        run<16, 4, 108>("tiled 16, drift bound 8 blocks", d, 256, 3808, 0);
+        run<8, 4, 101>("tiled 8, drift bound 1 block", d, 256, 3808, 0);
+        run<8, 4, 1>("tiled 8, barrier every step", d, 256, 3808, 0);
+        run<8, 4, 18>("tiled 8, barrier every 8 steps", d, 256, 3808, 0);
+        run<8, 4, 0>("tiled 8, no barrier", d, 256, 3808, 0);
+        run<16, 4, 1>("131 072 envs tiled 16, barrier every step", d, 512, 1904, 1);
+        run<16, 4, 18>("131 072 envs tiled 16, barrier every 8", d, 512, 1904, 1);
+        run<16, 4, 0>("131 072 envs tiled 16, no barrier", d, 512, 1904, 1);
+    }
+    if (want("barriers2")) {
+        for (int remap = 0; remap < 2; ++remap) {
+            run<0, 4, 1>("quads only, barrier per step", d, 256, 3808, remap);
+            run<8, 4, 1>("quads + tiled 8, barrier per step", d, 256, 3808, remap);
+            run<16, 4, 1>("quads + tiled 16, barrier per step", d, 256, 3808, remap);
+            run<0, 4, 2>("quads tiled by 4 steps, no flags", d, 256, 3808, remap);
+            run<16, 4, 2>("quads tiled by 4 + flags tiled 16", d, 256, 3808, remap);
+            run<16, 4, 3>("same, contiguous store instrs", d, 256, 3808, remap);
+            run<0, 4, 0>("quads only (again)", d, 256, 3808, remap);
+        }
+        // two wavefronts per SIMD (BASELINE configs[4]'s 131 072 envs per GPU) and the 5-layout mix's shape
+        for (int remap = 0; remap < 2; ++remap) {
+            run<8, 4>("131 072 envs, flags tiled by 8", d, 512, 1904, remap);
+            run<16, 4>("131 072 envs, flags tiled by 16", d, 512, 1904, remap);
+        }
     }
     (void)hipFree(d);
     return 0;
