@@ -208,7 +208,7 @@ void run(const char* name, void* d, int n_wg, int n_steps, int remap) {
 }
 
 int main(int argc, char** argv) {
-    // sections (any number of them as arguments; none = all): formats stride policy tiles barriers (barrier periods, jitter, drift bounds) barriers2 (barrier per step x formats, tiled quads, 131 072 envs)
+    // sections (any number of them as arguments; none = all): formats stride policy tiles barriers (barrier periods, jitter, drift bounds) barriers2 (a barrier per step x formats, quads tiled by 4, 131 072 envs)
     auto want = [&](const char* name) {
         if (argc < 2) return true;
         for (int i = 1; i < argc; ++i) if (!strcmp(argv[i], name)) return true;
@@ -225,6 +225,8 @@ int main(int argc, char** argv) {
             run<8, 4>("quads + flags tiled by 8", d, 256, 3808, remap);
             run<16, 4>("quads + flags tiled by 16", d, 256, 3808, remap);
         }
+    }
+    if (want("stride")) {
         // row stride: 256 workgroups = rows of exactly 1 MiB (quads) — is the power of two special?
         for (int wg : {256, 255, 257, 248, 264, 240, 272}) {
             char nm[64];
@@ -232,7 +234,7 @@ int main(int argc, char** argv) {
             run<8, 4>(nm, d, wg, 3808, 0);
         }
     }
-    if (want("stride")) {
+    if (want("policy")) {
         run_pol<0>("plain", d, 256, 3808);
         run_pol<1>("nt", d, 256, 3808);
         run_pol<2>("sc1", d, 256, 3808);
@@ -247,7 +249,7 @@ int main(int argc, char** argv) {
         run_pol<5>("sc0 sc1 nt", d, 512, 1904);
         run_pol<0>("plain", d, 512, 1904);
     }
-    if (want("policy")) {
+    if (want("tiles")) {
         for (int remap = 0; remap < 2; ++remap) {
             run_tiles<4, 0>("wave tiles of 4 steps, flags tiled 16", d, 256, 3840, remap);
             run_tiles<4, 1>("wave tiles of 4 steps, flag tiles of 64 steps", d, 256, 3840, remap);
@@ -259,7 +261,7 @@ int main(int argc, char** argv) {
         run<16, 4, 0>("tiled 16, no barrier (control)", d, 256, 3808, 0);
         run<8, 4, 0>("tiled 8, no barrier (control)", d, 256, 3808, 0);
     }
-    if (want("tiles")) {
+    if (want("barriers")) {
         run<16, 4, 1>("tiled 16, barrier every step", d, 256, 3808, 0);
         run<16, 4, 12>("tiled 16, barrier every 2 steps", d, 256, 3808, 0);
         run<16, 4, 14>("tiled 16, barrier every 4 steps", d, 256, 3808, 0);
