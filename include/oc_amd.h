@@ -104,12 +104,14 @@ extern "C" {
                                      cramped_room —, at most ~98 000 envs) or the per-env-terrain kernels of mixed two-player
                                      tables (up to 32 layouts: at most ~98 000 envs; one-pot tables of more layouts: any
                                      batch size) — BASELINE configs[1], [3], [4] —, or the mover / interact kernel described
-                                     under OC_OPT_ONE_WAVEFRONT (single two-player layouts included); OC_EINVAL otherwise, so a
-                                     caller can try it once and fall back */
+                                     under OC_OPT_ONE_WAVEFRONT (single two-player layouts included; batches of whole 256-env
+                                     workgroups up to 524 288 envs); OC_EINVAL otherwise, so a caller can try it once and
+                                     fall back */
 #define OC_OPT_ONE_WAVEFRONT 0x80u /* oc_rollout_random: keep every env-step in ONE wavefront.  Without this bit, batches of
                                      two-player layouts with at most two pots and 64 cells (new dynamics, one set of shaping
-                                     rewards, both output arrays, no event sink) that consist of whole 256-env workgroups, at
-                                     most one per CU (65 536 envs on MI355X), and are launched over whole 8-step blocks (t0
+                                     rewards, both output arrays, no event sink) that consist of whole 256-env workgroups —
+                                     one per CU at a time: batches above 65 536 envs (MI355X) run in up to 8 rounds, tables
+                                     read through L2 from the third round on — and are launched over whole 8-step blocks (t0
                                      and n_steps multiples of 8) run with the step split between two wavefronts per 64 envs: a
                                      mover (actions, resolve_movement, horizon, flag bytes) running up to 16 steps ahead of
                                      an interact wavefront (resolve_interacts, env effects, rewards) through a ring in LDS.

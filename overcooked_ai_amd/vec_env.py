@@ -306,7 +306,7 @@ class VecOvercookedEnv:
         int64 [n_steps, n_envs] event masks or None.
         flags_tiled8 (OC_OPT_FLAGS_TILED8): flags_out is [n_steps // 8, n_envs, 8] — byte [k // 8, e, k % 8] = step k of env e
         (`untile_flags` gives the [n_steps, n_envs] view's copy) —, which the kernel writes as full lines: worth ~6 % on the
-        joint-table kernel (one cramped_room-like layout, up to ~98 000 envs; n_steps and the step counter multiples of 8;
+        joint-table kernel (one cramped_room-like layout; whole 256-env workgroups up to 524 288 envs, else up to ~98 000; n_steps and the step counter multiples of 8;
         ValueError via OC_EINVAL otherwise)."""
         if events_out is not None:
             self._check(events_out, torch.int64, int(n_steps) * self.n_envs, "events_out")

@@ -115,7 +115,8 @@ def _mix_table_and_ids(n, rank):
     return table, ((np.arange(n) + rank * n) % 5).astype(np.uint16)
 
 
-@pytest.mark.parametrize("shape", ["cramped_room_65536", "five_layout_mix_65536", "generated_4096_131072"])
+@pytest.mark.parametrize("shape", ["cramped_room_65536", "five_layout_mix_65536", "generated_4096_131072",
+                                   "cramped_room_131072_two_rounds", "five_layout_mix_196608_three_rounds"])
 def test_tiled_flags_launch_shapes_against_oracle(shape, gpu):
     """The OC_OPT_FLAGS_TILED8 instances — the ones every number of bench.py's default line is timed on (headline: joint-table
     kernel; configs[3]: the mover / interact kernel on the 5-layout mix; configs[4]: the one-pot per-env-terrain kernel at
@@ -123,6 +124,11 @@ def test_tiled_flags_launch_shapes_against_oracle(shape, gpu):
     flag byte, final states, episode returns (VERDICT r4 #3: they used to be compared with their [step][env] siblings only)."""
     if shape == "cramped_room_65536":
         sparse, _ = _long_launch_against_oracle(gpu, "cramped_room", 65536, flags_tiled8=True)
+    elif shape == "cramped_room_131072_two_rounds":  # (round 5: the mover / interact workgroups of a bigger batch run in rounds of one per CU)
+        sparse, _ = _long_launch_against_oracle(gpu, "cramped_room", 131072, flags_tiled8=True, steps=400)
+    elif shape == "five_layout_mix_196608_three_rounds":
+        table, lid = _mix_table_and_ids(196608, 1)
+        sparse, _ = _long_launch_against_oracle(gpu, table, 196608, lid=lid, env_offset=196608, flags_tiled8=True, steps=400)
     elif shape == "five_layout_mix_65536":
         table, lid = _mix_table_and_ids(65536, 5)
         sparse, _ = _long_launch_against_oracle(gpu, table, 65536, lid=lid, env_offset=5 * 65536, flags_tiled8=True)
