@@ -29,6 +29,21 @@ __device__ __forceinline__ uint32_t xcd_block() {
 #endif
 }
 
+// A 16-byte store of output that nobody on this GPU reads again before the launch ends, `sc1 nt` = streaming, written through.
+// Pays only where the output does not fit the 256 MB MALL AND leaves in large pieces: the rollout's reward rows beside
+// [step][env] flags (+7 %), k_encode's f32 observations (616 MB: +9 %); it costs 28-31 % on outputs that are rewritten in place
+// inside the MALL (u8 observations, the training step) and on k_rollout_encode's per-wavefront 28 KB pieces (profiles/
+// r05_ab_streaming_stores.txt).  -DOC_PLAIN_STREAM: plain stores, for A/B.
+__device__ __forceinline__ void stream_store16(uint4* p, const uint4 v) {
+#ifdef OC_PLAIN_STREAM
+    *p = v;
+#else
+    typedef uint32_t oc_stream_u32x4 __attribute__((ext_vector_type(4)));
+    const oc_stream_u32x4 w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(w) : "memory");
+#endif
+}
+
 using oc_detail::g_err;
 using oc_detail::g_lds_refused;
 using oc_detail::StartArgs;

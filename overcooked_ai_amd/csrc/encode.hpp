@@ -149,8 +149,15 @@ __global__ __launch_bounds__(BLOCK) void k_encode(const OcLayout* __restrict__ g
     uint8_t* gdst = reinterpret_cast<uint8_t*>(obs) + env_bytes * (size_t)e0;
     const uint8_t* ssrc = reinterpret_cast<const uint8_t*>(s_out);
     const size_t n16 = total / 16;
-    for (size_t i = threadIdx.x; i < n16; i += BLOCK)
-        reinterpret_cast<uint4*>(gdst)[i] = reinterpret_cast<const uint4*>(ssrc)[i];
+    // An output larger than the 256 MB MALL (f32 observations of 65 536 9x5 envs: 616 MB) streams past it — `sc1 nt`: 5.5 -> 6.0
+    // TB/s; one that fits is rewritten in place inside it and must NOT (u8, 153 MB: 5.7 -> 4.1 TB/s with streaming stores)
+    if (env_bytes * (size_t)n > ((size_t)320 << 20)) {
+        for (size_t i = threadIdx.x; i < n16; i += BLOCK)
+            stream_store16(reinterpret_cast<uint4*>(gdst) + i, reinterpret_cast<const uint4*>(ssrc)[i]);
+    } else {
+        for (size_t i = threadIdx.x; i < n16; i += BLOCK)
+            reinterpret_cast<uint4*>(gdst)[i] = reinterpret_cast<const uint4*>(ssrc)[i];
+    }
     const size_t rem4 = (total - n16 * 16) / 4;
     if (threadIdx.x < rem4)
         reinterpret_cast<uint32_t*>(gdst + n16 * 16)[threadIdx.x] =

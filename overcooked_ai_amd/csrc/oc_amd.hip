@@ -216,7 +216,7 @@ __global__ __launch_bounds__(BLOCK) void k_output_stores_only(float4* __restrict
     uint8_t* flg_k = flags ? flags + (int64_t)blk * BLOCK : nullptr;
 #pragma unroll 1
     for (int k = 0; k < n_steps; ++k) {
-        rew_k[threadIdx.x] = zero4;
+        stream_store16(reinterpret_cast<uint4*>(rew_k + threadIdx.x), make_uint4(0u, 0u, 0u, 0u));  // (as k_rollout4 stores them beside [step][env] flags)
         if (flg_k) { flg_k[threadIdx.x] = 0; flg_k += n; }
         rew_k += n;
     }

@@ -710,14 +710,17 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
 #else
 #define OC_R4_QUAD_POLICY " sc1 nt"
 #endif
-        if (DUO) {  // (MODE 3 / 4: the mover stores the flags; the second wait state behind the store is a no-op)
+        if (DUO && FT8) {  // (MODE 3 / 4: the mover stores the flags; the second wait state behind the store is a no-op)
             asm volatile("global_store_dwordx4 %1, %2, %4\n\tv_pk_add_f32 %0, %0, %3\n\ts_nop 0"
+                         : "+v"(epsh) : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k) : "memory");
+        } else if (DUO) {  // ([step][env] flag rows from the mover: 64-byte pieces beside them — the quads stream)
+            asm volatile("global_store_dwordx4 %1, %2, %4" OC_R4_QUAD_POLICY "\n\tv_pk_add_f32 %0, %0, %3\n\ts_nop 0"
                          : "+v"(epsh) : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k) : "memory");
         } else if (FT8) {  // (the flag byte has gone into the block's tile)
             asm volatile("global_store_dwordx4 %1, %2, %4" OC_R4_QUAD_POLICY "\n\tv_pk_add_f32 %0, %0, %3\n\ts_nop 0"
                          : "+v"(epsh) : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k) : "memory");
         } else {
-            asm volatile("global_store_dwordx4 %1, %2, %4\n\tglobal_store_byte %5, %6, %7\n\t"
+            asm volatile("global_store_dwordx4 %1, %2, %4" OC_R4_QUAD_POLICY "\n\tglobal_store_byte %5, %6, %7\n\t"
                          "v_pk_add_f32 %0, %0, %3"
                          : "+v"(epsh)
                          : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k), "v"(flg_off[k8 & 7]), "v"(p.fl), "s"(flg_k)

@@ -142,7 +142,52 @@ __global__ __launch_bounds__(256) void k_pol(float4* __restrict__ rew, uint8_t* 
     }
 }
 
+// the [step][env] flags layout (one byte per env-step, 64 bytes per wavefront and row): cache-policy bits of the BYTE store
+// BP: 0 plain, 1 nt, 2 sc1 nt, 3 sc0 sc1 nt, 4 sc1; QP: the quad store's policy (0 plain, 1 sc1 nt)
+template <int BP, int QP>
+__global__ __launch_bounds__(256) void k_bytes(float4* __restrict__ rew, uint8_t* __restrict__ fl, int n_steps) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)gridDim.x * 256;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 v = {0.f, 0.f, (float)(threadIdx.x & 63), 1.f};
+    uint32_t acc = threadIdx.x;
+    for (int k = 0; k < n_steps; ++k) {
+        float4* p = rew + (size_t)k * n + e;
+        uint8_t* q = fl + (size_t)k * n + e;
+        if (QP == 0) asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(v) : "memory");
+        if (BP == 0) asm volatile("global_store_byte %0, %1, off" : : "v"(q), "v"(acc) : "memory");
+        if (BP == 1) asm volatile("global_store_byte %0, %1, off nt" : : "v"(q), "v"(acc) : "memory");
+        if (BP == 2) asm volatile("global_store_byte %0, %1, off sc1 nt" : : "v"(q), "v"(acc) : "memory");
+        if (BP == 3) asm volatile("global_store_byte %0, %1, off sc0 sc1 nt" : : "v"(q), "v"(acc) : "memory");
+        if (BP == 4) asm volatile("global_store_byte %0, %1, off sc1" : : "v"(q), "v"(acc) : "memory");
+        acc = acc * 1664525u + 1013904223u;
+        v.w = (float)(acc >> 31);
+    }
+}
+template <int BP, int QP>
+void run_bytes(const char* name, void* d, int n_wg, int n_steps);
+
 static hipEvent_t e0, e1;
+template <int BP, int QP>
+void run_bytes(const char* name, void* d, int n_wg, int n_steps) {
+    const size_t n = (size_t)n_wg * 256;
+    float4* rew = (float4*)d;
+    uint8_t* fl = (uint8_t*)d + (size_t)n_steps * n * 16;
+    double sum = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipLaunchKernelGGL((k_bytes<BP, QP>), dim3(n_wg), dim3(256), 0, 0, rew, fl, n_steps);
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0);
+        for (int r = 0; r < 6; ++r) hipLaunchKernelGGL((k_bytes<BP, QP>), dim3(n_wg), dim3(256), 0, 0, rew, fl, n_steps);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        sum += 6.0 * 17.0 * (double)n * n_steps / (ms * 1e-3) / 1e12;
+    }
+    printf("quads + flag byte [step][env], %-28s %7zu envs x %d steps: mean %5.2f TB/s = %.3f of 8; %6.1f G env-steps/s\n", name, n, n_steps, sum / 3, sum / 3 / 8, sum / 3 * 1e12 / 17.0 / 1e9);
+}
 template <int POL>
 void run_pol(const char* name, void* d, int n_wg, int n_steps) {
     const size_t n = (size_t)n_wg * 256;
@@ -233,6 +278,16 @@ int main(int argc, char** argv) {
             snprintf(nm, sizeof nm, "quads + flags tiled 8, %d workgroups", wg);
             run<8, 4>(nm, d, wg, 3808, 0);
         }
+    }
+    if (want("bytes")) {
+        run_bytes<0, 0>("plain / plain", d, 256, 3808);
+        run_bytes<1, 0>("byte nt", d, 256, 3808);
+        run_bytes<2, 0>("byte sc1 nt", d, 256, 3808);
+        run_bytes<3, 0>("byte sc0 sc1 nt", d, 256, 3808);
+        run_bytes<4, 0>("byte sc1", d, 256, 3808);
+        run_bytes<0, 1>("quad sc1 nt", d, 256, 3808);
+        run_bytes<2, 1>("both sc1 nt", d, 256, 3808);
+        run_bytes<0, 0>("plain / plain", d, 256, 3808);
     }
     if (want("policy")) {
         run_pol<0>("plain", d, 256, 3808);
