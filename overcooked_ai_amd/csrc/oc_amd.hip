@@ -433,7 +433,9 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         // MODE 3 (step_lut4.hpp): the per-env-terrain step split between mover and interact wavefronts — whole workgroups of
         // envs (every wavefront meets every barrier) and whole 8-step blocks; a workgroup's 139-158 KB of LDS leave room for one
         // per CU
-        const bool joint_duo = c.joint && b->width * b->height <= 64 && (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0;  // (MODE 4)
+        // (MODE 4's 126 000 B of tables, ring and counters + (16 n_obj + 3) KiB of cell words fit the CU's 160 KiB up to 32 cells:
+        //  larger one-pot joint-table layouts stay on the one-wavefront MODE 1 instance)
+        const bool joint_duo = c.joint && n_obj <= 2 && (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0;  // (MODE 4)
         // Bigger batches run the mover / interact workgroups in ROUNDS, one per CU at a time — the next round's workgroups start as
         // the first ones finish their launch's steps — which keeps the one-workgroup-per-CU rate where the one-wavefront instances
         // fall behind (same box, 131 072 / 262 144 envs: cramped_room 264 / 263 -> 331 / 330 G env-steps/s, the 5-layout mix 250 /

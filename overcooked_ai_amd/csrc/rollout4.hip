@@ -20,6 +20,9 @@ namespace {
 #include "step_predicate.hpp"
 #include "step_table.hpp"
 #include "step_lut4.hpp"
+#if OC_R4_PART == 1
+#include "step_duo5.hpp"
+#endif
 
 // dynamic LDS of a k_rollout4 instance: its tables + the cell words of a workgroup's 256 envs
 template <bool U, int MP, bool LL, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false, bool PIPE = true,
@@ -47,6 +50,17 @@ constexpr size_t lds4_bytes(size_t cell_rows) {
                            b->d_layouts, b->n_layouts, b->d_layout_id, (uint4*)c.d_state, (float4*)c.d_rewards, c.d_flags, \
                            (float4*)c.d_ep_returns, b->n_envs, b->width, c.n_obj, c.horizon, c.options,             \
                            (uint32_t)c.seed, (uint32_t)(c.seed >> 32), c.env_offset, c.t0, c.n_steps, c.sa, c.ea);  \
+    } while (0)
+
+// k_rollout5 (step_duo5.hpp): the per-env-terrain mover / interact kernel of round 6; two spare cell rows per lane
+#define GO5(LL, FT8F)                                                                                               \
+    do {                                                                                                            \
+        const size_t smem5 = (size_t)Lds5<LL>::CELLS + ((size_t)c.n_obj * 16 + 2) * BLOCK * 4;                      \
+        if (!want_lds(k_rollout5<LL, FT8F>, smem5)) break;                                                          \
+        hipLaunchKernelGGL((k_rollout5<LL, FT8F>), grid4, dim3(2 * BLOCK), smem5, c.stream, b->d_layouts, b->n_layouts, \
+                           b->d_layout_id, (uint4*)c.d_state, (float4*)c.d_rewards, c.d_flags, (float4*)c.d_ep_returns, \
+                           b->n_envs, b->width, c.n_obj, c.horizon, c.options, (uint32_t)c.seed, (uint32_t)(c.seed >> 32), \
+                           c.env_offset, c.t0, c.n_steps, c.sa);                                                    \
     } while (0)
 
 // MODE 4: the joint-table kernel (one cramped_room-like layout) with the same split — the mover reads the joint move table
@@ -102,8 +116,13 @@ void launch_rollout4_mode2(const Rollout4Call& c) {
         if (c.pipe) GO4(U, MP, LL, 2, true, false, 0, false, true, RUF, 4); else GO4(U, MP, LL, 2, true, false, 0, false, false, RUF); \
     } while (0)
     if (c.duo) {  // whole workgroups of envs, whole 8-step blocks, at most one workgroup per CU: mover + interact wavefronts
+#ifdef OC_R4_DUO_MODE3  // (A/B builds: round 5's k_rollout4 MODE 3 instances instead of k_rollout5)
         if (c.lds) { if (c.tiled8) GO4D(false, 2, true, true); else GO4D(false, 2, true, false); }
         else { if (c.tiled8) GO4D(false, 2, false, true); else GO4D(false, 2, false, false); }
+#else
+        if (c.lds) { if (c.tiled8) GO5(true, true); else GO5(true, false); }
+        else { if (c.tiled8) GO5(false, true); else GO5(false, false); }
+#endif
         return;
     }
     if (c.tiled8) {  // OC_OPT_FLAGS_TILED8: the instances BASELINE configs[3] / [4] run (oc_rollout_random has checked the conditions)

@@ -1,0 +1,556 @@
+// step_duo5.hpp — get_state_transition, fifth formulation: k_rollout5, the per-env-terrain mover / interact kernel (round 6)
+// Part of liboc_amd.so: included by rollout4.hip (OC_R4_PART 1) inside its anonymous namespace after step_lut4.hpp, whose helpers
+// (LDS accessors by absolute address, the Philox block, the flag-byte store) it shares.
+#pragma once
+
+// ==========================================================================================
+// Why a fifth formulation.  Round 6 measured what bounds k_rollout4's MODE 3 (the mover / interact split of round 5) on BASELINE
+// configs[3] (profiles/r06_interact_stream.txt): with its rare branch compiled out the step runs at the store ceiling (363 G
+// env-steps/s on every layout), reading the next step's cells early and patching them in registers (one LDS round trip off the
+// dependent chain, +5 VALU) made it 2.7 % SLOWER, and taking 11 VALU out of the mover (round 5) changed nothing: the step is the
+// INTERACT wavefront's own instruction stream — a wavefront issues one instruction per ~5 clocks whatever the partner does
+// (tools/valu_cost.hip) — plus the ~300 clocks of every rare-branch entry.  So this kernel keeps MODE 3's structure (a mover
+// wavefront runs resolve_movement up to three 8-step blocks ahead and hands the interact wavefront, per step and lane, the LDS
+// addresses of the two cell words the players act on) and shortens the interact wavefront's stream from ~60 to ~43 instructions:
+//
+//  * cell word (u32, [cell][lane]) = [K16][object][junk]: K16 = the LDS ADDRESS of the LUT row of the cell's key
+//        key = 6 * type + class; type = terrain type, 7 for the pot in slot 1, 8 = "nothing" (what a player that does not
+//        INTERACT acts on); class = counter: {empty, onion, tomato, dish, soup}, pot: {empty, idle 1..3, cooking, ready}
+//    and a row = 5 entries (hand class) x 16 bytes.  The entry of (cell, hand) is at  word.hi16 + 16 * hand class: ONE
+//    v_add_u32_sdwa (k_rollout4: four instructions — hand class, x 6, key byte, add-shift).
+//  * every entry knows the class of the hand it leaves (counter classes tell what is picked up), and carries it as its
+//    byte z.0 = 16 * class: the next step's address term is a byte of this step's entry, not recomputed from the hand.
+//  * is_dish_pickup_useful's gate without reading the pots: one counter N = 64 x (loose dishes) - (useful pots: 1..2 idle
+//    items, cooking or ready) kept by signed deltas in the entries (as the dish count was); "no loose dish and some useful
+//    pot" = N < 0; the exact predicate (mdp.py:2180-2204: stale pots, live counters) is arithmetic on N in the rare branch.
+//    No pot words in registers, no pot reads in the step.
+//  * entry (16 bytes): .x selectors — r = v_perm(.y, pool, .x) = [new K16][new object][new hand] with
+//        pool = [K16][object + add][hand] of (faced cell, hand);  .y = [new K16][delta N][dispensed object];
+//        .z = [0][flags][add][16 * new hand class];  .w = the shaped reward float (one set of shaping rewards per batch).
+//  * the pot in slot 1 has its own type, so an entry's START flag says WHICH countdown starts (no address compares).
+// Semantics are k_rollout4's / the oracle's: conflict replay for player 1, stale pot states for the usefulness predicate, the
+// same restart at the horizon (standard, drawn, or on a re-drawn layout).  Served batches: two players everywhere, <= 2 pots,
+// <= 64 cells, new dynamics, one set of shaping rewards, whole 256-env workgroups and 8-step blocks (what MODE 3 served).
+// ==========================================================================================
+constexpr int K5_TYPES = 9, K5_POT_B = 7, K5_NOTHING = 8, K5_ROW = 80, K5_KEYS = K5_TYPES * 6;
+constexpr int LUT5_BYTES = K5_KEYS * K5_ROW;  // 4 320
+enum { F5_TAKE_DISH = 1, F5_PLACE = 2, F5_PLATE = 4, F5_START_A = 8, F5_SERVE = 16, F5_START_B = 32, F5_CHG = 128 };
+// the flags sit in byte 2 of .z: masks in place
+constexpr uint32_t Z5_TAKE = (uint32_t)F5_TAKE_DISH << 16, Z5_SERVE = (uint32_t)F5_SERVE << 16, Z5_CHG = (uint32_t)F5_CHG << 16,
+                   Z5_START_A = (uint32_t)F5_START_A << 16, Z5_START_B = (uint32_t)F5_START_B << 16;
+constexpr uint32_t REC5_DONE = 0x80000000u, REC5_SAME = Z5_CHG;  // the mover's flag word: the horizon; both players act on one cell
+
+template <int LUT_BASE> constexpr uint32_t k16_of(int type5, int cls) { return (uint32_t)(LUT_BASE + (type5 * 6 + cls) * K5_ROW); }
+
+template <int LUT_BASE>
+constexpr Lut4Entry lut5_entry(int type5, int hc, int oc) {
+    // selectors: 0 hand, 1 object (+ add), 2 / 3 K16 | 4 dispensed object, 6 / 7 new K16 | 0x0C zero
+    uint32_t sel_h = 0, sel_o = 1, cobj = 0, flags = 0, add = 0, rew = RW4_NONE, hcn = (uint32_t)hc;
+    int nkey = -1, dd = 0, du = 0;  // new key (type, class) or -1 = unchanged; change of the loose-dish / useful-pot counts
+    const bool pot = type5 == OC_T_POT || type5 == K5_POT_B;
+    if (type5 == OC_T_COUNTER) {
+        if (hc == 0 && oc >= 1 && oc <= 4) {         // pick up from a counter (mdp.py:1473-1485): the class of what lies there = the hand's
+            sel_h = 1; sel_o = 0x0C; nkey = 0; flags = F5_CHG; dd = oc == 3 ? -1 : 0; hcn = (uint32_t)oc;
+        } else if (hc != 0 && oc == 0) {             // drop on a counter (mdp.py:1459-1471)
+            sel_h = 0x0C; sel_o = 0; nkey = hc; flags = F5_CHG; dd = hc == 3 ? 1 : 0; hcn = 0;
+        }
+    } else if (type5 == OC_T_ONION_DISP) {
+        if (hc == 0) { sel_h = 4; cobj = OC_O_ONION; hcn = 1; }
+    } else if (type5 == OC_T_TOMATO_DISP) {
+        if (hc == 0) { sel_h = 4; cobj = OC_O_TOMATO; hcn = 2; }
+    } else if (type5 == OC_T_DISH_DISP) {
+        if (hc == 0) { sel_h = 4; cobj = OC_O_DISH; flags = F5_TAKE_DISH; hcn = 3; }
+    } else if (pot) {
+        if (hc == 0 && oc >= PC_IDLE1 && oc <= PC_IDLE3) {               // begin_cooking (mdp.py:1515-1522)
+            nkey = PC_COOKING; flags = F5_CHG | (type5 == K5_POT_B ? F5_START_B : F5_START_A); du = oc == PC_IDLE3 ? 1 : 0;
+        } else if (hc == 3 && oc == PC_READY) {                          // soup pickup (mdp.py:1525-1539)
+            sel_h = 1; sel_o = 0x0C; nkey = PC_EMPTY; flags = F5_CHG | F5_PLATE; rew = RW4_PLATE; du = -1; hcn = 4;
+        } else if ((hc == 1 || hc == 2) && oc <= PC_IDLE2) {             // add ingredient (mdp.py:1541-1568)
+            sel_h = 0x0C; nkey = oc + 1; flags = F5_CHG | F5_PLACE; rew = RW4_PLACE; hcn = 0;
+            add = 8u + ((hc == 2 ? 1u : 0u) << oc) + (oc == 0 ? 0x80u : 0u);
+            du = oc == 0 ? 1 : oc == 2 ? -1 : 0;
+        }
+    } else if (type5 == OC_T_SERVE) {
+        if (hc == 4) { sel_h = 0x0C; flags = F5_SERVE; hcn = 0; }        // deliver (mdp.py:1570-1577)
+    }
+    const uint32_t nk16 = nkey < 0 ? 0u : k16_of<LUT_BASE>(type5, nkey);
+    const uint32_t sel_k = nkey < 0 ? 0x0302u : 0x0706u;
+    const int dn = 64 * dd - du;
+    return Lut4Entry{sel_h | (sel_o << 8) | (sel_k << 16), cobj | (((uint32_t)dn & 0xFFu) << 8) | (nk16 << 16),
+                     (hcn * 16u) | (add << 8) | (flags << 16), rew};
+}
+template <int LUT_BASE>
+struct Lut5Table { Lut4Entry e[K5_KEYS][5]; };
+template <int LUT_BASE>
+constexpr Lut5Table<LUT_BASE> make_lut5() {
+    Lut5Table<LUT_BASE> t{};
+    for (int type5 = 0; type5 < K5_TYPES; ++type5)
+        for (int oc = 0; oc < 6; ++oc)
+            for (int hc = 0; hc < 5; ++hc) t.e[type5 * 6 + oc][hc] = lut5_entry<LUT_BASE>(type5, hc, oc);
+    return t;
+}
+
+// LDS map of k_rollout5 (one dynamic region from address 0, as k_rollout4): LUT | layout records | progress counters | ring | cells
+template <bool LAY_LDS>
+struct Lds5 {
+    static constexpr int LUT = 0, LAY = (LUT5_BYTES + 15) & ~15, LAY_BYTES = LAY_LDS ? LDS_LAYOUT_MAX * 256 : 16;
+    static constexpr int SYNC = LAY + LAY_BYTES, RING = SYNC + 64;
+    static constexpr int RING_REC = 12, RING_BUF = 8 * BLOCK * RING_REC, CELLS = RING + 3 * RING_BUF;
+    static_assert(LUT5_BYTES < 65536, "K16 is an LDS address in 16 bits");
+};
+__device__ const Lut5Table<0> g_lut5 = make_lut5<0>();
+
+// class of what lies on a counter; the key of (terrain byte, object) for cells that are not pots
+__device__ __forceinline__ uint32_t counter_class5(uint32_t o) { return o == 0u ? 0u : (o & OC_O_SOUP) ? 4u : o; }
+__device__ __forceinline__ uint32_t cw5(uint32_t k16, uint32_t obj) { return (k16 << 16) | (obj << 8); }
+__device__ __forceinline__ uint32_t cw5_obj(uint32_t w) { return (w >> 8) & 0xFFu; }
+// pot class from the word of a pot cell of type `type5` (x / 80 for x = 0, 80 .. 400)
+__device__ __forceinline__ uint32_t cw5_pot_class(uint32_t w, uint32_t type5) { return (((w >> 16) - type5 * 480u) * 205u) >> 14; }
+__device__ __forceinline__ uint32_t pot_type5(int k) { return k == 0 ? (uint32_t)OC_T_POT : (uint32_t)K5_POT_B; }
+// the K16 half of a cell word (a 16-bit store into words that are otherwise read and written as u32: may_alias keeps it ordered
+// between them — under strict aliasing the compiler moved the next step's cell reads in front of it)
+typedef uint16_t __attribute__((may_alias)) oc_u16_alias;
+__device__ __forceinline__ void cw5_wr_k16(uint32_t a, uint32_t k16) { *(OC_LDS oc_u16_alias*)(uintptr_t)(a + 2u) = (uint16_t)k16; }
+
+template <bool LAY_LDS, bool FT8>
+__global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_rollout5(
+    const OcLayout* __restrict__ g_layouts, int n_layouts, const uint16_t* layout_id, uint4* st, float4* __restrict__ rewards,
+    uint8_t* __restrict__ flags, float4* __restrict__ ep_returns, int64_t n, int W, int n_obj, int horizon, uint32_t options,
+    uint32_t seed_lo, uint32_t seed_hi, int64_t env_offset, int64_t t0, int n_steps, StartArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn5[];
+    using M = Lds5<LAY_LDS>;
+    if ((uint32_t)(uintptr_t)(OC_LDS uint8_t*)s_dyn5 != 0u) __builtin_trap();  // folds away: the region starts at address 0
+    uint4* const s_lay = reinterpret_cast<uint4*>(s_dyn5 + M::LAY);
+    uint4* const s_lut = reinterpret_cast<uint4*>(s_dyn5 + M::LUT);
+    constexpr int MAXP = 2;
+    constexpr uint32_t CS = (uint32_t)BLOCK * 4u;  // bytes between two cells' words in a lane's column
+    const uint32_t tid = threadIdx.x & (uint32_t)(BLOCK - 1);  // lanes tid of the two halves share env e: threads 0..255 interact, the others move
+    const bool mover = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
+    const uint32_t blk = xcd_block();
+    const int64_t e = (int64_t)blk * BLOCK + tid;  // (the host launches whole workgroups of envs only)
+    Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, true, s_lay);  // contains a barrier
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(&g_lut5);
+        for (int i = threadIdx.x; i < K5_KEYS * 5; i += 2 * BLOCK) {
+            uint4 ent = src[i];  // one set of shaping rewards for the whole table: the entry carries the shaped reward itself
+            ent.w = ent.w == RW4_PLACE ? __float_as_uint(L.rew_placement()) : ent.w == RW4_PLATE ? __float_as_uint(L.rew_soup()) : 0u;
+            s_lut[i] = ent;
+        }
+    }
+    if (threadIdx.x < 8) reinterpret_cast<uint32_t*>(s_dyn5 + M::SYNC)[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t col = (uint32_t)M::CELLS + tid * 4u;  // LDS address of this lane's column of cell words
+    const uint32_t dummy = col + (uint32_t)n_obj * 16u * CS, noact = dummy + CS;  // two spare words per lane behind the grid
+    LayC C = load_consts<false>(L);
+    const uint32_t delta4 = make_delta4(W);
+    const uint64_t g = (uint64_t)(env_offset + e);
+    const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
+    const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u));
+    const uint32_t lane = tid & 63u;
+    uint8_t* flg_k = flags + ((int64_t)blk * BLOCK + wave_base) * (FT8 ? 8 : 1);
+    constexpr uint32_t RING_SLOT = (uint32_t)BLOCK * (uint32_t)M::RING_REC;
+    const uint32_t sync_pair = (uint32_t)M::SYNC + (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * 8u;
+    const uint32_t ring0 = (uint32_t)M::RING + tid * (uint32_t)M::RING_REC;
+    const int n_blocks = n_steps >> 3;
+    auto floor_mask_of = [&](const Lay Lx) __attribute__((always_inline)) {
+        uint64_t m = 0;
+        for (int i = 0; i < n_obj * 4; ++i) {
+            const uint32_t T = Lx.u32(L_TERRAIN + 4 * i);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (((T >> (8 * b)) & 7u) == OC_T_FLOOR && (uint32_t)(4 * i + b) < Lx.u8(L_NCELLS)) m |= 1ull << (4 * i + b);
+        }
+        return m;
+    };
+
+    // ---- the MOVER wavefronts: resolve_movement (mdp.py:1644-1727) for the whole launch, one 8-step block at a time, up to
+    //      three blocks ahead (k_rollout4 MODE 3's mover; the flag word's shared-cell bit sits where the entries' CHG flag does)
+    if (mover) {
+        auto ahead = [&](uint32_t c, uint32_t d) __attribute__((always_inline)) {
+            return c + (uint32_t)(int32_t)(int8_t)(uint8_t)__builtin_amdgcn_perm(0u, delta4, d);
+        };
+        const uint4 h = st[e];
+        uint32_t P0 = h.x & 0xFFu, O0 = (h.x >> 8) & 0xFFu, P1 = h.x >> 24, O1 = h.y & 0xFFu;
+        const uint32_t t_in = h.y >> 16;
+        uint32_t tleft = t_in < (uint32_t)horizon ? (uint32_t)horizon - 1u - t_in : 0u;
+        uint32_t over = t_in < (uint32_t)horizon ? 0u : t_in - ((uint32_t)horizon - 1u);
+        uint64_t fm = floor_mask_of(L);
+        uint32_t flg_off[8];
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) flg_off[k8] = lane + (uint32_t)k8 * (uint32_t)n;
+        auto produce = [&](int b, uint32_t ring) __attribute__((always_inline)) {
+            if (b >= n_blocks) {  // the stub block: one "nothing" record for the last step's look-ahead, then the final pose
+                lds_wr96(ring, noact, noact, 0u);
+                lds_wr96(ring + RING_SLOT, P0 | (O0 << 8) | (P1 << 16) | (O1 << 24), tleft, over);
+                return;
+            }
+            const Phx4 wb = philox_words(((uint64_t)t0 >> 3) + (uint64_t)b, g_lo, g_hi, seed_lo, seed_hi);
+            uint32_t tile_lo = 0, tile_hi = 0;
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) {
+                uint32_t x = (k8 >> 1) == 0 ? wb.w0 : (k8 >> 1) == 1 ? wb.w1 : (k8 >> 1) == 2 ? wb.w2 : wb.w3;
+                if (k8 & 1) x *= 36u;
+                const uint32_t a0 = __umulhi(x, 6u), a1 = __umulhi(x * 6u, 6u);
+                const uint32_t f0 = col + ahead(P0, O0) * CS, f1 = col + ahead(P1, O1) * CS;
+                const uint32_t rec0 = a0 == 5u ? f0 : noact, rec1 = a1 == 5u ? f1 : noact;
+                const uint32_t f_same = rec0 == rec1 ? (a0 == 5u ? REC5_SAME : 0u) : 0u;
+                const uint32_t t0_ = ahead(P0, a0), t1_ = ahead(P1, a1);
+                uint32_t fb0 = (uint32_t)(fm >> t0_), fb1 = (uint32_t)(fm >> t1_);
+                asm("" : "+v"(fb0));
+                asm("" : "+v"(fb1));
+                const uint32_t np0 = (fb0 & 1u) ? t0_ : P0, np1 = (fb1 & 1u) ? t1_ : P1;
+                const bool collide = (np0 == np1) | ((np0 == P1) & (np1 == P0));
+                const uint32_t q0 = collide ? P0 : np0, q1 = collide ? P1 : np1;
+                O0 = a0 < 4u ? a0 : O0; O1 = a1 < 4u ? a1 : O1;
+                P0 = q0; P1 = q1;
+                uint32_t fl = 0;
+                const bool done = tleft == 0u;
+                tleft -= 1u;
+                lds_wr96(ring + (uint32_t)k8 * RING_SLOT, rec0, rec1, f_same | (done ? REC5_DONE : 0u));
+                if (__builtin_expect(done, 0)) {  // OvercookedEnv.step at the horizon (env.py:266-267, 321-325)
+                    fl = OC_F_DONE;
+                    tleft = 0u;
+                    over += 1u;
+                    if (options & OC_OPT_AUTO_RESET) {
+                        over = 0u;
+                        fl |= OC_F_RESET;
+                        tleft = (uint32_t)horizon - 1u;
+                        const uint32_t ep_k = sa.epoch + (uint32_t)(b * 8 + k8);
+                        if (sa.enabled) {
+                            if (sa.regen_count) {  // (the interact wavefront records the new id in layout_ids)
+                                const uint32_t lid = draw_layout(sa, g, ep_k);
+                                L = LAY_LDS ? Lay{reinterpret_cast<const uint8_t*>(s_lay) + lid * 256u}
+                                            : Lay{reinterpret_cast<const uint8_t*>(g_layouts) + (size_t)lid * 256u};
+                                fm = floor_mask_of(L);
+                            }
+                            const StartDraw d = draw_start(L, g, ep_k, sa.seed_lo, sa.seed_hi, sa.random_start_pos, sa.thresh);
+                            P0 = d.pos0; P1 = d.pos1;
+                        } else {
+                            P0 = L.u8(L_START_POS); P1 = L.u8(L_START_POS + 1);
+                        }
+                        O0 = L.u8(L_START_OR); O1 = L.u8(L_START_OR + 1);
+                    }
+                }
+                if (FT8) {
+                    uint32_t& half = (k8 & 4) ? tile_hi : tile_lo;
+                    half = (k8 & 3) == 0 ? fl : (half | (fl << (8 * (k8 & 3))));
+                } else {
+                    store_flag_byte(flg_k, flg_off[k8], fl);
+                }
+            }
+            if (FT8) {
+                const uint64_t tile = ((uint64_t)tile_hi << 32) | tile_lo;
+                asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lane * 8u), "v"(tile), "s"(flg_k) : "memory");
+            }
+            flg_k += 8 * n;
+        };
+        uint32_t wbuf = 0;
+        for (int j = 0; j <= n_blocks; ++j) {
+            if (j >= 3)
+                while (lds_poll32(sync_pair + 4u) + 2u < (uint32_t)j) __builtin_amdgcn_s_sleep(2);
+            produce(j, ring0 + wbuf);
+            wbuf = wbuf == 2u * (uint32_t)M::RING_BUF ? 0u : wbuf + (uint32_t)M::RING_BUF;
+            lds_post32(sync_pair, (uint32_t)j + 1u);
+        }
+        return;
+    }
+
+    // ---- the INTERACT wavefronts --------------------------------------------------------------------------------------------
+    // per-lane state: hands (code in byte 0 of the last result word), the .z word of the entry that left each hand (byte 0 = 16 x
+    // its class), N, the pots' countdowns (k_rollout4's: steps until ready, REM_IDLE when not cooking) and cell addresses
+    uint32_t h0, h1, hz0, hz1, rem[MAXP], tk[MAXP], pa[MAXP], exotic = 0;
+    int32_t N = 0;
+    auto hand_z = [](uint32_t code) __attribute__((always_inline)) { return min(code, 4u) * 16u; };
+    auto pot_addrs = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) pa[k] = (uint32_t)k < C.n_pots ? col + L.pot_cell(k) * CS : dummy;
+    };
+    // the cell words of an empty grid (restart) — every cell, the pots as empty pots of their slot's type
+    auto write_empty_grid = [&]() __attribute__((always_inline)) {
+        for (int c = 0; c < n_obj * 16; ++c) {
+            const uint32_t tb = L.terrain((uint32_t)c), type = tb & 7u;
+            const uint32_t type5 = (type == OC_T_POT && (tb >> 3) == 1u) ? (uint32_t)K5_POT_B : type;
+            lds_wr32(col + (uint32_t)c * CS, cw5(k16_of<M::LUT>(0, 0) + type5 * 480u, 0u));
+        }
+    };
+    {   // load (include/oc_amd.h wire format -> key words, N, countdowns)
+        const uint4 h = st[e];
+        h0 = (h.x >> 16) & 0xFFu; h1 = (h.y >> 8) & 0xFFu;
+        hz0 = hand_z(h0); hz1 = hand_z(h1);
+        pot_addrs();
+        int32_t dishes = 0;
+        for (int p = 0; p < n_obj; ++p) {
+            const uint4 v = st[(int64_t)(1 + p) * n + e];
+            const uint32_t ow[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t T = L.u32(L_TERRAIN + 16 * p + 4 * q);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t o = (ow[q] >> (8 * b)) & 0xFFu, tb = (T >> (8 * b)) & 0xFFu, type = tb & 7u;
+                    const uint32_t type5 = (type == OC_T_POT && (tb >> 3) == 1u) ? (uint32_t)K5_POT_B : type;
+                    const uint32_t cls = type == OC_T_COUNTER ? counter_class5(o) : 0u;
+                    dishes += (type == OC_T_COUNTER && o == OC_O_DISH) ? 1 : 0;
+                    lds_wr32(col + (uint32_t)(16 * p + 4 * q + b) * CS, cw5(k16_of<M::LUT>(0, 0) + (type5 * 6u + cls) * K5_ROW, o));
+                }
+            }
+        }
+        lds_wr32(noact, cw5(k16_of<M::LUT>(K5_NOTHING, 0), 0u));
+        int32_t useful = 0;
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            rem[k] = REM_IDLE; tk[k] = 0;
+            if ((uint32_t)k < C.n_pots) {
+                uint32_t o = cw5_obj(lds_rd32(pa[k]));
+                const uint32_t tkb = (h.z >> (8 * k)) & 0xFFu;
+                const uint32_t pc = pot_class(C, o, tkb);
+                if (o == OC_O_SOUP) { exotic |= 1u << k; o = 0; }  // a soup object without ingredients behaves as an empty pot
+                tk[k] = tkb;
+                rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) : REM_IDLE;
+                useful += (pc != PC_EMPTY && pc != PC_IDLE3) ? 1 : 0;
+                lds_wr32(pa[k], cw5(k16_of<M::LUT>(0, 0) + (pot_type5(k) * 6u + pc) * K5_ROW, o));
+            }
+        }
+        N = 64 * dishes - useful;
+    }
+    float4 ep = ep_returns ? ep_returns[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 epsh = {ep.z, ep.w};  // the episode's shaped returns gain the upper half of every step's reward quad (k_rollout4)
+    float4* rew_k = rewards + (int64_t)blk * BLOCK;
+    uint32_t rew_off[8];
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8) rew_off[k8] = (tid + (uint32_t)k8 * (uint32_t)n) * 16u;
+    uint32_t step_k = 0;  // index of the step within this launch (wave-uniform): the epoch offset of a restart
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    struct Pend { uint64_t lo, hi; };  // a step's reward quad, stored by the next step of the block in the shadow of its look-ups
+    auto flush = [&](const Pend& p, int k8) __attribute__((always_inline)) {
+        typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+        const u64x2 q = {p.lo, p.hi};
+        if (FT8) {  // (beside flag tiles the quads keep plain stores, beside [step][env] flag bytes they stream: k_rollout4, round 5)
+            asm volatile("global_store_dwordx4 %1, %2, %4\n\tv_pk_add_f32 %0, %0, %3\n\ts_nop 0"
+                         : "+v"(epsh) : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k) : "memory");
+        } else {
+            asm volatile("global_store_dwordx4 %1, %2, %4 sc1 nt\n\tv_pk_add_f32 %0, %0, %3\n\ts_nop 0"
+                         : "+v"(epsh) : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k) : "memory");
+        }
+    };
+    auto entry_at = [](uint32_t cw, uint32_t hz) __attribute__((always_inline)) {  // LUT address of (cell word, hand): one instruction
+        uint32_t a;
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_0" : "=v"(a) : "v"(cw), "v"(hz));
+        return a;
+    };
+    auto interact5 = [](const uint4 ent, uint32_t h, uint32_t cw) __attribute__((always_inline)) {
+        uint32_t pool = __builtin_amdgcn_perm(cw, h, 0x07060500u);  // [K16][object][hand]
+        asm("v_add_u32_sdwa %0, %1, %0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1" : "+v"(pool) : "v"(ent.z));
+        return __builtin_amdgcn_perm(ent.y, pool, ent.x);           // [new K16][new object][new hand]
+    };
+    auto sext_b1 = [](uint32_t y) __attribute__((always_inline)) { return (int32_t)(int8_t)(uint8_t)(y >> 8); };
+
+    while (lds_poll32(sync_pair) < 1u) __builtin_amdgcn_s_sleep(1);
+    uint32_t fo0, fo1, f_rec, c0, c1;
+    {
+        const oc_rec3 rec = lds_rd96(ring0);
+        fo0 = rec.x; fo1 = rec.y; f_rec = rec.z;
+    }
+    c0 = lds_rd32(fo0);
+    c1 = lds_rd32(fo1);
+    Pend pend = {0ull, 0ull};
+    // One step.  k8: its index in the block; next_rec: LDS address of the mover's record of the next step.
+    auto dstep = [&](int k8, uint32_t next_rec) __attribute__((always_inline)) {
+        const uint4 e0 = lds_rd128(entry_at(c0, hz0));
+        uint4 e1 = lds_rd128(entry_at(c1, hz1));
+        const oc_rec3 nrec = lds_rd96(next_rec);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k8 >= 1) flush(pend, k8 - 1);  // the previous step's quad, while the look-ups are in flight
+        // step_environment_effects (mdp.py:1691-1703): the countdowns; a finished one turns the pot ready — every lane stores,
+        // the others into their spare word
+        bool ripe[MAXP];
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            rem[k] -= 1u;
+            ripe[k] = rem[k] == 0u;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t r0 = interact5(e0, h0, c0);
+        uint32_t r1 = interact5(e1, h1, c1);
+        lds_wr32(fo0, r0);
+        lds_wr32(fo1, r1);
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k)
+            cw5_wr_k16(ripe[k] ? pa[k] : dummy, k16_of<M::LUT>((int)(k == 0 ? OC_T_POT : K5_POT_B), PC_READY));
+        uint32_t nc0 = lds_rd32(nrec.x), nc1 = lds_rd32(nrec.y);  // the next step's cells: everything this step writes has been issued
+        const int32_t N_mid = N + sext_b1(e0.y);
+        int32_t N_new = N_mid + sext_b1(e1.y);
+        // ---- ONE branch for everything rare: cooking starts, deliveries, dish pick-ups that may be useful (N < 0 before or
+        //      after player 0's interact: no loose dish, some useful pot), a shared cell player 0 has changed, the horizon
+        const uint32_t take = (uint32_t)(min(N, N_mid) >> 31) & Z5_TAKE;
+        const uint32_t gate = take | Z5_SERVE | Z5_START_A | Z5_START_B;
+        const uint32_t rare_bits = ((e0.z | e1.z) & gate) | ((e0.z | REC5_DONE) & f_rec);
+        uint64_t q_lo, q_hi;  // the reward quad as two register pairs: zeros, and the two entries' shaped floats
+        {
+            const uint64_t a64 = ((uint64_t)e0.w << 32) | e0.z, b64 = ((uint64_t)e1.w << 32) | e1.z;
+            asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1]" : "=v"(q_hi) : "v"(a64), "v"(b64));
+            asm("v_mov_b64 %0, 0" : "=v"(q_lo));
+        }
+        uint32_t nh0 = r0, nh1 = r1, nz0 = e0.z, nz1 = e1.z;
+        if (__builtin_expect(rare_bits != 0u, 0)) {
+            bool grid_changed = false;
+            const uint32_t hb0 = h0 & 0xFFu, hb1 = h1 & 0xFFu, hn0 = r0 & 0xFFu;
+            if (e0.z & f_rec & Z5_CHG) {  // player 1 acts on the cell player 0 has just changed: redo its interact on what is there now (Q2 / Q3)
+                e1 = lds_rd128(entry_at(r0, hz1));
+                r1 = interact5(e1, h1, r0);
+                nh1 = r1; nz1 = e1.z;
+                lds_wr32(fo1, r1);
+                N_new = N_mid + sext_b1(e1.y);
+                grid_changed = true;
+            }
+            const uint32_t fz = e0.z | e1.z;
+            // begin_cooking (mdp.py:1515-1522) = load the countdown: tick 0 now, cooked once by this step's env effects (Q4)
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k) {
+                const uint32_t sk = k == 0 ? Z5_START_A : Z5_START_B;
+                if (fz & sk) {
+                    const uint32_t soup = cw5_obj((e0.z & sk) ? r0 : r1);
+                    const uint32_t cook = cook_of(C, soup);
+                    rem[k] = cook - 1u;
+                    exotic &= ~(1u << k);
+                    if (cook <= 1u) {  // ready with this step's env effects (cook == 0: at once, never ticks)
+                        cw5_wr_k16(pa[k], k16_of<M::LUT>((int)(k == 0 ? OC_T_POT : K5_POT_B), PC_READY));
+                        grid_changed = true;
+                    }
+                }
+            }
+            float4 rw = make_float4(0.f, 0.f, __uint_as_float(e0.w), __uint_as_float(e1.w));
+            if (fz & (Z5_SERVE | Z5_TAKE)) {
+                // is_dish_pickup_useful (mdp.py:2180-2204): pot_states of before the interacts (the useful pots in N), live hands
+                // and counters; N = 64 x dishes - useful pots with at most 2 pots
+                const int32_t dishes_b = (N + 63) >> 6, useful = 64 * dishes_b - N;
+                const bool du0 = (((hb1 == OC_O_DISH) ? 1 : 0) < useful) & (dishes_b == 0);
+                const bool du1 = (((hn0 == OC_O_DISH) ? 1 : 0) < useful) & (N_mid <= 0);
+                float4 r;
+                r.z = (((e0.z & Z5_TAKE) != 0u) & du0) ? C.rew_dish : 0.f;
+                r.w = (((e1.z & Z5_TAKE) != 0u) & du1) ? C.rew_dish : 0.f;
+                r.x = r.y = 0.f;
+                if (fz & Z5_SERVE) {  // deliver_soup (mdp.py:1631-1642)
+                    r.x = (e0.z & Z5_SERVE) ? L.value(recipe_idx(hb0) & 15u) : 0.f;
+                    r.y = (e1.z & Z5_SERVE) ? L.value(recipe_idx(hb1) & 15u) : 0.f;
+                }
+                ep.x += r.x; ep.y += r.y;
+                rw.x = r.x; rw.y = r.y; rw.z += r.z; rw.w += r.w;
+            }
+            if (f_rec & REC5_DONE) {  // OvercookedEnv.step at the horizon (env.py:266-267, 321-325); the mover stores the flag byte
+                if (options & OC_OPT_AUTO_RESET) {
+                    StartDraw d;
+                    d.held0 = d.held1 = d.ticks0 = d.ticks1 = d.pots0 = d.pots1 = 0u;
+                    if (sa.enabled) {  // the batch's start_state_fn, drawn from (seed, global env, epoch of this step)
+                        if (sa.regen_count) {  // ... on a layout drawn for the new episode (regen_mdp, env.py:288-302)
+                            const uint32_t lid = draw_layout(sa, g, sa.epoch + step_k);
+                            sa.layout_ids[e] = (uint16_t)lid;
+                            L = LAY_LDS ? Lay{reinterpret_cast<const uint8_t*>(s_lay) + lid * 256u}
+                                        : Lay{reinterpret_cast<const uint8_t*>(g_layouts) + (size_t)lid * 256u};
+                            C = load_consts<false>(L);
+                            pot_addrs();
+                        }
+                        d = draw_start(L, g, sa.epoch + step_k, sa.seed_lo, sa.seed_hi, sa.random_start_pos, sa.thresh);
+                    }
+                    write_empty_grid();
+                    int32_t useful = 0;
+                    exotic = 0;
+#pragma unroll
+                    for (int k = 0; k < MAXP; ++k) {
+                        rem[k] = REM_IDLE; tk[k] = 0;
+                        if ((uint32_t)k < C.n_pots) {
+                            const uint32_t o = d.pot_obj((uint32_t)k), tkb = d.tick((uint32_t)k);
+                            const uint32_t pc = pot_class(C, o, tkb);
+                            tk[k] = tkb;
+                            rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) : REM_IDLE;
+                            useful += (pc != PC_EMPTY && pc != PC_IDLE3) ? 1 : 0;
+                            lds_wr32(pa[k], cw5(k16_of<M::LUT>(0, 0) + (pot_type5(k) * 6u + pc) * K5_ROW, o));
+                        }
+                    }
+                    N_new = -useful;
+                    nh0 = d.held0; nh1 = d.held1;
+                    nz0 = hand_z(d.held0); nz1 = hand_z(d.held1);
+                    ep = zero4;  // the episode ends with this step: its returns restart from zero
+                    epsh.x = -rw.z; epsh.y = -rw.w;
+                    grid_changed = true;
+                }
+            }
+            if (grid_changed) {  // read the next step's cells again, behind everything this step wrote
+                nc0 = lds_rd32(nrec.x);
+                nc1 = lds_rd32(nrec.y);
+            }
+            q_lo = ((uint64_t)__float_as_uint(rw.y) << 32) | __float_as_uint(rw.x);
+            q_hi = ((uint64_t)__float_as_uint(rw.w) << 32) | __float_as_uint(rw.z);
+            // (wait for the reads in here: left pending, the join behind the branch would wait for them at its first LDS use)
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+        if (k8 < 7) { pend.lo = q_lo; pend.hi = q_hi; }
+        else { const Pend now = {q_lo, q_hi}; flush(now, 7); }
+        h0 = nh0; h1 = nh1; hz0 = nz0; hz1 = nz1; N = N_new;
+        fo0 = nrec.x; fo1 = nrec.y; f_rec = nrec.z; c0 = nc0; c1 = nc1;
+        step_k += 1u;
+    };
+    uint32_t rbuf = 0;  // (wave-uniform) offset of the ring buffer that holds the block being run
+    for (int b = 0; b < n_blocks; ++b) {
+        // Block b's own records are there (checked by block b - 1's step 7); step 7 looks ahead to the first record of block
+        // b + 1: the mover must have finished b + 2 blocks by then (the stub behind the launch counts as one).  The count is read
+        // before step 6 and looked at after it, so that the read's latency is not the loop's.
+        const uint32_t cur = ring0 + rbuf;
+        rbuf = rbuf == 2u * (uint32_t)M::RING_BUF ? 0u : rbuf + (uint32_t)M::RING_BUF;
+#pragma unroll
+        for (int k8 = 0; k8 < 6; ++k8) dstep(k8, cur + (uint32_t)(k8 + 1) * RING_SLOT);
+        const uint32_t produced = *(const volatile OC_LDS uint32_t*)(uintptr_t)sync_pair;
+        dstep(6, cur + 7u * RING_SLOT);
+        if (__builtin_amdgcn_readfirstlane((int)produced) < b + 2)
+            while (lds_poll32(sync_pair) < (uint32_t)b + 2u) __builtin_amdgcn_s_sleep(1);
+        dstep(7, ring0 + rbuf);
+        rew_k += 8 * n;
+        lds_post32(sync_pair + 4u, (uint32_t)b + 1u);
+    }
+    // ---- store (key words -> wire format); the pose and the episode clock come from the mover's stub record
+    const oc_rec3 fin = lds_rd96(ring0 + rbuf + RING_SLOT);
+    {
+        const uint32_t t = min((uint32_t)horizon - 1u - fin.y + fin.z, 0xFFFFu);  // the wire format's u16: saturates
+        uint4 h;
+        h.x = (fin.x & 0xFFFFu) | ((h0 & 0xFFu) << 16) | ((fin.x >> 16) << 24);
+        h.y = (fin.x >> 24) | ((h1 & 0xFFu) << 8) | (t << 16);
+        h.z = 0; h.w = 0;
+        uint32_t fix_cell[MAXP], fix_obj[MAXP];
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            fix_cell[k] = 0xFFFFFFFFu; fix_obj[k] = 0;
+            if ((uint32_t)k < C.n_pots) {
+                const uint32_t cw = lds_rd32(pa[k]), o = cw5_obj(cw), pc = cw5_pot_class(cw, pot_type5(k));
+                uint32_t tkb = tk[k];
+                const bool live = rem_live(rem[k]);
+                if (live) {
+                    const uint32_t cook = cook_of(C, o);
+                    tkb = (pc == PC_COOKING ? cook - rem[k] : cook) + 1u;
+                }
+                if (pc < PC_COOKING) tkb = 0;  // empty or idle
+                h.z |= tkb << (8 * k);
+                if (o == 0u && ((exotic >> k) & 1u) && !live) { fix_cell[k] = L.pot_cell(k); fix_obj[k] = OC_O_SOUP; }
+            }
+        }
+        st[e] = h;
+        for (int p = 0; p < n_obj; ++p) {
+            uint32_t ow[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ow[q] = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t c = (uint32_t)(16 * p + 4 * q + b);
+                    uint32_t o = cw5_obj(lds_rd32(col + c * CS));
+#pragma unroll
+                    for (int k = 0; k < MAXP; ++k) o = c == fix_cell[k] ? fix_obj[k] : o;
+                    ow[q] |= o << (8 * b);
+                }
+            }
+            st[(int64_t)(1 + p) * n + e] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
+    }
+    ep.z = epsh.x; ep.w = epsh.y;
+    if (ep_returns) ep_returns[e] = ep;
+}

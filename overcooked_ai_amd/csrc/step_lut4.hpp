@@ -538,6 +538,15 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
     uint8_t* const s_fi = s_dyn4 + M::FI;
     // MODE 3 / 4: lanes tid of the two halves of the workgroup share env e — threads 0..BLOCK-1 interact, the others move
     constexpr bool DUO = MODE == 3 || MODE == 4;
+    // EARLY (round 6): the interact wavefront reads the cells of step k + 1 BEFORE step k's two cell writes (their ring record is
+    // read two steps ahead) and patches them in registers where an address equals a cell this step writes: the step's dependent
+    // chain loses its second LDS round trip (cell write -> cell read).  The pots' "ready" stores leave the straight line with it:
+    // the countdown registers hold (steps until ready) - 1, a pot turning ready shows as a sign bit in the rare-branch test.
+#ifndef OC_R4_EARLY
+#define OC_R4_EARLY 0
+#endif
+    constexpr bool EARLY = MODE == 3 ? OC_R4_EARLY >= 1 : MODE == 4 ? OC_R4_EARLY >= 2 : false;
+    constexpr uint32_t RB = EARLY ? 1u : 0u;  // bias of the countdown registers
     static_assert(MODE != 3 || (MAXP <= 2 && OUT && !OLD && !EV && PIPE && (UNIFORM || RU) && CW == 4 && !NOCONF),
                   "MODE 3 = the pipelined MODE 2 instance, split");
     static_assert(MODE != 4 || (UNIFORM && MAXP == 1 && LAY_LDS && OUT && !OLD && !EV && PIPE && CW == 4 && NOCONF),
@@ -753,10 +762,12 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
 #pragma unroll
         for (int k = 0; k < MAXP; ++k) {
             rem_before[k] = s.rem[k];
-            if (FAST_START) s.rem[k] = ((r0 | r1) & F4_START) ? cookv : s.rem[k];
+            if (FAST_START) s.rem[k] = ((r0 | r1) & F4_START) ? cookv - RB : s.rem[k];
             s.rem[k] -= 1u;
-            ripe[k] = s.rem[k] == 0u;
-            if (PIPE) {
+            ripe[k] = EARLY ? (int32_t)s.rem[k] < 0 : s.rem[k] == 0u;
+            if (EARLY) {
+                // (the "ready" store is the rare branch's: the sign bit joins its test below)
+            } else if (PIPE) {
                 if (MAXP <= 2 || (uint32_t)k < C.n_pots) cw_wr_kb<CW>(ripe[k] ? col + s.poff[k] : dummy, KB_POT + PC_READY);
             } else if (ripe[k]) {  // only the lanes concerned store
                 cw_wr_kb<CW>(col + s.poff[k], KB_POT + PC_READY);
@@ -766,7 +777,13 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
             nf0 = col + (m1 & 0xFFFFu);
             nf1 = col + (m1 >> 16);
         }
-        if ((MODE == 1 || MODE == 2 || DUO) && PIPE) {  // the next step's cells: everything this step writes to the grid has been issued
+        if (EARLY) {  // nc0 / nc1 were read before this step's cell writes: what the writes changed is patched in (player 1's is the later write)
+            nc0 = nf0 == fo0 ? cw_of_result<CW>(r0) : nc0;
+            if (!NOCONF) nc0 = nf0 == fo1 ? cw_of_result<CW>(r1) : nc0;
+            if (!NOCONF) nc1 = nf1 == fo0 ? cw_of_result<CW>(r0) : nc1;
+            nc1 = nf1 == fo1 ? cw_of_result<CW>(r1) : nc1;
+            rd_pots(npw);
+        } else if ((MODE == 1 || MODE == 2 || DUO) && PIPE) {  // the next step's cells: everything this step writes to the grid has been issued
             nc0 = cw_rd<CW>(nf0);
             nc1 = cw_rd<CW>(nf1);
             rd_pots(npw);
@@ -807,6 +824,12 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
         bool rare;
         if (DUO) {  // the mover has decided the horizon and seen whether the players share a cell: two and-or's and one compare
             rare_bits = NOCONF ? (((r0 | r1) & (take | gate)) | f_rec) : (((r0 | r1) & (take | gate)) | ((r0 | 0x80000000u) & f_rec));
+            if (EARLY) {  // a pot turns ready with this step's env effects
+                uint32_t u = s.rem[0];
+#pragma unroll
+                for (int k = 1; k < MAXP; ++k) u |= s.rem[k];
+                rare_bits |= u & 0x80000000u;
+            }
             rare = rare_bits != 0u;
         } else {
             const uint32_t tleft_new = s.tleft - 1u;               // the horizon: the sign bit (tleft < 2^31)
@@ -815,6 +838,9 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
             if (OLD) rare_bits |= s.pending;
             rare = (rare_bits != 0u) | conflict;
         }
+#ifdef OC_X_NORARE  // (timing experiments only: the straight line without its corrective branch — results are wrong)
+        if (DUO) rare = false;
+#endif
         uint32_t nh0 = r0, nh1 = r1;  // the hands after the step
         float4 rw = make_float4(0.f, 0.f, sh0, sh1);  // this step's reward quad and flag byte: stored ONCE, after the branch
         uint64_t q_lo = 0, q_hi = 0;  // the same quad as two register pairs (what the unrolled blocks store; the rare branch rewrites both whole)
@@ -861,8 +887,9 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
                     // (the straight line may have loaded or not loaded the countdown from player 1's stale interact: redo)
                     uint32_t cook = 0;
                     if (go) cook = cook_time(soup);
-                    s.rem[k] = (go ? cook : rem_before[k]) - 1u;
-                    ripe[k] = s.rem[k] == 0u;
+                    s.rem[k] = (go ? cook : rem_before[k] + RB) - 1u - RB;
+                    ripe[k] = s.rem[k] + RB == 0u;
+                    if (EARLY && go && cook == 0u) ripe[k] = true;  // (the countdown is put away below)
                     if (go) {  // (cook == 0: ready at once, never ticks)
                         s.exotic &= ~(1u << k);
                         cw_wr_kb<CW>(pa, (cook == 0u || ripe[k]) ? KB_POT + PC_READY : KB_POT + PC_COOKING);
@@ -873,6 +900,19 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
                     }
                 }
                 if (OLD) s.pending = 0;
+            }
+            if (EARLY) {  // step_environment_effects (mdp.py:1691-1703): the pots that turn ready with this step
+#pragma unroll
+                for (int k = 0; k < MAXP; ++k) {
+                    if (MAXP > 1 && (uint32_t)k >= C.n_pots) break;
+                    if (ripe[k]) {  // the countdown is put away: the tick byte a ready pot is stored with is cook time + 1
+                        const uint32_t pa = col + s.poff[k];
+                        cw_wr_kb<CW>(pa, KB_POT + PC_READY);
+                        s.tk[k] = cook_time(cw_obj<CW>(cw_rd<CW>(pa))) + 1u;
+                        s.rem[k] = REM_IDLE;
+                        grid_changed = true;
+                    }
+                }
             }
             // deliveries and dish pick-ups
             const uint32_t hb0 = (h0_before >> 8) & 0xFFu, hb1 = (h1_before >> 8) & 0xFFu, hn0 = (r0 >> 8) & 0xFFu;
@@ -929,6 +969,10 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
                         env_reset4_draw<MAXP, CW>(C, L, n_obj, horizon, s, col,
                                               draw_start(L, g, sa.epoch + step_k, sa.seed_lo, sa.seed_hi, sa.random_start_pos, sa.thresh));
                         nh0 = s.h0; nh1 = s.h1;
+                        if (EARLY) {
+#pragma unroll
+                            for (int k = 0; k < MAXP; ++k) s.rem[k] -= RB;
+                        }
                     } else {
                         env_reset4<MAXP, CW>(C, L, n_obj, horizon, s, col);
                         nh0 = nh1 = 0;
@@ -960,7 +1004,14 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
                 nf0 = col + (m1 & 0xFFFFu);
                 nf1 = col + (m1 >> 16);
             }
-            if ((MODE == 1 || MODE == 2 || DUO) && PIPE && grid_changed) {  // read the next step's cells again
+            if (EARLY) {  // the lanes in here read the next step's cells again, behind everything the step wrote
+                nc0 = cw_rd<CW>(nf0);
+                nc1 = cw_rd<CW>(nf1);
+                if (grid_changed) rd_pots(npw);
+                // ... and wait for them in here: left pending, the join behind the branch would wait for every LDS operation
+                // of the straight line as well (the counters retire in order) — the pot words' round trip back on the chain
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            } else if ((MODE == 1 || MODE == 2 || DUO) && PIPE && grid_changed) {  // read the next step's cells again
                 nc0 = cw_rd<CW>(nf0);
                 nc1 = cw_rd<CW>(nf1);
                 rd_pots(npw);
@@ -1076,7 +1127,8 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
                     P0 = s_fl[I0 >> 2]; O0 = I0 & 3u; P1 = s_fl[I1 >> 2]; O1 = I1 & 3u;
                 }
                 lds_wr96(ring, noact, noact, 0u);
-                lds_wr96(ring + RING_SLOT, P0 | (O0 << 8) | (P1 << 16) | (O1 << 24), tleft, over);
+                if (EARLY) lds_wr96(ring + RING_SLOT, noact, noact, 0u);  // (the interact wavefront looks two records ahead)
+                lds_wr96(ring + (EARLY ? 2u : 1u) * RING_SLOT, P0 | (O0 << 8) | (P1 << 16) | (O1 << 24), tleft, over);
                 return;
             }
             const Phx4 wb = philox_words(((uint64_t)t0 >> 3) + (uint64_t)b, g_lo, g_hi, seed_lo, seed_hi);
@@ -1353,6 +1405,7 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
         const int n_blocks = n_steps >> 3;
         while (lds_poll32(sync_pair) < 1u) __builtin_amdgcn_s_sleep(1);
         uint32_t fo0, fo1, f_rec, c0, c1, pw[MAXP];
+        uint32_t nf0 = 0, nf1 = 0, nf_rec = 0;  // EARLY: the record of the step after this one (records are read two steps ahead)
         {
             const oc_rec3 rec = lds_rd96(ring0);
             fo0 = rec.x; fo1 = rec.y; f_rec = rec.z;
@@ -1360,36 +1413,60 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
         c0 = cw_rd<CW>(fo0);
         c1 = cw_rd<CW>(fo1);
         rd_pots(pw);
-        auto dstep = [&](int k8, uint32_t next_rec) __attribute__((always_inline)) {
+        if (EARLY) {
+            const oc_rec3 rec = lds_rd96(ring0 + RING_SLOT);
+            nf0 = rec.x; nf1 = rec.y; nf_rec = rec.z;
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k) s.rem[k] -= RB;
+        }
+        // k8: the step's index in its block; ahead_rec: the ring record of the next step (EARLY: of the step after the next)
+        auto dstep = [&](int k8, uint32_t ahead_rec) __attribute__((always_inline)) {
             const Looked looked = look_up(lut_var, lut_var, c0, c1, pw);
-            const oc_rec3 nrec = lds_rd96(next_rec);
-            uint32_t u0 = f_rec, u1 = 0, u2 = 0, u3 = 0, u4 = 0, nf0 = nrec.x, nf1 = nrec.y, nc0 = 0, nc1 = 0, npw[MAXP];
-            core(fo0, fo1, lut_var, lut_var, c0, c1, 0u, pw, u0, u1, u2, u3, u4, nf0, nf1, nc0, nc1, npw, k8, looked);
-            fo0 = nf0; fo1 = nf1; c0 = nc0; c1 = nc1; f_rec = nrec.z;
+            if (EARLY) {
+                uint32_t nc0 = cw_rd<CW>(nf0), nc1 = cw_rd<CW>(nf1);  // the next step's cells as they are BEFORE this step's writes
+                const oc_rec3 arec = lds_rd96(ahead_rec);
+                uint32_t u0 = f_rec, u1 = 0, u2 = 0, u3 = 0, u4 = 0, a0 = nf0, a1 = nf1, npw[MAXP];
+                core(fo0, fo1, lut_var, lut_var, c0, c1, 0u, pw, u0, u1, u2, u3, u4, a0, a1, nc0, nc1, npw, k8, looked);
+                fo0 = nf0; fo1 = nf1; f_rec = nf_rec; c0 = nc0; c1 = nc1;
+                nf0 = arec.x; nf1 = arec.y; nf_rec = arec.z;
+#pragma unroll
+                for (int k = 0; k < MAXP; ++k) pw[k] = npw[k];
+                return;
+            }
+            const oc_rec3 nrec = lds_rd96(ahead_rec);
+            uint32_t u0 = f_rec, u1 = 0, u2 = 0, u3 = 0, u4 = 0, a0 = nrec.x, a1 = nrec.y, nc0 = 0, nc1 = 0, npw[MAXP];
+            core(fo0, fo1, lut_var, lut_var, c0, c1, 0u, pw, u0, u1, u2, u3, u4, a0, a1, nc0, nc1, npw, k8, looked);
+            fo0 = a0; fo1 = a1; c0 = nc0; c1 = nc1; f_rec = nrec.z;
 #pragma unroll
             for (int k = 0; k < MAXP; ++k) pw[k] = npw[k];
         };
         uint32_t rbuf = 0;  // (wave-uniform) offset of the ring buffer that holds the block being run
         for (int b = 0; b < n_blocks; ++b) {
-            // Block b's own records are there (checked by block b - 1's step 7); step 7 looks ahead to the first record of
+            // Block b's own records are there (checked by block b - 1); its last step (EARLY: last two steps) looks ahead into
             // block b + 1: the mover must have finished b + 2 blocks by then (the stub behind the launch counts as one).
-            // The count is read before step 6 and looked at after it, so that the read's latency is not the loop's.
+            // The count is read one step before it is looked at, so that the read's latency is not the loop's.
             const uint32_t cur = ring0 + rbuf;
             rbuf = rbuf == 2u * (uint32_t)M::RING_BUF ? 0u : rbuf + (uint32_t)M::RING_BUF;
+            constexpr int LA = EARLY ? 2 : 1;  // records looked ahead
 #pragma unroll
-            for (int k8 = 0; k8 < 6; ++k8) dstep(k8, cur + (uint32_t)(k8 + 1) * RING_SLOT);
+            for (int k8 = 0; k8 < 7 - LA; ++k8) dstep(k8, cur + (uint32_t)(k8 + LA) * RING_SLOT);
             const uint32_t produced = *(const volatile OC_LDS uint32_t*)(uintptr_t)sync_pair;
-            dstep(6, cur + 7u * RING_SLOT);
+            dstep(7 - LA, cur + 7u * RING_SLOT);
             if (__builtin_amdgcn_readfirstlane((int)produced) < b + 2)
                 while (lds_poll32(sync_pair) < (uint32_t)b + 2u) __builtin_amdgcn_s_sleep(1);
-            dstep(7, ring0 + rbuf);
+            if (EARLY) dstep(6, ring0 + rbuf);
+            dstep(7, ring0 + rbuf + (EARLY ? RING_SLOT : 0u));
             advance_rows();
             lds_post32(sync_pair + 4u, (uint32_t)b + 1u);
         }
-        {   // the stub block's second record: the pose after the last step and where the episode clock stands
-            const oc_rec3 fin = lds_rd96(ring0 + rbuf + RING_SLOT);
+        {   // the stub block's last record: the pose after the last step and where the episode clock stands
+            const oc_rec3 fin = lds_rd96(ring0 + rbuf + (EARLY ? 2u : 1u) * RING_SLOT);
             s.pos0 = fin.x & 0xFFu; s.or0 = (fin.x >> 8) & 0xFFu; s.pos1 = (fin.x >> 16) & 0xFFu; s.or1 = fin.x >> 24;
             s.tleft = fin.y; s.over = fin.z;
+        }
+        if (EARLY) {
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k) s.rem[k] += RB;
         }
     } else {
         auto astep = [&](uint32_t a0, uint32_t a1) __attribute__((always_inline)) {

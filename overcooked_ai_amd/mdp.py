@@ -15,7 +15,8 @@ import numpy as np
 
 from .actions import Action, Direction
 from .layouts import BASE_REW_SHAPING_PARAMS, LayoutSpec, read_layout_dict
-from .state import ObjectState, OvercookedState, PlayerState, SoupState, pack_states, unpack_states  # noqa: F401
+from .state import (ObjectState, OvercookedState, PlayerState, SoupState, configure_recipes, pack_states,  # noqa: F401
+                    unpack_states)
 
 EVENT_TYPES = [  # mdp.py:1027-1058
     "tomato_pickup", "useful_tomato_pickup", "tomato_drop", "useful_tomato_drop", "potting_tomato",
@@ -180,7 +181,13 @@ class _SingleEnvPort:
         if self.mailbox is None and self.mailbox_ok:
             self.calls += 1
             if self.calls > self.MAILBOX_AFTER:
-                self._open_mailbox()
+                try:
+                    self._open_mailbox()
+                except RuntimeError as exc:  # (pinned / mapped memory or streams exhausted with many mdps alive)
+                    import warnings
+
+                    self.mailbox_ok = False  # this port stays on the launch path instead of retrying at every call
+                    warnings.warn("oc_mailbox_open failed (%s): single-state calls keep launching oc_step" % exc)
         if self.mailbox is not None:
             rc = self._step(self.mailbox)
             if rc:
@@ -216,6 +223,7 @@ class OvercookedGridworld:
 
     def _init_from_spec(self, spec, start_state=None, device=None):
         self.spec = spec
+        configure_recipes(spec)  # (Recipe.configure of the reference's constructor, mdp.py:1014: hand-built SoupStates resolve here)
         self.terrain_mtx = spec.terrain_mtx
         self.height, self.width = spec.height, spec.width
         self.shape = (self.width, self.height)

@@ -56,6 +56,18 @@ class ObjectState:
         return ObjectState(d["name"], d["position"])
 
 
+# The reference's Recipe class is process-global state configured by the most recently constructed OvercookedGridworld
+# (Recipe.configure, mdp.py:221-336).  The kernels carry recipes per layout instead; this one hook keeps the reference's
+# behaviour for SoupStates a user builds by hand and cooks / finishes through the mutators below (mdp.py:565-612): their cook
+# time resolves against the layout of the mdp constructed last, exactly as upstream.
+_RECIPE_SPEC = [None]
+
+
+def configure_recipes(spec):
+    """Called by OvercookedGridworld's constructors (the mirror of Recipe.configure)."""
+    _RECIPE_SPEC[0] = spec
+
+
 class SoupState(ObjectState):
     """Soup record. `cook_time` is the recipe's cook time as resolved by the layout (Recipe.time,
     mdp.py:163-188); -1 / None while the soup is idle, exactly like the reference's to_dict (mdp.py:625)."""
@@ -76,7 +88,17 @@ class SoupState(ObjectState):
 
     @property
     def cook_time(self):
-        return self._cook_time
+        """The cook time the soup came with (state dicts, kernel states), else — once it cooks — its recipe's time under the
+        layout configured last (mdp.py:520-526)."""
+        if self._cook_time is not None:
+            return self._cook_time
+        if self.is_idle:
+            return None
+        spec = _RECIPE_SPEC[0]
+        if spec is None:
+            return None
+        n_o = sum(1 for i in self._ingredients if i == "onion")
+        return spec.recipe_time((n_o, len(self._ingredients) - n_o))
 
     @property
     def is_idle(self):
@@ -86,7 +108,56 @@ class SoupState(ObjectState):
     def is_ready(self):
         if self.is_idle:
             return False
-        return self._cook_time is not None and self._cooking_tick >= self._cook_time
+        ct = self.cook_time
+        return ct is not None and self._cooking_tick >= ct
+
+    @property
+    def is_full(self):
+        return not self.is_idle or len(self._ingredients) == 3  # Recipe.MAX_NUM_INGREDIENTS (mdp.py:546-551)
+
+    # ---- the mutating API of mdp.py:565-612, with the reference's checks and messages
+    def auto_finish(self):
+        if len(self._ingredients) == 0:
+            raise ValueError("Cannot finish soup with no ingredients")
+        self._cooking_tick = 0
+        ct = self.cook_time
+        if ct is None:
+            raise ValueError("Recipe class must be configured before recipes can be created")
+        self._cooking_tick = ct
+
+    def add_ingredient(self, ingredient):
+        name = ingredient if isinstance(ingredient, str) else ingredient.name
+        if name not in ("onion", "tomato"):
+            raise ValueError("Invalid ingredient")
+        if self.is_full:
+            raise ValueError("Reached maximum number of ingredients in recipe")
+        if not isinstance(ingredient, str):
+            ingredient.position = self.position
+        self._ingredients.append(name)
+
+    def add_ingredient_from_str(self, ingredient_str):
+        self.add_ingredient(ObjectState(ingredient_str, self.position))
+
+    def pop_ingredient(self):
+        if not self.is_idle:
+            raise ValueError("Cannot remove an ingredient from this soup at this time")
+        if len(self._ingredients) == 0:
+            raise ValueError("No ingredient to remove")
+        return ObjectState(self._ingredients.pop(), self.position)
+
+    def begin_cooking(self):
+        if not self.is_idle:
+            raise ValueError("Cannot begin cooking this soup at this time")
+        if len(self._ingredients) == 0:
+            raise ValueError("Must add at least one ingredient to soup before you can begin cooking")
+        self._cooking_tick = 0
+
+    def cook(self):
+        if self.is_idle:
+            raise ValueError("Must begin cooking before advancing cook tick")
+        if self.is_ready:
+            raise ValueError("Cannot cook a soup that is already done")
+        self._cooking_tick += 1
 
     @property
     def is_cooking(self):
@@ -119,7 +190,7 @@ class SoupState(ObjectState):
         d["is_cooking"] = self.is_cooking
         d["is_ready"] = self.is_ready
         d["is_idle"] = self.is_idle
-        d["cook_time"] = -1 if self.is_idle else self._cook_time
+        d["cook_time"] = -1 if self.is_idle else self.cook_time
         d["_cooking_tick"] = self._cooking_tick
         return d
 
@@ -154,7 +225,7 @@ class SoupState(ObjectState):
             raise ValueError("Empty soup cannot be finished")
         soup = cls(position, ["onion"] * num_onions + ["tomato"] * num_tomatoes, cooking_tick, cook_time)
         if finished:
-            soup._finished = True  # tick is resolved against the layout's cook time when packed
+            soup.auto_finish()  # (mdp.py:693-694: the tick jumps to the recipe's cook time)
         return soup
 
 
@@ -638,9 +709,8 @@ class SingleStateCodec:
             code = self._soup_code.get(tuple(obj._ingredients))
             if code is None:
                 return None
-            if not in_pot and (not obj._ingredients or obj._cooking_tick != self._soup[code][1]
-                               or getattr(obj, "_finished", False)):
-                return None  # soups outside pots are fully cooked; get_soup(finished=True) resolves in the slow path
+            if not in_pot and (not obj._ingredients or obj._cooking_tick != self._soup[code][1]):
+                return None  # soups outside pots are fully cooked (the general path raises the proper error)
             return code
         return None
 

@@ -485,3 +485,78 @@ def test_lazy_single_state_is_a_plain_state_after_the_first_look():
         codec.unpack_lazy(buf).no_such_attribute
     with pytest.raises(TypeError):
         _LazyState()
+
+
+def test_soup_state_mutators_follow_the_reference():
+    """The mutating SoupState API (mdp.py:565-612): same transitions, same errors; cook times resolve against the layout of the
+    mdp constructed last (the reference's process-global Recipe.configure).  With /root/reference present the same script runs
+    on the reference's SoupState and every observable must agree."""
+    from overcooked_ai_amd.mdp import OvercookedGridworld
+
+    def script(Soup, Obj, make_mdp):
+        out = []
+        make_mdp()  # configures the recipes (cook time 20 for every soup on cramped_room)
+        s = Soup.get_soup((2, 0), num_onions=0, num_tomatoes=0)
+        out.append((s.ingredients, s.is_idle, s.is_full, s.is_cooking, s.is_ready))
+        for call in (lambda: s.begin_cooking(), lambda: s.cook(), lambda: s.pop_ingredient(), lambda: s.auto_finish(),
+                     lambda: s.add_ingredient(Obj("dish", (2, 0)))):
+            try:
+                call()
+                out.append("ok")
+            except ValueError as e:
+                out.append(str(e))
+        s.add_ingredient(Obj("onion", (0, 0)))
+        s.add_ingredient_from_str("tomato")
+        out.append((s.ingredients, s.is_full))
+        popped = s.pop_ingredient()
+        out.append((popped.name, tuple(popped.position), s.ingredients))
+        s.add_ingredient_from_str("onion")
+        s.add_ingredient_from_str("onion")
+        out.append((s.ingredients, s.is_full))
+        try:
+            s.add_ingredient_from_str("onion")
+        except ValueError as e:
+            out.append(str(e))
+        s.begin_cooking()
+        out.append((s.is_idle, s.is_cooking, s.is_ready, s.cook_time, s.cook_time_remaining, s.is_full))
+        for call in (lambda: s.begin_cooking(), lambda: s.pop_ingredient(), lambda: s.add_ingredient_from_str("onion")):
+            try:
+                call()
+            except ValueError as e:
+                out.append(str(e))
+        for _ in range(20):
+            s.cook()
+        out.append((s.is_cooking, s.is_ready, s.cook_time_remaining, s.to_dict()["cooking_tick"], s.to_dict()["cook_time"]))
+        try:
+            s.cook()
+        except ValueError as e:
+            out.append(str(e))
+        f = Soup.get_soup((2, 0), num_onions=2, num_tomatoes=1, finished=True)
+        out.append((f.is_ready, f.to_dict()["cooking_tick"], f.ingredients))
+        g = Soup.get_soup((2, 0), num_onions=1)
+        g.auto_finish()
+        out.append((g.is_ready, g.to_dict()["cooking_tick"]))
+        return out
+
+    mine = script(S.SoupState, S.ObjectState, lambda: OvercookedGridworld.from_layout_name("cramped_room"))
+    assert mine[0] == ([], True, False, False, False)
+    assert mine[1:6] == ["Must add at least one ingredient to soup before you can begin cooking",
+                         "Must begin cooking before advancing cook tick", "No ingredient to remove",
+                         "Cannot finish soup with no ingredients", "Invalid ingredient"]
+    assert mine[-2] == (True, 20, ["onion", "onion", "tomato"]) and mine[-1] == (True, 20)
+    if os.path.isdir("/root/reference/src/overcooked_ai_py"):
+        from oracle import ref_harness
+
+        R = ref_harness.load()
+        theirs = script(R.SoupState, R.ObjectState, lambda: R.OvercookedGridworld.from_layout_name("cramped_room"))
+        assert mine == theirs
+
+    # a finished soup built by hand goes through the packed format like the reference's
+    mdp = OvercookedGridworld.from_layout_name("cramped_room")
+    soup = S.SoupState.get_soup((2, 0), num_onions=3, finished=True)
+    spec = mdp.spec
+    st = mdp.get_standard_start_state()
+    st.objects[(2, 0)] = soup
+    packed = S.pack_states(spec, [st])
+    back = S.unpack_states(spec, packed)[0]
+    assert back.objects[(2, 0)].is_ready and back.objects[(2, 0)].ingredients == ["onion"] * 3

@@ -1,0 +1,65 @@
+"""Find the first env-step where the mover / interact rollout differs from the oracle and print what happened there:
+python tools/debug_duo.py [layout[,layout...]] [n_envs] [n_steps]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from oracle import oracle as O
+from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+from overcooked_ai_amd.vec_env import VecOvercookedEnv
+
+names = (sys.argv[1] if len(sys.argv) > 1 else "asymmetric_advantages").split(",")
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+dev = torch.device("cuda:0")
+table = LayoutTable([spec_from_name(nm) for nm in names], pad_to=(9, 5) if len(names) > 1 else None)
+lid = (np.arange(n) % len(names)).astype(np.uint16)
+env = VecOvercookedEnv(table, n, horizon=400, device=dev, auto_reset=True, seed=0, layout_id=lid if len(names) > 1 else None)
+orc = O.Oracle([O.mdp_from_layout_dict(s.to_layout_dict()) for s in table.specs])
+lid_o = lid if len(names) > 1 else None
+st = orc.reset(orc.new_state(n), layout_id=lid_o)
+rew = torch.zeros((8, n, 4), dtype=torch.float32, device=dev)
+fl = torch.zeros((8, n), dtype=torch.uint8, device=dev)
+W, H = orc.W, orc.H
+for t in range(0, T, 8):
+    prev = st.copy()
+    env.rollout_random(8, rew, fl)
+    got = env.get_packed_state()
+    # oracle step by step to find the exact step
+    cur = prev.copy()
+    states = [cur.copy()]
+    rews = []
+    for k in range(8):
+        a = O.random_actions(0, 0, t + k, n)
+        cur, r, f = orc.step(cur, a, horizon=400, options=1, layout_id=lid_o)
+        states.append(cur.copy())
+        rews.append(r)
+    st = cur
+    rew_g = rew.cpu().numpy()
+    bad_r = np.argwhere(np.abs(rew_g - np.stack(rews)) > 1e-6)
+    bad_s = np.argwhere(got != st)
+    if len(bad_r) or len(bad_s):
+        print("block at t=%d: %d reward mismatches, %d state byte mismatches" % (t, len(bad_r), len(bad_s)))
+        envs = sorted(set(int(x[1]) for x in bad_r) | set(int(x[1]) for x in bad_s))[:3]
+        for e in envs:
+            print("== env %d layout %s" % (e, names[lid[e]]))
+            for k in range(8):
+                a = O.random_actions(0, 0, t + k, n)[e]
+                s0 = states[k][:, e, :]
+                print(" t=%d actions %s  hdr %s" % (t + k, a.tolist(), s0[0].tolist()))
+                cells = np.concatenate([s0[1 + p] for p in range(orc.n_planes - 1)])[:W * H].reshape(H, W)
+                nz = [(int(y), int(x), int(cells[y, x])) for y in range(H) for x in range(W) if cells[y, x]]
+                print("      objects (y,x,code) %s  oracle rew %s  gpu rew %s" % (nz, rews[k][e].tolist(), rew_g[k, e].tolist()))
+            print(" final oracle hdr %s" % st[0][e].tolist())
+            print(" final gpu    hdr %s" % got[0][e].tolist())
+            for p in range(1, orc.n_planes):
+                if (st[p][e] != got[p][e]).any():
+                    print("  plane %d oracle %s\n           gpu    %s" % (p, st[p][e].tolist(), got[p][e].tolist()))
+        g = table.specs[lid[envs[0]]].terrain_mtx
+        print("\n".join("".join(r) for r in g))
+        break
+else:
+    print("no mismatch in %d steps x %d envs" % (T, n))
