@@ -26,7 +26,7 @@
 //    No pot words in registers, no pot reads in the step.
 //  * entry (16 bytes): .x selectors — r = v_perm(.y, pool, .x) = [new K16][new object][new hand] with
 //        pool = [K16][object + add][hand] of (faced cell, hand);  .y = [new K16][delta N][dispensed object];
-//        .z = [0][flags][add][16 * new hand class];  .w = the shaped reward float (one set of shaping rewards per batch).
+//        .z = [bit 7: takes a dish from the dispenser][flags][add][16 * new hand class];  .w = the shaped reward float (one set of shaping rewards per batch).
 //  * the pot in slot 1 has its own type, so an entry's START flag says WHICH countdown starts (no address compares).
 // Semantics are k_rollout4's / the oracle's: conflict replay for player 1, stale pot states for the usefulness predicate, the
 // same restart at the horizon (standard, drawn, or on a re-drawn layout).  Served batches: two players everywhere, <= 2 pots,
@@ -34,9 +34,9 @@
 // ==========================================================================================
 constexpr int K5_TYPES = 9, K5_POT_B = 7, K5_NOTHING = 8, K5_ROW = 80, K5_KEYS = K5_TYPES * 6;
 constexpr int LUT5_BYTES = K5_KEYS * K5_ROW;  // 4 320
-enum { F5_TAKE_DISH = 1, F5_PLACE = 2, F5_PLATE = 4, F5_START_A = 8, F5_SERVE = 16, F5_START_B = 32, F5_CHG = 128 };
-// the flags sit in byte 2 of .z: masks in place
-constexpr uint32_t Z5_TAKE = (uint32_t)F5_TAKE_DISH << 16, Z5_SERVE = (uint32_t)F5_SERVE << 16, Z5_CHG = (uint32_t)F5_CHG << 16,
+enum { F5_PLACE = 2, F5_PLATE = 4, F5_START_A = 8, F5_SERVE = 16, F5_START_B = 32, F5_CHG = 128 };
+// the flags sit in byte 2 of .z: masks in place; "a dish is taken from the dispenser" is bit 31 of .z, where the sign of N meets it
+constexpr uint32_t Z5_TAKE = 0x80000000u, Z5_SERVE = (uint32_t)F5_SERVE << 16, Z5_CHG = (uint32_t)F5_CHG << 16,
                    Z5_START_A = (uint32_t)F5_START_A << 16, Z5_START_B = (uint32_t)F5_START_B << 16;
 constexpr uint32_t REC5_DONE = 0x80000000u, REC5_SAME = Z5_CHG;  // the mover's flag word: the horizon; both players act on one cell
 
@@ -45,7 +45,7 @@ template <int LUT_BASE> constexpr uint32_t k16_of(int type5, int cls) { return (
 template <int LUT_BASE>
 constexpr Lut4Entry lut5_entry(int type5, int hc, int oc) {
     // selectors: 0 hand, 1 object (+ add), 2 / 3 K16 | 4 dispensed object, 6 / 7 new K16 | 0x0C zero
-    uint32_t sel_h = 0, sel_o = 1, cobj = 0, flags = 0, add = 0, rew = RW4_NONE, hcn = (uint32_t)hc;
+    uint32_t sel_h = 0, sel_o = 1, cobj = 0, flags = 0, add = 0, rew = RW4_NONE, hcn = (uint32_t)hc, take = 0;
     int nkey = -1, dd = 0, du = 0;  // new key (type, class) or -1 = unchanged; change of the loose-dish / useful-pot counts
     const bool pot = type5 == OC_T_POT || type5 == K5_POT_B;
     if (type5 == OC_T_COUNTER) {
@@ -59,7 +59,7 @@ constexpr Lut4Entry lut5_entry(int type5, int hc, int oc) {
     } else if (type5 == OC_T_TOMATO_DISP) {
         if (hc == 0) { sel_h = 4; cobj = OC_O_TOMATO; hcn = 2; }
     } else if (type5 == OC_T_DISH_DISP) {
-        if (hc == 0) { sel_h = 4; cobj = OC_O_DISH; flags = F5_TAKE_DISH; hcn = 3; }
+        if (hc == 0) { sel_h = 4; cobj = OC_O_DISH; take = Z5_TAKE; hcn = 3; }
     } else if (pot) {
         if (hc == 0 && oc >= PC_IDLE1 && oc <= PC_IDLE3) {               // begin_cooking (mdp.py:1515-1522)
             nkey = PC_COOKING; flags = F5_CHG | (type5 == K5_POT_B ? F5_START_B : F5_START_A); du = oc == PC_IDLE3 ? 1 : 0;
@@ -77,7 +77,7 @@ constexpr Lut4Entry lut5_entry(int type5, int hc, int oc) {
     const uint32_t sel_k = nkey < 0 ? 0x0302u : 0x0706u;
     const int dn = 64 * dd - du;
     return Lut4Entry{sel_h | (sel_o << 8) | (sel_k << 16), cobj | (((uint32_t)dn & 0xFFu) << 8) | (nk16 << 16),
-                     (hcn * 16u) | (add << 8) | (flags << 16), rew};
+                     (hcn * 16u) | (add << 8) | (flags << 16) | take, rew};
 }
 template <int LUT_BASE>
 struct Lut5Table { Lut4Entry e[K5_KEYS][5]; };
@@ -95,7 +95,10 @@ template <bool LAY_LDS>
 struct Lds5 {
     static constexpr int LUT = 0, LAY = (LUT5_BYTES + 15) & ~15, LAY_BYTES = LAY_LDS ? LDS_LAYOUT_MAX * 256 : 16;
     static constexpr int SYNC = LAY + LAY_BYTES, RING = SYNC + 64;
-    static constexpr int RING_REC = 12, RING_BUF = 8 * BLOCK * RING_REC, CELLS = RING + 3 * RING_BUF;
+    // the ring, three buffers of one 8-step block each: [step][lane] pairs of LDS addresses (the cell words the two players act
+    // on), then [step][lane] flag words — two arrays, so that the interact wavefront reads a record with two instructions whose
+    // offsets are immediates (12-byte records: ds_read2_b32 + ds_read_b32 behind an address add)
+    static constexpr int RING_XY = 8 * BLOCK * 8, RING_BUF = RING_XY + 8 * BLOCK * 4, CELLS = RING + 3 * RING_BUF;
     static_assert(LUT5_BYTES < 65536, "K16 is an LDS address in 16 bits");
 };
 __device__ const Lut5Table<0> g_lut5 = make_lut5<0>();
@@ -148,9 +151,17 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
     const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u));
     const uint32_t lane = tid & 63u;
     uint8_t* flg_k = flags + ((int64_t)blk * BLOCK + wave_base) * (FT8 ? 8 : 1);
-    constexpr uint32_t RING_SLOT = (uint32_t)BLOCK * (uint32_t)M::RING_REC;
+    constexpr uint32_t SLOT_XY = (uint32_t)BLOCK * 8u, SLOT_F = (uint32_t)BLOCK * 4u;  // bytes of one step's records in the two arrays
     const uint32_t sync_pair = (uint32_t)M::SYNC + (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * 8u;
-    const uint32_t ring0 = (uint32_t)M::RING + tid * (uint32_t)M::RING_REC;
+    const uint32_t ring_xy = (uint32_t)M::RING + tid * 8u, ring_f = (uint32_t)(M::RING + M::RING_XY) + tid * 4u;
+    auto ring_wr = [&](uint32_t buf, uint32_t k, uint32_t x, uint32_t y, uint32_t z) __attribute__((always_inline)) {
+        lds_wr64(ring_xy + buf + k * SLOT_XY, x, y);
+        lds_wr32(ring_f + buf + k * SLOT_F, z);
+    };
+    auto ring_rd = [&](uint32_t buf, uint32_t k) __attribute__((always_inline)) {
+        const uint2 xy = lds_rd64(ring_xy + buf + k * SLOT_XY);
+        return oc_rec3{xy.x, xy.y, lds_rd32(ring_f + buf + k * SLOT_F)};
+    };
     const int n_blocks = n_steps >> 3;
     auto floor_mask_of = [&](const Lay Lx) __attribute__((always_inline)) {
         uint64_t m = 0;
@@ -180,8 +191,8 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
         for (int k8 = 0; k8 < 8; ++k8) flg_off[k8] = lane + (uint32_t)k8 * (uint32_t)n;
         auto produce = [&](int b, uint32_t ring) __attribute__((always_inline)) {
             if (b >= n_blocks) {  // the stub block: one "nothing" record for the last step's look-ahead, then the final pose
-                lds_wr96(ring, noact, noact, 0u);
-                lds_wr96(ring + RING_SLOT, P0 | (O0 << 8) | (P1 << 16) | (O1 << 24), tleft, over);
+                ring_wr(ring, 0u, noact, noact, 0u);
+                ring_wr(ring, 1u, P0 | (O0 << 8) | (P1 << 16) | (O1 << 24), tleft, over);
                 return;
             }
             const Phx4 wb = philox_words(((uint64_t)t0 >> 3) + (uint64_t)b, g_lo, g_hi, seed_lo, seed_hi);
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
                 uint32_t fl = 0;
                 const bool done = tleft == 0u;
                 tleft -= 1u;
-                lds_wr96(ring + (uint32_t)k8 * RING_SLOT, rec0, rec1, f_same | (done ? REC5_DONE : 0u));
+                ring_wr(ring, (uint32_t)k8, rec0, rec1, f_same | (done ? REC5_DONE : 0u));
                 if (__builtin_expect(done, 0)) {  // OvercookedEnv.step at the horizon (env.py:266-267, 321-325)
                     fl = OC_F_DONE;
                     tleft = 0u;
@@ -248,7 +259,7 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
         for (int j = 0; j <= n_blocks; ++j) {
             if (j >= 3)
                 while (lds_poll32(sync_pair + 4u) + 2u < (uint32_t)j) __builtin_amdgcn_s_sleep(2);
-            produce(j, ring0 + wbuf);
+            produce(j, wbuf);
             wbuf = wbuf == 2u * (uint32_t)M::RING_BUF ? 0u : wbuf + (uint32_t)M::RING_BUF;
             lds_post32(sync_pair, (uint32_t)j + 1u);
         }
@@ -349,27 +360,24 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
     while (lds_poll32(sync_pair) < 1u) __builtin_amdgcn_s_sleep(1);
     uint32_t fo0, fo1, f_rec, c0, c1;
     {
-        const oc_rec3 rec = lds_rd96(ring0);
+        const oc_rec3 rec = ring_rd(0u, 0u);
         fo0 = rec.x; fo1 = rec.y; f_rec = rec.z;
     }
     c0 = lds_rd32(fo0);
     c1 = lds_rd32(fo1);
     Pend pend = {0ull, 0ull};
-    // One step.  k8: its index in the block; next_rec: LDS address of the mover's record of the next step.
-    auto dstep = [&](int k8, uint32_t next_rec) __attribute__((always_inline)) {
+    // One step.  k8: its index in the block; (next_buf, next_k): the mover's record of the next step.
+    auto dstep = [&](int k8, uint32_t next_buf, uint32_t next_k) __attribute__((always_inline)) {
         const uint4 e0 = lds_rd128(entry_at(c0, hz0));
         uint4 e1 = lds_rd128(entry_at(c1, hz1));
-        const oc_rec3 nrec = lds_rd96(next_rec);
+        const oc_rec3 nrec = ring_rd(next_buf, next_k);
         __builtin_amdgcn_sched_barrier(0);
         if (k8 >= 1) flush(pend, k8 - 1);  // the previous step's quad, while the look-ups are in flight
         // step_environment_effects (mdp.py:1691-1703): the countdowns; a finished one turns the pot ready — every lane stores,
         // the others into their spare word
-        bool ripe[MAXP];
+        bool ripe[MAXP];  // (rem counts from the block's first step: the countdowns are moved once per block, not per step)
 #pragma unroll
-        for (int k = 0; k < MAXP; ++k) {
-            rem[k] -= 1u;
-            ripe[k] = rem[k] == 0u;
-        }
+        for (int k = 0; k < MAXP; ++k) ripe[k] = rem[k] == (uint32_t)(k8 + 1);
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t r0 = interact5(e0, h0, c0);
         uint32_t r1 = interact5(e1, h1, c1);
@@ -383,8 +391,7 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
         int32_t N_new = N_mid + sext_b1(e1.y);
         // ---- ONE branch for everything rare: cooking starts, deliveries, dish pick-ups that may be useful (N < 0 before or
         //      after player 0's interact: no loose dish, some useful pot), a shared cell player 0 has changed, the horizon
-        const uint32_t take = (uint32_t)(min(N, N_mid) >> 31) & Z5_TAKE;
-        const uint32_t gate = take | Z5_SERVE | Z5_START_A | Z5_START_B;
+        const uint32_t gate = ((uint32_t)(N | N_mid) & Z5_TAKE) | Z5_SERVE | Z5_START_A | Z5_START_B;
         const uint32_t rare_bits = ((e0.z | e1.z) & gate) | ((e0.z | REC5_DONE) & f_rec);
         uint64_t q_lo, q_hi;  // the reward quad as two register pairs: zeros, and the two entries' shaped floats
         {
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
                 if (fz & sk) {
                     const uint32_t soup = cw5_obj((e0.z & sk) ? r0 : r1);
                     const uint32_t cook = cook_of(C, soup);
-                    rem[k] = cook - 1u;
+                    rem[k] = cook + (uint32_t)k8;  // (= cook - 1 steps after this one, counted from the block's first step)
                     exotic &= ~(1u << k);
                     if (cook <= 1u) {  // ready with this step's env effects (cook == 0: at once, never ticks)
                         cw5_wr_k16(pa[k], k16_of<M::LUT>((int)(k == 0 ? OC_T_POT : K5_POT_B), PC_READY));
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
                             const uint32_t o = d.pot_obj((uint32_t)k), tkb = d.tick((uint32_t)k);
                             const uint32_t pc = pot_class(C, o, tkb);
                             tk[k] = tkb;
-                            rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) : REM_IDLE;
+                            rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) + (uint32_t)(k8 + 1) : REM_IDLE;
                             useful += (pc != PC_EMPTY && pc != PC_IDLE3) ? 1 : 0;
                             lds_wr32(pa[k], cw5(k16_of<M::LUT>(0, 0) + (pot_type5(k) * 6u + pc) * K5_ROW, o));
                         }
@@ -496,20 +503,22 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
         // Block b's own records are there (checked by block b - 1's step 7); step 7 looks ahead to the first record of block
         // b + 1: the mover must have finished b + 2 blocks by then (the stub behind the launch counts as one).  The count is read
         // before step 6 and looked at after it, so that the read's latency is not the loop's.
-        const uint32_t cur = ring0 + rbuf;
+        const uint32_t cur = rbuf;
         rbuf = rbuf == 2u * (uint32_t)M::RING_BUF ? 0u : rbuf + (uint32_t)M::RING_BUF;
 #pragma unroll
-        for (int k8 = 0; k8 < 6; ++k8) dstep(k8, cur + (uint32_t)(k8 + 1) * RING_SLOT);
+        for (int k8 = 0; k8 < 6; ++k8) dstep(k8, cur, (uint32_t)(k8 + 1));
         const uint32_t produced = *(const volatile OC_LDS uint32_t*)(uintptr_t)sync_pair;
-        dstep(6, cur + 7u * RING_SLOT);
+        dstep(6, cur, 7u);
         if (__builtin_amdgcn_readfirstlane((int)produced) < b + 2)
             while (lds_poll32(sync_pair) < (uint32_t)b + 2u) __builtin_amdgcn_s_sleep(1);
-        dstep(7, ring0 + rbuf);
+        dstep(7, rbuf, 0u);
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) rem[k] -= 8u;
         rew_k += 8 * n;
         lds_post32(sync_pair + 4u, (uint32_t)b + 1u);
     }
     // ---- store (key words -> wire format); the pose and the episode clock come from the mover's stub record
-    const oc_rec3 fin = lds_rd96(ring0 + rbuf + RING_SLOT);
+    const oc_rec3 fin = ring_rd(rbuf, 1u);
     {
         const uint32_t t = min((uint32_t)horizon - 1u - fin.y + fin.z, 0xFFFFu);  // the wire format's u16: saturates
         uint4 h;
