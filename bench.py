@@ -604,14 +604,15 @@ def measure_traffic(args, kernel, tiled8=False):
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f, newline="")):
                     low = {k.lower(): v for k, v in row.items()}
-                    if kernel + "<" in low.get("kernel_name", "") and low.get("counter_name") == counter:
+                    if any(k + "<" in low.get("kernel_name", "") for k in kernel.split("|")) and low.get("counter_name") == counter:
                         vals.append(float(low["counter_value"]))
             if not vals:
                 for f in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
                     db = sqlite3.connect(f)
                     try:
-                        vals += [float(r[0]) for r in db.execute(
-                            "select counter_value from pmc_events where counter_name=? and name like ?", (counter, "%" + kernel + "<%"))]
+                        for k in kernel.split("|"):
+                            vals += [float(r[0]) for r in db.execute(
+                                "select counter_value from pmc_events where counter_name=? and name like ?", (counter, "%" + k + "<%"))]
                     finally:
                         db.close()
             if not vals:
@@ -643,7 +644,7 @@ def traffic_from_file(kernel, n, fuse, layout, bytes_per_launch):
                                                       % tj.get("_kernel_source_sha")}
     best, traffic = 0, None
     for k, v in tj.items():
-        if k.startswith(kernel + "<") and n == N_ENVS_PER_GPU and fuse == DEFAULT_FUSE and layout == "cramped_room" \
+        if any(k.startswith(kn + "<") for kn in kernel.split("|")) and n == N_ENVS_PER_GPU and fuse == DEFAULT_FUSE and layout == "cramped_room" \
                 and v.get("launches", 0) > best:
             best, traffic = v["launches"], v["hbm_bytes_per_launch"]
     if traffic is None or not 0.5 < traffic / bytes_per_launch < 2.0:
@@ -660,7 +661,7 @@ def issue_counters(kernel, n, layout):
             sq = json.load(f)
     except (OSError, ValueError):
         return None
-    if kernel != sq.get("kernel", "").split("<")[0] or n != N_ENVS_PER_GPU or layout != "cramped_room":
+    if sq.get("kernel", "").split("<")[0] not in kernel.split("|") or n != N_ENVS_PER_GPU or layout != "cramped_room":
         return None
     if sq.get("kernel_source_sha") != src_hash():
         return None
@@ -670,11 +671,10 @@ def issue_counters(kernel, n, layout):
             "wavefronts_per_64_envs": sq.get("wavefronts_per_64_envs", 1),
             "source": "replayed from profiles/sq_counters.json (rocprofv3 --pmc SQ_* passes of tools/pmc_rollout.sh on the same "
                       "kernel sources, sha %s), NOT measured in this run" % sq.get("kernel_source_sha"),
-            "note": "instructions per env-step of a 64-env group; since round 5 two wavefronts share them (k_rollout4 MODE 4: a mover "
-                    "and an interact wavefront per 64 envs, two wavefronts per SIMD at 65 536 envs), so a batched step costs about "
-                    "max(mover, interact) instructions x the ~4-8 clk a lone dependent instruction stream needs per instruction — "
-                    "wave_clk_per_env_step is what one wavefront measured — whatever the bytes moved; the launch sits at the "
-                    "store-only ceiling of its output format (roofline.store_only)"}
+            "note": "instructions per env-step of a 64-env group; two wavefronts share them (k_rollout5: a mover and an interact "
+                    "wavefront per 64 envs, two wavefronts per SIMD at 65 536 envs), and a batched step costs about the interact "
+                    "wavefront's own instruction stream x the ~5 clk one wavefront needs per instruction (profiles/"
+                    "r06_interact_stream.txt) — wave_clk_per_env_step is what one wavefront measured — whatever the bytes moved"}
 
 
 def main():
@@ -896,7 +896,8 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
     state_bytes = wl["sbytes"]
     bytes_per_launch = n * (2 * state_bytes + OUT_BYTES * fuse)
     achieved = bytes_per_launch / (launch_med * 1e-3) / 1e9
-    kernel = "k_rollout" if args.predicate_interact else "k_rollout_pair" if args.lane_pair else "k_rollout4"
+    # (whole 256-env workgroups and 8-step blocks run k_rollout5's mover / interact workgroups, other shapes k_rollout4)
+    kernel = "k_rollout" if args.predicate_interact else "k_rollout_pair" if args.lane_pair else "k_rollout5|k_rollout4"
     traffic, traffic_src = None, {"how": "not collected", "why": "only rank 0 of a 1-GPU run collects PMC traffic"}
     if rank == 0 and world == 1 and not args.stub:
         if not args.no_traffic:
@@ -1063,7 +1064,7 @@ def side_legs(args, torch, VecOvercookedEnv, sharding, dev):
             leg = {"value": envs * fuse * k / wall, "unit": "env steps/s (one GPU)", "envs": envs, "launches": k,
                    "timed_region_s": wall, "launch_ms": med, "launch_ms_min": ms[0], "workload": wl["workload"],
                    "flags_layout": "[steps/8][envs][8] (OC_OPT_FLAGS_TILED8)" if tiled8 else "[steps][envs]",
-                   "roofline": {"bound": "hbm", "kernel": "k_rollout4", "achieved": bpl / (med * 1e-3) / 1e9,
+                   "roofline": {"bound": "hbm", "kernel": "k_rollout5|k_rollout4", "achieved": bpl / (med * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bpl / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "bytes_per_launch": bpl, "traffic": None,
                                 "traffic_source": {"how": "not collected", "why": "side leg; `bench.py --config %d` collects it" % cfg},
@@ -1073,7 +1074,7 @@ def side_legs(args, torch, VecOvercookedEnv, sharding, dev):
             del env, rew, fl
             if not getattr(args, "no_traffic", False):  # two --pmc child passes of this leg's launch shape (no nulls)
                 torch.cuda.empty_cache()
-                leg["roofline"]["traffic"], leg["roofline"]["traffic_source"] = measure_traffic(a, "k_rollout4", tiled8)
+                leg["roofline"]["traffic"], leg["roofline"]["traffic_source"] = measure_traffic(a, "k_rollout5|k_rollout4", tiled8)
             legs[str(cfg)] = leg
             continue
         except Exception as exc:

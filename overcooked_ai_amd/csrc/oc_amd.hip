@@ -428,42 +428,39 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         c.joint = uniform && two && b->max_pots == 1 && b->max_free_cells >= 2 && b->max_free_cells <= 6u && c.out &&
                   !c.old_dyn && n_steps >= 8 && !c.events;
         const bool shaping_uniform = uniform || (b->batch_flags & OC_BATCH_UNIFORM_SHAPING) != 0;
-        const bool mode2 = !c.joint && two && !c.old_dyn && c.out && small && shaping_uniform && b->width * b->height <= 64 &&
-                           !c.events && !no_mode2;
-        // MODE 3 (step_lut4.hpp): the per-env-terrain step split between mover and interact wavefronts — whole workgroups of
-        // envs (every wavefront meets every barrier) and whole 8-step blocks; a workgroup's 139-158 KB of LDS leave room for one
-        // per CU
-        // (MODE 4's 126 000 B of tables, ring and counters + (16 n_obj + 3) KiB of cell words fit the CU's 160 KiB up to 32 cells:
-        //  larger one-pot joint-table layouts stay on the one-wavefront MODE 1 instance)
-        const bool joint_duo = c.joint && n_obj <= 2 && (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0;  // (MODE 4)
-        // Bigger batches run the mover / interact workgroups in ROUNDS, one per CU at a time — the next round's workgroups start as
-        // the first ones finish their launch's steps — which keeps the one-workgroup-per-CU rate where the one-wavefront instances
-        // fall behind (same box, 131 072 / 262 144 envs: cramped_room 264 / 263 -> 331 / 330 G env-steps/s, the 5-layout mix 250 /
-        // 243 -> 290 / 293 G, asymmetric_advantages 250 / 240 -> 269 / 272 G; 524 288 cramped_room envs: equal; 1 M: the
-        // one-wavefront instance wins, 352 G).  Tables read through L2 (BASELINE configs[4]'s generated terrains) gain only from
-        // the third round on (131 072 envs: 313 G with one wavefront per env group, 310 G in two rounds; 262 144: 298 -> 310 G).
+        // what the per-env-terrain kernels serve: two players everywhere, at most two pots and 64 cells, new dynamics, one set of
+        // shaping rewards, both output arrays (a one-pot joint-table layout is such a batch too)
+        const bool terrain_ok = two && !c.old_dyn && c.out && small && shaping_uniform && b->width * b->height <= 64 && !c.events && !no_mode2;
+        const bool mode2 = !c.joint && terrain_ok;
+        // k_rollout5 (step_duo5.hpp): the step split between mover and interact wavefronts — whole workgroups of envs (every
+        // wavefront meets every barrier) and whole 8-step blocks; a workgroup's 127-154 KB of LDS leave room for one per CU.
+        // Bigger batches run these workgroups in ROUNDS, one per CU at a time — the next round's workgroups start as the first ones
+        // finish their launch's steps — which keeps the one-workgroup-per-CU rate where the one-wavefront instances fall behind
+        // (round 6, same box: the 5-layout mix at 65 536 / 131 072 / 262 144 envs 343 / 344 / 343 G env-steps/s; generated
+        // terrains, table read through L2, 131 072 envs: 332 G in two rounds against 315 G with one wavefront per env group).
+        // Beyond 8 rounds the one-wavefront instances win (round 5: 1 M cramped_room envs 356 G in 16 rounds against 384 G).
 #ifdef OC_AMD_TUNING
         static const int forced_rounds = []() { const char* e = getenv("OC_DUO_ROUNDS"); return e ? atoi(e) : 0; }();  // tuning builds
 #else
         constexpr int forced_rounds = 0;
 #endif
         const int64_t per_round = (simd_count() / 4) * BLOCK;
-        int64_t max_rounds = (joint_duo || lds || b->n_envs > 2 * per_round) ? 8 : 1;
-        if (forced_rounds > 0) max_rounds = forced_rounds;
-        c.duo = (mode2 || joint_duo) && !(options & OC_OPT_ONE_WAVEFRONT) && b->n_envs % BLOCK == 0 &&
+        const int64_t max_rounds = forced_rounds > 0 ? forced_rounds : 8;
+        c.duo = terrain_ok && n_steps >= 8 && !(options & OC_OPT_ONE_WAVEFRONT) && b->n_envs % BLOCK == 0 &&
                 b->n_envs <= per_round * max_rounds && (t0 & 7) == 0 && (n_steps & 7) == 0;
         c.tiled8 = tiled8;
         if (tiled8) {  // which instances write the tiled flags array: the pipelined joint-table one, the per-env-terrain ones of
                        // mixed tables in LDS (pipelined) and of one-pot tables in HBM
-            const bool by_joint = c.joint && (c.pipe || c.duo) && b->width * b->height <= 64 && (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0;
-            const bool by_mode2 = mode2 && (c.duo || (!uniform && ((lds && c.pipe) || (!lds && b->max_pots == 1))));
-            if (!(by_joint || by_mode2) || b->n_envs >= ((int64_t)1 << 24))
+            const bool by_joint = c.joint && c.pipe && b->width * b->height <= 64 && (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0;
+            const bool by_mode2 = mode2 && !uniform && ((lds && c.pipe) || (!lds && b->max_pots == 1));
+            if (!(c.duo || by_joint || by_mode2) || b->n_envs >= ((int64_t)1 << 24))
                 return fail(OC_EINVAL, "oc_rollout_random: OC_OPT_FLAGS_TILED8 is served by the pipelined joint-table kernel (one two-player, "
                                        "one-pot layout with <= 6 free cells and no shared faced cells, <= ~98 000 envs) and by the per-env-"
                                        "terrain kernels of mixed tables (<= 32 layouts: <= ~98 000 envs; one-pot tables beyond that), or by the mover / interact kernel "
                                        "(whole 256-env workgroups, <= 524 288 envs)");
         }
-        if (c.joint || c.events) oc_detail::launch_rollout4_joint_events(c);
+        if (c.duo) oc_detail::launch_rollout4_mode2(c);
+        else if (c.joint || c.events) oc_detail::launch_rollout4_joint_events(c);
         else if (mode2) oc_detail::launch_rollout4_mode2(c);
         else oc_detail::launch_rollout4_mode0(c);
         return check_launch("oc_rollout_random");

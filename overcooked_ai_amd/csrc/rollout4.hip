@@ -1,6 +1,6 @@
-// rollout4.hip — the instances of k_rollout4 (step_lut4.hpp), in three translation units: this file is compiled with
-// -DOC_R4_PART=0 (joint move table + event logging), 1 (MODE 2: per-env terrain, pose one step ahead) and 2 (MODE 0:
-// arithmetic movement), so that a clean build runs four hipcc processes side by side (overcooked_ai_amd/build.py) instead
+// rollout4.hip — the instances of k_rollout4 (step_lut4.hpp) and k_rollout5 (step_duo5.hpp), in three translation units: this
+// file is compiled with -DOC_R4_PART=0 (joint move table + event logging), 1 (per-env terrain: k_rollout5's mover / interact
+// workgroups and MODE 2, the pose one step ahead in one wavefront) and 2 (MODE 0: arithmetic movement), so that a clean build runs four hipcc processes side by side (overcooked_ai_amd/build.py) instead
 // of one 80-second compile.  oc_amd.hip (oc_rollout_random) decides the family and calls the unit's launcher.
 #include <stdio.h>
 #include <stdlib.h>
@@ -41,17 +41,6 @@ constexpr size_t lds4_bytes(size_t cell_rows) {
                            (uint32_t)c.seed, (uint32_t)(c.seed >> 32), c.env_offset, c.t0, c.n_steps, c.sa, c.ea);  \
     } while (0)
 
-// MODE 3 (two wavefronts per 64 envs: step_lut4.hpp): workgroups of 2 x BLOCK threads over BLOCK envs, a third spare cell row
-#define GO4D(U, MP, LL, FT8F)                                                                                       \
-    do {                                                                                                            \
-        const size_t smem4 = lds4_bytes<U, MP, LL, 3, true, false, 0, false, true, true, 4, false, FT8F>(cell_rows + 1); \
-        if (!want_lds(k_rollout4<U, MP, LL, 3, true, false, 0, false, true, true, 4, false, FT8F>, smem4)) break;   \
-        hipLaunchKernelGGL((k_rollout4<U, MP, LL, 3, true, false, 0, false, true, true, 4, false, FT8F>), grid4, dim3(2 * BLOCK), smem4, c.stream, \
-                           b->d_layouts, b->n_layouts, b->d_layout_id, (uint4*)c.d_state, (float4*)c.d_rewards, c.d_flags, \
-                           (float4*)c.d_ep_returns, b->n_envs, b->width, c.n_obj, c.horizon, c.options,             \
-                           (uint32_t)c.seed, (uint32_t)(c.seed >> 32), c.env_offset, c.t0, c.n_steps, c.sa, c.ea);  \
-    } while (0)
-
 // k_rollout5 (step_duo5.hpp): the per-env-terrain mover / interact kernel of round 6; two spare cell rows per lane
 #define GO5(LL, FT8F)                                                                                               \
     do {                                                                                                            \
@@ -61,17 +50,6 @@ constexpr size_t lds4_bytes(size_t cell_rows) {
                            b->d_layout_id, (uint4*)c.d_state, (float4*)c.d_rewards, c.d_flags, (float4*)c.d_ep_returns, \
                            b->n_envs, b->width, c.n_obj, c.horizon, c.options, (uint32_t)c.seed, (uint32_t)(c.seed >> 32), \
                            c.env_offset, c.t0, c.n_steps, c.sa);                                                    \
-    } while (0)
-
-// MODE 4: the joint-table kernel (one cramped_room-like layout) with the same split — the mover reads the joint move table
-#define GO4J(FT8F)                                                                                                  \
-    do {                                                                                                            \
-        const size_t smem4 = lds4_bytes<true, 1, true, 4, true, false, 6, false, true, false, 4, true, FT8F>(cell_rows + 1); \
-        if (!want_lds(k_rollout4<true, 1, true, 4, true, false, 6, false, true, false, 4, true, FT8F>, smem4)) break; \
-        hipLaunchKernelGGL((k_rollout4<true, 1, true, 4, true, false, 6, false, true, false, 4, true, FT8F>), grid4, dim3(2 * BLOCK), smem4, c.stream, \
-                           b->d_layouts, b->n_layouts, b->d_layout_id, (uint4*)c.d_state, (float4*)c.d_rewards, c.d_flags, \
-                           (float4*)c.d_ep_returns, b->n_envs, b->width, c.n_obj, c.horizon, c.options,             \
-                           (uint32_t)c.seed, (uint32_t)(c.seed >> 32), c.env_offset, c.t0, c.n_steps, c.sa, c.ea);  \
     } while (0)
 
 #define OC_R4_PROLOGUE                                                       \
@@ -96,10 +74,6 @@ void launch_rollout4_joint_events(const Rollout4Call& c) {
     // (cramped_room): 32-bit cell words and the faced cells read a step ahead; else (big batches, shared faced cells, grids
     // above 64 cells) 16-bit words without the one-step-ahead reads (see PIPE in step_lut4.hpp)
     const bool noconf = (b->batch_flags & OC_BATCH_NO_SHARED_FACES) != 0;
-    if (c.duo) {  // (oc_rollout_random: a joint-table batch on a grid of at most 64 cells without shared faced cells, whole workgroups and blocks)
-        if (c.tiled8) GO4J(true); else GO4J(false);
-        return;
-    }
     if (c.tiled8) {  // (oc_rollout_random has checked that this instance serves the batch and the launch)
         GO4(true, 1, true, 1, true, false, 6, false, true, false, 4, true, true);
         return;
@@ -116,13 +90,8 @@ void launch_rollout4_mode2(const Rollout4Call& c) {
         if (c.pipe) GO4(U, MP, LL, 2, true, false, 0, false, true, RUF, 4); else GO4(U, MP, LL, 2, true, false, 0, false, false, RUF); \
     } while (0)
     if (c.duo) {  // whole workgroups of envs, whole 8-step blocks, at most one workgroup per CU: mover + interact wavefronts
-#ifdef OC_R4_DUO_MODE3  // (A/B builds: round 5's k_rollout4 MODE 3 instances instead of k_rollout5)
-        if (c.lds) { if (c.tiled8) GO4D(false, 2, true, true); else GO4D(false, 2, true, false); }
-        else { if (c.tiled8) GO4D(false, 2, false, true); else GO4D(false, 2, false, false); }
-#else
         if (c.lds) { if (c.tiled8) GO5(true, true); else GO5(true, false); }
         else { if (c.tiled8) GO5(false, true); else GO5(false, false); }
-#endif
         return;
     }
     if (c.tiled8) {  // OC_OPT_FLAGS_TILED8: the instances BASELINE configs[3] / [4] run (oc_rollout_random has checked the conditions)

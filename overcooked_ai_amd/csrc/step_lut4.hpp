@@ -197,12 +197,6 @@ __device__ __forceinline__ uint32_t lut4_addr(uint32_t off, uint32_t h, uint32_t
 // Two spare cell words per lane behind the grid: row n_obj * 16 takes the "ready" stores of pots that are not ripe, row
 // n_obj * 16 + 1 is what the unused pot slots of a lane point at (an empty pot for ever: no pot slot needs a validity test)
 template <int CW> __device__ __forceinline__ uint32_t nopot_off(int n_obj) { return ((uint32_t)n_obj * 16u + 1u) * (BLOCK * CW); }
-// MODE 3, a third spare word per lane (row n_obj * 16 + 2): what a player that does NOT interact "faces" — terrain type 7, whose
-// LUT entries are no-ops for every hand (the result is the word itself and the hand unchanged), so that the interact
-// wavefront runs the same look-up for every player and step: no second LUT variant, no address select
-constexpr uint32_t KB_NOTHING = 7u * 30u;
-template <int CW> __device__ __forceinline__ uint32_t noact_off(int n_obj) { return ((uint32_t)n_obj * 16u + 2u) * (BLOCK * CW); }
-
 template <int MAXP, int CW>
 __device__ __forceinline__ void load_env4(const LayC& C, const Lay L, const uint4* __restrict__ st, int64_t n, int64_t e,
                                           int n_obj, int horizon, Env4<MAXP>& s, uint32_t col) {
@@ -425,38 +419,21 @@ __device__ __forceinline__ uint32_t joint_action_of(uint32_t w0, uint32_t w1, ui
 //    LAY               staged layout records
 //    FL / FI           free-cell list / cell -> free-cell index (MODE 1)
 //    CT                [32] cook time by the low five bits of the soup code (one layout)
-//    SYNC / RING       MODE 3 / 4 only: progress counters of the pairs; mover -> interact records, [3][8][BLOCK] x 12 bytes
-//    CELLS             cell words u16 / u32 [n_obj * 16 + 2 (+ 1 with MODE 3)][BLOCK]
+//    CELLS             cell words u16 / u32 [n_obj * 16 + 2][BLOCK]
 // With u16 table entries (CW = 2) the move table comes first, so that row addresses and the LUT addresses in ACT fit 16 bits;
 // with u32 entries (CW = 4, an 85 KB move table) the small tables come first instead, so that THEIR addresses stay below
 // 64 KiB and fold into the 16-bit offset field of the DS instructions.
 template <bool UNIFORM, bool LAY_LDS, int MODE, int NF, bool ONE_LUT = UNIFORM, int CW = 2>
 struct Lds4 {
-    static constexpr bool DUO = MODE == 3 || MODE == 4;  // mover + interact wavefronts
-    // MODE 4 (the joint table read by a mover wavefront): compact rows of u16 whatever the cell words' width
-    static constexpr int MVJ_ROW = MODE == 4 ? Mvj<2>::ROW_BYTES : Mvj<CW>::ROW_BYTES;
-    static constexpr int MVJ_CAP = (MODE == 1 || MODE == 4) ? ((16 * NF * NF * MVJ_ROW + 15) & ~15) : 0;
+    static constexpr int MVJ_CAP = MODE == 1 ? ((16 * NF * NF * Mvj<CW>::ROW_BYTES + 15) & ~15) : 0;
     static constexpr bool TABLE_FIRST = CW == 2;
-    // MODE 1: [player][40] u16 / u32 LUT addresses; MODE 4: [40] x {mask of player 0, mask of player 1}: all ones when the
-    // joint action has that player INTERACT (the mover then records the faced cell), zero otherwise (the "nothing" word)
-    static constexpr int ACT = TABLE_FIRST ? MVJ_CAP : 0, ACT_P1 = 40 * CW, ACT_BYTES = MODE == 1 ? 2 * ACT_P1 : MODE == 4 ? 40 * 8 : 0;
+    // MODE 1: [player][40] u16 / u32 LUT addresses
+    static constexpr int ACT = TABLE_FIRST ? MVJ_CAP : 0, ACT_P1 = 40 * CW, ACT_BYTES = MODE == 1 ? 2 * ACT_P1 : 0;
     static constexpr int LUT = ACT + ACT_BYTES, LUT_BYTES = ONE_LUT ? LUT4_BYTES : 2 * LUT4_BYTES;
     static constexpr int LAY = LUT + LUT_BYTES, LAY_BYTES = LAY_LDS ? (UNIFORM ? 256 : LDS_LAYOUT_MAX * 256) : 16;
-    static constexpr int FL = LAY + LAY_BYTES, FI = FL + 16, CT = FI + ((MODE == 1 || MODE == 4) ? OC_MAX_CELLS : 0);
+    static constexpr int FL = LAY + LAY_BYTES, FI = FL + 16, CT = FI + (MODE == 1 ? OC_MAX_CELLS : 0);
     static constexpr int MVJ = TABLE_FIRST ? 0 : CT + 32;  // LDS address of the move table
-    // MODE 3 / 4: the ring the mover wavefronts feed the interact wavefronts through — three buffers of one 8-step block
-    // each, [step in block][lane] records of three u32: the LDS addresses of the two cell words the players act on in that
-    // step, and a flag word — bit 31: the episode ends with this step (the horizon), F4_CHG: both players interact with the
-    // same cell, so player 1 must redo its interact if player 0 changes the cell.  (Measured: with TWO buffers — 16-byte
-    // records would leave room for no more — the mover cannot build a lead, every block the interact wavefront waits for
-    // the record it looks ahead to: counter_circuit 330 -> 283 G, the 5-layout mix 269 -> 258 G.)
-    static constexpr int RING_REC = 12, RING_BUF = 8 * BLOCK * RING_REC, RING_BYTES = DUO ? 3 * RING_BUF : 0;
-    // ... and the progress counters of the four mover / interact pairs of a workgroup: {blocks produced, blocks consumed} x 4
-    static constexpr int SYNC = TABLE_FIRST ? CT + 32 : MVJ + MVJ_CAP, SYNC_BYTES = DUO ? 64 : 0;
-    static constexpr int RING = SYNC + SYNC_BYTES;
-    static constexpr int CELLS = RING + RING_BYTES;
-    static_assert(!DUO || (CW == 4 && RING % 4 == 0), "the ring goes with 32-bit cell words");
-    static_assert(MODE != 4 || MVJ + MVJ_CAP < 65536, "MODE 4: row addresses are u16");
+    static constexpr int CELLS = TABLE_FIRST ? CT + 32 : MVJ + MVJ_CAP;
     static_assert(CW == 4 || MVJ_CAP + ACT_BYTES + LUT4_KEYS * 16 < 65536, "row / LUT addresses are u16 in the tables");
     static_assert(CW == 2 || CT + 32 < 65536, "the small tables' addresses must fit the DS offset field");
 };
@@ -490,18 +467,8 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
 //   static terrain, so the pose runs ONE STEP AHEAD of the interacts on a per-lane 64-bit floor mask (no cell reads for the
 //   move targets), the faced cells of the next step are read as soon as this step's cell writes are issued (PIPE), and the
 //   ~25 VALU of the movement fill the shadow of this step's LUT reads
-// MODE 3: MODE 2's transition with the work of an env-step split between TWO wavefronts (workgroups of 2 x BLOCK threads:
-//   wavefronts 0..3 interact, wavefronts 4..7 move).  A wavefront alone on its SIMD issues one instruction every 6-8 clocks
-//   (tools/issue_rate.hip: a dependent integer VALU stream with LDS look-ups; the VALU itself is busy 4 clocks per
-//   instruction), and at 65 536 envs every SIMD holds exactly one: MODE 2's ~125 instructions per env-step cost ~780 clocks
-//   however little each of them does.  resolve_movement needs only the static terrain and the actions, so the whole pose
-//   chain — Philox block, action digits, floor test, both collision rules, orientations, the horizon with its restart pose,
-//   the flag bytes — is computed by a MOVER wavefront that runs up to two 8-step blocks ahead and leaves, per step and lane,
-//   the LDS addresses of the two cell words the players act on (the faced cell, or a spare "nothing to interact with" word
-//   when the action is not INTERACT: one LUT variant, no address select) in a ring in LDS; the INTERACT wavefront of the same
-//   64 envs runs look-up, interact, cell writes, env effects, rewards and the rare branch.  Two progress counters per
-//   pair in LDS (blocks produced / consumed, polled once per 8-step block) keep the mover at most three blocks ahead; no
-//   workgroup barrier in the loop, so a pair whose interact wavefront sits in its rare branch delays nobody else.
+// (The per-env-terrain step split between a mover and an interact wavefront per 64 envs — round 5's MODE 3 / MODE 4 of this
+//  kernel — is k_rollout5, step_duo5.hpp, since round 6.)
 // RU: every layout of the table has the same shaping rewards and dynamics flag (hint OC_BATCH_UNIFORM_SHAPING): one LUT
 //   variant whose entries carry the reward floats, as with a single layout
 // OLD: some layout of the table may use old dynamics (auto-start of full pots in the env effects)
@@ -521,7 +488,7 @@ template <bool UNIFORM, int MAXP, bool LAY_LDS, int MODE, bool OUT, bool OLD, in
 #ifndef OC_R4_WAVES_MAX
 #define OC_R4_WAVES_MAX 4
 #endif
-__global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_WAVES_MAX))) void k_rollout4(const OcLayout* __restrict__ g_layouts, int n_layouts,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, OC_R4_WAVES_MAX))) void k_rollout4(const OcLayout* __restrict__ g_layouts, int n_layouts,
                                                     const uint16_t* layout_id, uint4* st,
                                                     float4* __restrict__ rewards, uint8_t* __restrict__ flags,
                                                     float4* __restrict__ ep_returns, int64_t n, int W, int n_obj,
@@ -536,26 +503,10 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
     uint4* const s_lut = reinterpret_cast<uint4*>(s_dyn4 + M::LUT);
     uint8_t* const s_fl = s_dyn4 + M::FL;
     uint8_t* const s_fi = s_dyn4 + M::FI;
-    // MODE 3 / 4: lanes tid of the two halves of the workgroup share env e — threads 0..BLOCK-1 interact, the others move
-    constexpr bool DUO = MODE == 3 || MODE == 4;
-    // EARLY (round 6): the interact wavefront reads the cells of step k + 1 BEFORE step k's two cell writes (their ring record is
-    // read two steps ahead) and patches them in registers where an address equals a cell this step writes: the step's dependent
-    // chain loses its second LDS round trip (cell write -> cell read).  The pots' "ready" stores leave the straight line with it:
-    // the countdown registers hold (steps until ready) - 1, a pot turning ready shows as a sign bit in the rare-branch test.
-#ifndef OC_R4_EARLY
-#define OC_R4_EARLY 0
-#endif
-    constexpr bool EARLY = MODE == 3 ? OC_R4_EARLY >= 1 : MODE == 4 ? OC_R4_EARLY >= 2 : false;
-    constexpr uint32_t RB = EARLY ? 1u : 0u;  // bias of the countdown registers
-    static_assert(MODE != 3 || (MAXP <= 2 && OUT && !OLD && !EV && PIPE && (UNIFORM || RU) && CW == 4 && !NOCONF),
-                  "MODE 3 = the pipelined MODE 2 instance, split");
-    static_assert(MODE != 4 || (UNIFORM && MAXP == 1 && LAY_LDS && OUT && !OLD && !EV && PIPE && CW == 4 && NOCONF),
-                  "MODE 4 = the pipelined joint-table instance (MODE 1), split");
-    const uint32_t tid = DUO ? (threadIdx.x & (uint32_t)(BLOCK - 1)) : threadIdx.x;
-    const bool mover = DUO && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
+    const uint32_t tid = threadIdx.x;
     const uint32_t blk = xcd_block();  // (common.hpp: each XCD owns a contiguous eighth of the envs)
     const int64_t e = (int64_t)blk * BLOCK + tid;
-    const bool active = e < n;  // (MODE 3 / 4: the host launches whole workgroups only — every wavefront runs to the end)
+    const bool active = e < n;
     Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, active, s_lay);  // contains a barrier
     {
         const uint4* src = reinterpret_cast<const uint4*>(&g_lut4);
@@ -567,7 +518,6 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
             s_lut[i] = ent;
         }
     }
-    if (DUO && threadIdx.x < 8) reinterpret_cast<uint32_t*>(s_dyn4 + M::SYNC)[threadIdx.x] = 0u;
     if (UNIFORM && threadIdx.x < 32) {
         const LayC Cs = load_consts<true>(L);
         s_dyn4[M::CT + threadIdx.x] = (uint8_t)cook_of(Cs, OC_O_SOUP | threadIdx.x);
@@ -586,24 +536,16 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
         }
         build_joint_table<CW>(L, W, s_dyn4 + M::MVJ, (uint32_t)M::MVJ, s_fl, s_fi, s_dyn4 + M::CELLS);  // (scratch: the cell words come later)
     }
-    if (MODE == 4) {  // the mover's tables: who interacts under each joint action, and the joint move table in its compact form
-        if (threadIdx.x < 36) {
-            uint2* sel = reinterpret_cast<uint2*>(s_dyn4 + M::ACT);
-            sel[threadIdx.x] = make_uint2(threadIdx.x / 6 == 5 ? 0xFFFFFFFFu : 0u, threadIdx.x % 6 == 5 ? 0xFFFFFFFFu : 0u);
-        }
-        build_joint_table<2, BLOCK * CW>(L, W, s_dyn4 + M::MVJ, (uint32_t)M::MVJ, s_fl, s_fi, s_dyn4 + M::CELLS);
-    }
     __syncthreads();
-    if (!DUO && !active) return;
+    if (!active) return;
     const uint32_t col = (uint32_t)M::CELLS + tid * (uint32_t)CW;  // LDS address of this lane's column of cell words
     // (L, C, lut_var, two and MODE 2's floor mask change when a restart moves the env to another layout: StartArgs.regen_count)
     LayC C = load_consts<UNIFORM>(L);
     uint32_t lut_var = (uint32_t)M::LUT + (RUX ? 0u : (C.old_dyn ? (uint32_t)LUT4_BYTES : 0u));  // this lane's LUT
     const uint32_t delta4 = make_delta4(W);
     Env4<MAXP> s;
-    if (!mover) load_env4<MAXP, CW>(C, L, st, n, e, n_obj, horizon, s, col);
-    if (DUO && !mover) cw_wr<CW>(col + noact_off<CW>(n_obj), cw_make<CW>(0u, KB_NOTHING));
-    bool two = MODE == 1 || MODE == 2 || DUO || s.pos1 != 0xFFu;
+    load_env4<MAXP, CW>(C, L, st, n, e, n_obj, horizon, s, col);
+    bool two = MODE == 1 || MODE == 2 || s.pos1 != 0xFFu;
     uint64_t fm = 0;  // MODE 2: bit c = cell c is floor (static per layout)
     auto floor_mask_of = [&](const Lay Lx) __attribute__((always_inline)) {
         uint64_t m = 0;
@@ -615,7 +557,7 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
         }
         return m;
     };
-    if (MODE == 2 || (MODE == 3 && mover)) fm = floor_mask_of(L);  // (MODE 4's mover reads the joint move table instead)
+    if (MODE == 2) fm = floor_mask_of(L);
     auto joint_row = [&]() {  // LDS address of the row of the joint pose (pos0, or0, pos1, or1)
         const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR];
         return (uint32_t)M::MVJ + ((s_fi[s.pos0] * 4u + s.or0) * NP + (s_fi[s.pos1] * 4u + s.or1)) * (uint32_t)Mvj<CW>::ROW_BYTES;
@@ -632,7 +574,7 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
     const uint32_t g_lo = (uint32_t)g, g_hi = (uint32_t)(g >> 32);
     float4* rew_k = rewards ? rewards + (int64_t)blk * BLOCK : nullptr;  // wave-uniform row pointers
     const uint32_t wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u));  // first lane of this wavefront
-    static_assert(!FT8 || ((MODE == 1 || MODE == 2 || DUO) && OUT && !EV), "the tiled flags array is served by joint-table and per-env-terrain instances");
+    static_assert(!FT8 || ((MODE == 1 || MODE == 2) && OUT && !EV), "the tiled flags array is served by joint-table and per-env-terrain instances");
     uint8_t* flg_k = flags ? flags + ((int64_t)blk * BLOCK + wave_base) * (FT8 ? 8 : 1) : nullptr;  // (FT8: the tile row of 8 steps)
     uint32_t flt_lo = 0, flt_hi = 0;  // FT8: the flag bytes of the block's steps 0..3 / 4..7
     const uint32_t lane = tid & 63u;
@@ -711,21 +653,14 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
         // Two or more wavefronts per SIMD (the one-wavefront-per-env-group instances on big batches: BASELINE configs[4] at
         // 131 072 envs per GPU) store the quads with `sc1 nt` — streaming, written through: a step's row is written once and read by
         // nobody on this GPU before the launch ends.  Measured: 304 -> 315 G env-steps/s there (tools/store_rollout.hip: the store
-        // path alone 5.36 -> 5.52 TB/s; the same bits on the flag tiles cost it all again).  The mover / interact instances at one
-        // workgroup per CU lose 1 % with it (they sit at the plain stores' ceiling) and keep plain stores.
+        // path alone 5.36 -> 5.52 TB/s; the same bits on the flag tiles cost it all again).
         // -DOC_R4_PLAIN_QUADS: plain stores everywhere, for A/B.
 #ifdef OC_R4_PLAIN_QUADS
 #define OC_R4_QUAD_POLICY ""
 #else
 #define OC_R4_QUAD_POLICY " sc1 nt"
 #endif
-        if (DUO && FT8) {  // (MODE 3 / 4: the mover stores the flags; the second wait state behind the store is a no-op)
-            asm volatile("global_store_dwordx4 %1, %2, %4\n\tv_pk_add_f32 %0, %0, %3\n\ts_nop 0"
-                         : "+v"(epsh) : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k) : "memory");
-        } else if (DUO) {  // ([step][env] flag rows from the mover: 64-byte pieces beside them — the quads stream)
-            asm volatile("global_store_dwordx4 %1, %2, %4" OC_R4_QUAD_POLICY "\n\tv_pk_add_f32 %0, %0, %3\n\ts_nop 0"
-                         : "+v"(epsh) : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k) : "memory");
-        } else if (FT8) {  // (the flag byte has gone into the block's tile)
+        if (FT8) {  // (the flag byte has gone into the block's tile)
             asm volatile("global_store_dwordx4 %1, %2, %4" OC_R4_QUAD_POLICY "\n\tv_pk_add_f32 %0, %0, %3\n\ts_nop 0"
                          : "+v"(epsh) : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k) : "memory");
         } else {
@@ -762,12 +697,10 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
 #pragma unroll
         for (int k = 0; k < MAXP; ++k) {
             rem_before[k] = s.rem[k];
-            if (FAST_START) s.rem[k] = ((r0 | r1) & F4_START) ? cookv - RB : s.rem[k];
+            if (FAST_START) s.rem[k] = ((r0 | r1) & F4_START) ? cookv : s.rem[k];
             s.rem[k] -= 1u;
-            ripe[k] = EARLY ? (int32_t)s.rem[k] < 0 : s.rem[k] == 0u;
-            if (EARLY) {
-                // (the "ready" store is the rare branch's: the sign bit joins its test below)
-            } else if (PIPE) {
+            ripe[k] = s.rem[k] == 0u;
+            if (PIPE) {
                 if (MAXP <= 2 || (uint32_t)k < C.n_pots) cw_wr_kb<CW>(ripe[k] ? col + s.poff[k] : dummy, KB_POT + PC_READY);
             } else if (ripe[k]) {  // only the lanes concerned store
                 cw_wr_kb<CW>(col + s.poff[k], KB_POT + PC_READY);
@@ -777,13 +710,7 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
             nf0 = col + (m1 & 0xFFFFu);
             nf1 = col + (m1 >> 16);
         }
-        if (EARLY) {  // nc0 / nc1 were read before this step's cell writes: what the writes changed is patched in (player 1's is the later write)
-            nc0 = nf0 == fo0 ? cw_of_result<CW>(r0) : nc0;
-            if (!NOCONF) nc0 = nf0 == fo1 ? cw_of_result<CW>(r1) : nc0;
-            if (!NOCONF) nc1 = nf1 == fo0 ? cw_of_result<CW>(r0) : nc1;
-            nc1 = nf1 == fo1 ? cw_of_result<CW>(r1) : nc1;
-            rd_pots(npw);
-        } else if ((MODE == 1 || MODE == 2 || DUO) && PIPE) {  // the next step's cells: everything this step writes to the grid has been issued
+        if ((MODE == 1 || MODE == 2) && PIPE) {  // the next step's cells: everything this step writes to the grid has been issued
             nc0 = cw_rd<CW>(nf0);
             nc1 = cw_rd<CW>(nf1);
             rd_pots(npw);
@@ -797,10 +724,8 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
         };
         const float sh0 = shaped_of(e0.w);
         float sh1 = shaped_of(e1.w);
-        // (MODE 3 / 4: m0 carries the record's flag word of this step: bit 31 = the horizon, F4_CHG = the players share a cell)
-        const uint32_t f_rec = DUO ? m0 : 0u;
-        const bool done = DUO ? (f_rec & 0x80000000u) != 0u : s.tleft == 0u;
-        const bool conflict = NOCONF ? false : DUO ? (r0 & f_rec & F4_CHG) != 0u : (fo0 == fo1) & ((r0 & F4_CHG) != 0u);
+        const bool done = s.tleft == 0u;
+        const bool conflict = NOCONF ? false : (fo0 == fo1) & ((r0 & F4_CHG) != 0u);
         // ---- ONE branch for everything rare; its test is integer arithmetic up to one compare (no SGPR hand-offs) ----
         // bit 0 (= F4_TAKE_DISH) of `take`: a dish taken from the dispenser may be "useful" — some pot was (pot_states
         // before the interacts: class idle 1, idle 2, cooking or ready) and no dish lay on a counter, before or after
@@ -822,25 +747,13 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
         if (OLD) gate |= C.old_dyn ? (uint32_t)F4_PLACE : 0u;  // old dynamics: the third item starts the pot (Q11)
         uint32_t rare_bits;
         bool rare;
-        if (DUO) {  // the mover has decided the horizon and seen whether the players share a cell: two and-or's and one compare
-            rare_bits = NOCONF ? (((r0 | r1) & (take | gate)) | f_rec) : (((r0 | r1) & (take | gate)) | ((r0 | 0x80000000u) & f_rec));
-            if (EARLY) {  // a pot turns ready with this step's env effects
-                uint32_t u = s.rem[0];
-#pragma unroll
-                for (int k = 1; k < MAXP; ++k) u |= s.rem[k];
-                rare_bits |= u & 0x80000000u;
-            }
-            rare = rare_bits != 0u;
-        } else {
-            const uint32_t tleft_new = s.tleft - 1u;               // the horizon: the sign bit (tleft < 2^31)
+        {
+            const uint32_t tleft_new = s.tleft - 1u;  // the horizon: the sign bit (tleft < 2^31)
             s.tleft = tleft_new;
             rare_bits = ((r0 | r1) & (take | gate)) | (tleft_new & 0x80000000u);
             if (OLD) rare_bits |= s.pending;
             rare = (rare_bits != 0u) | conflict;
         }
-#ifdef OC_X_NORARE  // (timing experiments only: the straight line without its corrective branch — results are wrong)
-        if (DUO) rare = false;
-#endif
         uint32_t nh0 = r0, nh1 = r1;  // the hands after the step
         float4 rw = make_float4(0.f, 0.f, sh0, sh1);  // this step's reward quad and flag byte: stored ONCE, after the branch
         uint64_t q_lo = 0, q_hi = 0;  // the same quad as two register pairs (what the unrolled blocks store; the rare branch rewrites both whole)
@@ -887,9 +800,8 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
                     // (the straight line may have loaded or not loaded the countdown from player 1's stale interact: redo)
                     uint32_t cook = 0;
                     if (go) cook = cook_time(soup);
-                    s.rem[k] = (go ? cook : rem_before[k] + RB) - 1u - RB;
-                    ripe[k] = s.rem[k] + RB == 0u;
-                    if (EARLY && go && cook == 0u) ripe[k] = true;  // (the countdown is put away below)
+                    s.rem[k] = (go ? cook : rem_before[k]) - 1u;
+                    ripe[k] = s.rem[k] == 0u;
                     if (go) {  // (cook == 0: ready at once, never ticks)
                         s.exotic &= ~(1u << k);
                         cw_wr_kb<CW>(pa, (cook == 0u || ripe[k]) ? KB_POT + PC_READY : KB_POT + PC_COOKING);
@@ -900,19 +812,6 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
                     }
                 }
                 if (OLD) s.pending = 0;
-            }
-            if (EARLY) {  // step_environment_effects (mdp.py:1691-1703): the pots that turn ready with this step
-#pragma unroll
-                for (int k = 0; k < MAXP; ++k) {
-                    if (MAXP > 1 && (uint32_t)k >= C.n_pots) break;
-                    if (ripe[k]) {  // the countdown is put away: the tick byte a ready pot is stored with is cook time + 1
-                        const uint32_t pa = col + s.poff[k];
-                        cw_wr_kb<CW>(pa, KB_POT + PC_READY);
-                        s.tk[k] = cook_time(cw_obj<CW>(cw_rd<CW>(pa))) + 1u;
-                        s.rem[k] = REM_IDLE;
-                        grid_changed = true;
-                    }
-                }
             }
             // deliveries and dish pick-ups
             const uint32_t hb0 = (h0_before >> 8) & 0xFFu, hb1 = (h1_before >> 8) & 0xFFu, hn0 = (r0 >> 8) & 0xFFu;
@@ -969,10 +868,6 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
                         env_reset4_draw<MAXP, CW>(C, L, n_obj, horizon, s, col,
                                               draw_start(L, g, sa.epoch + step_k, sa.seed_lo, sa.seed_hi, sa.random_start_pos, sa.thresh));
                         nh0 = s.h0; nh1 = s.h1;
-                        if (EARLY) {
-#pragma unroll
-                            for (int k = 0; k < MAXP; ++k) s.rem[k] -= RB;
-                        }
                     } else {
                         env_reset4<MAXP, CW>(C, L, n_obj, horizon, s, col);
                         nh0 = nh1 = 0;
@@ -986,8 +881,6 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
                         m0 = joint_row();
                         m1 = lds_rd32(m0 + (uint32_t)Mvj<CW>::FACES);
                         m2 = CW == 2 ? lds_rd16(m0 + ja2n) : lds_rd32(m0 + ja2n);
-                    } else if (DUO) {
-                        // (the mover has seen the same horizon: its record of the next step already faces from the start pose)
                     } else if (MODE == 2) {
                         m0 = s.pos0; m2 = s.pos1; m3 = s.or0; m4 = s.or1;
                         nf0 = col + step_cell(s.pos0, s.or0, delta4) * (BLOCK * CW);
@@ -1004,14 +897,7 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
                 nf0 = col + (m1 & 0xFFFFu);
                 nf1 = col + (m1 >> 16);
             }
-            if (EARLY) {  // the lanes in here read the next step's cells again, behind everything the step wrote
-                nc0 = cw_rd<CW>(nf0);
-                nc1 = cw_rd<CW>(nf1);
-                if (grid_changed) rd_pots(npw);
-                // ... and wait for them in here: left pending, the join behind the branch would wait for every LDS operation
-                // of the straight line as well (the counters retire in order) — the pot words' round trip back on the chain
-                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-            } else if ((MODE == 1 || MODE == 2 || DUO) && PIPE && grid_changed) {  // read the next step's cells again
+            if ((MODE == 1 || MODE == 2) && PIPE && grid_changed) {  // read the next step's cells again
                 nc0 = cw_rd<CW>(nf0);
                 nc1 = cw_rd<CW>(nf1);
                 rd_pots(npw);
@@ -1056,7 +942,7 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
             if (ea.events) ea.events[(int64_t)step_k * n + e] = ev;
             count_events(ea, e, ev, done, (options & OC_OPT_AUTO_RESET) != 0u);
         }
-        if (FT8 && !DUO && k8 >= 0) {  // this step's byte of the block's flag tile (k8 is a constant of the unrolled step)
+        if (FT8 && k8 >= 0) {  // this step's byte of the block's flag tile (k8 is a constant of the unrolled step)
             uint32_t& half = (k8 & 4) ? flt_hi : flt_lo;
             half = (k8 & 3) == 0 ? fl : (half | (fl << (8 * (k8 & 3))));
         }
@@ -1082,148 +968,13 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
     // after the eight steps of an unrolled block (FT8: first the block's flag tile — 8 bytes per env, 512 contiguous bytes
     // per wavefront)
     auto advance_rows = [&]() __attribute__((always_inline)) {
-        if (FT8 && !DUO) {
+        if (FT8) {
             const uint64_t tile = ((uint64_t)flt_hi << 32) | flt_lo;
             asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lane * 8u), "v"(tile), "s"(flg_k) : "memory");
         }
         if (OUT) { rew_k += 8 * n; flg_k += 8 * n; }
     };
 
-
-    // ---- MODE 3, the MOVER wavefronts: resolve_movement (mdp.py:1644-1727) for the whole launch, one 8-step block at a time,
-    //      up to two blocks ahead of the interact wavefronts.  Per step and lane one ring record {a0, a1}: the LDS address of the
-    //      cell word player p acts on at that step — the cell it faces when its action is INTERACT, else the lane's "nothing"
-    //      word.  The horizon is decided here as well (it depends on the step count alone): the flag bytes are stored by the
-    //      mover, and a restart puts the pose back to the start pose (standard, drawn, or on a re-drawn layout — the same
-    //      counter-based draws as the interact wavefront's env_reset4_draw, keyed by (seed, global env, epoch)).
-    //      Block n_steps / 8 (one past the launch) is a stub: record 0 = {nothing, nothing} for the last step's look-ahead
-    //      and record 1 = the final pose, which the interact wavefront puts into the stored state.
-    constexpr uint32_t RING_SLOT = (uint32_t)BLOCK * (uint32_t)M::RING_REC;  // bytes of one step's records
-    // progress counters of this lane's mover / interact pair: {blocks the mover has finished, blocks the interact wavefront has finished}
-    const uint32_t sync_pair = (uint32_t)M::SYNC + (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * 8u;
-    if (DUO && mover) {
-        auto ahead = [&](uint32_t c, uint32_t d) __attribute__((always_inline)) {
-            return c + (uint32_t)(int32_t)(int8_t)(uint8_t)__builtin_amdgcn_perm(0u, delta4, d);
-        };
-        const uint4 h = st[e];
-        uint32_t P0 = h.x & 0xFFu, O0 = (h.x >> 8) & 0xFFu, P1 = h.x >> 24, O1 = h.y & 0xFFu;
-        // MODE 4: the pose is a ROW of the joint move table (compact form: u16 entries, 76 bytes per row)
-        constexpr uint32_t ROW4 = (uint32_t)Mvj<2>::ROW_BYTES, FACES4 = (uint32_t)Mvj<2>::FACES;
-        auto row_of = [&](uint32_t p0, uint32_t o0, uint32_t p1, uint32_t o1) __attribute__((always_inline)) {
-            const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR];
-            return (uint32_t)M::MVJ + ((s_fi[p0] * 4u + o0) * NP + (s_fi[p1] * 4u + o1)) * ROW4;
-        };
-        uint32_t J = MODE == 4 ? row_of(P0, O0, P1, O1) : 0u;
-        const uint32_t t_in = h.y >> 16;
-        uint32_t tleft = t_in < (uint32_t)horizon ? (uint32_t)horizon - 1u - t_in : 0u;
-        uint32_t over = t_in < (uint32_t)horizon ? 0u : t_in - ((uint32_t)horizon - 1u);  // (as Env4: steps run past the horizon)
-        const uint32_t noact = col + noact_off<CW>(n_obj);
-        const uint32_t ring0 = (uint32_t)M::RING + tid * (uint32_t)M::RING_REC;
-        const int n_blocks = n_steps >> 3;
-        auto produce = [&](int b, uint32_t ring) __attribute__((always_inline)) {
-            if (b >= n_blocks) {  // the stub block
-                if (MODE == 4) {  // joint pose -> cells / orientations
-                    const uint32_t NP = 4u * s_fl[JOINT_MAX_FLOOR], Jidx = (J - (uint32_t)M::MVJ) / ROW4, I0 = Jidx / NP, I1 = Jidx - I0 * NP;
-                    P0 = s_fl[I0 >> 2]; O0 = I0 & 3u; P1 = s_fl[I1 >> 2]; O1 = I1 & 3u;
-                }
-                lds_wr96(ring, noact, noact, 0u);
-                if (EARLY) lds_wr96(ring + RING_SLOT, noact, noact, 0u);  // (the interact wavefront looks two records ahead)
-                lds_wr96(ring + (EARLY ? 2u : 1u) * RING_SLOT, P0 | (O0 << 8) | (P1 << 16) | (O1 << 24), tleft, over);
-                return;
-            }
-            const Phx4 wb = philox_words(((uint64_t)t0 >> 3) + (uint64_t)b, g_lo, g_hi, seed_lo, seed_hi);
-            uint32_t tile_lo = 0, tile_hi = 0;
-#pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8) {
-                // the actions of this step: the base-6 digits of the block's word k8 / 2 (second pair of digits: 36 x)
-                uint32_t x = (k8 >> 1) == 0 ? wb.w0 : (k8 >> 1) == 1 ? wb.w1 : (k8 >> 1) == 2 ? wb.w2 : wb.w3;
-                if (k8 & 1) x *= 36u;
-                uint32_t rec0, rec1, f_same = 0u;
-                if (MODE == 4) {
-                    // the joint action as a byte offset into a row of u16 (2 x the top base-36 digit of x); three look-ups:
-                    // the faced cells of this pose, who interacts under this joint action, the row of the next pose
-                    // (resolve_movement with both collision rules is that one table read, as in MODE 1)
-                    const uint32_t ja2 = __umulhi(x, 72u) & ~1u;
-                    const uint32_t fa = lds_rd32(J + FACES4);
-                    const uint2 sel = lds_rd64((uint32_t)M::ACT + 4u * ja2);
-                    const uint32_t Jn = lds_rd16(J + ja2);
-                    const uint32_t f0 = col + (fa & 0xFFFFu), f1 = col + (fa >> 16);
-                    rec0 = (f0 & sel.x) | (noact & ~sel.x);
-                    rec1 = (f1 & sel.y) | (noact & ~sel.y);
-                    J = Jn;  // (NOCONF: two players never face the same cell on this layout — no shared-cell flag)
-                } else {
-                const uint32_t a0 = __umulhi(x, 6u), a1 = __umulhi(x * 6u, 6u);
-                const uint32_t f0 = col + ahead(P0, O0) * (BLOCK * CW), f1 = col + ahead(P1, O1) * (BLOCK * CW);
-                rec0 = a0 == 5u ? f0 : noact;
-                rec1 = a1 == 5u ? f1 : noact;
-                f_same = rec0 == rec1 ? (a0 == 5u ? (uint32_t)F4_CHG : 0u) : 0u;  // both interact with the same cell
-                // the pose of the next step, on the static terrain (as MODE 2)
-                const uint32_t t0_ = ahead(P0, a0), t1_ = ahead(P1, a1);
-                uint32_t fb0 = (uint32_t)(fm >> t0_), fb1 = (uint32_t)(fm >> t1_);
-                asm("" : "+v"(fb0));
-                asm("" : "+v"(fb1));
-                const uint32_t np0 = (fb0 & 1u) ? t0_ : P0, np1 = (fb1 & 1u) ? t1_ : P1;
-                const bool collide = (np0 == np1) | ((np0 == P1) & (np1 == P0));
-                const uint32_t q0 = collide ? P0 : np0, q1 = collide ? P1 : np1;
-                O0 = a0 < 4u ? a0 : O0; O1 = a1 < 4u ? a1 : O1;
-                P0 = q0; P1 = q1;
-                }
-                // OvercookedEnv.step at the horizon (env.py:266-267, 321-325): the flag byte; a restart moves the players
-                uint32_t fl = 0;
-                const bool done = tleft == 0u;
-                tleft -= 1u;
-                lds_wr96(ring + (uint32_t)k8 * RING_SLOT, rec0, rec1, f_same | (done ? 0x80000000u : 0u));
-                if (__builtin_expect(done, 0)) {
-                    fl = OC_F_DONE;
-                    tleft = 0u;
-                    over += 1u;
-                    if (options & OC_OPT_AUTO_RESET) {
-                        over = 0u;
-                        fl |= OC_F_RESET;
-                        tleft = (uint32_t)horizon - 1u;
-                        const uint32_t ep_k = sa.epoch + (uint32_t)(b * 8 + k8);
-                        if (sa.enabled) {
-                            if (!UNIFORM && sa.regen_count) {  // (the interact wavefront records the new id in layout_ids)
-                                const uint32_t lid = draw_layout(sa, g, ep_k);
-                                L = LAY_LDS ? Lay{reinterpret_cast<const uint8_t*>(s_lay) + lid * 256u}
-                                            : Lay{reinterpret_cast<const uint8_t*>(g_layouts) + (size_t)lid * 256u};
-                                fm = floor_mask_of(L);
-                            }
-                            const StartDraw d = draw_start(L, g, ep_k, sa.seed_lo, sa.seed_hi, sa.random_start_pos, sa.thresh);
-                            P0 = d.pos0; P1 = d.pos1;
-                        } else {
-                            P0 = L.u8(L_START_POS); P1 = L.u8(L_START_POS + 1);
-                        }
-                        O0 = L.u8(L_START_OR); O1 = L.u8(L_START_OR + 1);
-                        if (MODE == 4) J = row_of(P0, O0, P1, O1);
-                    }
-                }
-                if (FT8) {
-                    uint32_t& half = (k8 & 4) ? tile_hi : tile_lo;
-                    half = (k8 & 3) == 0 ? fl : (half | (fl << (8 * (k8 & 3))));
-                } else {
-                    store_flag_byte(flg_k, flg_off[k8], fl);
-                }
-            }
-            if (FT8) {
-                const uint64_t tile = ((uint64_t)tile_hi << 32) | tile_lo;
-                asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lane * 8u), "v"(tile), "s"(flg_k) : "memory");
-            }
-            flg_k += 8 * n;
-        };
-        // Block j goes to buffer j % 3, which held block j - 3: the interact wavefront must have finished block j - 3 (its
-        // count of finished blocks >= j - 2) — the mover runs at most three blocks ahead, and only ITS partner holds it back
-        // (a workgroup barrier per block, the first version, made every pair wait for the workgroup's slowest interact wavefront).
-        uint32_t wbuf = 0;  // (wave-uniform) offset of the buffer block j goes to
-        for (int j = 0; j <= n_blocks; ++j) {
-            if (j >= 3)
-                while (lds_poll32(sync_pair + 4u) + 2u < (uint32_t)j) __builtin_amdgcn_s_sleep(2);
-            produce(j, ring0 + wbuf);
-            wbuf = wbuf == 2u * (uint32_t)M::RING_BUF ? 0u : wbuf + (uint32_t)M::RING_BUF;
-            lds_post32(sync_pair, (uint32_t)j + 1u);
-        }
-        return;
-    }
 
     Phx4 w = {0, 0, 0, 0};  // the Philox block of the step being looked at
 #define OC_JA_AT(T, FIRST)                                                                                   \
@@ -1397,77 +1148,6 @@ __global__ __launch_bounds__((MODE == 3 || MODE == 4) ? 2 * BLOCK : BLOCK) __att
             }
         }
         s.pos0 = P0; s.or0 = O0; s.pos1 = P1; s.or1 = O1;
-    } else if (DUO) {
-        // The INTERACT wavefronts of MODE 3 / 4: the step of MODE 2 without its movement — the two cell words a step acts on come
-        // out of the mover's ring (the next step's record is read while this step's look-ups are in flight, its cells right
-        // after this step's cell writes).
-        const uint32_t ring0 = (uint32_t)M::RING + tid * (uint32_t)M::RING_REC;
-        const int n_blocks = n_steps >> 3;
-        while (lds_poll32(sync_pair) < 1u) __builtin_amdgcn_s_sleep(1);
-        uint32_t fo0, fo1, f_rec, c0, c1, pw[MAXP];
-        uint32_t nf0 = 0, nf1 = 0, nf_rec = 0;  // EARLY: the record of the step after this one (records are read two steps ahead)
-        {
-            const oc_rec3 rec = lds_rd96(ring0);
-            fo0 = rec.x; fo1 = rec.y; f_rec = rec.z;
-        }
-        c0 = cw_rd<CW>(fo0);
-        c1 = cw_rd<CW>(fo1);
-        rd_pots(pw);
-        if (EARLY) {
-            const oc_rec3 rec = lds_rd96(ring0 + RING_SLOT);
-            nf0 = rec.x; nf1 = rec.y; nf_rec = rec.z;
-#pragma unroll
-            for (int k = 0; k < MAXP; ++k) s.rem[k] -= RB;
-        }
-        // k8: the step's index in its block; ahead_rec: the ring record of the next step (EARLY: of the step after the next)
-        auto dstep = [&](int k8, uint32_t ahead_rec) __attribute__((always_inline)) {
-            const Looked looked = look_up(lut_var, lut_var, c0, c1, pw);
-            if (EARLY) {
-                uint32_t nc0 = cw_rd<CW>(nf0), nc1 = cw_rd<CW>(nf1);  // the next step's cells as they are BEFORE this step's writes
-                const oc_rec3 arec = lds_rd96(ahead_rec);
-                uint32_t u0 = f_rec, u1 = 0, u2 = 0, u3 = 0, u4 = 0, a0 = nf0, a1 = nf1, npw[MAXP];
-                core(fo0, fo1, lut_var, lut_var, c0, c1, 0u, pw, u0, u1, u2, u3, u4, a0, a1, nc0, nc1, npw, k8, looked);
-                fo0 = nf0; fo1 = nf1; f_rec = nf_rec; c0 = nc0; c1 = nc1;
-                nf0 = arec.x; nf1 = arec.y; nf_rec = arec.z;
-#pragma unroll
-                for (int k = 0; k < MAXP; ++k) pw[k] = npw[k];
-                return;
-            }
-            const oc_rec3 nrec = lds_rd96(ahead_rec);
-            uint32_t u0 = f_rec, u1 = 0, u2 = 0, u3 = 0, u4 = 0, a0 = nrec.x, a1 = nrec.y, nc0 = 0, nc1 = 0, npw[MAXP];
-            core(fo0, fo1, lut_var, lut_var, c0, c1, 0u, pw, u0, u1, u2, u3, u4, a0, a1, nc0, nc1, npw, k8, looked);
-            fo0 = a0; fo1 = a1; c0 = nc0; c1 = nc1; f_rec = nrec.z;
-#pragma unroll
-            for (int k = 0; k < MAXP; ++k) pw[k] = npw[k];
-        };
-        uint32_t rbuf = 0;  // (wave-uniform) offset of the ring buffer that holds the block being run
-        for (int b = 0; b < n_blocks; ++b) {
-            // Block b's own records are there (checked by block b - 1); its last step (EARLY: last two steps) looks ahead into
-            // block b + 1: the mover must have finished b + 2 blocks by then (the stub behind the launch counts as one).
-            // The count is read one step before it is looked at, so that the read's latency is not the loop's.
-            const uint32_t cur = ring0 + rbuf;
-            rbuf = rbuf == 2u * (uint32_t)M::RING_BUF ? 0u : rbuf + (uint32_t)M::RING_BUF;
-            constexpr int LA = EARLY ? 2 : 1;  // records looked ahead
-#pragma unroll
-            for (int k8 = 0; k8 < 7 - LA; ++k8) dstep(k8, cur + (uint32_t)(k8 + LA) * RING_SLOT);
-            const uint32_t produced = *(const volatile OC_LDS uint32_t*)(uintptr_t)sync_pair;
-            dstep(7 - LA, cur + 7u * RING_SLOT);
-            if (__builtin_amdgcn_readfirstlane((int)produced) < b + 2)
-                while (lds_poll32(sync_pair) < (uint32_t)b + 2u) __builtin_amdgcn_s_sleep(1);
-            if (EARLY) dstep(6, ring0 + rbuf);
-            dstep(7, ring0 + rbuf + (EARLY ? RING_SLOT : 0u));
-            advance_rows();
-            lds_post32(sync_pair + 4u, (uint32_t)b + 1u);
-        }
-        {   // the stub block's last record: the pose after the last step and where the episode clock stands
-            const oc_rec3 fin = lds_rd96(ring0 + rbuf + (EARLY ? 2u : 1u) * RING_SLOT);
-            s.pos0 = fin.x & 0xFFu; s.or0 = (fin.x >> 8) & 0xFFu; s.pos1 = (fin.x >> 16) & 0xFFu; s.or1 = fin.x >> 24;
-            s.tleft = fin.y; s.over = fin.z;
-        }
-        if (EARLY) {
-#pragma unroll
-            for (int k = 0; k < MAXP; ++k) s.rem[k] += RB;
-        }
     } else {
         auto astep = [&](uint32_t a0, uint32_t a1) __attribute__((always_inline)) {
             const uint32_t f0 = step_cell(s.pos0, s.or0, delta4), f1 = two ? step_cell(s.pos1, s.or1, delta4) : f0;

@@ -29,12 +29,12 @@ for kern in kerns:
         import os
 
         # per env-step of a 64-env group: one wavefront per group in the one-wavefront kernels, a mover + an interact wavefront in
-        # k_rollout4's MODE 3 / 4 (their counters add up)
+        # k_rollout5 (their counters add up)
         # (the database holds one row per counter instance — XCD x shader engine —, so only RATIOS of its means are meaningful:
         #  per wavefront = counter / SQ_WAVES; wavefronts per group from the kernel's MODE template argument)
         kname = sorted(n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] for n in names)[0] if names else kern
         targs = kname.split("<", 1)[1].split(",") if "<" in kname else []
-        wpg = 2 if kname.startswith("k_rollout4") and len(targs) > 3 and targs[3].strip() in ("3", "4") else 1
+        wpg = 2 if kname.startswith("k_rollout5") else 1  # (k_rollout5: a mover + an interact wavefront per 64 envs)
         per = lambda k: round(vals.get(k, 0.0) / w / steps * wpg, 2)
 
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -43,7 +43,7 @@ for kern in kerns:
         json.dump({
             "kernel_source_sha": build.source_hash(),
             "_note": "rocprofv3 --pmc SQ_* passes of tools/prof_rollout.py (tools/pmc_rollout.sh), 65 536 cramped_room envs, %d fused "
-                     "steps per launch; per 64-env group and env-step — with MODE 3 / 4 the mover's and the interact wavefront's instructions "
+                     "steps per launch; per 64-env group and env-step — with k_rollout5 the mover's and the interact wavefront's instructions "
                      "together (wavefronts_per_64_envs = 2) — the launch prologue (e.g. the joint move table build) included; "
                      "wave_clk_per_env_step = clocks of ONE wavefront per step (mean over movers and interact wavefronts)" % steps,
             "kernel": sorted(n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] for n in names)[0] if names else kern,
