@@ -169,15 +169,26 @@ def reference_python(args=None):
     src = os.path.join(ROOT, "oracle", "_ref", "src")
     if os.path.exists(os.path.join(src, "overcooked_ai_py", "mdp", "overcooked_env.pyc")):
         try:
-            env = dict(os.environ, OVERCOOKED_REFERENCE_SRC=src, LAYOUTS="cramped_room", EPISODES="25", PYTHONDONTWRITEBYTECODE="1")
+            # >= 50 timed episodes, cramped_room and asymmetric_advantages (config 3), with and without the encoding
+            env = dict(os.environ, OVERCOOKED_REFERENCE_SRC=src, LAYOUTS="cramped_room,asymmetric_advantages", EPISODES="50",
+                       PYTHONDONTWRITEBYTECODE="1")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k, None)
             t0 = time.perf_counter()
             p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "time_reference_python.py")], env=env, cwd=ROOT,
-                               capture_output=True, text=True, timeout=240)
+                               capture_output=True, text=True, timeout=400)
             j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-            cr = j["cramped_room"]
+            cr, aa = j["cramped_room"], j.get("asymmetric_advantages")
+            aa_leg = None
+            if aa:  # BASELINE configs[2]'s CPU side: asymmetric_advantages with lossless_state_encoding_mdp every step
+                aa_leg = {"value": aa["step_encode_allcores"]["steps_per_s"], "unit": "env steps/s", "kind": "reference",
+                          "cores": aa["step_encode_allcores"]["processes"], "single_core": aa["step_encode_1core"]["steps_per_s"],
+                          "without_encoding": {"value": aa["step_allcores"]["steps_per_s"], "single_core": aa["step_1core"]["steps_per_s"]},
+                          "sample": "the reference's OvercookedEnv.step + lossless_state_encoding_mdp (overcooked_env.py:244, 276) on "
+                                    "asymmetric_advantages, horizon 400, %s episodes per process after 1 warm-up, one env per process, "
+                                    "same run, same box" % j.get("episodes_per_process")}
             return {
+                "asymmetric_advantages": aa_leg,
                 "value": cr["step_1core"]["steps_per_s"], "unit": "env steps/s", "cores": 1,
                 "all_cores": {"value": cr["step_allcores"]["steps_per_s"], "cores": cr["step_allcores"]["processes"],
                               "note": "one env per process, multiprocessing.Pool"},
@@ -187,7 +198,7 @@ def reference_python(args=None):
                 "where": "this box, this run (%s, %s usable cores, CPython %s, numpy %s)"
                          % (j.get("cpu_model"), j.get("usable_cores"), j.get("python"), j.get("numpy")),
                 "what": j.get("what", "") + ": cramped_room, horizon 400, np.random.RandomState joint actions, %s episodes per "
-                                            "process after 1 warm-up (%d steps on one core)"
+                                            "process after 1 warm-up (%d timed steps on one core)"
                                             % (j.get("episodes_per_process"), cr["step_1core"]["steps"]),
                 "source": "tools/time_reference_python.py on oracle/_ref/src: the reference's own modules (overcooked_env.py, "
                           "overcooked_mdp.py, actions.py, ...) byte-compiled from /root/reference by oracle/build_ref.py",
@@ -999,6 +1010,7 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
         out["training_env"] = bench_training_env(dev, torch)
         # the other BASELINE configs, each with its own roofline and parity check, in this same line
         out["configs"] = side_legs(args, torch, VecOvercookedEnv, sharding, dev)
+        out["general_path"] = general_legs(args, torch, VecOvercookedEnv, sharding, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stub:  # the CPU leg runs at N = 1 only
         wl_cpu = make_workload(args, rank)
         port = cpu_baseline(wl_cpu, n, args.cpu_seconds)
@@ -1010,15 +1022,18 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
                 "value": ref["all_cores"]["value"], "unit": "env steps/s", "cores": ref["all_cores"]["cores"], "kind": "reference",
                 "single_core": ref["value"], "with_lossless_encoding": ref["with_lossless_encoding"],
                 "sample": "the reference's own OvercookedEnv.step (overcooked_env.py:244) on cramped_room, horizon 400, random joint "
-                          "actions: 25 episodes per process after 1 warm-up, one env per process on every usable core "
-                          "(multiprocessing.Pool), and on one core; %.1f s in this run" % ref.get("seconds", 0.0),
-                "where": ref["where"], "source": ref["source"], "same_run": True, "same_box": True,
-                "port": port, "reference_python": ref}
+                          "actions: 50 episodes per process after 1 warm-up (BASELINE.md 3.2), one env per process on every usable "
+                          "core (multiprocessing.Pool), and on one core; both layouts, with and without the encoding: %.1f s in "
+                          "this run" % ref.get("seconds", 0.0),
+                "where": ref["where"], "source": ref["source"], "same_run": True, "same_box": True, "port": port}
+            if ref.get("asymmetric_advantages") and "3" in out.get("configs", {}) and "error" not in out["configs"]["3"]:
+                out["configs"]["3"]["cpu_baseline"] = ref["asymmetric_advantages"]  # configs[2]: the same workload on the host
         else:
             out["cpu_baseline"] = dict(port, reference_python=ref)
         if "single_env_api" in out:
             out["single_env_api"]["reference_python"] = ref["value"]
     if rank == 0:
+        out["summary"] = summarize(out)  # (last: the driver keeps the line's tail)
         emit(out)
     sharding.barrier()
 
@@ -1097,6 +1112,110 @@ def side_legs(args, torch, VecOvercookedEnv, sharding, dev):
     except Exception as exc:
         legs["3"]["roofline"]["traffic_source"] = {"how": "not collected", "why": repr(exc)[:200]}
     return legs
+
+
+def general_legs(args, torch, VecOvercookedEnv, sharding, dev):
+    """The batches OUTSIDE "two players, <= 2 pots, <= 64 cells, new dynamics, no event log" (VERDICT r5 #3): old dynamics — what
+    the reference's paper-reproduction runs use (human_aware_rl/ppo/run_experiments.sh:4-12; mdp.py:1517-1518, 1696-1701) —,
+    per-episode event logging (env.py:382-401 game_stats), and a 13 x 5 layout (65 cells).  Same launch shape as the headline
+    (65 536 envs x 4 000 fused steps), each with roofline and an oracle parity check."""
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    legs = {}
+    n, fuse = N_ENVS_PER_GPU, DEFAULT_FUSE
+    cases = (("coordination_ring_old_dynamics", lambda: LayoutTable([spec_from_name("coordination_ring", old_dynamics=True)]), {}),
+             ("asymmetric_advantages_old_dynamics", lambda: LayoutTable([spec_from_name("asymmetric_advantages", old_dynamics=True)]), {}),
+             ("cramped_room_event_log", lambda: LayoutTable([spec_from_name("cramped_room")]), {"track_events": True}),
+             ("marshmallow_experiment", lambda: LayoutTable([spec_from_name("marshmallow_experiment")]), {}))
+    for name, make_table, kw in cases:
+        try:
+            table = make_table()
+            wl = {"table": table, "specs": table.specs, "lid": None, "sbytes": 4 * ((table.n_planes * 16) // 4),
+                  "workload": "%s x %d envs, random policy, horizon %d auto-reset, outputs every step" % (name, n, HORIZON)}
+
+            def make_env():
+                return VecOvercookedEnv(table, n, horizon=HORIZON, device=dev, auto_reset=True, seed=0, **kw)
+
+            env = make_env()
+            rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
+            fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
+            a = argparse.Namespace(flags_layout=getattr(args, "flags_layout", "step"), stub=False)
+            tiled8 = flags_tiled8_ok(a, env, fuse, rew, fl)
+            fl_t = fl.view(fuse // 8, n, 8) if tiled8 else None
+
+            def launch():
+                if tiled8:
+                    env.rollout_random(fuse, rew, fl_t, flags_tiled8=True)
+                else:
+                    env.rollout_random(fuse, rew, fl)
+
+            launch()
+            k = launches_for(torch, dev, launch, args.leg_seconds)
+            wall, ms = timed_launches(torch, dev, sharding, launch, k)
+            ms = sorted(ms)
+            med = ms[len(ms) // 2]
+            bpl = n * (2 * wl["sbytes"] + OUT_BYTES * fuse)
+            leg = {"value": n * fuse * k / wall, "unit": "env steps/s (one GPU)", "envs": n, "launches": k, "launch_ms": med,
+                   "workload": wl["workload"], "flags_layout": "tiled8" if tiled8 else "[steps][envs]",
+                   "roofline": {"bound": "hbm", "achieved": bpl / (med * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": bpl / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": bpl}}
+            if not args.no_parity_check:
+                leg["parity_check"] = parity_check(torch, wl, make_env, n, 0, 1200, rew, fl, usable_cores(), tiled8=tiled8)
+            legs[name] = leg
+            del env, rew, fl
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            legs[name] = {"error": repr(exc)[:300]}
+    return legs
+
+
+def summarize(out):
+    """The line's claims in <= 1.2 KB, emitted as its LAST key so that a 2 000-character tail shows every one of them: per leg
+    G env-steps/s (1e9), roofline fraction, PMC traffic over algorithmic bytes, parity mismatches."""
+    def leg(d, scale=1e9):
+        if not isinstance(d, dict) or "error" in d or "roofline" not in d:
+            return {"error": True}
+        rl = d["roofline"]
+        r = {"G": round(d["value"] / scale, 2), "frac": round(rl["frac"], 3)}
+        if rl.get("traffic"):
+            r["t/a"] = round(rl["traffic"] / rl["bytes_per_launch"], 3)
+        pc = d.get("parity_check") or {}
+        if "mismatches" in pc or "mismatching_observations" in pc:
+            r["mis"] = pc.get("mismatches", pc.get("mismatching_observations"))
+        return r
+
+    sm = {"headline": leg(out)}
+    so = (out.get("roofline") or {}).get("store_only") or {}
+    if "rollout_over_store_only" in so:
+        sm["headline"]["over_store_only"] = round(so["rollout_over_store_only"], 3)
+    ib = (out.get("roofline") or {}).get("issue_bound")
+    if ib:
+        sm["wave_clk_per_env_step"] = ib.get("wave_clk_per_env_step")
+    for k, v in (out.get("configs") or {}).items():
+        sm["cfg" + k] = leg(v)
+    for k, v in (out.get("general_path") or {}).items():
+        sm[k] = leg(v)
+    try:
+        sa = out.get("step_api") or {}
+        if "launch_ms" in sa:
+            sm["step_api"] = {"us": round(sa["launch_ms"] * 1e3, 2), "frac": round(sa["frac"], 3),
+                              "many_frac": round((sa.get("step_many") or {}).get("frac", 0.0), 3)}
+            if "resident" in sa and "us_per_batched_step" in sa["resident"]:
+                sm["step_api"]["resident_us"] = round(sa["resident"]["us_per_batched_step"], 2)
+        enc = out.get("encode") or {}
+        sm["encode_frac"] = {k: round(v["frac"], 3) for k, v in enc.items() if isinstance(v, dict) and "frac" in v}
+        tr = out.get("training_env") or {}
+        sm["train_us"] = {k: round(v["us_per_batched_step"], 1) for k, v in tr.items() if isinstance(v, dict) and "us_per_batched_step" in v}
+        se = out.get("single_env_api") or {}
+        if "value" in se:
+            sm["single_env_steps_s"] = round(se["value"])
+    except Exception:
+        pass
+    cb = out.get("cpu_baseline") or {}
+    if cb:
+        sm["cpu"] = {"kind": cb.get("kind"), "value": round(cb.get("value", 0)), "cores": cb.get("cores"),
+                     "single_core": round(cb.get("single_core", 0)), "port": round((cb.get("port") or {}).get("value", 0))}
+    return sm
 
 
 def encode_measure(torch, VecOvercookedEnv, sharding, dev, rank, world, n, launches=0, warm_launches=2, seconds=0.0,
@@ -1224,6 +1343,7 @@ def run_encode_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world)
            "roofline": m["roofline"], "parity_check": m["parity_check"],
            "f32_observations": m.get("f32_observations"), "caller_actions_one_step": m.get("caller_actions_one_step")}
     if rank == 0:
+        out["summary"] = summarize(out)  # (last: the driver keeps the line's tail)
         emit(out)
     sharding.barrier()
 

@@ -42,11 +42,12 @@ constexpr size_t lds4_bytes(size_t cell_rows) {
     } while (0)
 
 // k_rollout5 (step_duo5.hpp): the per-env-terrain mover / interact kernel of round 6; two spare cell rows per lane
-#define GO5(LL, FT8F)                                                                                               \
+#define GO5(LL, FT8F) do { if (c.old_dyn) GO5X(LL, FT8F, true); else GO5X(LL, FT8F, false); } while (0)
+#define GO5X(LL, FT8F, OLDF)                                                                                        \
     do {                                                                                                            \
         const size_t smem5 = (size_t)Lds5<LL>::CELLS + ((size_t)c.n_obj * 16 + 2) * BLOCK * 4;                      \
-        if (!want_lds(k_rollout5<LL, FT8F>, smem5)) break;                                                          \
-        hipLaunchKernelGGL((k_rollout5<LL, FT8F>), grid4, dim3(2 * BLOCK), smem5, c.stream, b->d_layouts, b->n_layouts, \
+        if (!want_lds(k_rollout5<LL, FT8F, OLDF>, smem5)) break;                                                    \
+        hipLaunchKernelGGL((k_rollout5<LL, FT8F, OLDF>), grid4, dim3(2 * BLOCK), smem5, c.stream, b->d_layouts, b->n_layouts, \
                            b->d_layout_id, (uint4*)c.d_state, (float4*)c.d_rewards, c.d_flags, (float4*)c.d_ep_returns, \
                            b->n_envs, b->width, c.n_obj, c.horizon, c.options, (uint32_t)c.seed, (uint32_t)(c.seed >> 32), \
                            c.env_offset, c.t0, c.n_steps, c.sa);                                                    \

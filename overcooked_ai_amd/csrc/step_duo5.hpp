@@ -30,7 +30,8 @@
 //  * the pot in slot 1 has its own type, so an entry's START flag says WHICH countdown starts (no address compares).
 // Semantics are k_rollout4's / the oracle's: conflict replay for player 1, stale pot states for the usefulness predicate, the
 // same restart at the horizon (standard, drawn, or on a re-drawn layout).  Served batches: two players everywhere, <= 2 pots,
-// <= 64 cells, new dynamics, one set of shaping rewards, whole 256-env workgroups and 8-step blocks (what MODE 3 served).
+// <= 64 cells, one set of shaping rewards and ONE dynamics flag for the whole table (new or old), whole 256-env workgroups and
+// 8-step blocks.
 // ==========================================================================================
 constexpr int K5_TYPES = 9, K5_POT_B = 7, K5_NOTHING = 8, K5_ROW = 80, K5_KEYS = K5_TYPES * 6;
 constexpr int LUT5_BYTES = K5_KEYS * K5_ROW;  // 4 320
@@ -42,8 +43,10 @@ constexpr uint32_t REC5_DONE = 0x80000000u, REC5_SAME = Z5_CHG;  // the mover's 
 
 template <int LUT_BASE> constexpr uint32_t k16_of(int type5, int cls) { return (uint32_t)(LUT_BASE + (type5 * 6 + cls) * K5_ROW); }
 
+// old_dyn (mdp.py:1517-1518, 1696-1701): an INTERACT with an empty hand starts nothing; a pot that receives its third item starts
+// by itself in this step's env effects — the placement's entry leaves the pot COOKING and carries the START flag
 template <int LUT_BASE>
-constexpr Lut4Entry lut5_entry(int type5, int hc, int oc) {
+constexpr Lut4Entry lut5_entry(int old_dyn, int type5, int hc, int oc) {
     // selectors: 0 hand, 1 object (+ add), 2 / 3 K16 | 4 dispensed object, 6 / 7 new K16 | 0x0C zero
     uint32_t sel_h = 0, sel_o = 1, cobj = 0, flags = 0, add = 0, rew = RW4_NONE, hcn = (uint32_t)hc, take = 0;
     int nkey = -1, dd = 0, du = 0;  // new key (type, class) or -1 = unchanged; change of the loose-dish / useful-pot counts
@@ -61,7 +64,7 @@ constexpr Lut4Entry lut5_entry(int type5, int hc, int oc) {
     } else if (type5 == OC_T_DISH_DISP) {
         if (hc == 0) { sel_h = 4; cobj = OC_O_DISH; take = Z5_TAKE; hcn = 3; }
     } else if (pot) {
-        if (hc == 0 && oc >= PC_IDLE1 && oc <= PC_IDLE3) {               // begin_cooking (mdp.py:1515-1522)
+        if (hc == 0 && oc >= PC_IDLE1 && oc <= PC_IDLE3 && !old_dyn) {   // begin_cooking (mdp.py:1515-1522)
             nkey = PC_COOKING; flags = F5_CHG | (type5 == K5_POT_B ? F5_START_B : F5_START_A); du = oc == PC_IDLE3 ? 1 : 0;
         } else if (hc == 3 && oc == PC_READY) {                          // soup pickup (mdp.py:1525-1539)
             sel_h = 1; sel_o = 0x0C; nkey = PC_EMPTY; flags = F5_CHG | F5_PLATE; rew = RW4_PLATE; du = -1; hcn = 4;
@@ -69,6 +72,9 @@ constexpr Lut4Entry lut5_entry(int type5, int hc, int oc) {
             sel_h = 0x0C; nkey = oc + 1; flags = F5_CHG | F5_PLACE; rew = RW4_PLACE; hcn = 0;
             add = 8u + ((hc == 2 ? 1u : 0u) << oc) + (oc == 0 ? 0x80u : 0u);
             du = oc == 0 ? 1 : oc == 2 ? -1 : 0;
+            if (old_dyn && oc == PC_IDLE2) {  // the third item: cooking from this step's env effects on (two idle items -> cooking: as useful as before)
+                nkey = PC_COOKING; flags |= type5 == K5_POT_B ? F5_START_B : F5_START_A; du = 0;
+            }
         }
     } else if (type5 == OC_T_SERVE) {
         if (hc == 4) { sel_h = 0x0C; flags = F5_SERVE; hcn = 0; }        // deliver (mdp.py:1570-1577)
@@ -80,13 +86,14 @@ constexpr Lut4Entry lut5_entry(int type5, int hc, int oc) {
                      (hcn * 16u) | (add << 8) | (flags << 16) | take, rew};
 }
 template <int LUT_BASE>
-struct Lut5Table { Lut4Entry e[K5_KEYS][5]; };
+struct Lut5Table { Lut4Entry e[2][K5_KEYS][5]; };  // [old_dynamics][key][hand class]
 template <int LUT_BASE>
 constexpr Lut5Table<LUT_BASE> make_lut5() {
     Lut5Table<LUT_BASE> t{};
-    for (int type5 = 0; type5 < K5_TYPES; ++type5)
-        for (int oc = 0; oc < 6; ++oc)
-            for (int hc = 0; hc < 5; ++hc) t.e[type5 * 6 + oc][hc] = lut5_entry<LUT_BASE>(type5, hc, oc);
+    for (int od = 0; od < 2; ++od)
+        for (int type5 = 0; type5 < K5_TYPES; ++type5)
+            for (int oc = 0; oc < 6; ++oc)
+                for (int hc = 0; hc < 5; ++hc) t.e[od][type5 * 6 + oc][hc] = lut5_entry<LUT_BASE>(od, type5, hc, oc);
     return t;
 }
 
@@ -115,7 +122,9 @@ __device__ __forceinline__ uint32_t pot_type5(int k) { return k == 0 ? (uint32_t
 typedef uint16_t __attribute__((may_alias)) oc_u16_alias;
 __device__ __forceinline__ void cw5_wr_k16(uint32_t a, uint32_t k16) { *(OC_LDS oc_u16_alias*)(uintptr_t)(a + 2u) = (uint16_t)k16; }
 
-template <bool LAY_LDS, bool FT8>
+// OLD: the table's layouts use old dynamics (the LUT variant above; a pot that arrives idle with three items starts in the first
+//      step's env effects)
+template <bool LAY_LDS, bool FT8, bool OLD = false>
 __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_rollout5(
     const OcLayout* __restrict__ g_layouts, int n_layouts, const uint16_t* layout_id, uint4* st, float4* __restrict__ rewards,
     uint8_t* __restrict__ flags, float4* __restrict__ ep_returns, int64_t n, int W, int n_obj, int horizon, uint32_t options,
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
     const int64_t e = (int64_t)blk * BLOCK + tid;  // (the host launches whole workgroups of envs only)
     Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, true, s_lay);  // contains a barrier
     {
-        const uint4* src = reinterpret_cast<const uint4*>(&g_lut5);
+        const uint4* src = reinterpret_cast<const uint4*>(&g_lut5) + (OLD ? K5_KEYS * 5 : 0);
         for (int i = threadIdx.x; i < K5_KEYS * 5; i += 2 * BLOCK) {
             uint4 ent = src[i];  // one set of shaping rewards for the whole table: the entry carries the shaped reward itself
             ent.w = ent.w == RW4_PLACE ? __float_as_uint(L.rew_placement()) : ent.w == RW4_PLATE ? __float_as_uint(L.rew_soup()) : 0u;
@@ -271,6 +280,19 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
     // its class), N, the pots' countdowns (k_rollout4's: steps until ready, REM_IDLE when not cooking) and cell addresses
     uint32_t h0, h1, hz0, hz1, rem[MAXP], tk[MAXP], pa[MAXP], exotic = 0;
     int32_t N = 0;
+    // OLD: pots that arrive idle with three items start cooking in the coming step's env effects (mdp.py:1696-1701).  Nothing can be
+    // done to such a pot in that step (every interact with a full pot is a no-op), so it is set COOKING at once, with the countdown
+    // of a pot that starts in that step; only the usefulness predicate still sees it idle for one step: N gains it a step later
+    int32_t N_late = 0;
+    auto arrive_class = [&](uint32_t pc, uint32_t o, uint32_t& rem_k, uint32_t first_k8) __attribute__((always_inline)) {
+        if (OLD && pc == PC_IDLE3) {  // ripe when rem == (index of the step in its block) + 1; a zero cook time: ready with that first step
+            const uint32_t cook = cook_of(C, o);
+            rem_k = max(cook, 1u) + first_k8;
+            N_late += 1;
+            return (uint32_t)PC_COOKING;
+        }
+        return pc;
+    };
     auto hand_z = [](uint32_t code) __attribute__((always_inline)) { return min(code, 4u) * 16u; };
     auto pot_addrs = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -314,11 +336,12 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
             if ((uint32_t)k < C.n_pots) {
                 uint32_t o = cw5_obj(lds_rd32(pa[k]));
                 const uint32_t tkb = (h.z >> (8 * k)) & 0xFFu;
-                const uint32_t pc = pot_class(C, o, tkb);
+                uint32_t pc = pot_class(C, o, tkb);
                 if (o == OC_O_SOUP) { exotic |= 1u << k; o = 0; }  // a soup object without ingredients behaves as an empty pot
                 tk[k] = tkb;
                 rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) : REM_IDLE;
                 useful += (pc != PC_EMPTY && pc != PC_IDLE3) ? 1 : 0;
+                pc = arrive_class(pc, o, rem[k], 0u);
                 lds_wr32(pa[k], cw5(k16_of<M::LUT>(0, 0) + (pot_type5(k) * 6u + pc) * K5_ROW, o));
             }
         }
@@ -389,6 +412,8 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
         uint32_t nc0 = lds_rd32(nrec.x), nc1 = lds_rd32(nrec.y);  // the next step's cells: everything this step writes has been issued
         const int32_t N_mid = N + sext_b1(e0.y);
         int32_t N_new = N_mid + sext_b1(e1.y);
+        int32_t late_now = 0;  // OLD: pots that arrived idle and full count as useful from the step after their first one on
+        if (OLD) { late_now = N_late; N_late = 0; }
         // ---- ONE branch for everything rare: cooking starts, deliveries, dish pick-ups that may be useful (N < 0 before or
         //      after player 0's interact: no loose dish, some useful pot), a shared cell player 0 has changed, the horizon
         const uint32_t gate = ((uint32_t)(N | N_mid) & Z5_TAKE) | Z5_SERVE | Z5_START_A | Z5_START_B;
@@ -468,14 +493,16 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
                         rem[k] = REM_IDLE; tk[k] = 0;
                         if ((uint32_t)k < C.n_pots) {
                             const uint32_t o = d.pot_obj((uint32_t)k), tkb = d.tick((uint32_t)k);
-                            const uint32_t pc = pot_class(C, o, tkb);
+                            uint32_t pc = pot_class(C, o, tkb);
                             tk[k] = tkb;
                             rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) + (uint32_t)(k8 + 1) : REM_IDLE;
                             useful += (pc != PC_EMPTY && pc != PC_IDLE3) ? 1 : 0;
+                            pc = arrive_class(pc, o, rem[k], (uint32_t)(k8 + 1));
                             lds_wr32(pa[k], cw5(k16_of<M::LUT>(0, 0) + (pot_type5(k) * 6u + pc) * K5_ROW, o));
                         }
                     }
                     N_new = -useful;
+                    late_now = 0;  // (pots drawn idle and full for the new episode: N_late, from the next step on)
                     nh0 = d.held0; nh1 = d.held1;
                     nz0 = hand_z(d.held0); nz1 = hand_z(d.held1);
                     ep = zero4;  // the episode ends with this step: its returns restart from zero
@@ -494,7 +521,7 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
         }
         if (k8 < 7) { pend.lo = q_lo; pend.hi = q_hi; }
         else { const Pend now = {q_lo, q_hi}; flush(now, 7); }
-        h0 = nh0; h1 = nh1; hz0 = nz0; hz1 = nz1; N = N_new;
+        h0 = nh0; h1 = nh1; hz0 = nz0; hz1 = nz1; N = N_new - late_now;
         fo0 = nrec.x; fo1 = nrec.y; f_rec = nrec.z; c0 = nc0; c1 = nc1;
         step_k += 1u;
     };

@@ -457,6 +457,9 @@ __device__ __forceinline__ void env_reset4_draw(const LayC& C, const Lay L, int 
             const uint32_t pc = pot_class(C, o, tkb);
             s.tk[k] = tkb;
             s.rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) : REM_IDLE;
+            // old dynamics: a pot drawn idle with three items starts in the new episode's first step, as one that arrives so in the
+            // loaded state (round 6: this line was missing — such pots never started after an in-kernel restart)
+            if (C.old_dyn && pc == PC_IDLE3) s.pending |= 1u << k;
             cw_wr<CW>(col + s.poff[k], cw_make<CW>(o, KB_POT + pc));
         }
     }

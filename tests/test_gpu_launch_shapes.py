@@ -145,18 +145,27 @@ def test_tiled_flags_launch_shapes_against_oracle(shape, gpu):
 
 @pytest.mark.parametrize("tiled", [False, True])
 @pytest.mark.parametrize("layout", ["cramped_room", "asymmetric_advantages", "coordination_ring", "forced_coordination",
-                                    "counter_circuit", "mix5", "generated_4096"])
+                                    "counter_circuit", "mix5", "generated_4096", "cramped_room_old", "coordination_ring_old",
+                                    "asymmetric_advantages_old", "mix4_old"])
 def test_mover_interact_split_against_oracle(layout, tiled, gpu):
-    """k_rollout4 MODE 3 / 4 (two wavefronts per 64 envs: a mover running ahead of an interact wavefront through a ring in LDS) on
-    every batch kind it serves — cramped_room (MODE 4: the mover reads the joint move table), single two-player layouts, the
-    5-layout table in LDS, 4 096 generated terrains read through L2 (MODE 3: the mover moves on a floor mask) — against the oracle over episodes of 23 steps with DRAWN start states (so that every restart exercises the mover's own
-    draw of the start pose), tiled and [step][env] flags; then the same launch with OC_OPT_ONE_WAVEFRONT must agree as well."""
+    """k_rollout5 (two wavefronts per 64 envs: a mover running ahead of an interact wavefront through a ring in LDS) on every batch
+    kind it serves — cramped_room, single two-player layouts, the 5-layout table in LDS, 4 096 generated terrains read through L2,
+    and the same with OLD dynamics (pots that start by themselves with their third item; drawn start states bring pots that arrive
+    idle and full) — against the oracle over episodes of 23 steps with DRAWN start states (so that every restart exercises the
+    mover's own draw of the start pose), tiled and [step][env] flags; then the same launch with OC_OPT_ONE_WAVEFRONT must agree."""
     from overcooked_ai_amd.layout_gen import reference_generated_layouts
-    from overcooked_ai_amd.layouts import LayoutTable
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
 
     n, rank = 4096, 2
     if layout == "mix5":
         table, lid = _mix_table_and_ids(n, rank)
+    elif layout == "mix4_old":
+        # (the canonical layouts whose orders all have three items: old dynamics accepts no others, mdp.py:1121-1127)
+        names = ("cramped_room", "asymmetric_advantages", "coordination_ring", "forced_coordination")
+        table = LayoutTable([spec_from_name(nm, old_dynamics=True) for nm in names], pad_to=(9, 5))
+        lid = ((np.arange(n) + rank * n) % len(names)).astype(np.uint16)
+    elif layout.endswith("_old"):
+        table, lid = LayoutTable([spec_from_name(layout[:-4], old_dynamics=True)]), None
     elif layout == "generated_4096":
         table, lid = LayoutTable(reference_generated_layouts(4096)), ((np.arange(n) * 5 + 1) % 4096).astype(np.uint16)
     else:
@@ -165,7 +174,9 @@ def test_mover_interact_split_against_oracle(layout, tiled, gpu):
               start={"random_start_pos": True, "rnd_obj_prob_thresh": 0.35}, random_start_pos=True, rnd_obj_prob_thresh=0.35)
     a = _long_launch_against_oracle(gpu, table, n, flags_tiled8=tiled, **kw)
     # (single layouts get the tiled flags from the split kernel only: their one-wavefront run writes [step][env] rows)
-    b = _long_launch_against_oracle(gpu, table, n, flags_tiled8=tiled and lid is not None, one_wavefront=True, **kw)
+    # (... and old dynamics in one wavefront is MODE 0: [step][env] rows as well)
+    b = _long_launch_against_oracle(gpu, table, n, flags_tiled8=tiled and lid is not None and not layout.endswith("_old"),
+                                    one_wavefront=True, **kw)
     assert a == b
     # standard start states, a launch that begins in the middle of an episode (t0 = 96 from the env's own counter)
     _long_launch_against_oracle(gpu, table, n, lid=lid, env_offset=rank * n, seed=3, steps=416, horizon=HORIZON, flags_tiled8=tiled)

@@ -15,26 +15,34 @@ names = (sys.argv[1] if len(sys.argv) > 1 else "asymmetric_advantages").split(",
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 dev = torch.device("cuda:0")
-table = LayoutTable([spec_from_name(nm) for nm in names], pad_to=(9, 5) if len(names) > 1 else None)
-lid = (np.arange(n) % len(names)).astype(np.uint16)
-env = VecOvercookedEnv(table, n, horizon=400, device=dev, auto_reset=True, seed=0, layout_id=lid if len(names) > 1 else None)
+OLD = os.environ.get("OLD") == "1"  # OLD=1: old dynamics; DRAW=0.35: drawn start states with that rnd_obj_prob_thresh; HORIZON
+DRAW = float(os.environ.get("DRAW", "0"))
+HZ = int(os.environ.get("HORIZON", "400"))
+SEED, OFF, FUSE = int(os.environ.get("SEED", "0")), int(os.environ.get("ENV_OFFSET", "0")), int(os.environ.get("FUSE", "8"))
+table = LayoutTable([spec_from_name(nm, old_dynamics=True) if OLD else spec_from_name(nm) for nm in names],
+                    pad_to=(9, 5) if len(names) > 1 else None)
+lid = ((np.arange(n) + OFF) % len(names)).astype(np.uint16)
+kw = dict(random_start_pos=True, rnd_obj_prob_thresh=DRAW) if DRAW else {}
+env = VecOvercookedEnv(table, n, horizon=HZ, device=dev, auto_reset=True, seed=SEED, env_offset=OFF, layout_id=lid if len(names) > 1 else None, **kw)
+env.one_wavefront = os.environ.get("ONE_WAVEFRONT") == "1"
 orc = O.Oracle([O.mdp_from_layout_dict(s.to_layout_dict()) for s in table.specs])
 lid_o = lid if len(names) > 1 else None
-st = orc.reset(orc.new_state(n), layout_id=lid_o)
-rew = torch.zeros((8, n, 4), dtype=torch.float32, device=dev)
-fl = torch.zeros((8, n), dtype=torch.uint8, device=dev)
+st = env.get_packed_state().copy() if DRAW else orc.reset(orc.new_state(n), layout_id=lid_o)
+rew = torch.zeros((FUSE, n, 4), dtype=torch.float32, device=dev)
+fl = torch.zeros((FUSE, n), dtype=torch.uint8, device=dev)
 W, H = orc.W, orc.H
-for t in range(0, T, 8):
+for t in range(0, T, FUSE):
     prev = st.copy()
-    env.rollout_random(8, rew, fl)
+    env.rollout_random(FUSE, rew, fl)
     got = env.get_packed_state()
     # oracle step by step to find the exact step
     cur = prev.copy()
     states = [cur.copy()]
     rews = []
-    for k in range(8):
-        a = O.random_actions(0, 0, t + k, n)
-        cur, r, f = orc.step(cur, a, horizon=400, options=1, layout_id=lid_o)
+    for k in range(FUSE):
+        a = O.random_actions(SEED, OFF, t + k, n)
+        sp = O.start_spec(seed=SEED, env_offset=OFF, epoch=1 + t + k, random_start_pos=True, rnd_obj_prob_thresh=DRAW) if DRAW else None
+        cur, r, f = orc.step(cur, a, horizon=HZ, options=1, layout_id=lid_o, start=sp)
         states.append(cur.copy())
         rews.append(r)
     st = cur
@@ -46,8 +54,10 @@ for t in range(0, T, 8):
         envs = sorted(set(int(x[1]) for x in bad_r) | set(int(x[1]) for x in bad_s))[:3]
         for e in envs:
             print("== env %d layout %s" % (e, names[lid[e]]))
-            for k in range(8):
-                a = O.random_actions(0, 0, t + k, n)[e]
+            ks = sorted(set(int(x[0]) for x in bad_r if int(x[1]) == e))
+            k_lo = max(0, (ks[0] if ks else FUSE - 8) - 6)
+            for k in range(k_lo, min(FUSE, k_lo + 10)):
+                a = O.random_actions(SEED, OFF, t + k, n)[e]
                 s0 = states[k][:, e, :]
                 print(" t=%d actions %s  hdr %s" % (t + k, a.tolist(), s0[0].tolist()))
                 cells = np.concatenate([s0[1 + p] for p in range(orc.n_planes - 1)])[:W * H].reshape(H, W)
