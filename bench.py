@@ -97,6 +97,12 @@ def parse():
                          "1 200 steps per rank otherwise)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not collect roofline.traffic with rocprofv3 --pmc child passes of this same launch shape")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend of a multi-rank run (nccl = RCCL: what the driver's scaling runs use; gloo: rehearsals)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: rank r runs on GPU r %% device_count (with --backend gloo: RCCL "
+                         "refuses two ranks on one device).  Exercises the per-rank path — process group, env_offset, NUMA pinning, "
+                         "per-rank parity, the metric reductions — with real kernels; it says NOTHING about scaling or xGMI")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # internal: the process rocprofv3 wraps
     return ap.parse_args()
 
@@ -707,7 +713,7 @@ def main():
         # every rank may do it: the build writes a per-process temp file and renames it atomically
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X; there is no CPU path")
-        if args.gpus > torch.cuda.device_count():
+        if args.gpus > torch.cuda.device_count() and not args.share_device:
             raise SystemExit("--gpus %d but only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
     else:
         VecOvercookedEnv = None
@@ -722,7 +728,9 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
     try:
-        rank, local_rank, world = sharding.init_process_group("gloo" if args.stub else None)
+        if args.share_device and not args.stub:  # (before the process group: nccl would set_device(local_rank))
+            os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+        rank, local_rank, world = sharding.init_process_group("gloo" if args.stub or args.backend == "gloo" else None)
         if sharding._live():
             if not args.stub:
                 torch.cuda.set_device(local_rank)
@@ -744,9 +752,10 @@ def main():
     if sharding._live():
         import torch.distributed as dist
 
-        if dist.get_world_size() != args.gpus or (not args.stub and dist.get_backend() != "nccl"):
-            raise SystemExit("process group has %d ranks over %s; expected %d over nccl (RCCL)"
-                             % (dist.get_world_size(), dist.get_backend(), args.gpus))
+        want = "gloo" if args.stub else args.backend
+        if dist.get_world_size() != args.gpus or dist.get_backend() != want:
+            raise SystemExit("process group has %d ranks over %s; expected %d over %s"
+                             % (dist.get_world_size(), dist.get_backend(), args.gpus, want))
     dev = torch.device("cpu") if args.stub else torch.device("cuda", local_rank)
     numa = None
     if not args.stub:
@@ -980,7 +989,11 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
                    "flags_layout": "[steps/8][envs][8] (OC_OPT_FLAGS_TILED8: the flag bytes of 8 steps of an env side by side; "
                                    "17 B per env-step as before; parity_check untiles them)" if tiled8 else "[steps][envs]",
                    "envs_per_gpu": n, "fused_transitions_per_launch": fuse, "launches_per_step": lps, "launches": launches,
-                   "parallelism": "env-shard x%d" % world, "numa_node_rank0": numa,
+                   "parallelism": "env-shard x%d" % world + (
+                       " — %d ranks SHARING %d GPU(s) over %s: a rehearsal of the per-rank path (process group, env_offset, NUMA "
+                       "pinning, per-rank parity, metric reductions) with real kernels; NOT a scaling measurement, nothing about xGMI"
+                       % (world, torch.cuda.device_count(), args.backend) if getattr(args, "share_device", False) else ""),
+                   "backend": ("gloo" if args.stub else args.backend) if world > 1 else None, "numa_node_rank0": numa,
                    "step_definition": "one bench step = %d back-to-back oc_rollout_random launches of %d transitions = %d "
                                       "batched transitions of all %d envs of a GPU (%d episodes per env); exactly --steps of "
                                       "them are timed after --warmup untimed ones; value = n_gpus x envs x transitions / wall "
@@ -997,7 +1010,7 @@ def run_rollout_config(args, torch, VecOvercookedEnv, sharding, dev, rank, world
         "device_ms_timed_region": dev_ms,
         "aggregate": {"sparse_return_last_launch": float(metrics[0]), "shaped_return_last_launch": float(metrics[1]),
                       "episodes_done_last_step": float(metrics[2]),
-                      "reduced_over": ("RCCL all-reduce" if not args.stub else "gloo all-reduce") if sharding._live() else "single rank"},
+                      "reduced_over": ("RCCL all-reduce" if not args.stub and args.backend == "nccl" else "gloo all-reduce") if sharding._live() else "single rank"},
     }
 
     side = rank == 0 and world == 1 and not args.no_extras and not args.stub and args.config == 2

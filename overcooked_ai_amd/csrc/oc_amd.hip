@@ -428,11 +428,12 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         c.joint = uniform && two && b->max_pots == 1 && b->max_free_cells >= 2 && b->max_free_cells <= 6u && c.out &&
                   !c.old_dyn && n_steps >= 8 && !c.events;
         const bool shaping_uniform = uniform || (b->batch_flags & OC_BATCH_UNIFORM_SHAPING) != 0;
-        // what the per-env-terrain kernels serve: two players everywhere, at most two pots and 64 cells, one set of shaping rewards,
-        // both output arrays (a one-pot joint-table layout is such a batch too)
+        // what the per-env-terrain kernels serve: two players everywhere, at most two pots, 64 cells (k_rollout5: 128 with the table
+        // in LDS), one set of shaping rewards, both output arrays (a one-pot joint-table layout is such a batch too)
         // (one dynamics flag for the whole table — OC_BATCH_UNIFORM_SHAPING —: old dynamics is served by k_rollout5, not by MODE 2)
-        const bool terrain_ok = two && c.out && small && shaping_uniform && b->width * b->height <= 64 && !c.events && !no_mode2;
-        const bool mode2 = !c.joint && terrain_ok && !c.old_dyn;
+        const int n_cells = b->width * b->height;
+        const bool terrain_ok = two && c.out && small && shaping_uniform && (n_cells <= 64 || (n_cells <= 128 && lds)) && !c.events && !no_mode2;
+        const bool mode2 = !c.joint && terrain_ok && !c.old_dyn && n_cells <= 64;
         // k_rollout5 (step_duo5.hpp): the step split between mover and interact wavefronts — whole workgroups of envs (every
         // wavefront meets every barrier) and whole 8-step blocks; a workgroup's 127-154 KB of LDS leave room for one per CU.
         // Bigger batches run these workgroups in ROUNDS, one per CU at a time — the next round's workgroups start as the first ones

@@ -42,12 +42,13 @@ constexpr size_t lds4_bytes(size_t cell_rows) {
     } while (0)
 
 // k_rollout5 (step_duo5.hpp): the per-env-terrain mover / interact kernel of round 6; two spare cell rows per lane
-#define GO5(LL, FT8F) do { if (c.old_dyn) GO5X(LL, FT8F, true); else GO5X(LL, FT8F, false); } while (0)
-#define GO5X(LL, FT8F, OLDF)                                                                                        \
+#define GO5(LL, FT8F) do { if (c.old_dyn) GO5X(LL, FT8F, true, false); else GO5X(LL, FT8F, false, false); } while (0)
+#define GO5BIG(FT8F) do { if (c.old_dyn) GO5X(true, FT8F, true, true); else GO5X(true, FT8F, false, true); } while (0)
+#define GO5X(LL, FT8F, OLDF, BIGF)                                                                                  \
     do {                                                                                                            \
-        const size_t smem5 = (size_t)Lds5<LL>::CELLS + ((size_t)c.n_obj * 16 + 2) * BLOCK * 4;                      \
-        if (!want_lds(k_rollout5<LL, FT8F, OLDF>, smem5)) break;                                                    \
-        hipLaunchKernelGGL((k_rollout5<LL, FT8F, OLDF>), grid4, dim3(2 * BLOCK), smem5, c.stream, b->d_layouts, b->n_layouts, \
+        const size_t smem5 = (size_t)Lds5<LL>::CELLS + ((size_t)c.n_obj * 16 + 2) * BLOCK * (BIGF ? 2 : 4);         \
+        if (!want_lds(k_rollout5<LL, FT8F, OLDF, BIGF>, smem5)) break;                                              \
+        hipLaunchKernelGGL((k_rollout5<LL, FT8F, OLDF, BIGF>), grid4, dim3(2 * BLOCK), smem5, c.stream, b->d_layouts, b->n_layouts, \
                            b->d_layout_id, (uint4*)c.d_state, (float4*)c.d_rewards, c.d_flags, (float4*)c.d_ep_returns, \
                            b->n_envs, b->width, c.n_obj, c.horizon, c.options, (uint32_t)c.seed, (uint32_t)(c.seed >> 32), \
                            c.env_offset, c.t0, c.n_steps, c.sa);                                                    \
@@ -91,7 +92,8 @@ void launch_rollout4_mode2(const Rollout4Call& c) {
         if (c.pipe) GO4(U, MP, LL, 2, true, false, 0, false, true, RUF, 4); else GO4(U, MP, LL, 2, true, false, 0, false, false, RUF); \
     } while (0)
     if (c.duo) {  // whole workgroups of envs, whole 8-step blocks, at most one workgroup per CU: mover + interact wavefronts
-        if (c.lds) { if (c.tiled8) GO5(true, true); else GO5(true, false); }
+        if (b->width * b->height > 64) { if (c.tiled8) GO5BIG(true); else GO5BIG(false); }  // (65..128 cells: tables in LDS only)
+        else if (c.lds) { if (c.tiled8) GO5(true, true); else GO5(true, false); }
         else { if (c.tiled8) GO5(false, true); else GO5(false, false); }
         return;
     }

@@ -45,9 +45,11 @@ template <int LUT_BASE> constexpr uint32_t k16_of(int type5, int cls) { return (
 
 // old_dyn (mdp.py:1517-1518, 1696-1701): an INTERACT with an empty hand starts nothing; a pot that receives its third item starts
 // by itself in this step's env effects — the placement's entry leaves the pot COOKING and carries the START flag
+// big (grids of 65..128 cells: 16-bit cell words [key][object], key = 6 * type + class, the LUT row at 80 * key): the same entry
+// with the result laid out as [0][new hand][new key][new object] and the pool as [0][hand][key][object + add]
 template <int LUT_BASE>
-constexpr Lut4Entry lut5_entry(int old_dyn, int type5, int hc, int oc) {
-    // selectors: 0 hand, 1 object (+ add), 2 / 3 K16 | 4 dispensed object, 6 / 7 new K16 | 0x0C zero
+constexpr Lut4Entry lut5_entry(int big, int old_dyn, int type5, int hc, int oc) {
+    // what the new hand / object are taken from: 0 the hand, 1 the object (+ add), 4 the dispensed object, 0x0C zero
     uint32_t sel_h = 0, sel_o = 1, cobj = 0, flags = 0, add = 0, rew = RW4_NONE, hcn = (uint32_t)hc, take = 0;
     int nkey = -1, dd = 0, du = 0;  // new key (type, class) or -1 = unchanged; change of the loose-dish / useful-pot counts
     const bool pot = type5 == OC_T_POT || type5 == K5_POT_B;
@@ -79,21 +81,29 @@ constexpr Lut4Entry lut5_entry(int old_dyn, int type5, int hc, int oc) {
     } else if (type5 == OC_T_SERVE) {
         if (hc == 4) { sel_h = 0x0C; flags = F5_SERVE; hcn = 0; }        // deliver (mdp.py:1570-1577)
     }
+    const int dn = 64 * dd - du;
+    const uint32_t z = (hcn * 16u) | (add << 8) | (flags << 16) | take;
+    if (big) {  // pool bytes: 0 object (+ add), 1 key, 2 hand; constants (.y): byte 0 dispensed object, byte 1 new key, byte 2 delta N
+        auto at = [](uint32_t sel) { return sel == 0u ? 2u : sel == 1u ? 0u : sel; };  // (4 = .y byte 0, 0x0C = zero: as they are)
+        const uint32_t sel_k = nkey < 0 ? 1u : 5u;
+        return Lut4Entry{at(sel_o) | (sel_k << 8) | (at(sel_h) << 16) | (0x0Cu << 24),
+                         cobj | ((nkey < 0 ? 0u : (uint32_t)(type5 * 6 + nkey)) << 8) | (((uint32_t)dn & 0xFFu) << 16), z, rew};
+    }
+    // pool bytes: 0 hand, 1 object (+ add), 2 / 3 K16; constants (.y): byte 0 dispensed object, byte 1 delta N, bytes 2 / 3 new K16
     const uint32_t nk16 = nkey < 0 ? 0u : k16_of<LUT_BASE>(type5, nkey);
     const uint32_t sel_k = nkey < 0 ? 0x0302u : 0x0706u;
-    const int dn = 64 * dd - du;
-    return Lut4Entry{sel_h | (sel_o << 8) | (sel_k << 16), cobj | (((uint32_t)dn & 0xFFu) << 8) | (nk16 << 16),
-                     (hcn * 16u) | (add << 8) | (flags << 16) | take, rew};
+    return Lut4Entry{sel_h | (sel_o << 8) | (sel_k << 16), cobj | (((uint32_t)dn & 0xFFu) << 8) | (nk16 << 16), z, rew};
 }
 template <int LUT_BASE>
-struct Lut5Table { Lut4Entry e[2][K5_KEYS][5]; };  // [old_dynamics][key][hand class]
+struct Lut5Table { Lut4Entry e[2][2][K5_KEYS][5]; };  // [big][old_dynamics][key][hand class]
 template <int LUT_BASE>
 constexpr Lut5Table<LUT_BASE> make_lut5() {
     Lut5Table<LUT_BASE> t{};
-    for (int od = 0; od < 2; ++od)
-        for (int type5 = 0; type5 < K5_TYPES; ++type5)
-            for (int oc = 0; oc < 6; ++oc)
-                for (int hc = 0; hc < 5; ++hc) t.e[od][type5 * 6 + oc][hc] = lut5_entry<LUT_BASE>(od, type5, hc, oc);
+    for (int big = 0; big < 2; ++big)
+        for (int od = 0; od < 2; ++od)
+            for (int type5 = 0; type5 < K5_TYPES; ++type5)
+                for (int oc = 0; oc < 6; ++oc)
+                    for (int hc = 0; hc < 5; ++hc) t.e[big][od][type5 * 6 + oc][hc] = lut5_entry<LUT_BASE>(big, od, type5, hc, oc);
     return t;
 }
 
@@ -110,21 +120,40 @@ struct Lds5 {
 };
 __device__ const Lut5Table<0> g_lut5 = make_lut5<0>();
 
-// class of what lies on a counter; the key of (terrain byte, object) for cells that are not pots
+// class of what lies on a counter
 __device__ __forceinline__ uint32_t counter_class5(uint32_t o) { return o == 0u ? 0u : (o & OC_O_SOUP) ? 4u : o; }
-__device__ __forceinline__ uint32_t cw5(uint32_t k16, uint32_t obj) { return (k16 << 16) | (obj << 8); }
-__device__ __forceinline__ uint32_t cw5_obj(uint32_t w) { return (w >> 8) & 0xFFu; }
-// pot class from the word of a pot cell of type `type5` (x / 80 for x = 0, 80 .. 400)
-__device__ __forceinline__ uint32_t cw5_pot_class(uint32_t w, uint32_t type5) { return (((w >> 16) - type5 * 480u) * 205u) >> 14; }
 __device__ __forceinline__ uint32_t pot_type5(int k) { return k == 0 ? (uint32_t)OC_T_POT : (uint32_t)K5_POT_B; }
-// the K16 half of a cell word (a 16-bit store into words that are otherwise read and written as u32: may_alias keeps it ordered
-// between them — under strict aliasing the compiler moved the next step's cell reads in front of it)
+// (stores of a part of a cell word between whole-word reads and writes: may_alias keeps them ordered — under strict aliasing
+//  the compiler moved the next step's cell reads in front of a uint16_t store)
 typedef uint16_t __attribute__((may_alias)) oc_u16_alias;
-__device__ __forceinline__ void cw5_wr_k16(uint32_t a, uint32_t k16) { *(OC_LDS oc_u16_alias*)(uintptr_t)(a + 2u) = (uint16_t)k16; }
+// The two cell-word formats.  BIG = false: u32 [K16][object][junk], K16 = LDS address of the key's LUT row (LUT at address 0);
+// BIG = true (grids of 65..128 cells): u16 [key][object]
+template <bool BIG>
+struct Cw5 {
+    static constexpr uint32_t BYTES = BIG ? 2u : 4u, CS = (uint32_t)BLOCK * BYTES;  // CS: bytes between two cells' words in a lane's column
+    static constexpr int HAND_BYTE = BIG ? 2 : 0;  // where a result word carries the hand
+    static __device__ __forceinline__ uint32_t make(uint32_t type5, uint32_t cls, uint32_t obj) {
+        return BIG ? (((type5 * 6u + cls) << 8) | obj) : (((type5 * 6u + cls) * K5_ROW << 16) | (obj << 8));
+    }
+    static __device__ __forceinline__ uint32_t rd(uint32_t a) { return BIG ? lds_rd16(a) : lds_rd32(a); }
+    static __device__ __forceinline__ void wr(uint32_t a, uint32_t w) { if (BIG) *(OC_LDS oc_u16_alias*)(uintptr_t)a = (uint16_t)w; else lds_wr32(a, w); }
+    static __device__ __forceinline__ uint32_t obj(uint32_t w) { return BIG ? (w & 0xFFu) : ((w >> 8) & 0xFFu); }
+    static __device__ __forceinline__ uint32_t hand(uint32_t r) { return (r >> (8 * HAND_BYTE)) & 0xFFu; }
+    // pot class from the word of a pot cell of type `type5` (x / 80 for x = 0, 80 .. 400)
+    static __device__ __forceinline__ uint32_t pot_class(uint32_t w, uint32_t type5) {
+        return BIG ? ((w >> 8) & 0xFFu) - type5 * 6u : ((((w >> 16) - type5 * 480u) * 205u) >> 14);
+    }
+    // the key part of a cell word alone
+    static __device__ __forceinline__ void wr_key(uint32_t a, uint32_t type5, uint32_t cls) {
+        if (BIG) lds_wr8(a + 1u, type5 * 6u + cls);
+        else *(OC_LDS oc_u16_alias*)(uintptr_t)(a + 2u) = (uint16_t)((type5 * 6u + cls) * K5_ROW);
+    }
+};
 
 // OLD: the table's layouts use old dynamics (the LUT variant above; a pot that arrives idle with three items starts in the first
 //      step's env effects)
-template <bool LAY_LDS, bool FT8, bool OLD = false>
+// BIG: grids of 65..128 cells (16-bit cell words, a 128-bit floor mask in the mover)
+template <bool LAY_LDS, bool FT8, bool OLD = false, bool BIG = false>
 __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_rollout5(
     const OcLayout* __restrict__ g_layouts, int n_layouts, const uint16_t* layout_id, uint4* st, float4* __restrict__ rewards,
     uint8_t* __restrict__ flags, float4* __restrict__ ep_returns, int64_t n, int W, int n_obj, int horizon, uint32_t options,
@@ -135,14 +164,16 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
     uint4* const s_lay = reinterpret_cast<uint4*>(s_dyn5 + M::LAY);
     uint4* const s_lut = reinterpret_cast<uint4*>(s_dyn5 + M::LUT);
     constexpr int MAXP = 2;
-    constexpr uint32_t CS = (uint32_t)BLOCK * 4u;  // bytes between two cells' words in a lane's column
+    using CW = Cw5<BIG>;
+    constexpr uint32_t CS = CW::CS;
+    static_assert(M::LUT == 0, "K16 = 80 * key: the LUT starts at LDS address 0");
     const uint32_t tid = threadIdx.x & (uint32_t)(BLOCK - 1);  // lanes tid of the two halves share env e: threads 0..255 interact, the others move
     const bool mover = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
     const uint32_t blk = xcd_block();
     const int64_t e = (int64_t)blk * BLOCK + tid;  // (the host launches whole workgroups of envs only)
     Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, e, true, s_lay);  // contains a barrier
     {
-        const uint4* src = reinterpret_cast<const uint4*>(&g_lut5) + (OLD ? K5_KEYS * 5 : 0);
+        const uint4* src = reinterpret_cast<const uint4*>(&g_lut5) + ((BIG ? 2 : 0) + (OLD ? 1 : 0)) * (K5_KEYS * 5);
         for (int i = threadIdx.x; i < K5_KEYS * 5; i += 2 * BLOCK) {
             uint4 ent = src[i];  // one set of shaping rewards for the whole table: the entry carries the shaped reward itself
             ent.w = ent.w == RW4_PLACE ? __float_as_uint(L.rew_placement()) : ent.w == RW4_PLATE ? __float_as_uint(L.rew_soup()) : 0u;
@@ -151,7 +182,7 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
     }
     if (threadIdx.x < 8) reinterpret_cast<uint32_t*>(s_dyn5 + M::SYNC)[threadIdx.x] = 0u;
     __syncthreads();
-    const uint32_t col = (uint32_t)M::CELLS + tid * 4u;  // LDS address of this lane's column of cell words
+    const uint32_t col = (uint32_t)M::CELLS + tid * CW::BYTES;  // LDS address of this lane's column of cell words
     const uint32_t dummy = col + (uint32_t)n_obj * 16u * CS, noact = dummy + CS;  // two spare words per lane behind the grid
     LayC C = load_consts<false>(L);
     const uint32_t delta4 = make_delta4(W);
@@ -172,15 +203,23 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
         return oc_rec3{xy.x, xy.y, lds_rd32(ring_f + buf + k * SLOT_F)};
     };
     const int n_blocks = n_steps >> 3;
+    struct FloorMask { uint64_t lo, hi; };  // bit c = cell c is floor (static per layout); hi: cells 64..127 (BIG)
     auto floor_mask_of = [&](const Lay Lx) __attribute__((always_inline)) {
-        uint64_t m = 0;
+        FloorMask m = {0ull, 0ull};
         for (int i = 0; i < n_obj * 4; ++i) {
             const uint32_t T = Lx.u32(L_TERRAIN + 4 * i);
 #pragma unroll
             for (int b = 0; b < 4; ++b)
-                if (((T >> (8 * b)) & 7u) == OC_T_FLOOR && (uint32_t)(4 * i + b) < Lx.u8(L_NCELLS)) m |= 1ull << (4 * i + b);
+                if (((T >> (8 * b)) & 7u) == OC_T_FLOOR && (uint32_t)(4 * i + b) < Lx.u8(L_NCELLS)) {
+                    if (4 * i + b < 64) m.lo |= 1ull << (4 * i + b); else m.hi |= 1ull << ((4 * i + b) & 63);
+                }
         }
         return m;
+    };
+    auto is_floor = [](const FloorMask& m, uint32_t c) __attribute__((always_inline)) {
+        uint32_t fb = (uint32_t)((BIG && c >= 64u ? m.hi : m.lo) >> (c & 63u));
+        asm("" : "+v"(fb));  // (tested as a 32-bit value: k_rollout4 MODE 2)
+        return (fb & 1u) != 0u;
     };
 
     // ---- the MOVER wavefronts: resolve_movement (mdp.py:1644-1727) for the whole launch, one 8-step block at a time, up to
@@ -194,7 +233,7 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
         const uint32_t t_in = h.y >> 16;
         uint32_t tleft = t_in < (uint32_t)horizon ? (uint32_t)horizon - 1u - t_in : 0u;
         uint32_t over = t_in < (uint32_t)horizon ? 0u : t_in - ((uint32_t)horizon - 1u);
-        uint64_t fm = floor_mask_of(L);
+        FloorMask fm = floor_mask_of(L);
         uint32_t flg_off[8];
 #pragma unroll
         for (int k8 = 0; k8 < 8; ++k8) flg_off[k8] = lane + (uint32_t)k8 * (uint32_t)n;
@@ -215,10 +254,7 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
                 const uint32_t rec0 = a0 == 5u ? f0 : noact, rec1 = a1 == 5u ? f1 : noact;
                 const uint32_t f_same = rec0 == rec1 ? (a0 == 5u ? REC5_SAME : 0u) : 0u;
                 const uint32_t t0_ = ahead(P0, a0), t1_ = ahead(P1, a1);
-                uint32_t fb0 = (uint32_t)(fm >> t0_), fb1 = (uint32_t)(fm >> t1_);
-                asm("" : "+v"(fb0));
-                asm("" : "+v"(fb1));
-                const uint32_t np0 = (fb0 & 1u) ? t0_ : P0, np1 = (fb1 & 1u) ? t1_ : P1;
+                const uint32_t np0 = is_floor(fm, t0_) ? t0_ : P0, np1 = is_floor(fm, t1_) ? t1_ : P1;
                 const bool collide = (np0 == np1) | ((np0 == P1) & (np1 == P0));
                 const uint32_t q0 = collide ? P0 : np0, q1 = collide ? P1 : np1;
                 O0 = a0 < 4u ? a0 : O0; O1 = a1 < 4u ? a1 : O1;
@@ -303,13 +339,14 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
         for (int c = 0; c < n_obj * 16; ++c) {
             const uint32_t tb = L.terrain((uint32_t)c), type = tb & 7u;
             const uint32_t type5 = (type == OC_T_POT && (tb >> 3) == 1u) ? (uint32_t)K5_POT_B : type;
-            lds_wr32(col + (uint32_t)c * CS, cw5(k16_of<M::LUT>(0, 0) + type5 * 480u, 0u));
+            CW::wr(col + (uint32_t)c * CS, CW::make(type5, 0u, 0u));
         }
     };
     {   // load (include/oc_amd.h wire format -> key words, N, countdowns)
         const uint4 h = st[e];
         h0 = (h.x >> 16) & 0xFFu; h1 = (h.y >> 8) & 0xFFu;
         hz0 = hand_z(h0); hz1 = hand_z(h1);
+        h0 <<= 8 * CW::HAND_BYTE; h1 <<= 8 * CW::HAND_BYTE;
         pot_addrs();
         int32_t dishes = 0;
         for (int p = 0; p < n_obj; ++p) {
@@ -324,17 +361,17 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
                     const uint32_t type5 = (type == OC_T_POT && (tb >> 3) == 1u) ? (uint32_t)K5_POT_B : type;
                     const uint32_t cls = type == OC_T_COUNTER ? counter_class5(o) : 0u;
                     dishes += (type == OC_T_COUNTER && o == OC_O_DISH) ? 1 : 0;
-                    lds_wr32(col + (uint32_t)(16 * p + 4 * q + b) * CS, cw5(k16_of<M::LUT>(0, 0) + (type5 * 6u + cls) * K5_ROW, o));
+                    CW::wr(col + (uint32_t)(16 * p + 4 * q + b) * CS, CW::make(type5, cls, o));
                 }
             }
         }
-        lds_wr32(noact, cw5(k16_of<M::LUT>(K5_NOTHING, 0), 0u));
+        CW::wr(noact, CW::make(K5_NOTHING, 0u, 0u));
         int32_t useful = 0;
 #pragma unroll
         for (int k = 0; k < MAXP; ++k) {
             rem[k] = REM_IDLE; tk[k] = 0;
             if ((uint32_t)k < C.n_pots) {
-                uint32_t o = cw5_obj(lds_rd32(pa[k]));
+                uint32_t o = CW::obj(CW::rd(pa[k]));
                 const uint32_t tkb = (h.z >> (8 * k)) & 0xFFu;
                 uint32_t pc = pot_class(C, o, tkb);
                 if (o == OC_O_SOUP) { exotic |= 1u << k; o = 0; }  // a soup object without ingredients behaves as an empty pot
@@ -342,7 +379,7 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
                 rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) : REM_IDLE;
                 useful += (pc != PC_EMPTY && pc != PC_IDLE3) ? 1 : 0;
                 pc = arrive_class(pc, o, rem[k], 0u);
-                lds_wr32(pa[k], cw5(k16_of<M::LUT>(0, 0) + (pot_type5(k) * 6u + pc) * K5_ROW, o));
+                CW::wr(pa[k], CW::make(pot_type5(k), pc, o));
             }
         }
         N = 64 * dishes - useful;
@@ -368,17 +405,24 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
                          : "+v"(epsh) : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k) : "memory");
         }
     };
-    auto entry_at = [](uint32_t cw, uint32_t hz) __attribute__((always_inline)) {  // LUT address of (cell word, hand): one instruction
+    auto entry_at = [](uint32_t cw, uint32_t hz) __attribute__((always_inline)) {  // LUT address of (cell word, hand): one instruction (BIG: two)
         uint32_t a;
-        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_0" : "=v"(a) : "v"(cw), "v"(hz));
+        if (BIG) {
+            asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(a) : "v"(cw), "v"((uint32_t)K5_ROW));
+            asm("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "+v"(a) : "v"(hz));
+        } else {
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_0" : "=v"(a) : "v"(cw), "v"(hz));
+        }
         return a;
     };
     auto interact5 = [](const uint4 ent, uint32_t h, uint32_t cw) __attribute__((always_inline)) {
-        uint32_t pool = __builtin_amdgcn_perm(cw, h, 0x07060500u);  // [K16][object][hand]
-        asm("v_add_u32_sdwa %0, %1, %0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1" : "+v"(pool) : "v"(ent.z));
-        return __builtin_amdgcn_perm(ent.y, pool, ent.x);           // [new K16][new object][new hand]
+        uint32_t pool = __builtin_amdgcn_perm(cw, h, BIG ? 0x0C020504u : 0x07060500u);  // [K16][object][hand] / [0][hand][key][object]
+        if (BIG) asm("v_add_u32_sdwa %0, %1, %0 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_0" : "+v"(pool) : "v"(ent.z));
+        else asm("v_add_u32_sdwa %0, %1, %0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1" : "+v"(pool) : "v"(ent.z));
+        return __builtin_amdgcn_perm(ent.y, pool, ent.x);           // [new K16][new object][new hand] / [0][new hand][new key][new object]
     };
-    auto sext_b1 = [](uint32_t y) __attribute__((always_inline)) { return (int32_t)(int8_t)(uint8_t)(y >> 8); };
+    // an entry's signed change of N (.y byte 1; BIG: byte 2)
+    auto sext_b1 = [](uint32_t y) __attribute__((always_inline)) { return (int32_t)(int8_t)(uint8_t)(y >> (BIG ? 16 : 8)); };
 
     while (lds_poll32(sync_pair) < 1u) __builtin_amdgcn_s_sleep(1);
     uint32_t fo0, fo1, f_rec, c0, c1;
@@ -386,8 +430,8 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
         const oc_rec3 rec = ring_rd(0u, 0u);
         fo0 = rec.x; fo1 = rec.y; f_rec = rec.z;
     }
-    c0 = lds_rd32(fo0);
-    c1 = lds_rd32(fo1);
+    c0 = CW::rd(fo0);
+    c1 = CW::rd(fo1);
     Pend pend = {0ull, 0ull};
     // One step.  k8: its index in the block; (next_buf, next_k): the mover's record of the next step.
     auto dstep = [&](int k8, uint32_t next_buf, uint32_t next_k) __attribute__((always_inline)) {
@@ -404,12 +448,11 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t r0 = interact5(e0, h0, c0);
         uint32_t r1 = interact5(e1, h1, c1);
-        lds_wr32(fo0, r0);
-        lds_wr32(fo1, r1);
+        CW::wr(fo0, r0);
+        CW::wr(fo1, r1);
 #pragma unroll
-        for (int k = 0; k < MAXP; ++k)
-            cw5_wr_k16(ripe[k] ? pa[k] : dummy, k16_of<M::LUT>((int)(k == 0 ? OC_T_POT : K5_POT_B), PC_READY));
-        uint32_t nc0 = lds_rd32(nrec.x), nc1 = lds_rd32(nrec.y);  // the next step's cells: everything this step writes has been issued
+        for (int k = 0; k < MAXP; ++k) CW::wr_key(ripe[k] ? pa[k] : dummy, pot_type5(k), PC_READY);
+        uint32_t nc0 = CW::rd(nrec.x), nc1 = CW::rd(nrec.y);  // the next step's cells: everything this step writes has been issued
         const int32_t N_mid = N + sext_b1(e0.y);
         int32_t N_new = N_mid + sext_b1(e1.y);
         int32_t late_now = 0;  // OLD: pots that arrived idle and full count as useful from the step after their first one on
@@ -427,12 +470,12 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
         uint32_t nh0 = r0, nh1 = r1, nz0 = e0.z, nz1 = e1.z;
         if (__builtin_expect(rare_bits != 0u, 0)) {
             bool grid_changed = false;
-            const uint32_t hb0 = h0 & 0xFFu, hb1 = h1 & 0xFFu, hn0 = r0 & 0xFFu;
+            const uint32_t hb0 = CW::hand(h0), hb1 = CW::hand(h1), hn0 = CW::hand(r0);
             if (e0.z & f_rec & Z5_CHG) {  // player 1 acts on the cell player 0 has just changed: redo its interact on what is there now (Q2 / Q3)
                 e1 = lds_rd128(entry_at(r0, hz1));
                 r1 = interact5(e1, h1, r0);
                 nh1 = r1; nz1 = e1.z;
-                lds_wr32(fo1, r1);
+                CW::wr(fo1, r1);
                 N_new = N_mid + sext_b1(e1.y);
                 grid_changed = true;
             }
@@ -442,12 +485,12 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
             for (int k = 0; k < MAXP; ++k) {
                 const uint32_t sk = k == 0 ? Z5_START_A : Z5_START_B;
                 if (fz & sk) {
-                    const uint32_t soup = cw5_obj((e0.z & sk) ? r0 : r1);
+                    const uint32_t soup = CW::obj((e0.z & sk) ? r0 : r1);
                     const uint32_t cook = cook_of(C, soup);
                     rem[k] = cook + (uint32_t)k8;  // (= cook - 1 steps after this one, counted from the block's first step)
                     exotic &= ~(1u << k);
                     if (cook <= 1u) {  // ready with this step's env effects (cook == 0: at once, never ticks)
-                        cw5_wr_k16(pa[k], k16_of<M::LUT>((int)(k == 0 ? OC_T_POT : K5_POT_B), PC_READY));
+                        CW::wr_key(pa[k], pot_type5(k), PC_READY);
                         grid_changed = true;
                     }
                 }
@@ -498,12 +541,12 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
                             rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) + (uint32_t)(k8 + 1) : REM_IDLE;
                             useful += (pc != PC_EMPTY && pc != PC_IDLE3) ? 1 : 0;
                             pc = arrive_class(pc, o, rem[k], (uint32_t)(k8 + 1));
-                            lds_wr32(pa[k], cw5(k16_of<M::LUT>(0, 0) + (pot_type5(k) * 6u + pc) * K5_ROW, o));
+                            CW::wr(pa[k], CW::make(pot_type5(k), pc, o));
                         }
                     }
                     N_new = -useful;
                     late_now = 0;  // (pots drawn idle and full for the new episode: N_late, from the next step on)
-                    nh0 = d.held0; nh1 = d.held1;
+                    nh0 = d.held0 << (8 * CW::HAND_BYTE); nh1 = d.held1 << (8 * CW::HAND_BYTE);
                     nz0 = hand_z(d.held0); nz1 = hand_z(d.held1);
                     ep = zero4;  // the episode ends with this step: its returns restart from zero
                     epsh.x = -rw.z; epsh.y = -rw.w;
@@ -511,8 +554,8 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
                 }
             }
             if (grid_changed) {  // read the next step's cells again, behind everything this step wrote
-                nc0 = lds_rd32(nrec.x);
-                nc1 = lds_rd32(nrec.y);
+                nc0 = CW::rd(nrec.x);
+                nc1 = CW::rd(nrec.y);
             }
             q_lo = ((uint64_t)__float_as_uint(rw.y) << 32) | __float_as_uint(rw.x);
             q_hi = ((uint64_t)__float_as_uint(rw.w) << 32) | __float_as_uint(rw.z);
@@ -549,15 +592,15 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
     {
         const uint32_t t = min((uint32_t)horizon - 1u - fin.y + fin.z, 0xFFFFu);  // the wire format's u16: saturates
         uint4 h;
-        h.x = (fin.x & 0xFFFFu) | ((h0 & 0xFFu) << 16) | ((fin.x >> 16) << 24);
-        h.y = (fin.x >> 24) | ((h1 & 0xFFu) << 8) | (t << 16);
+        h.x = (fin.x & 0xFFFFu) | (CW::hand(h0) << 16) | ((fin.x >> 16) << 24);
+        h.y = (fin.x >> 24) | (CW::hand(h1) << 8) | (t << 16);
         h.z = 0; h.w = 0;
         uint32_t fix_cell[MAXP], fix_obj[MAXP];
 #pragma unroll
         for (int k = 0; k < MAXP; ++k) {
             fix_cell[k] = 0xFFFFFFFFu; fix_obj[k] = 0;
             if ((uint32_t)k < C.n_pots) {
-                const uint32_t cw = lds_rd32(pa[k]), o = cw5_obj(cw), pc = cw5_pot_class(cw, pot_type5(k));
+                const uint32_t cw = CW::rd(pa[k]), o = CW::obj(cw), pc = CW::pot_class(cw, pot_type5(k));
                 uint32_t tkb = tk[k];
                 const bool live = rem_live(rem[k]);
                 if (live) {
@@ -578,7 +621,7 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const uint32_t c = (uint32_t)(16 * p + 4 * q + b);
-                    uint32_t o = cw5_obj(lds_rd32(col + c * CS));
+                    uint32_t o = CW::obj(CW::rd(col + c * CS));
 #pragma unroll
                     for (int k = 0; k < MAXP; ++k) o = c == fix_cell[k] ? fix_obj[k] : o;
                     ow[q] |= o << (8 * b);

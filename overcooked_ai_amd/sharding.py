@@ -49,12 +49,25 @@ def _live():
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or bool(os.environ.get("OC_FORCE_DIST")))
 
 
+def _all_reduce(t, op):
+    """all_reduce in place; a device tensor under a gloo group (CPU tests, one-GPU rehearsals) goes through a host copy."""
+    import torch.distributed as dist
+
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def allreduce_metrics(t):
     """In-place SUM of a small metrics tensor over all ranks (no-op for a single process)."""
     import torch.distributed as dist
 
     if _live():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _all_reduce(t, dist.ReduceOp.SUM)
     return t
 
 
@@ -62,7 +75,7 @@ def allreduce_max(t):
     import torch.distributed as dist
 
     if _live():
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        _all_reduce(t, dist.ReduceOp.MAX)
     return t
 
 

@@ -35,7 +35,7 @@ def _oracle(specs):
 
 
 def _long_launch_against_oracle(gpu, table, n, lid=None, env_offset=0, seed=0, steps=T, horizon=HORIZON, start=None,
-                                flags_tiled8=False, one_wavefront=False, **env_kw):
+                                flags_tiled8=False, one_wavefront=False, expect_shaped=True, **env_kw):
     """flags_tiled8: the launch writes the OC_OPT_FLAGS_TILED8 layout (the instances bench.py times), untiled before the
     comparison; one_wavefront: OC_OPT_ONE_WAVEFRONT (no mover / interact split where the batch would get it)."""
     from overcooked_ai_amd.vec_env import VecOvercookedEnv
@@ -73,7 +73,7 @@ def _long_launch_against_oracle(gpu, table, n, lid=None, env_offset=0, seed=0, s
         shaped += float(rew_o[..., 2:].sum())
     assert np.array_equal(env.get_packed_state(), st_o), "final states differ"
     assert np.array_equal(env.ep_returns.cpu().numpy(), ep_o), "episode returns differ"
-    assert restarts == n * (steps // horizon) and shaped > 0
+    assert restarts == n * (steps // horizon) and (shaped > 0 or not expect_shaped)
     return sparse, shaped
 
 
@@ -146,12 +146,13 @@ def test_tiled_flags_launch_shapes_against_oracle(shape, gpu):
 @pytest.mark.parametrize("tiled", [False, True])
 @pytest.mark.parametrize("layout", ["cramped_room", "asymmetric_advantages", "coordination_ring", "forced_coordination",
                                     "counter_circuit", "mix5", "generated_4096", "cramped_room_old", "coordination_ring_old",
-                                    "asymmetric_advantages_old", "mix4_old"])
+                                    "asymmetric_advantages_old", "mix4_old", "marshmallow_experiment", "corridor", "long_cook_time",
+                                    "small_corridor_old", "big_mix"])
 def test_mover_interact_split_against_oracle(layout, tiled, gpu):
     """k_rollout5 (two wavefronts per 64 envs: a mover running ahead of an interact wavefront through a ring in LDS) on every batch
     kind it serves — cramped_room, single two-player layouts, the 5-layout table in LDS, 4 096 generated terrains read through L2,
-    and the same with OLD dynamics (pots that start by themselves with their third item; drawn start states bring pots that arrive
-    idle and full) — against the oracle over episodes of 23 steps with DRAWN start states (so that every restart exercises the
+    the same with OLD dynamics (pots that start by themselves with their third item; drawn start states bring pots that arrive
+    idle and full), and grids of 65..126 cells — against the oracle over episodes of 23 steps with DRAWN start states (so that every restart exercises the
     mover's own draw of the start pose), tiled and [step][env] flags; then the same launch with OC_OPT_ONE_WAVEFRONT must agree."""
     from overcooked_ai_amd.layout_gen import reference_generated_layouts
     from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
@@ -164,22 +165,27 @@ def test_mover_interact_split_against_oracle(layout, tiled, gpu):
         names = ("cramped_room", "asymmetric_advantages", "coordination_ring", "forced_coordination")
         table = LayoutTable([spec_from_name(nm, old_dynamics=True) for nm in names], pad_to=(9, 5))
         lid = ((np.arange(n) + rank * n) % len(names)).astype(np.uint16)
+    elif layout == "big_mix":  # 13 x 5 layouts (65 cells: 16-bit cell words, the 128-bit floor mask) in one table
+        names = ("marshmallow_experiment", "inverse_marshmallow_experiment", "marshmallow_experiment_coordination", "small_corridor")
+        table = LayoutTable([spec_from_name(nm) for nm in names])
+        lid = ((np.arange(n) + rank * n) % len(names)).astype(np.uint16)
     elif layout.endswith("_old"):
         table, lid = LayoutTable([spec_from_name(layout[:-4], old_dynamics=True)]), None
     elif layout == "generated_4096":
         table, lid = LayoutTable(reference_generated_layouts(4096)), ((np.arange(n) * 5 + 1) % 4096).astype(np.uint16)
     else:
         table, lid = layout, None
-    kw = dict(lid=lid, env_offset=rank * n, seed=11, steps=96, horizon=23,
+    kw = dict(lid=lid, env_offset=rank * n, seed=11, steps=96, horizon=23, expect_shaped=layout != "corridor",  # (its pots are far away)
               start={"random_start_pos": True, "rnd_obj_prob_thresh": 0.35}, random_start_pos=True, rnd_obj_prob_thresh=0.35)
     a = _long_launch_against_oracle(gpu, table, n, flags_tiled8=tiled, **kw)
     # (single layouts get the tiled flags from the split kernel only: their one-wavefront run writes [step][env] rows)
-    # (... and old dynamics in one wavefront is MODE 0: [step][env] rows as well)
-    b = _long_launch_against_oracle(gpu, table, n, flags_tiled8=tiled and lid is not None and not layout.endswith("_old"),
-                                    one_wavefront=True, **kw)
+    # (... and old dynamics or more than 64 cells in one wavefront is MODE 0: [step][env] rows as well)
+    b = _long_launch_against_oracle(gpu, table, n, one_wavefront=True, **kw,
+                                    flags_tiled8=tiled and lid is not None and not layout.endswith("_old") and layout != "big_mix")
     assert a == b
     # standard start states, a launch that begins in the middle of an episode (t0 = 96 from the env's own counter)
-    _long_launch_against_oracle(gpu, table, n, lid=lid, env_offset=rank * n, seed=3, steps=416, horizon=HORIZON, flags_tiled8=tiled)
+    _long_launch_against_oracle(gpu, table, n, lid=lid, env_offset=rank * n, seed=3, steps=416, horizon=HORIZON, flags_tiled8=tiled,
+                                expect_shaped=layout != "corridor")
 
 
 @pytest.mark.parametrize("table_kind", ["generated_4096", "canonical_5"])
