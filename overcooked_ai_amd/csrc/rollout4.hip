@@ -28,7 +28,8 @@ namespace {
 template <bool U, int MP, bool LL, int MODE, bool OUT, bool OLD, int NF = JOINT_MAX_FLOOR, bool EV = false, bool PIPE = true,
           bool RU = false, int CW = 2, bool NOCONF = false, bool FT8 = false>
 constexpr size_t lds4_bytes(size_t cell_rows) {
-    return (size_t)Lds4<U, LL, MODE, NF, U || RU, CW>::CELLS + cell_rows * BLOCK * CW;
+    // (EV: + the per-episode event counters, [N_EVENT_TYPES][BLOCK] u32 behind the cell words)
+    return (size_t)Lds4<U, LL, MODE, NF, U || RU, CW>::CELLS + cell_rows * BLOCK * CW + (EV ? (size_t)N_EVENT_TYPES * BLOCK * 4 : 0);
 }
 
 #define GO4(U, MP, LL, MODE, OUT, OLD, NF, ...)                                                                     \

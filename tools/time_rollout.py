@@ -11,7 +11,7 @@ from overcooked_ai_amd.vec_env import VecOvercookedEnv
 layout = sys.argv[1] if len(sys.argv) > 1 else "cramped_room"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 dev = torch.device("cuda:0")
-env = VecOvercookedEnv(layout, n, horizon=400, device=dev, auto_reset=True, seed=0)
+env = VecOvercookedEnv(layout, n, horizon=400, device=dev, auto_reset=True, seed=0, track_events=os.environ.get("TRACK_EVENTS") == "1")
 T = 400
 rew = torch.zeros((T, n, 4), dtype=torch.float32, device=dev)
 fl = torch.zeros((T, n), dtype=torch.uint8, device=dev)
