@@ -366,8 +366,9 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
             return fail(OC_EINVAL, "oc_rollout_random: OC_OPT_FLAGS_TILED8 needs d_rewards and an 8-byte aligned d_flags");
         if ((t0 & 7) != 0 || (n_steps & 7) != 0)
             return fail(OC_EINVAL, "oc_rollout_random: OC_OPT_FLAGS_TILED8 needs t0 and n_steps to be multiples of 8");
-        if (ev_on(ea) || (options & (OC_OPT_LANE_PAIR | OC_OPT_PREDICATE_INTERACT)))
-            return fail(OC_EINVAL, "oc_rollout_random: OC_OPT_FLAGS_TILED8 goes with the default kernel and no event sink");
+        if (ea.events || (options & (OC_OPT_LANE_PAIR | OC_OPT_PREDICATE_INTERACT)))
+            return fail(OC_EINVAL, "oc_rollout_random: OC_OPT_FLAGS_TILED8 goes with the default kernel and no per-step event masks "
+                                   "(per-episode counters: the mover / interact kernel writes it)");
     }
     if (b->n_envs == 0 || n_steps == 0) return OC_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -432,8 +433,12 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         // in LDS), one set of shaping rewards, both output arrays (a one-pot joint-table layout is such a batch too)
         // (one dynamics flag for the whole table — OC_BATCH_UNIFORM_SHAPING —: old dynamics is served by k_rollout5, not by MODE 2)
         const int n_cells = b->width * b->height;
-        const bool terrain_ok = two && c.out && small && shaping_uniform && (n_cells <= 64 || (n_cells <= 128 && lds)) && !c.events && !no_mode2;
-        const bool mode2 = !c.joint && terrain_ok && !c.old_dyn && n_cells <= 64;
+        // (an event log: per-episode counters only — no per-step masks —, table in LDS, <= 64 cells, and the counters must fit the
+        //  CU's LDS beside the cell words: grids of up to 48 cells)
+        const bool ev_ok = !c.events || (ea.events == nullptr && lds && n_cells <= 64 &&
+                                         oc_detail::rollout5_lds_bytes(true, false, true, n_obj) <= (size_t)160 * 1024);
+        const bool terrain_ok = two && c.out && small && shaping_uniform && (n_cells <= 64 || (n_cells <= 128 && lds)) && ev_ok && !no_mode2;
+        const bool mode2 = !c.joint && terrain_ok && !c.old_dyn && n_cells <= 64 && !c.events;
         // k_rollout5 (step_duo5.hpp): the step split between mover and interact wavefronts — whole workgroups of envs (every
         // wavefront meets every barrier) and whole 8-step blocks; a workgroup's 127-154 KB of LDS leave room for one per CU.
         // Bigger batches run these workgroups in ROUNDS, one per CU at a time — the next round's workgroups start as the first ones

@@ -43,16 +43,17 @@ constexpr size_t lds4_bytes(size_t cell_rows) {
     } while (0)
 
 // k_rollout5 (step_duo5.hpp): the per-env-terrain mover / interact kernel of round 6; two spare cell rows per lane
-#define GO5(LL, FT8F) do { if (c.old_dyn) GO5X(LL, FT8F, true, false); else GO5X(LL, FT8F, false, false); } while (0)
-#define GO5BIG(FT8F) do { if (c.old_dyn) GO5X(true, FT8F, true, true); else GO5X(true, FT8F, false, true); } while (0)
-#define GO5X(LL, FT8F, OLDF, BIGF)                                                                                  \
+#define GO5(LL, FT8F) do { if (c.old_dyn) GO5X(LL, FT8F, true, false, false); else GO5X(LL, FT8F, false, false, false); } while (0)
+#define GO5BIG(FT8F) do { if (c.old_dyn) GO5X(true, FT8F, true, true, false); else GO5X(true, FT8F, false, true, false); } while (0)
+#define GO5EV(FT8F) do { if (c.old_dyn) GO5X(true, FT8F, true, false, true); else GO5X(true, FT8F, false, false, true); } while (0)
+#define GO5X(LL, FT8F, OLDF, BIGF, EVF)                                                                             \
     do {                                                                                                            \
-        const size_t smem5 = (size_t)Lds5<LL>::CELLS + ((size_t)c.n_obj * 16 + 2) * BLOCK * (BIGF ? 2 : 4);         \
-        if (!want_lds(k_rollout5<LL, FT8F, OLDF, BIGF>, smem5)) break;                                              \
-        hipLaunchKernelGGL((k_rollout5<LL, FT8F, OLDF, BIGF>), grid4, dim3(2 * BLOCK), smem5, c.stream, b->d_layouts, b->n_layouts, \
+        const size_t smem5 = rollout5_lds_bytes(LL, BIGF, EVF, c.n_obj);                                            \
+        if (!want_lds(k_rollout5<LL, FT8F, OLDF, BIGF, EVF>, smem5)) break;                                         \
+        hipLaunchKernelGGL((k_rollout5<LL, FT8F, OLDF, BIGF, EVF>), grid4, dim3(2 * BLOCK), smem5, c.stream, b->d_layouts, b->n_layouts, \
                            b->d_layout_id, (uint4*)c.d_state, (float4*)c.d_rewards, c.d_flags, (float4*)c.d_ep_returns, \
                            b->n_envs, b->width, c.n_obj, c.horizon, c.options, (uint32_t)c.seed, (uint32_t)(c.seed >> 32), \
-                           c.env_offset, c.t0, c.n_steps, c.sa);                                                    \
+                           c.env_offset, c.t0, c.n_steps, c.sa, c.ea);                                              \
     } while (0)
 
 #define OC_R4_PROLOGUE                                                       \
@@ -63,6 +64,15 @@ constexpr size_t lds4_bytes(size_t cell_rows) {
 }  // namespace
 
 namespace oc_detail {
+
+#if OC_R4_PART == 1
+// dynamic LDS of a k_rollout5 workgroup: tables, ring, the cell words of 256 envs (+ two spare rows) and, with the event log,
+// N_EVENT_TYPES rows of counters (9 x 5 grids: 163 120 of the CU's 163 840 bytes)
+size_t rollout5_lds_bytes(bool lay_lds, bool big, bool ev, int n_obj) {
+    return (size_t)(lay_lds ? Lds5<true>::CELLS : Lds5<false>::CELLS) + ((size_t)n_obj * 16 + 2) * BLOCK * (big ? 2 : 4) +
+           (ev ? (size_t)N_EVENT_TYPES * BLOCK * 4 : 0);
+}
+#endif
 
 #if OC_R4_PART == 0
 void launch_rollout4_joint_events(const Rollout4Call& c) {
@@ -93,7 +103,8 @@ void launch_rollout4_mode2(const Rollout4Call& c) {
         if (c.pipe) GO4(U, MP, LL, 2, true, false, 0, false, true, RUF, 4); else GO4(U, MP, LL, 2, true, false, 0, false, false, RUF); \
     } while (0)
     if (c.duo) {  // whole workgroups of envs, whole 8-step blocks, at most one workgroup per CU: mover + interact wavefronts
-        if (b->width * b->height > 64) { if (c.tiled8) GO5BIG(true); else GO5BIG(false); }  // (65..128 cells: tables in LDS only)
+        if (c.events) { if (c.tiled8) GO5EV(true); else GO5EV(false); }  // (event counters: tables in LDS, at most 64 cells)
+        else if (b->width * b->height > 64) { if (c.tiled8) GO5BIG(true); else GO5BIG(false); }  // (65..128 cells: tables in LDS only)
         else if (c.lds) { if (c.tiled8) GO5(true, true); else GO5(true, false); }
         else { if (c.tiled8) GO5(false, true); else GO5(false, false); }
         return;

@@ -58,5 +58,6 @@ struct Rollout4Call {
 OC_HIDDEN void launch_rollout4_joint_events(const Rollout4Call& c);  // rollout4.hip, OC_R4_PART 0
 OC_HIDDEN void launch_rollout4_mode2(const Rollout4Call& c);         // rollout4.hip, OC_R4_PART 1
 OC_HIDDEN void launch_rollout4_mode0(const Rollout4Call& c);         // rollout4.hip, OC_R4_PART 2
+OC_HIDDEN size_t rollout5_lds_bytes(bool lay_lds, bool big, bool ev, int n_obj);  // rollout4.hip, OC_R4_PART 1
 
 }  // namespace oc_detail

@@ -26,7 +26,8 @@
 //    No pot words in registers, no pot reads in the step.
 //  * entry (16 bytes): .x selectors — r = v_perm(.y, pool, .x) = [new K16][new object][new hand] with
 //        pool = [K16][object + add][hand] of (faced cell, hand);  .y = [new K16][delta N][dispensed object];
-//        .z = [bit 7: takes a dish from the dispenser][flags][add][16 * new hand class];  .w = the shaped reward float (one set of shaping rewards per batch).
+//        .z = [bit 7: takes a dish from the dispenser, bits 5-6: change of the full-pot count, bits 0-4: event kind][flags][add]
+//             [16 * new hand class];  .w = the shaped reward float (one set of shaping rewards per batch).
 //  * the pot in slot 1 has its own type, so an entry's START flag says WHICH countdown starts (no address compares).
 // Semantics are k_rollout4's / the oracle's: conflict replay for player 1, stale pot states for the usefulness predicate, the
 // same restart at the horizon (standard, drawn, or on a re-drawn layout).  Served batches: two players everywhere, <= 2 pots,
@@ -35,6 +36,7 @@
 // ==========================================================================================
 constexpr int K5_TYPES = 9, K5_POT_B = 7, K5_NOTHING = 8, K5_ROW = 80, K5_KEYS = K5_TYPES * 6;
 constexpr int LUT5_BYTES = K5_KEYS * K5_ROW;  // 4 320
+constexpr uint32_t Z5_PLACE = 2u << 16;
 enum { F5_PLACE = 2, F5_PLATE = 4, F5_START_A = 8, F5_SERVE = 16, F5_START_B = 32, F5_CHG = 128 };
 // the flags sit in byte 2 of .z: masks in place; "a dish is taken from the dispenser" is bit 31 of .z, where the sign of N meets it
 constexpr uint32_t Z5_TAKE = 0x80000000u, Z5_SERVE = (uint32_t)F5_SERVE << 16, Z5_CHG = (uint32_t)F5_CHG << 16,
@@ -52,26 +54,35 @@ constexpr Lut4Entry lut5_entry(int big, int old_dyn, int type5, int hc, int oc) 
     // what the new hand / object are taken from: 0 the hand, 1 the object (+ add), 4 the dispensed object, 0x0C zero
     uint32_t sel_h = 0, sel_o = 1, cobj = 0, flags = 0, add = 0, rew = RW4_NONE, hcn = (uint32_t)hc, take = 0;
     int nkey = -1, dd = 0, du = 0;  // new key (type, class) or -1 = unchanged; change of the loose-dish / useful-pot counts
+    // event log (EV instances): kind = 1 + index in EVENT_TYPES (mdp.py:1027-1058) of the event this interact always logs (0:
+    // none) — its USEFUL_* variant, the potting classes and useful dish pick-ups are decided at run time —, and the change of the
+    // number of FULL pots (three idle items, cooking or ready: get_full_pots, mdp.py:1804-1820)
+    int kind = 0, df = 0;
     const bool pot = type5 == OC_T_POT || type5 == K5_POT_B;
     if (type5 == OC_T_COUNTER) {
         if (hc == 0 && oc >= 1 && oc <= 4) {         // pick up from a counter (mdp.py:1473-1485): the class of what lies there = the hand's
             sel_h = 1; sel_o = 0x0C; nkey = 0; flags = F5_CHG; dd = oc == 3 ? -1 : 0; hcn = (uint32_t)oc;
+            kind = 1 + (oc == 1 ? EV_ONION_PICKUP : oc == 2 ? EV_TOMATO_PICKUP : oc == 3 ? EV_DISH_PICKUP : EV_SOUP_PICKUP);
         } else if (hc != 0 && oc == 0) {             // drop on a counter (mdp.py:1459-1471)
             sel_h = 0x0C; sel_o = 0; nkey = hc; flags = F5_CHG; dd = hc == 3 ? 1 : 0; hcn = 0;
+            kind = 1 + (hc == 1 ? EV_ONION_DROP : hc == 2 ? EV_TOMATO_DROP : hc == 3 ? EV_DISH_DROP : EV_SOUP_DROP);
         }
     } else if (type5 == OC_T_ONION_DISP) {
-        if (hc == 0) { sel_h = 4; cobj = OC_O_ONION; hcn = 1; }
+        if (hc == 0) { sel_h = 4; cobj = OC_O_ONION; hcn = 1; kind = 1 + EV_ONION_PICKUP; }
     } else if (type5 == OC_T_TOMATO_DISP) {
-        if (hc == 0) { sel_h = 4; cobj = OC_O_TOMATO; hcn = 2; }
+        if (hc == 0) { sel_h = 4; cobj = OC_O_TOMATO; hcn = 2; }  // (the reference logs no event here: mdp.py:1496-1498)
     } else if (type5 == OC_T_DISH_DISP) {
-        if (hc == 0) { sel_h = 4; cobj = OC_O_DISH; take = Z5_TAKE; hcn = 3; }
+        if (hc == 0) { sel_h = 4; cobj = OC_O_DISH; take = Z5_TAKE; hcn = 3; kind = 1 + EV_DISH_PICKUP; }
     } else if (pot) {
         if (hc == 0 && oc >= PC_IDLE1 && oc <= PC_IDLE3 && !old_dyn) {   // begin_cooking (mdp.py:1515-1522)
             nkey = PC_COOKING; flags = F5_CHG | (type5 == K5_POT_B ? F5_START_B : F5_START_A); du = oc == PC_IDLE3 ? 1 : 0;
+            df = oc == PC_IDLE3 ? 0 : 1;
         } else if (hc == 3 && oc == PC_READY) {                          // soup pickup (mdp.py:1525-1539)
             sel_h = 1; sel_o = 0x0C; nkey = PC_EMPTY; flags = F5_CHG | F5_PLATE; rew = RW4_PLATE; du = -1; hcn = 4;
+            kind = 1 + EV_SOUP_PICKUP; df = -1;
         } else if ((hc == 1 || hc == 2) && oc <= PC_IDLE2) {             // add ingredient (mdp.py:1541-1568)
             sel_h = 0x0C; nkey = oc + 1; flags = F5_CHG | F5_PLACE; rew = RW4_PLACE; hcn = 0;
+            kind = 1 + (hc == 1 ? EV_POTTING_ONION : EV_POTTING_TOMATO); df = oc == PC_IDLE2 ? 1 : 0;
             add = 8u + ((hc == 2 ? 1u : 0u) << oc) + (oc == 0 ? 0x80u : 0u);
             du = oc == 0 ? 1 : oc == 2 ? -1 : 0;
             if (old_dyn && oc == PC_IDLE2) {  // the third item: cooking from this step's env effects on (two idle items -> cooking: as useful as before)
@@ -79,10 +90,10 @@ constexpr Lut4Entry lut5_entry(int big, int old_dyn, int type5, int hc, int oc) 
             }
         }
     } else if (type5 == OC_T_SERVE) {
-        if (hc == 4) { sel_h = 0x0C; flags = F5_SERVE; hcn = 0; }        // deliver (mdp.py:1570-1577)
+        if (hc == 4) { sel_h = 0x0C; flags = F5_SERVE; hcn = 0; kind = 1 + EV_SOUP_DELIVERY; }  // deliver (mdp.py:1570-1577)
     }
     const int dn = 64 * dd - du;
-    const uint32_t z = (hcn * 16u) | (add << 8) | (flags << 16) | take;
+    const uint32_t z = (hcn * 16u) | (add << 8) | (flags << 16) | ((uint32_t)kind << 24) | (((uint32_t)df & 3u) << 29) | take;
     if (big) {  // pool bytes: 0 object (+ add), 1 key, 2 hand; constants (.y): byte 0 dispensed object, byte 1 new key, byte 2 delta N
         auto at = [](uint32_t sel) { return sel == 0u ? 2u : sel == 1u ? 0u : sel; };  // (4 = .y byte 0, 0x0C = zero: as they are)
         const uint32_t sel_k = nkey < 0 ? 1u : 5u;
@@ -153,11 +164,13 @@ struct Cw5 {
 // OLD: the table's layouts use old dynamics (the LUT variant above; a pot that arrives idle with three items starts in the first
 //      step's env effects)
 // BIG: grids of 65..128 cells (16-bit cell words, a 128-bit floor mask in the mover)
-template <bool LAY_LDS, bool FT8, bool OLD = false, bool BIG = false>
+// EV: per-episode event counters (OcEventSink.d_counts / d_counts_done: env.py:382-401 game_stats) — [1 + N_EVENT_TYPES][BLOCK]
+//     u32 in LDS behind the cell words for the launch (row 0 takes what is not an event), logged with ds_add
+template <bool LAY_LDS, bool FT8, bool OLD = false, bool BIG = false, bool EV = false>
 __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_rollout5(
     const OcLayout* __restrict__ g_layouts, int n_layouts, const uint16_t* layout_id, uint4* st, float4* __restrict__ rewards,
     uint8_t* __restrict__ flags, float4* __restrict__ ep_returns, int64_t n, int W, int n_obj, int horizon, uint32_t options,
-    uint32_t seed_lo, uint32_t seed_hi, int64_t env_offset, int64_t t0, int n_steps, StartArgs sa) {
+    uint32_t seed_lo, uint32_t seed_hi, int64_t env_offset, int64_t t0, int n_steps, StartArgs sa, EvArgs ea) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn5[];
     using M = Lds5<LAY_LDS>;
     if ((uint32_t)(uintptr_t)(OC_LDS uint8_t*)s_dyn5 != 0u) __builtin_trap();  // folds away: the region starts at address 0
@@ -183,7 +196,9 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
     if (threadIdx.x < 8) reinterpret_cast<uint32_t*>(s_dyn5 + M::SYNC)[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t col = (uint32_t)M::CELLS + tid * CW::BYTES;  // LDS address of this lane's column of cell words
-    const uint32_t dummy = col + (uint32_t)n_obj * 16u * CS, noact = dummy + CS;  // two spare words per lane behind the grid
+    // two spare words per lane behind the grid: what a player that does not INTERACT acts on, then the sink of the "ready" stores of
+    // pots that are not ripe (EV: and of what is not an event — the counters' row 0)
+    const uint32_t noact = col + (uint32_t)n_obj * 16u * CS, dummy = noact + CS;
     LayC C = load_consts<false>(L);
     const uint32_t delta4 = make_delta4(W);
     const uint64_t g = (uint64_t)(env_offset + e);
@@ -316,6 +331,15 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
     // its class), N, the pots' countdowns (k_rollout4's: steps until ready, REM_IDLE when not cooking) and cell addresses
     uint32_t h0, h1, hz0, hz1, rem[MAXP], tk[MAXP], pa[MAXP], exotic = 0;
     int32_t N = 0;
+    int32_t F = 0;  // EV: pots that are full (three idle items, cooking or ready), kept by the entries' deltas like N
+    static_assert(!EV || !BIG, "the counters' row 0 is the spare cell row in front of them: 4-byte cell words");
+    const uint32_t cnt0 = dummy;  // EV: this lane's column of event counters, [row][BLOCK] u32: row 0 = the spare cell word, rows 1.. behind it
+    auto cnt_add = [&](uint32_t row, uint32_t v) __attribute__((always_inline)) {  // counters[row][lane] += v (row 0: nothing)
+        asm volatile("ds_add_u32 %0, %1" : : "v"(cnt0 + row * (uint32_t)(BLOCK * 4)), "v"(v) : "memory");
+    };
+    if (EV) {
+        for (int k = 0; k < N_EVENT_TYPES; ++k) lds_wr32(cnt0 + (uint32_t)(k + 1) * (BLOCK * 4u), ea.counts[e * N_EVENT_TYPES + k]);
+    }
     // OLD: pots that arrive idle with three items start cooking in the coming step's env effects (mdp.py:1696-1701).  Nothing can be
     // done to such a pot in that step (every interact with a full pot is a no-op), so it is set COOKING at once, with the countdown
     // of a pot that starts in that step; only the usefulness predicate still sees it idle for one step: N gains it a step later
@@ -378,6 +402,7 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
                 tk[k] = tkb;
                 rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) : REM_IDLE;
                 useful += (pc != PC_EMPTY && pc != PC_IDLE3) ? 1 : 0;
+                F += pc >= PC_IDLE3 ? 1 : 0;
                 pc = arrive_class(pc, o, rem[k], 0u);
                 CW::wr(pa[k], CW::make(pot_type5(k), pc, o));
             }
@@ -459,7 +484,8 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
         if (OLD) { late_now = N_late; N_late = 0; }
         // ---- ONE branch for everything rare: cooking starts, deliveries, dish pick-ups that may be useful (N < 0 before or
         //      after player 0's interact: no loose dish, some useful pot), a shared cell player 0 has changed, the horizon
-        const uint32_t gate = ((uint32_t)(N | N_mid) & Z5_TAKE) | Z5_SERVE | Z5_START_A | Z5_START_B;
+        const uint32_t gate = ((uint32_t)(N | N_mid) & Z5_TAKE) | Z5_SERVE | Z5_START_A | Z5_START_B | (EV ? Z5_PLACE : 0u);
+        uint32_t c1_seen = c1;  // EV: the cell word player 1's interact saw (player 0's result when it redoes it)
         const uint32_t rare_bits = ((e0.z | e1.z) & gate) | ((e0.z | REC5_DONE) & f_rec);
         uint64_t q_lo, q_hi;  // the reward quad as two register pairs: zeros, and the two entries' shaped floats
         {
@@ -468,12 +494,14 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
             asm("v_mov_b64 %0, 0" : "=v"(q_lo));
         }
         uint32_t nh0 = r0, nh1 = r1, nz0 = e0.z, nz1 = e1.z;
+        int32_t F_reset = -1;  // EV: the full pots of a new episode's start state
         if (__builtin_expect(rare_bits != 0u, 0)) {
             bool grid_changed = false;
             const uint32_t hb0 = CW::hand(h0), hb1 = CW::hand(h1), hn0 = CW::hand(r0);
             if (e0.z & f_rec & Z5_CHG) {  // player 1 acts on the cell player 0 has just changed: redo its interact on what is there now (Q2 / Q3)
                 e1 = lds_rd128(entry_at(r0, hz1));
                 r1 = interact5(e1, h1, r0);
+                c1_seen = r0;
                 nh1 = r1; nz1 = e1.z;
                 CW::wr(fo1, r1);
                 N_new = N_mid + sext_b1(e1.y);
@@ -512,6 +540,24 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
                 }
                 ep.x += r.x; ep.y += r.y;
                 rw.x = r.x; rw.y = r.y; rw.z += r.z; rw.w += r.w;
+                if (EV) {  // useful_dish_pickup (only a dish from the dispenser can be one: a dish on a counter is a loose dish)
+                    cnt_add((((e0.z & Z5_TAKE) != 0u) & du0) ? 1u + EV_USEFUL_DISH_PICKUP : 0u, 1u);
+                    cnt_add((((e1.z & Z5_TAKE) != 0u) & du1) ? 1u + EV_USEFUL_DISH_PICKUP : 0u, 1u << 16);
+                }
+            }
+            if (EV && (fz & Z5_PLACE)) {  // log_object_potting (mdp.py:2251-2308): the classes of (old soup, ingredient), as interact_events
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const uint32_t ez = pl ? e1.z : e0.z, o = CW::obj(pl ? c1_seen : c0), hb = pl ? hb1 : hb0;
+                    const uint32_t n = (o >> 3) & 3u, nt = __popc(o & 7u), no = n - nt, pi = no + 3u * nt;
+                    const uint32_t pw = pi < 4u ? C.pclass[0] : C.pclass[1], tom = hb == OC_O_TOMATO ? 1u : 0u;
+                    const uint32_t nib = (ez & Z5_PLACE) ? (pw >> (8u * (pi & 3u) + 4u * tom)) & 0xFu : 0u;
+                    const uint32_t v = pl ? 1u << 16 : 1u;
+                    cnt_add((nib & 1u) ? 1u + EV_OPTIMAL_ONION_POTTING + tom : 0u, v);
+                    cnt_add((nib & 2u) ? 1u + EV_VIABLE_ONION_POTTING + tom : 0u, v);
+                    cnt_add((nib & 4u) ? 1u + EV_CATASTROPHIC_ONION_POTTING + tom : 0u, v);
+                    cnt_add((nib & 8u) ? 1u + EV_USELESS_ONION_POTTING + tom : 0u, v);
+                }
             }
             if (f_rec & REC5_DONE) {  // OvercookedEnv.step at the horizon (env.py:266-267, 321-325); the mover stores the flag byte
                 if (options & OC_OPT_AUTO_RESET) {
@@ -531,12 +577,14 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
                     write_empty_grid();
                     int32_t useful = 0;
                     exotic = 0;
+                    F_reset = 0;
 #pragma unroll
                     for (int k = 0; k < MAXP; ++k) {
                         rem[k] = REM_IDLE; tk[k] = 0;
                         if ((uint32_t)k < C.n_pots) {
                             const uint32_t o = d.pot_obj((uint32_t)k), tkb = d.tick((uint32_t)k);
                             uint32_t pc = pot_class(C, o, tkb);
+                            F_reset += pc >= PC_IDLE3 ? 1 : 0;
                             tk[k] = tkb;
                             rem[k] = pc == PC_COOKING ? cook_of(C, o) - (tkb - 1u) + (uint32_t)(k8 + 1) : REM_IDLE;
                             useful += (pc != PC_EMPTY && pc != PC_IDLE3) ? 1 : 0;
@@ -561,6 +609,35 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
             q_hi = ((uint64_t)__float_as_uint(rw.w) << 32) | __float_as_uint(rw.z);
             // (wait for the reads in here: left pending, the join behind the branch would wait for them at its first LDS use)
             __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+        if (EV) {
+            // event_infos of the step (mdp.py:2121-2308) into the episode's counters: the event each entry always logs, then its
+            // USEFUL_* variant (is_ingredient_pickup_useful / is_ingredient_drop_useful / is_dish_drop_useful, mdp.py:2206-2249:
+            // the full pots of BEFORE the interacts, the other player's hand as it is when the player acts — player 0's new
+            // hand for player 1).  Pick-ups are useful unless every pot is full and the other player holds no dish, drops of
+            // ingredients exactly then: one of the two masks is on.
+            constexpr uint32_t PICKM = (1u << (1 + EV_TOMATO_PICKUP)) | (1u << (1 + EV_ONION_PICKUP));
+            constexpr uint32_t DROPM = (1u << (1 + EV_TOMATO_DROP)) | (1u << (1 + EV_ONION_DROP)), DDM = 1u << (1 + EV_DISH_DROP);
+            const uint32_t k0 = (e0.z >> 24) & 31u, k1 = (e1.z >> 24) & 31u;
+            cnt_add(k0, 1u);
+            cnt_add(k1, 1u << 16);
+            const bool all_full = F == (int32_t)C.n_pots, none_full = F == 0;
+            auto useful_row = [&](uint32_t kind, uint32_t other_z) __attribute__((always_inline)) {
+                const uint32_t oc16 = other_z & 0xFFu;  // 16 x the class of the other player's hand: 48 a dish, 16 an onion
+                const uint32_t m = ((all_full & (oc16 != 48u)) ? DROPM : PICKM) | ((none_full & (oc16 != 16u)) ? DDM : 0u);
+                return ((m >> kind) & 1u) ? kind + 1u : 0u;
+            };
+            cnt_add(useful_row(k0, hz1), 1u);
+            cnt_add(useful_row(k1, e0.z), 1u << 16);
+            F += ((int32_t)(e0.z << 1) >> 30) + ((int32_t)(e1.z << 1) >> 30);
+            if (F_reset >= 0) F = F_reset;
+            if (f_rec & REC5_DONE) {  // the episode ends with this step: publish its counts, start the next one from zero
+                for (int k = 0; k < N_EVENT_TYPES; ++k) {
+                    const uint32_t a = cnt0 + (uint32_t)(k + 1) * (BLOCK * 4u);
+                    if (ea.counts_done) ea.counts_done[e * N_EVENT_TYPES + k] = lds_rd32(a);
+                    if ((options & OC_OPT_AUTO_RESET) || ea.clear_on_done) lds_wr32(a, 0u);
+                }
+            }
         }
         if (k8 < 7) { pend.lo = q_lo; pend.hi = q_hi; }
         else { const Pend now = {q_lo, q_hi}; flush(now, 7); }
@@ -630,6 +707,8 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
             st[(int64_t)(1 + p) * n + e] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         }
     }
+    if (EV)
+        for (int k = 0; k < N_EVENT_TYPES; ++k) ea.counts[e * N_EVENT_TYPES + k] = lds_rd32(cnt0 + (uint32_t)(k + 1) * (BLOCK * 4u));
     ep.z = epsh.x; ep.w = epsh.y;
     if (ep_returns) ep_returns[e] = ep;
 }

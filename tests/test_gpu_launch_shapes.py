@@ -353,3 +353,58 @@ def test_xcd_contiguous_block_mapping_on_ragged_batches(n, gpu):
             assert np.array_equal(rew[k].cpu().numpy(), r_o[0]) and np.array_equal(fl[k].cpu().numpy(), f_o[0]), (name, n, k)
             assert np.array_equal(obs[k].cpu().numpy().astype(np.int32), orc.encode_lossless(st, horizon=9)), (name, n, k)
         assert np.array_equal(env.get_packed_state(), st), (name, n)
+
+
+@pytest.mark.parametrize("layouts", ["cramped_room", "asymmetric_advantages", "coordination_ring", "mix5", "cramped_room_tomato",
+                                     "coordination_ring_old"])
+def test_mover_interact_event_log_against_oracle(layouts, gpu):
+    """k_rollout5 with the event log (track_events, whole workgroups and 8-step blocks): the per-episode counters — the entries'
+    event kinds, the USEFUL_* variants from the full-pot count and the other player's hand, useful dish pick-ups and the potting
+    classes from the rare branch — equal the per-episode popcounts of the oracle's event_infos, are published when an episode
+    ends and restart from zero; drawn start states, three episode boundaries inside the launches; rewards and states as well."""
+    from oracle import oracle as O
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+    from overcooked_ai_amd.vec_env import VecOvercookedEnv
+
+    n, horizon, seed, off = 2048, 37, 5, 4096
+    if layouts == "mix5":
+        table = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+        lid = ((np.arange(n) + off) % 5).astype(np.uint16)
+    elif layouts.endswith("_old"):
+        table, lid = LayoutTable([spec_from_name(layouts[:-4], old_dynamics=True)]), None
+    else:
+        table, lid = LayoutTable([spec_from_name(layouts)]), None
+    orc = _oracle(table.specs)
+    env = VecOvercookedEnv(table, n, horizon=horizon, device=gpu, auto_reset=True, seed=seed, env_offset=off, layout_id=lid,
+                           track_events=True, random_start_pos=True, rnd_obj_prob_thresh=0.5)
+    st = env.get_packed_state().copy()
+    counts = np.zeros((n, 25, 2), np.int64)
+    done_counts = np.zeros((n, 25, 2), np.int64)
+    steps = 0
+    for T_, tiled in ((64, False), (56, True)):
+        rew = torch.zeros((T_, n, 4), dtype=torch.float32, device=gpu)
+        fl = torch.zeros((T_ // 8, n, 8) if tiled else (T_, n), dtype=torch.uint8, device=gpu)
+        env.rollout_random(T_, rew, fl, flags_tiled8=tiled)
+        fl_np = (VecOvercookedEnv.untile_flags(fl) if tiled else fl).cpu().numpy()
+        rew_np = rew.cpu().numpy()
+        for k in range(T_):
+            acts = O.random_actions(seed, off, steps, n)
+            st, r_o, f_o = orc.step(st, acts, horizon=horizon, options=1, layout_id=lid,
+                                    start=O.start_spec(seed, off, 1 + steps, True, 0.5))
+            steps += 1
+            assert np.array_equal(fl_np[k], f_o) and np.array_equal(rew_np[k], r_o), steps
+            bits = ((orc.last_events[:, None] >> np.arange(50, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.int64)
+            counts += bits.reshape(n, 25, 2)
+            fin = (f_o & 1) != 0
+            done_counts[fin] = counts[fin]
+            counts[(f_o & 4) != 0] = 0
+        assert np.array_equal(env.get_packed_state(), st)
+        got = env.event_counts.cpu().numpy().astype(np.int64)
+        got2 = np.stack([got & 0xFFFF, (got >> 16) & 0xFFFF], -1)
+        bad = np.argwhere(got2 != counts)
+        assert len(bad) == 0, "running counters after %d steps: %d differ, first (env, event, player) %s: %d vs %d; events that differ %s, layouts %s" % (
+            steps, len(bad), bad[0].tolist(), got2[tuple(bad[0])], counts[tuple(bad[0])], sorted(set(bad[:, 1].tolist())),
+            sorted(set((lid[bad[:, 0]] if lid is not None else np.zeros(1, int)).tolist())))
+        gd = env.event_counts_done.cpu().numpy().astype(np.int64)
+        assert np.array_equal(np.stack([gd & 0xFFFF, (gd >> 16) & 0xFFFF], -1), done_counts), "published counters after %d steps" % steps
+    assert done_counts.sum() > 0 and done_counts[:, 1].sum() + done_counts[:, 6].sum() > 0  # useful pick-ups were logged

@@ -23,6 +23,10 @@ table = LayoutTable([spec_from_name(nm, old_dynamics=True) if OLD else spec_from
                     pad_to=(9, 5) if len(names) > 1 else None)
 lid = ((np.arange(n) + OFF) % len(names)).astype(np.uint16)
 kw = dict(random_start_pos=True, rnd_obj_prob_thresh=DRAW) if DRAW else {}
+TRACK = os.environ.get("TRACK") == "1"  # TRACK=1: the event log (per-episode counters) against the oracle's event masks
+if TRACK:
+    kw["track_events"] = True
+counts = np.zeros((n, 25, 2), np.int64)
 env = VecOvercookedEnv(table, n, horizon=HZ, device=dev, auto_reset=True, seed=SEED, env_offset=OFF, layout_id=lid if len(names) > 1 else None, **kw)
 env.one_wavefront = os.environ.get("ONE_WAVEFRONT") == "1"
 orc = O.Oracle([O.mdp_from_layout_dict(s.to_layout_dict()) for s in table.specs])
@@ -45,7 +49,33 @@ for t in range(0, T, FUSE):
         cur, r, f = orc.step(cur, a, horizon=HZ, options=1, layout_id=lid_o, start=sp)
         states.append(cur.copy())
         rews.append(r)
+        if TRACK:
+            bits = ((orc.last_events[:, None] >> np.arange(50, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.int64)
+            counts += bits.reshape(n, 25, 2)
+            counts[(f & 4) != 0] = 0
+            states[-1] = (states[-1], orc.last_events.copy())
     st = cur
+    if TRACK:
+        evs = [x[1] for x in states[1:]]
+        states = [states[0]] + [x[0] for x in states[1:]]
+        got = env.event_counts.cpu().numpy().astype(np.int64)
+        got2 = np.stack([got & 0xFFFF, (got >> 16) & 0xFFFF], -1)
+        badc = np.argwhere(got2 != counts)
+        if len(badc):
+            e = int(badc[0][0])
+            print("event counters differ at t=%d..%d: env %d layout %s (event, player) %s gpu %s oracle %s" % (
+                t, t + FUSE, e, names[lid[e]], badc[badc[:, 0] == e][:, 1:].tolist(), got2[e][got2[e] != counts[e]].tolist(),
+                counts[e][got2[e] != counts[e]].tolist()))
+            for k in range(FUSE):
+                a = O.random_actions(SEED, OFF, t + k, n)[e]
+                s0 = states[k][:, e, :]
+                cells = np.concatenate([s0[1 + p] for p in range(orc.n_planes - 1)])[:W * H].reshape(H, W)
+                nz = [(int(y), int(x), int(cells[y, x])) for y in range(H) for x in range(W) if cells[y, x]]
+                evk = int(evs[k][e])
+                print(" t=%d actions %s hdr %s objects %s oracle events %s" % (t + k, a.tolist(), s0[0][:10].tolist(), nz,
+                                                                             [(b >> 1, b & 1) for b in range(50) if (evk >> b) & 1]))
+            print("\n".join("".join(r) for r in table.specs[lid[e]].terrain_mtx))
+            break
     rew_g = rew.cpu().numpy()
     bad_r = np.argwhere(np.abs(rew_g - np.stack(rews)) > 1e-6)
     bad_s = np.argwhere(got != st)
