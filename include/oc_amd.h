@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define OC_ABI_VERSION 5
+#define OC_ABI_VERSION 6
 
 #define OC_MAX_CELLS 128
 #define OC_MAX_POTS 8
@@ -502,6 +502,21 @@ int oc_mailbox_close(OcMailbox* mailbox);
  * d_flags 8-byte aligned and not NULL), so that the ceiling is reported in the layout the rollout was timed in.
  */
 int oc_output_stores_only(int64_t n_envs, int n_steps, float* d_rewards, uint8_t* d_flags, uint32_t options, void* stream);
+
+/*
+ * oc_rollout_plan (ABI 6) — which kernel instance oc_rollout_random would launch for this batch and launch shape, as text
+ * (e.g. "k_rollout5<LAY_LDS=true, FT8=true, OLD=false, BIG=false, EV=false> mover + interact wavefronts, 1 round(s), 130864 B LDS").
+ * The answer comes from oc_rollout_random's own dispatch, walked with stand-in pointers: every argument check applies, every branch
+ * is the one a real call takes, nothing is launched and no device memory is touched — so it also runs on a host without a GPU
+ * (the device's SIMD count then defaults to MI355X's 1 024).  docs/DISPATCH.md is generated from it (tools/gen_dispatch_table.py)
+ * and tests/test_dispatch_table.py keeps that file equal to what the library answers.
+ *   with_outputs  1: d_rewards and d_flags are given; 0: both NULL
+ *   event_sink    0 none, 1 per-episode counters (OcEventSink.d_counts), 2 per-step masks as well (d_events)
+ *   start         NULL or the start-state description the call would carry
+ *   out, out_size caller's text buffer (>= 256 bytes holds every answer)
+ */
+int oc_rollout_plan(const OcBatch* batch, int horizon, uint32_t options, int64_t t0, int n_steps, int with_outputs,
+                    int event_sink, const OcStartSpec* start, char* out, size_t out_size);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OC_AMD_LIB") or os.path.join(PKG, "liboc_amd.so")  # OC_AMD_LIB: developer override
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 F_DONE, F_BAD_ACTION, F_RESET = 0x01, 0x02, 0x04
 OPT_AUTO_RESET = 0x1
 OPT_LANE_PAIR = 0x4
@@ -23,7 +23,7 @@ OBS_U8, OBS_F32 = 0, 1
 EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_batch_hints", "oc_step", "oc_step_many",
            "oc_rollout_random", "oc_encode_lossless", "oc_step_encode", "oc_rollout_encode", "oc_featurize", "oc_potential",
            "oc_phi_table_size", "oc_reset", "oc_reset_random", "oc_regen_layouts", "oc_shape_rewards", "oc_multi_agent_step",
-           "oc_mailbox_open", "oc_mailbox_buffer", "oc_mailbox_step", "oc_mailbox_close", "oc_output_stores_only")
+           "oc_mailbox_open", "oc_mailbox_buffer", "oc_mailbox_step", "oc_mailbox_close", "oc_output_stores_only", "oc_rollout_plan")
 MB_STATE_IN, MB_ACTIONS, MB_STATE_OUT, MB_REWARDS, MB_FLAGS, MB_EVENTS, MB_BYTES = 256, 336, 512, 592, 608, 616, 4096
 
 
@@ -133,6 +133,8 @@ def load():
     L.oc_mailbox_close.argtypes = [vp]
     L.oc_output_stores_only.restype = i32
     L.oc_output_stores_only.argtypes = [i64, i32, vp, vp, u32, vp]
+    L.oc_rollout_plan.restype = i32
+    L.oc_rollout_plan.argtypes = [bp, i32, u32, i64, i32, i32, i32, sp, ctypes.c_char_p, ctypes.c_size_t]
     if L.oc_abi_version() != ABI_VERSION:
         raise OcAmdError("liboc_amd.so ABI version %d != expected %d; rebuild" % (L.oc_abi_version(), ABI_VERSION))
     if L.oc_layout_size() != 256:

@@ -32,8 +32,9 @@
 #include "shared.hpp"
 
 namespace oc_detail {
-thread_local char g_err[256] = "";
-thread_local bool g_lds_refused = false;
+__thread char g_err[256] = "";
+__thread bool g_lds_refused = false;
+__thread char* g_describe = nullptr;
 }  // namespace oc_detail
 
 namespace {
@@ -383,6 +384,7 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
     const bool want_pair = (options & OC_OPT_LANE_PAIR) != 0;
     if (pair_ok && want_pair) {
         // two lanes per env (k_rollout_pair)
+        if (oc_detail::g_describe) { snprintf(oc_detail::g_describe, 256, "k_rollout_pair (OC_OPT_LANE_PAIR: two lanes per env)"); return OC_OK; }
         const size_t smem2 = (size_t)n_obj * 8 * PAIR_ENVS * sizeof(uint32_t);
         const dim3 grid2((unsigned)((b->n_envs + PAIR_ENVS - 1) / PAIR_ENVS)), block2(BLOCK);
         if (uniform)
@@ -470,8 +472,10 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         else if (c.joint || c.events) oc_detail::launch_rollout4_joint_events(c);
         else if (mode2) oc_detail::launch_rollout4_mode2(c);
         else oc_detail::launch_rollout4_mode0(c);
+        if (oc_detail::g_describe) return OC_OK;  // (oc_rollout_plan: nothing was launched)
         return check_launch("oc_rollout_random");
     }
+    if (oc_detail::g_describe) { snprintf(oc_detail::g_describe, 256, "k_rollout (OC_OPT_PREDICATE_INTERACT: the predicate-network interact)"); return OC_OK; }
     const size_t smem = (size_t)n_obj * 8 * BLOCK * sizeof(uint32_t);
     const dim3 grid(grid_for(b->n_envs)), block(BLOCK);
 #define GO(U, MP, LL)                                                                                       \
@@ -486,6 +490,28 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
     else GO(false, 8, false);
 #undef GO
     return check_launch("oc_rollout_random");
+}
+
+int oc_rollout_plan(const OcBatch* b, int horizon, uint32_t options, int64_t t0, int n_steps, int with_outputs, int event_sink,
+                    const OcStartSpec* start, char* out, size_t out_size) {
+    if (!out || out_size == 0) return fail(OC_EINVAL, "oc_rollout_plan: no output buffer");
+    out[0] = 0;
+    char buf[256] = "nothing to launch (no envs or no steps)";
+    // the call is made with stand-in pointers (the launch sites name their instance and launch nothing): every check of
+    // oc_rollout_random applies, every branch of its dispatch is the one a real call takes
+    void* const fake = reinterpret_cast<void*>((uintptr_t)4096);
+    OcEventSink sink;
+    sink.d_events = event_sink == 2 ? reinterpret_cast<uint64_t*>(fake) : nullptr;
+    sink.d_counts = event_sink >= 1 ? reinterpret_cast<uint32_t*>(fake) : nullptr;
+    sink.d_counts_done = nullptr;
+    oc_detail::g_describe = buf;
+    const int rc = oc_rollout_random(b, fake, with_outputs ? reinterpret_cast<float*>(fake) : nullptr,
+                                     with_outputs ? reinterpret_cast<uint8_t*>(fake) : nullptr, nullptr, horizon, options, 0, start ? start->env_offset : 0,
+                                     t0, n_steps, start, event_sink ? &sink : nullptr, nullptr);
+    oc_detail::g_describe = nullptr;
+    if (rc != OC_OK) return rc;
+    snprintf(out, out_size, "%s", buf);
+    return OC_OK;
 }
 
 int oc_featurize(const OcBatch* b, const uint8_t* d_plan_blob, const uint32_t* d_plan_off, const void* d_state,

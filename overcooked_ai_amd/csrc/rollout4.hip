@@ -32,9 +32,15 @@ constexpr size_t lds4_bytes(size_t cell_rows) {
     return (size_t)Lds4<U, LL, MODE, NF, U || RU, CW>::CELLS + cell_rows * BLOCK * CW + (EV ? (size_t)N_EVENT_TYPES * BLOCK * 4 : 0);
 }
 
+// (oc_rollout_plan: the instance is named instead of launched)
 #define GO4(U, MP, LL, MODE, OUT, OLD, NF, ...)                                                                     \
     do {                                                                                                            \
         const size_t smem4 = lds4_bytes<U, MP, LL, MODE, OUT, OLD, NF, ##__VA_ARGS__>(cell_rows);                   \
+        if (oc_detail::g_describe) {                                                                                \
+            snprintf(oc_detail::g_describe, 256, "k_rollout4<UNIFORM=" #U ", MAXP=" #MP ", LAY_LDS=" #LL ", MODE=" #MODE ", OUT=" #OUT \
+                     ", OLD=" #OLD ", NF=" #NF ", " #__VA_ARGS__ "> one wavefront per 64 envs, %zu B LDS", smem4);  \
+            break;                                                                                                  \
+        }                                                                                                           \
         if (!want_lds(k_rollout4<U, MP, LL, MODE, OUT, OLD, NF, ##__VA_ARGS__>, smem4)) break;                      \
         hipLaunchKernelGGL((k_rollout4<U, MP, LL, MODE, OUT, OLD, NF, ##__VA_ARGS__>), grid4, block4, smem4, c.stream, b->d_layouts, \
                            b->n_layouts, b->d_layout_id, (uint4*)c.d_state, (float4*)c.d_rewards, c.d_flags,        \
@@ -49,6 +55,12 @@ constexpr size_t lds4_bytes(size_t cell_rows) {
 #define GO5X(LL, FT8F, OLDF, BIGF, EVF)                                                                             \
     do {                                                                                                            \
         const size_t smem5 = rollout5_lds_bytes(LL, BIGF, EVF, c.n_obj);                                            \
+        if (oc_detail::g_describe) {                                                                                \
+            snprintf(oc_detail::g_describe, 256, "k_rollout5<LAY_LDS=" #LL ", FT8=" #FT8F ", OLD=" #OLDF ", BIG=" #BIGF ", EV=" #EVF \
+                     "> mover + interact wavefronts, %d round(s), %zu B LDS",                                       \
+                     (int)((b->n_envs + (simd_count() / 4) * BLOCK - 1) / ((simd_count() / 4) * BLOCK)), smem5);    \
+            break;                                                                                                  \
+        }                                                                                                           \
         if (!want_lds(k_rollout5<LL, FT8F, OLDF, BIGF, EVF>, smem5)) break;                                         \
         hipLaunchKernelGGL((k_rollout5<LL, FT8F, OLDF, BIGF, EVF>), grid4, dim3(2 * BLOCK), smem5, c.stream, b->d_layouts, b->n_layouts, \
                            b->d_layout_id, (uint4*)c.d_state, (float4*)c.d_rewards, c.d_flags, (float4*)c.d_ep_returns, \

@@ -13,8 +13,15 @@
 
 namespace oc_detail {
 
-extern thread_local char g_err[256] OC_HIDDEN;       // oc_last_error()
-extern thread_local bool g_lds_refused OC_HIDDEN;    // a dynamic-LDS request was refused: nothing was launched
+// (__thread, not thread_local: a C++ thread_local referenced from another translation unit goes through a "TLS init function"
+//  hook that is weak-undefined for these constant-initialised variables; with hidden visibility the null test is folded away and
+//  the first access from rollout4.hip jumped to the library's base address — found in round 6 by oc_rollout_plan, latent since
+//  round 4 on the error paths of the rollout4 units)
+extern __thread char g_err[256] OC_HIDDEN;       // oc_last_error()
+extern __thread bool g_lds_refused OC_HIDDEN;    // a dynamic-LDS request was refused: nothing was launched
+// oc_rollout_plan: when set, the launch sites of oc_rollout_random write the kernel instance they would launch here (256 bytes)
+// and launch nothing
+extern __thread char* g_describe OC_HIDDEN;
 
 // Launch-time description of the start_state_fn (include/oc_amd.h, OcStartSpec), by value in kernel arguments.
 struct StartArgs {

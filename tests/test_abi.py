@@ -23,7 +23,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
     for s in syms:
         assert getattr(L, s) is not None
-    assert L.oc_abi_version() == 5
+    assert L.oc_abi_version() == 6
     assert L.oc_layout_size() == 256
     assert L.oc_state_planes(5, 4) == 3 and L.oc_state_planes(9, 5) == 4 and L.oc_state_planes(14, 9) == 9
 
