@@ -491,6 +491,44 @@ int oc_mailbox_step(OcMailbox* mailbox);
 int oc_mailbox_close(OcMailbox* mailbox);
 
 /*
+ * The resident batched step (ABI 6) — OvercookedEnv.step (overcooked_env.py:244-274) for the whole batch WITHOUT a launch per step.
+ * oc_step costs a dependent kernel boundary plus its own load -> transition -> store chain per call (4.5 us for 65 536 envs); a
+ * caller that lives on the GPU (a persistent policy kernel, the last kernel of a forward pass) can instead talk to a resident
+ * kernel that keeps the envs in registers / LDS between steps, through per-env mailboxes in device memory:
+ *   request   uint64 [n_envs]     low word  a0 | a1 << 8 (| OC_SV_STOP), high word = tag      ONE aligned 8-byte store per env,
+ *                                 written through to device scope (gfx950: `global_store_dwordx2 ... sc1`)
+ *   response  uint32 [n_envs][8]  {sparse0, sparse1, shaped0 (float bits), tag} {shaped1, flags (OC_F_*), timestep, tag}
+ *                                 two aligned 16-byte stores by the server; a granule that shows the tag is complete
+ * tag = 1, 2, 3, ... = the number of the step since the server was opened (every env is sent every step; a wavefront steps when
+ * its 64 envs all show the next tag).  Readers poll with device-scope loads (`sc1`): plain loads may be served from the reader's
+ * own L2.  The transition, the bookkeeping, OC_OPT_AUTO_RESET and the drawn starts of `start` (restart at step k: epoch
+ * start->epoch + k - 1, as k consecutive oc_step calls) are oc_step's, bit for bit (tests/test_gpu_step_server.py).
+ * While the server is resident the states live on chip: d_state / d_ep_returns are current again after oc_step_server_sync (or
+ * close, or once the kernel has left by itself).  The kernel leaves after idle_ms without a request (0: 20 ms) and after life_s in
+ * any case (0: 600 s), writing the states back; oc_step_server_resume / _play relaunch it.  Device-wide synchronisation
+ * (hipDeviceSynchronize, torch.cuda.synchronize()) waits for it to leave — synchronise streams or events instead.
+ * Not served: OcEventSink, OC_OPT_PREDICATE_INTERACT; the batch's workgroups (n_envs / 256) must fit the GPU at once.
+ *   oc_step_server_play  the caller's side as a kernel on `stream` (k_step_client: lane = env; per step post the request, poll the
+ *                        response, leave rewards [n_steps][n_envs][4] / flags [n_steps][n_envs]) for actions uint8
+ *                        [n_steps][n_envs][2] — n_steps = 1: a drop-in oc_step; n_steps > 1: the parity tests' replay of
+ *                        oc_step_many's inputs and bench.py's round-trip measurement.  Host-synchronous; elapsed_ms (or NULL)
+ *                        receives the client kernel's duration (HIP events on `stream`).
+ *   oc_step_server_steps steps served so far (the host's count; exact after _play / _sync)
+ */
+#define OC_SV_STOP 0x10000u
+typedef struct OcStepServer OcStepServer;
+int oc_step_server_open(const OcBatch* batch, void* d_state, float* d_ep_returns, int horizon, uint32_t options,
+                        const OcStartSpec* start, double idle_ms, double life_s, OcStepServer** server);
+void* oc_step_server_requests(OcStepServer* server);  /* device pointer, uint64 [n_envs] */
+void* oc_step_server_responses(OcStepServer* server); /* device pointer, uint32 [n_envs][8] */
+int oc_step_server_resume(OcStepServer* server);
+int oc_step_server_play(OcStepServer* server, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags, int n_steps,
+                        void* stream, float* elapsed_ms);
+int oc_step_server_sync(OcStepServer* server);
+int64_t oc_step_server_steps(OcStepServer* server);
+int oc_step_server_close(OcStepServer* server);
+
+/*
  * Measurement aid (round 4): nothing but oc_rollout_random's OUTPUT STORES — one lane per env, per step one reward quad
  * (16 bytes, zeros) at d_rewards[k][e] and one flag byte (0) at d_flags[k][e], same workgroup shape and row addressing as the
  * rollout kernels, no state, no game.  Timing it says what the [step][env] output format of oc_rollout_random admits on the

@@ -23,7 +23,9 @@ OBS_U8, OBS_F32 = 0, 1
 EXPORTS = ("oc_abi_version", "oc_layout_size", "oc_last_error", "oc_state_planes", "oc_batch_hints", "oc_step", "oc_step_many",
            "oc_rollout_random", "oc_encode_lossless", "oc_step_encode", "oc_rollout_encode", "oc_featurize", "oc_potential",
            "oc_phi_table_size", "oc_reset", "oc_reset_random", "oc_regen_layouts", "oc_shape_rewards", "oc_multi_agent_step",
-           "oc_mailbox_open", "oc_mailbox_buffer", "oc_mailbox_step", "oc_mailbox_close", "oc_output_stores_only", "oc_rollout_plan")
+           "oc_mailbox_open", "oc_mailbox_buffer", "oc_mailbox_step", "oc_mailbox_close", "oc_output_stores_only", "oc_rollout_plan",
+           "oc_step_server_open", "oc_step_server_requests", "oc_step_server_responses", "oc_step_server_resume",
+           "oc_step_server_play", "oc_step_server_sync", "oc_step_server_steps", "oc_step_server_close")
 MB_STATE_IN, MB_ACTIONS, MB_STATE_OUT, MB_REWARDS, MB_FLAGS, MB_EVENTS, MB_BYTES = 256, 336, 512, 592, 608, 616, 4096
 
 
@@ -133,6 +135,18 @@ def load():
     L.oc_mailbox_close.argtypes = [vp]
     L.oc_output_stores_only.restype = i32
     L.oc_output_stores_only.argtypes = [i64, i32, vp, vp, u32, vp]
+    L.oc_step_server_open.restype = i32
+    L.oc_step_server_open.argtypes = [bp, vp, vp, i32, u32, sp, ctypes.c_double, ctypes.c_double, ctypes.POINTER(vp)]
+    for name in ("oc_step_server_requests", "oc_step_server_responses"):
+        getattr(L, name).restype = vp
+        getattr(L, name).argtypes = [vp]
+    for name in ("oc_step_server_resume", "oc_step_server_sync", "oc_step_server_close"):
+        getattr(L, name).restype = i32
+        getattr(L, name).argtypes = [vp]
+    L.oc_step_server_steps.restype = i64
+    L.oc_step_server_steps.argtypes = [vp]
+    L.oc_step_server_play.restype = i32
+    L.oc_step_server_play.argtypes = [vp, vp, vp, vp, i32, vp, ctypes.POINTER(ctypes.c_float)]
     L.oc_rollout_plan.restype = i32
     L.oc_rollout_plan.argtypes = [bp, i32, u32, i64, i32, i32, i32, sp, ctypes.c_char_p, ctypes.c_size_t]
     if L.oc_abi_version() != ABI_VERSION:

@@ -46,6 +46,7 @@ namespace {
 #include "step_table.hpp"
 #include "step_one.hpp"
 #include "mailbox.hpp"
+#include "step_server.hpp"
 #include "rollout_pair.hpp"
 #include "encode.hpp"
 #include "rollout_encode.hpp"
@@ -969,6 +970,278 @@ int oc_rollout_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions,
 
 // ---- the single-env mailbox (mailbox.hpp)
 }  // extern "C"
+
+// ---- the resident batched step (step_server.hpp)
+struct OcStepServer {
+    OcBatch b;
+    int n_obj, horizon, device;
+    uint32_t options;
+    StartArgs sa;
+    void* d_state;
+    float* d_ep_returns;
+    hipStream_t stream;      // the resident kernel's own stream
+    hipStream_t ctl_stream;  // posts that must overtake it (SV_STOP)
+    hipEvent_t ev0, ev1;
+    uint64_t* d_req;         // [n_envs] request granules
+    uint4* d_rsp;            // [n_envs][2] response granules
+    uint32_t* h_ctl;         // [grid + SV_ERR_WORDS] pinned, GPU-mapped: 1 per resident workgroup, then the error words
+    uint32_t* d_ctl;         // its device address
+    uint32_t* d_claims;      // [32] block claims per XCD: [0..8] the server's, [16..24] the client's (sv_claim_block)
+    unsigned grid;
+    uint32_t seq;            // the tag of the last request served (= steps served since the server was opened)
+    uint64_t idle_ticks, life_ticks, client_ticks;
+    double idle_s;
+    struct timespec last_use;
+    bool launched;
+};
+
+namespace {
+static_assert(OC_SV_STOP == SV_STOP, "command bit of include/oc_amd.h");
+// how the two ends wait: bits 0..7 naps (64 clk each) before the first look, 8..15 naps between looks, bit 16 light polls (the
+// wavefront's first env alone until it shows the tag), bit 17 never look through the L2, bits 24..26 (client) which XCD's blocks
+// a workgroup claims: its own + this.  Measured on MI355X, 65 536 envs, 1 000 dependent steps (gpurun_out -> profiles/
+// r06_step_server.txt): naps and light polls change nothing (3.3 us either way, light polls +0.3: one more load round trip);
+// both ends of every env on ONE XCD 4.17 us (5.37 without the looks through the L2: 32 pairs share one L2's channels), on
+// neighbouring XCDs 3.2, four XCDs apart 3.02 — so the client claims the blocks of the XCD opposite its own; a single pair
+// alone: 2.27 same XCD, 2.63 across.  (tuning builds: the named environment variable overrides the value)
+uint32_t sv_knobs(const char* name, uint32_t dflt) {
+#ifdef OC_AMD_TUNING
+    if (const char* e = getenv(name)) return (uint32_t)strtoul(e, nullptr, 0);
+#endif
+    (void)name;
+    return dflt;
+}
+double sv_since(const struct timespec& t) {
+    struct timespec now;
+    clock_gettime(CLOCK_MONOTONIC, &now);
+    return (double)(now.tv_sec - t.tv_sec) + 1e-9 * (double)(now.tv_nsec - t.tv_nsec);
+}
+unsigned sv_resident(const OcStepServer* m) {
+    unsigned alive = 0;
+    for (unsigned i = 0; i < m->grid; ++i) alive += __atomic_load_n(m->h_ctl + i, __ATOMIC_ACQUIRE) != 0u;
+    return alive;
+}
+void sv_mark(OcStepServer* m, uint32_t v) {
+    for (unsigned i = 0; i < m->grid; ++i) __atomic_store_n(m->h_ctl + i, v, __ATOMIC_RELEASE);
+}
+template <typename K>
+bool sv_fits(K kernel, const OcStepServer* m, size_t smem) {  // every workgroup must be resident at once: they all poll
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, smem) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return (int64_t)m->grid <= (int64_t)per_cu * cus;
+}
+// the resident kernel leaves (writes the states back) and its stream drains; the host's step count follows the device's
+int sv_stop(OcStepServer* m) {
+    if (!m->launched) return OC_OK;
+    if (sv_resident(m) != 0u)  // (on the control stream: behind the resident kernel on its own stream the post would never run)
+        hipLaunchKernelGGL(k_step_server_post, dim3(m->grid), dim3(BLOCK), 0, m->ctl_stream, m->d_req, m->b.n_envs, SV_STOP, m->d_rsp, 1u);
+    if (hipStreamSynchronize(m->ctl_stream) != hipSuccess || hipStreamSynchronize(m->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(OC_ELAUNCH, "oc_step_server: the resident kernel did not leave");
+    }
+    m->launched = false;
+    sv_mark(m, 0u);
+    uint32_t tag = 0;  // env 0's last served tag (device-side callers may have advanced it without the host)
+    if (hipMemcpy(&tag, reinterpret_cast<const uint8_t*>(m->d_rsp) + 28, 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(OC_ELAUNCH, "oc_step_server: reading the step count back failed");
+    }
+    m->seq = tag;
+    return OC_OK;
+}
+// (re)launch the resident kernel; the requests first lose any stale STOP (a no-op request: the tag already served)
+int sv_launch(OcStepServer* m) {
+    const OcBatch* b = &m->b;
+    const size_t smem = (size_t)m->n_obj * 8 * BLOCK * sizeof(uint32_t);
+    const bool uniform = b->n_layouts == 1, lds = b->n_layouts <= LDS_LAYOUT_MAX, small = b->max_pots >= 1 && b->max_pots <= 2;
+    sv_mark(m, 1u);
+    hipLaunchKernelGGL(k_step_server_post, dim3(m->grid), dim3(BLOCK), 0, m->stream, m->d_req, b->n_envs, 0u, m->d_rsp, 0u);
+    (void)hipMemsetAsync(m->d_claims, 0, 16 * sizeof(uint32_t), m->stream);
+#define GOSV(U, MP, LL)                                                                                              \
+    do {                                                                                                             \
+        if (!want_lds(k_step_server<U, MP, LL>, smem)) break;                                                        \
+        if (!sv_fits(k_step_server<U, MP, LL>, m, smem)) {                                                           \
+            sv_mark(m, 0u);                                                                                          \
+            return fail(OC_EINVAL, "oc_step_server: the batch needs more workgroups than the GPU keeps resident at once"); \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_step_server<U, MP, LL>), dim3(m->grid), dim3(BLOCK), smem, m->stream, b->d_layouts, b->n_layouts, \
+                           b->d_layout_id, (uint4*)m->d_state, (float4*)m->d_ep_returns, m->d_req, m->d_rsp, m->d_ctl, m->d_claims, b->n_envs, \
+                           b->width, m->n_obj, m->horizon, m->options, m->sa, m->idle_ticks, m->life_ticks, sv_knobs("OC_SV_SERVER", 0x0100u)); \
+    } while (0)
+    if (uniform && small) GOSV(true, 2, true);
+    else if (lds && small) GOSV(false, 2, true);
+    else GOSV(false, 8, false);
+#undef GOSV
+    const int rc = check_launch("oc_step_server");
+    if (rc) { sv_mark(m, 0u); return rc; }
+    m->launched = true;
+    clock_gettime(CLOCK_MONOTONIC, &m->last_use);
+    return OC_OK;
+}
+// resident and fresh (no workgroup about to leave for idleness), or relaunched
+int sv_ensure(OcStepServer* m) {
+    if (m->launched && sv_resident(m) == m->grid && sv_since(m->last_use) < 0.5 * m->idle_s) return OC_OK;
+    if (int rc = sv_stop(m)) return rc;
+    return sv_launch(m);
+}
+struct SvDevice {  // the server's device current for the scope
+    int prev = 0, want;
+    explicit SvDevice(int d) : want(d) { (void)hipGetDevice(&prev); if (prev != want) (void)hipSetDevice(want); }
+    ~SvDevice() { if (prev != want) (void)hipSetDevice(prev); }
+};
+}  // namespace
+
+extern "C" {
+
+int oc_step_server_open(const OcBatch* b, void* d_state, float* d_ep_returns, int horizon, uint32_t options,
+                        const OcStartSpec* start, double idle_ms, double life_s, OcStepServer** out) {
+    int n_obj = 0;
+    if (!out) return fail(OC_EINVAL, "oc_step_server_open: NULL result pointer");
+    *out = nullptr;
+    if (int rc = check_batch(b, &n_obj)) return rc;
+    StartArgs sa;
+    if (!start_args(start, &sa, b)) return fail(OC_EINVAL, "oc_step_server_open: start.rnd_obj_prob_thresh must be in [0, 1] and its regen range within the table");
+    if (!d_state) return fail(OC_EINVAL, "oc_step_server_open: NULL state pointer");
+    if (horizon < 1 || horizon > 65535) return fail(OC_EINVAL, "oc_step_server_open: horizon must be in 1..65535");
+    if (options & ~(uint32_t)OC_OPT_AUTO_RESET) return fail(OC_EINVAL, "oc_step_server_open: the only option is OC_OPT_AUTO_RESET");
+    if (b->n_envs < 1) return fail(OC_EINVAL, "oc_step_server_open: no envs");
+    if (!(idle_ms >= 0.0 && idle_ms <= 10000.0) || !(life_s >= 0.0 && life_s <= 86400.0))
+        return fail(OC_EINVAL, "oc_step_server_open: idle_ms in 0..10 000 (0: 20 ms), life_s in 0..86 400 (0: 600 s)");
+    OcStepServer* m = new OcStepServer();
+    memset(m, 0, sizeof(*m));
+    m->b = *b; m->n_obj = n_obj; m->horizon = horizon; m->options = options; m->sa = sa; m->d_state = d_state; m->d_ep_returns = d_ep_returns;
+    m->grid = grid_for(b->n_envs);
+    if (idle_ms == 0.0) idle_ms = 20.0;
+    if (life_s == 0.0) life_s = 600.0;
+    int khz = 0;
+    bool ok = hipGetDevice(&m->device) == hipSuccess;
+    if (ok && (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, m->device) != hipSuccess || khz <= 0)) khz = 100000;  // 100 MHz
+    m->idle_s = idle_ms * 1e-3;
+    m->idle_ticks = (uint64_t)((double)khz * idle_ms);
+    m->life_ticks = (uint64_t)((double)khz * 1000.0 * life_s);
+    m->client_ticks = (uint64_t)khz * 1000;  // a client wavefront gives up after 1 s without its responses
+    const size_t ctl_bytes = ((size_t)m->grid + SV_ERR_WORDS) * sizeof(uint32_t);
+    ok = ok && hipMalloc((void**)&m->d_req, (size_t)b->n_envs * 8) == hipSuccess;
+    ok = ok && hipMalloc((void**)&m->d_rsp, (size_t)b->n_envs * 32) == hipSuccess;
+    ok = ok && hipMalloc((void**)&m->d_claims, 32 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&m->h_ctl, ctl_bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    ok = ok && hipHostGetDevicePointer((void**)&m->d_ctl, m->h_ctl, 0) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&m->ctl_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreate(&m->ev0) == hipSuccess && hipEventCreate(&m->ev1) == hipSuccess;
+    if (ok) {
+        memset(m->h_ctl, 0, ctl_bytes);
+        ok = hipMemsetAsync(m->d_req, 0, (size_t)b->n_envs * 8, m->stream) == hipSuccess &&
+             hipMemsetAsync(m->d_rsp, 0, (size_t)b->n_envs * 32, m->stream) == hipSuccess &&
+             hipMemsetAsync(m->d_claims, 0, 32 * sizeof(uint32_t), m->stream) == hipSuccess &&
+             hipStreamSynchronize(m->stream) == hipSuccess;  // (before the resident kernel occupies the stream: clients run on other streams)
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        (void)oc_step_server_close(m);
+        return fail(OC_ELAUNCH, "oc_step_server_open: device / pinned memory, streams or events refused");
+    }
+    if (int rc = sv_launch(m)) { (void)oc_step_server_close(m); return rc; }
+    *out = m;
+    return OC_OK;
+}
+
+void* oc_step_server_requests(OcStepServer* m) { return m ? m->d_req : nullptr; }
+void* oc_step_server_responses(OcStepServer* m) { return m ? m->d_rsp : nullptr; }
+
+int oc_step_server_resume(OcStepServer* m) {
+    if (!m) return fail(OC_EINVAL, "oc_step_server_resume: NULL server");
+    SvDevice dev(m->device);
+    return sv_ensure(m);
+}
+
+int oc_step_server_play(OcStepServer* m, const uint8_t* d_actions, float* d_rewards, uint8_t* d_flags, int n_steps, void* stream,
+                        float* elapsed_ms) {
+    if (!m) return fail(OC_EINVAL, "oc_step_server_play: NULL server");
+    if (!d_actions || !d_rewards || !d_flags) return fail(OC_EINVAL, "oc_step_server_play: NULL actions/rewards/flags pointer");
+    if (n_steps < 0 || n_steps > (1 << 24)) return fail(OC_EINVAL, "oc_step_server_play: n_steps must be in 0..2^24");
+    if (elapsed_ms) *elapsed_ms = 0.f;
+    if (n_steps == 0) return OC_OK;
+    SvDevice dev(m->device);
+    if (int rc = sv_ensure(m)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    __atomic_store_n(m->h_ctl + m->grid + SV_ERR_CLIENT, 0u, __ATOMIC_RELEASE);
+    uint32_t* dbg = nullptr;
+#ifdef OC_AMD_TUNING
+    if (getenv("OC_SV_DEBUG")) (void)hipMalloc((void**)&dbg, (size_t)m->grid * 16);
+#endif
+    (void)hipEventRecord(m->ev0, s);
+    hipLaunchKernelGGL(k_step_client, dim3(m->grid), dim3(BLOCK), 0, s, m->d_req, m->d_rsp, d_actions, (float4*)d_rewards, d_flags,
+                       m->d_ctl + m->grid, m->d_claims + 16, m->b.n_envs, m->seq + 1u, n_steps, m->client_ticks, sv_knobs("OC_SV_CLIENT", 0x04000100u), dbg);
+    (void)hipEventRecord(m->ev1, s);
+    if (int rc = check_launch("oc_step_server_play")) return rc;
+    if (hipEventSynchronize(m->ev1) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(OC_ELAUNCH, "oc_step_server_play: the client kernel failed");
+    }
+    clock_gettime(CLOCK_MONOTONIC, &m->last_use);
+    if (__atomic_load_n(m->h_ctl + m->grid + SV_ERR_CLIENT, __ATOMIC_ACQUIRE) != 0u) {
+        (void)sv_stop(m);  // (the host's step count follows whatever the device got to)
+        return fail(OC_ELAUNCH, "oc_step_server_play: no answer from the resident kernel within 1 s");
+    }
+    m->seq += (uint32_t)n_steps;
+    if (elapsed_ms) (void)hipEventElapsedTime(elapsed_ms, m->ev0, m->ev1);
+#ifdef OC_AMD_TUNING
+    if (dbg) {  // where a round trip goes, in 10 ns ticks: the client's post -> response seen, of which the server's seen -> sent
+        uint32_t* h = (uint32_t*)malloc((size_t)m->grid * 16);
+        (void)hipMemcpy(h, dbg, (size_t)m->grid * 16, hipMemcpyDeviceToHost);
+        double rt = 0, sv = 0, worst = 0;
+        int cross = 0;
+        for (unsigned b = 0; b < m->grid; ++b) {
+            rt += h[4 * b]; sv += h[4 * b + 1];
+            if (h[4 * b] > worst) worst = h[4 * b];
+            cross += (h[4 * b + 2] & 0xFu) != (h[4 * b + 3] & 0xFu);
+        }
+        fprintf(stderr, "[oc_step_server] %d steps x %u workgroups: round trip mean %.0f ns (in the server %.0f ns), slowest workgroup %.0f ns; %d pairs across XCDs\n",
+                n_steps, m->grid, 10.0 * rt / n_steps / m->grid, 10.0 * sv / n_steps / m->grid, 10.0 * worst / n_steps, cross);
+        if (getenv("OC_SV_DEBUG_ALL"))
+            for (unsigned b = 0; b < m->grid; ++b)
+                fprintf(stderr, "  wg %3u: rt %5.0f ns server %4.0f ns  server xcc %u  client xcc %u\n", b, 10.0 * h[4 * b] / n_steps, 10.0 * h[4 * b + 1] / n_steps,
+                        h[4 * b + 2] & 0xFu, h[4 * b + 3] & 0xFu);
+        free(h);
+        (void)hipFree(dbg);
+    }
+#endif
+    return OC_OK;
+}
+
+int oc_step_server_sync(OcStepServer* m) {
+    if (!m) return fail(OC_EINVAL, "oc_step_server_sync: NULL server");
+    SvDevice dev(m->device);
+    return sv_stop(m);
+}
+
+int64_t oc_step_server_steps(OcStepServer* m) { return m ? (int64_t)m->seq : -1; }
+
+int oc_step_server_close(OcStepServer* m) {
+    if (!m) return OC_OK;
+    SvDevice dev(m->device);
+    int rc = OC_OK;
+    if (m->stream && m->ctl_stream) rc = sv_stop(m);
+    if (m->ev0) (void)hipEventDestroy(m->ev0);
+    if (m->ev1) (void)hipEventDestroy(m->ev1);
+    if (m->ctl_stream) (void)hipStreamDestroy(m->ctl_stream);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    if (m->h_ctl) (void)hipHostFree(m->h_ctl);
+    if (m->d_claims) (void)hipFree(m->d_claims);
+    if (m->d_rsp) (void)hipFree(m->d_rsp);
+    if (m->d_req) (void)hipFree(m->d_req);
+    (void)hipGetLastError();
+    delete m;
+    return rc;
+}
+
+}  // extern "C"
+
 
 struct OcMailbox {
     uint8_t* h;             // the mailbox (pinned host memory, mapped into the GPU's address space)

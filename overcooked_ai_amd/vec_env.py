@@ -298,6 +298,13 @@ class VecOvercookedEnv:
         self._advance(int(K))
         return rewards_out, flags_out
 
+    def step_server(self, idle_ms=0.0, life_s=0.0):
+        """A StepServer for this env: the resident batched step (no launch per step; include/oc_amd.h oc_step_server_*).  Event
+        tracking is not served."""
+        if self.event_counts is not None:
+            raise ValueError("step_server: event tracking (track_events) is not served by the resident kernel")
+        return StepServer(self, idle_ms, life_s)
+
     def rollout_random(self, n_steps, rewards_out=None, flags_out=None, events_out=None, flags_tiled8=False):
         """n_steps fused random-policy transitions in one launch (Philox actions, see include/oc_amd.h).  A launch
         costs ~16 us outside its step loop (tables, state load / store, dispatch): 12 % of a 400-step launch at 65 536
@@ -466,3 +473,80 @@ class VecOvercookedEnv:
         self._refresh_layout_ids()
         packed = self.get_packed_state()
         return [unpack_states(self.spec_of(e), packed[:, e:e + 1], as_dict=as_dict)[0] for e in range(self.n_envs)]
+
+
+class StepServer:
+    """The resident batched step of a VecOvercookedEnv (include/oc_amd.h, oc_step_server_*): a kernel that keeps the envs on chip
+    and serves every step through per-env mailboxes in device memory, for callers that live on the GPU themselves.
+
+        with env.step_server() as sv:
+            sv.play(actions, rewards_out, flags_out)   # K steps == env.step_many(actions, ...), bit for bit
+            r, f = sv.step(actions_1)                  # one step == env.step(actions_1)
+        # here env.state / env.ep_returns are current again
+
+    While it is open, `env.state` is stale (the states live on chip) until sync() / close().  Device-wide synchronisation
+    (torch.cuda.synchronize()) waits until the kernel leaves by itself (idle_ms without a request): synchronise streams or events.
+    `requests` / `responses` are the raw mailboxes for device-side callers (formats in include/oc_amd.h)."""
+
+    def __init__(self, env, idle_ms=0.0, life_s=0.0):
+        self.env = env
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(env.device):
+            rc = env.lib.oc_step_server_open(env._bref, env._state_ptr, env._ep_ptr, env.horizon, _lib.OPT_AUTO_RESET if env.auto_reset else 0,
+                                             env._start_spec() if env.auto_reset else None, float(idle_ms), float(life_s), ctypes.byref(self._h))
+        _lib.check(rc, "oc_step_server_open")
+        self.requests = env.lib.oc_step_server_requests(self._h)    # device pointer: uint64 [n_envs]
+        self.responses = env.lib.oc_step_server_responses(self._h)  # device pointer: uint32 [n_envs][8]
+        self.last_play_ms = 0.0
+        self._ms = ctypes.c_float()
+
+    def play(self, actions, rewards_out, flags_out):
+        """K steps with the caller's actions uint8 [K, n_envs, 2] -> rewards_out float32 [K, n_envs, 4], flags_out uint8 [K, n_envs]
+        (the client kernel on torch's current stream; returns when the outputs are there)."""
+        env, K = self.env, int(actions.shape[0])
+        env._check(actions, torch.uint8, K * env.n_envs * 2, "actions")
+        env._check(rewards_out, torch.float32, K * env.n_envs * 4, "rewards_out")
+        env._check(flags_out, torch.uint8, K * env.n_envs, "flags_out")
+        with torch.cuda.device(env.device):
+            rc = env.lib.oc_step_server_play(self._h, actions.data_ptr(), rewards_out.data_ptr(), flags_out.data_ptr(), K,
+                                             env._stream(), ctypes.byref(self._ms))
+        _lib.check(rc, "oc_step_server_play")
+        self.last_play_ms = float(self._ms.value)
+        env._advance(K)
+        return rewards_out, flags_out
+
+    def step(self, actions):
+        """One step: actions uint8 [n_envs, 2] -> (env.rewards, env.flags), as VecOvercookedEnv.step."""
+        env = self.env
+        self.play(actions.view(1, env.n_envs, 2), env.rewards.view(1, env.n_envs, 4), env.flags.view(1, env.n_envs))
+        return env.rewards, env.flags
+
+    def resume(self):
+        """(Re)launch the resident kernel if it has left — for device-side callers, before a burst of requests."""
+        _lib.check(self.env.lib.oc_step_server_resume(self._h), "oc_step_server_resume")
+
+    def sync(self):
+        """The resident kernel leaves and writes the states back: env.state / env.ep_returns are current (the next play relaunches)."""
+        _lib.check(self.env.lib.oc_step_server_sync(self._h), "oc_step_server_sync")
+
+    @property
+    def steps(self):
+        return int(self.env.lib.oc_step_server_steps(self._h))
+
+    def close(self):
+        if self._h:
+            h, self._h = self._h, ctypes.c_void_p()
+            _lib.check(self.env.lib.oc_step_server_close(h), "oc_step_server_close")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,102 @@
+"""The resident batched step (oc_step_server_*, csrc/step_server.hpp): k_step_server + its device-side client against
+oc_step_many / oc_step and the oracle — OvercookedEnv.step (overcooked_env.py:244-274) without a launch per step."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import CANONICAL_5, make_env, oracle_for
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def test_step_server_equals_single_steps_with_illegal_actions_and_resets(gpu):
+    """K steps through the resident kernel == K oc_step launches == oc_step_many == the oracle, across episode ends (auto-reset)
+    and with illegal actions sprinkled in, on a single layout, a mixed table, a 7-pot layout and ragged batches; the states come
+    back at sync() and the server resumes where it stopped."""
+    from overcooked_ai_amd.layouts import LayoutSpec, LayoutTable, spec_from_name
+
+    seven = LayoutSpec({"grid": "XPPPPPX\nO 1 2 O\nX     X\nXDPSPTX", "onion_time": 3, "tomato_time": 5,
+                        "onion_value": 7, "tomato_value": 4})
+    table5 = LayoutTable([spec_from_name(nm) for nm in CANONICAL_5], pad_to=(9, 5))
+    rng = np.random.default_rng(12)
+    for layouts, n_lay, n in (("cramped_room", 0, 2500), (table5, 5, 2560), (seven, 0, 700), ("asymmetric_advantages", 0, 65)):
+        K, horizon = 61, 17
+        lid = (np.arange(n) % n_lay).astype(np.uint16) if n_lay else None
+        a = rng.integers(0, 6, size=(K, n, 2)).astype(np.uint8)
+        a[rng.integers(0, K, 40), rng.integers(0, n, 40), rng.integers(0, 2, 40)] = 7
+        acts = torch.from_numpy(a).to(gpu)
+        res = make_env(layouts, n, gpu, horizon=horizon, auto_reset=True, layout_id=lid)
+        one = make_env(layouts, n, gpu, horizon=horizon, auto_reset=True, layout_id=lid)
+        rew = torch.zeros((K, n, 4), dtype=torch.float32, device=gpu)
+        fl = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
+        specs = layouts.specs if n_lay else [layouts if not isinstance(layouts, str) else spec_from_name(layouts)]
+        orc = oracle_for(specs)
+        st = orc.reset(orc.new_state(n), layout_id=lid)
+        ep = np.zeros((n, 4), np.float32)
+        with res.step_server(idle_ms=5.0, life_s=5.0) as sv:
+            half = 30
+            sv.play(acts[:half], rew[:half], fl[:half])  # one launch of the client, 30 round trips
+            sv.sync()                                    # the states come back ...
+            for k in range(half):
+                r1, f1 = one.step(acts[k])
+                assert torch.equal(r1, rew[k]) and torch.equal(f1, fl[k]), k
+            assert torch.equal(res.state, one.state) and torch.equal(res.ep_returns, one.ep_returns)
+            assert sv.steps == half
+            for k in range(half, K):                     # ... and the server resumes: one step per call from here
+                r2, f2 = sv.step(acts[k])
+                rew[k], fl[k] = r2, f2
+                r1, f1 = one.step(acts[k])
+                assert torch.equal(r1, r2) and torch.equal(f1, f2), k
+        for k in range(K):
+            st, r_o, f_o = orc.step(st, a[k], horizon=horizon, options=1, layout_id=lid, ep_returns=ep)
+            assert np.array_equal(r_o, rew[k].cpu().numpy()) and np.array_equal(f_o, fl[k].cpu().numpy()), k
+        assert torch.equal(res.state, one.state) and torch.equal(res.ep_returns, one.ep_returns)
+        assert np.array_equal(res.get_packed_state(), st) and np.array_equal(res.ep_returns.cpu().numpy(), ep)
+        assert (fl & 2).any() and (fl & 4).any()
+
+
+def test_step_server_drawn_starts_and_idle_exit(gpu):
+    """Restarts inside the resident kernel draw their start states (OcStartSpec) with the epochs consecutive oc_step calls use;
+    a server that has left for idleness (its states written back) is relaunched by the next play."""
+    import time
+
+    n, horizon, K = 3000, 9, 40
+    kw = dict(random_start_pos=True, rnd_obj_prob_thresh=0.35, seed=11, env_offset=1000)
+    res = make_env("asymmetric_advantages", n, gpu, horizon=horizon, auto_reset=True, **kw)
+    one = make_env("asymmetric_advantages", n, gpu, horizon=horizon, auto_reset=True, **kw)
+    assert torch.equal(res.state, one.state)
+    acts = torch.randint(0, 6, (K, n, 2), dtype=torch.uint8, device=gpu, generator=torch.Generator(device=gpu).manual_seed(3))
+    rew = torch.zeros((K, n, 4), dtype=torch.float32, device=gpu)
+    fl = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
+    with res.step_server(idle_ms=2.0, life_s=5.0) as sv:
+        sv.play(acts[:25], rew[:25], fl[:25])
+        time.sleep(0.05)  # 25 x the idle window: the kernel has left by itself
+        torch.cuda.synchronize()  # (a device-wide wait returns once it has)
+        for k in range(25):
+            r1, f1 = one.step(acts[k])
+            assert torch.equal(r1, rew[k]) and torch.equal(f1, fl[k]), k
+        assert torch.equal(res.state, one.state)  # written back at the idle exit
+        sv.play(acts[25:], rew[25:], fl[25:])     # relaunched
+        for k in range(25, K):
+            r1, f1 = one.step(acts[k])
+            assert torch.equal(r1, rew[k]) and torch.equal(f1, fl[k]), k
+    assert torch.equal(res.state, one.state) and torch.equal(res.ep_returns, one.ep_returns)
+    assert (fl & 4).any()
+
+
+def test_step_server_refuses_what_it_does_not_serve(gpu):
+    from overcooked_ai_amd import _lib
+
+    ev = make_env("cramped_room", 256, gpu, horizon=20, auto_reset=True, track_events=True)
+    with pytest.raises(ValueError, match="event tracking"):
+        ev.step_server()
+    big = make_env("cramped_room", 256, gpu, horizon=20, auto_reset=True)
+    with pytest.raises(_lib.OcAmdError, match="idle_ms"):
+        big.step_server(idle_ms=-1.0)
