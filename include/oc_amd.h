@@ -495,9 +495,12 @@ int oc_mailbox_close(OcMailbox* mailbox);
  * oc_step costs a dependent kernel boundary plus its own load -> transition -> store chain per call (4.5 us for 65 536 envs); a
  * caller that lives on the GPU (a persistent policy kernel, the last kernel of a forward pass) can instead talk to a resident
  * kernel that keeps the envs in registers / LDS between steps, through per-env mailboxes in device memory:
- *   request   uint64 [n_envs]     low word  a0 | a1 << 8 (| OC_SV_STOP), high word = tag      ONE aligned 8-byte store per env,
+ *   request   uint64 [n_envs]     low word  a0 | a1 << 8 (| OC_SV_STOP) [| caller's XCD << 20 | 1 << 24: lets the server look
+ *                                 through its L2 between device-scope looks when both ends share an XCD], high word = tag;
+ *                                 ONE aligned 8-byte store per env,
  *                                 written through to device scope (gfx950: `global_store_dwordx2 ... sc1`)
- *   response  uint32 [n_envs][8]  {sparse0, sparse1, shaped0 (float bits), tag} {shaped1, flags (OC_F_*), timestep, tag}
+ *   response  uint32 [n_envs][8]  {sparse0, sparse1, shaped0 (float bits), tag} {shaped1, flags (OC_F_*), info, tag}
+ *                                 info = timestep (bits 0..15) | XCD the server's workgroup runs on (20..23) | 1 << 24;
  *                                 two aligned 16-byte stores by the server; a granule that shows the tag is complete
  * tag = 1, 2, 3, ... = the number of the step since the server was opened (every env is sent every step; a wavefront steps when
  * its 64 envs all show the next tag).  Readers poll with device-scope loads (`sc1`): plain loads may be served from the reader's
