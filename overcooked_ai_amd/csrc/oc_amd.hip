@@ -1084,7 +1084,15 @@ int sv_launch(OcStepServer* m) {
 }
 // resident and fresh (no workgroup about to leave for idleness), or relaunched
 int sv_ensure(OcStepServer* m) {
-    if (m->launched && sv_resident(m) == m->grid && sv_since(m->last_use) < 0.5 * m->idle_s) return OC_OK;
+    if (m->launched) {
+        // announce the caller FIRST (a workgroup about to leave for idleness or age looks at this word and stays), give a workgroup
+        // that had already looked 20 us to say that it left, THEN count: whoever is counted is still there when the client arrives
+        __atomic_fetch_add(m->h_ctl + m->grid + SV_KEEPALIVE, 1u, __ATOMIC_RELEASE);
+        struct timespec t0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        while (sv_since(t0) < 20e-6) __builtin_ia32_pause();
+    }
+    if (m->launched && sv_resident(m) == m->grid) return OC_OK;
     if (int rc = sv_stop(m)) return rc;
     return sv_launch(m);
 }

@@ -43,7 +43,9 @@ __device__ __forceinline__ void sv_store16x2(void* p, sv_u32x4 a, sv_u32x4 b) {
 }
 
 // the host-visible control words (pinned, GPU-mapped host memory): [0 .. grid) 1 while workgroup b is resident; then
-enum { SV_ERR_CLIENT = 0, SV_ERR_WORDS = 4 };  // [grid + SV_ERR_CLIENT]: a client wavefront gave up waiting for its responses
+// [grid + SV_ERR_CLIENT]: a client wavefront gave up waiting for its responses; [grid + SV_KEEPALIVE]: bumped by the host before it
+// launches a client (a workgroup about to leave looks at it first)
+enum { SV_ERR_CLIENT = 0, SV_KEEPALIVE = 1, SV_ERR_WORDS = 4 };
 
 // L2-scope load (sc0: past this CU's vector cache, from the XCD's L2): sees a write-through store made on the SAME XCD ~3x sooner
 // than a device-scope load, and never one made on another XCD — used only between looks at device scope
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(BLOCK) void k_step_server(const OcLayout* __restric
     }
     const uint64_t born = wall_clock64();
     uint64_t last = born;
+    uint32_t keep = __hip_atomic_load(ctl + gridDim.x + SV_KEEPALIVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const bool wave_serves = __ballot(active) != 0ull;  // (a wavefront wholly beyond the batch has nobody to answer)
     while (wave_serves) {
         // ---- the request: payload and tag in one load per lane
@@ -143,7 +146,15 @@ __global__ __launch_bounds__(BLOCK) void k_step_server(const OcLayout* __restric
                 if (__ballot(!active || q.y == expect) == __ballot(true)) break;
             }
             const uint64_t now = wall_clock64();
-            if (now - last > idle_ticks || now - born > life_ticks) { leave = true; break; }
+            // leaving: idle for idle_ticks, or past life_ticks and not inside a burst of requests (200 us without one) — unless a
+            // host-side caller has announced itself since the last look at the keep-alive word (oc_amd.hip: sv_ensure bumps it
+            // BEFORE it checks who is resident, so a client launched after that check finds every workgroup it counted)
+            if (now - last > idle_ticks || (now - born > life_ticks && now - last > 20000u)) {
+                const uint32_t k = __hip_atomic_load(ctl + gridDim.x + SV_KEEPALIVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (k == keep) { leave = true; break; }
+                keep = k;
+                last = now;
+            }
             sv_nap((knobs >> 8) & 0xFFu);
         }
         if (leave || __ballot(active && (q.x & SV_STOP) != 0u) != 0ull) break;

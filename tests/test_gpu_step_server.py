@@ -75,9 +75,9 @@ def test_step_server_drawn_starts_and_idle_exit(gpu):
     acts = torch.randint(0, 6, (K, n, 2), dtype=torch.uint8, device=gpu, generator=torch.Generator(device=gpu).manual_seed(3))
     rew = torch.zeros((K, n, 4), dtype=torch.float32, device=gpu)
     fl = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
-    with res.step_server(idle_ms=2.0, life_s=5.0) as sv:
+    with res.step_server(idle_ms=4.0, life_s=5.0) as sv:
         sv.play(acts[:25], rew[:25], fl[:25])
-        time.sleep(0.05)  # 25 x the idle window: the kernel has left by itself
+        time.sleep(0.1)  # 25 x the idle window: the kernel has left by itself
         torch.cuda.synchronize()  # (a device-wide wait returns once it has)
         for k in range(25):
             r1, f1 = one.step(acts[k])
@@ -100,3 +100,30 @@ def test_step_server_refuses_what_it_does_not_serve(gpu):
     big = make_env("cramped_room", 256, gpu, horizon=20, auto_reset=True)
     with pytest.raises(_lib.OcAmdError, match="idle_ms"):
         big.step_server(idle_ms=-1.0)
+
+
+def test_step_server_leaves_and_returns_around_its_idle_and_life_windows(gpu):
+    """Bursts separated by pauses around the idle window (1 ms) and a lifetime (20 ms) that expires many times during the test: the
+    kernel leaves between bursts — never inside one — and every relaunch resumes from the states it wrote back."""
+    import time
+
+    n, horizon = 1500, 11
+    res = make_env("coordination_ring", n, gpu, horizon=horizon, auto_reset=True)
+    one = make_env("coordination_ring", n, gpu, horizon=horizon, auto_reset=True)
+    rng = np.random.default_rng(5)
+    g = torch.Generator(device=gpu).manual_seed(9)
+    with res.step_server(idle_ms=1.0, life_s=0.02) as sv:
+        total = 0
+        for burst in range(120):
+            K = int(rng.integers(1, 9))
+            acts = torch.randint(0, 6, (K, n, 2), dtype=torch.uint8, device=gpu, generator=g)
+            rew = torch.zeros((K, n, 4), dtype=torch.float32, device=gpu)
+            fl = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
+            sv.play(acts, rew, fl)
+            for k in range(K):
+                r1, f1 = one.step(acts[k])
+                assert torch.equal(r1, rew[k]) and torch.equal(f1, fl[k]), (burst, k)
+            total += K
+            time.sleep(float(rng.choice([0.0, 0.0005, 0.001, 0.002, 0.03])))
+        assert sv.steps == total
+    assert torch.equal(res.state, one.state) and torch.equal(res.ep_returns, one.ep_returns)
