@@ -647,7 +647,7 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
                     const size_t env_bytes = (size_t)2 * b->width * b->height * OC_NUM_LAYERS * elem;
                     int unit = 1;
                     while (((env_bytes * unit) & 15u) != 0) unit *= 2;  // 1, 2 or 4 envs per template
-                    const size_t fixed = (size_t)n_obj * BLOCK * 16 + env_bytes * unit + (size_t)4 * BLOCK * 16 + RE_LIST_BYTES;  // (+ the object lists)
+                    const size_t fixed = (size_t)n_obj * BLOCK * 16 + env_bytes * unit + (size_t)4 * BLOCK * 16;
                     const size_t budget = 150 * 1024;
                     int gmax = fixed < budget ? (int)((budget - fixed) / (8 * env_bytes)) : 0;
                     if (gmax > 64) gmax = 64;

@@ -58,7 +58,6 @@ __global__ __launch_bounds__(2 * BLOCK) void k_train_step_obs(
     __shared__ uint2 s_lut[2 * LUT_ENTRIES];
     __shared__ uint16_t s_ioff[64];   // cell -> offset of its item in a view, in values: 26 * (x * H + y)
     __shared__ uint32_t s_next[4];    // per owner wavefront: the next sub-group of its envs nobody has taken yet
-    __shared__ uint32_t s_gmax[4][32];  // per owner wavefront and sub-group: the largest object count of its envs
     const int cells_n = W * H;
     const int items_per_env = 2 * cells_n;
     const size_t env_bytes = (size_t)items_per_env * OC_NUM_LAYERS * sizeof(T);
@@ -70,11 +69,8 @@ __global__ __launch_bounds__(2 * BLOCK) void k_train_step_obs(
     uint4* s_pre = s_hdr + BLOCK;                              // [BLOCK] phi_record of s' before any restart
     uint4* s_post = s_pre + BLOCK;                             // [BLOCK] phi_record of a DRAWN start state
     float4* s_rw = reinterpret_cast<float4*>(s_post + BLOCK);  // [BLOCK] the step's reward quad
-    // what lies on each env's grid as a compact list (round 6, as k_rollout_encode's): cell | object << 8, in cell order
-    uint16_t* s_list = reinterpret_cast<uint16_t*>(s_rw + BLOCK);                // [RE_LIST_CAP][BLOCK]
-    uint8_t* s_cnt = reinterpret_cast<uint8_t*>(s_list + RE_LIST_CAP * BLOCK);   // [BLOCK] objects on the env's grid (255 = more)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint4* img = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(s_rw + BLOCK) + RE_LIST_BYTES) + (size_t)wave * img_chunks;
+    uint4* img = reinterpret_cast<uint4*>(s_rw + BLOCK) + (size_t)wave * img_chunks;
     T* imgT = reinterpret_cast<T*>(img);
     T* tmpl = reinterpret_cast<T*>(s_tmpl);
     const bool owner = threadIdx.x < BLOCK;
@@ -92,7 +88,6 @@ __global__ __launch_bounds__(2 * BLOCK) void k_train_step_obs(
     for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += 2 * BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
     if (threadIdx.x < 16) s_lay[threadIdx.x] = reinterpret_cast<const uint4*>(g_layouts)[threadIdx.x];
     if (threadIdx.x < 4) s_next[threadIdx.x] = 0u;
-    if (threadIdx.x < 128) s_gmax[threadIdx.x >> 5][threadIdx.x & 31] = 0u;
     for (int i = threadIdx.x; i < unit_chunks; i += 2 * BLOCK) s_tmpl[i] = make_uint4(0, 0, 0, 0);
     const uint32_t inv_w = 65536u / (uint32_t)W + 1u;
     if (threadIdx.x < 64) {
@@ -150,25 +145,6 @@ __global__ __launch_bounds__(2 * BLOCK) void k_train_step_obs(
         }
         one_store<MAXP>(C, L, st, n, e, n_obj, q, is_done, row);  // header + every plane, the planes left in this lane's rows
         s_hdr[tid] = one_header<MAXP>(C, s);
-        {   // the compact list of what lies on this env's grid (lane = env: every lane busy), the largest count per sub-group.
-            // The sub-groups' scatters then run lane = (env, k-th object) instead of lane = (env, object dword) with a divergent
-            // loop over each dword's bytes — most of the encode loop's instructions, and on small grids this kernel is bound by
-            // the instructions its two wavefronts per SIMD issue, not by HBM (round 6: streaming the static bytes of 2 of 5
-            // sub-groups while HBM idles, patching the rest in place, changed nothing).
-            uint32_t cnt = 0;
-            for (int j = 0; j < n_obj * 4; ++j) {
-                uint32_t w = reinterpret_cast<const uint32_t*>(s_rows + (j >> 2) * BLOCK + tid)[j & 3];
-                while (w != 0u) {
-                    const uint32_t b4 = (uint32_t)(__ffs((int)w) - 1) >> 3;
-                    const uint32_t o = (w >> (8u * b4)) & 0xFFu;
-                    w &= ~(0xFFu << (8u * b4));
-                    if (cnt < (uint32_t)RE_LIST_CAP) s_list[cnt * BLOCK + tid] = (uint16_t)((4u * (uint32_t)j + b4) | (o << 8));
-                    ++cnt;
-                }
-            }
-            s_cnt[tid] = (uint8_t)min(cnt, 255u);
-            atomicMax(&s_gmax[ow][lane / group_envs], cnt);
-        }
         rewards[e] = r;
         flags[e] = (uint8_t)fl;
         if (ep_returns) ep_returns[e] = ep;
@@ -238,31 +214,7 @@ __global__ __launch_bounds__(2 * BLOCK) void k_train_step_obs(
                 if (held) { enc_object_writes<T>(own, held, false, 0u, 0u); enc_object_writes<T>(other, held, false, 0u, 0u); }
             }
         }
-        // objects on the grid (mdp.py:2482-2534) from the compact lists: lane = (env, k-th object of its grid)
-        const uint32_t kmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_gmax[ow][g]);
-        if (kmax <= (uint32_t)RE_LIST_CAP) {
-            if (kmax != 0u) {
-                const int sh = kmax <= 1u ? 0 : 32 - __builtin_clz(kmax - 1u);  // slots per env: the next power of two
-                const int tasks = ne << sh;
-                for (int t = lane; t < tasks; t += 64) {
-                    const int le = t >> sh, l = ow * 64 + l0 + le;
-                    const uint32_t k = (uint32_t)t & ((1u << sh) - 1u);
-                    if (k < (uint32_t)s_cnt[l]) {
-                        const uint32_t ent = s_list[k * BLOCK + l];
-                        const uint32_t c = ent & 0xFFu, o = ent >> 8;
-                        const uint32_t tkw = s_hdr[l].z;
-                        const uint32_t tc = L.terrain(c);
-                        const bool in_pot = (tc & 7u) == OC_T_POT;
-                        const uint32_t tk = (tkw >> (8u * ((tc >> 3) & 3u))) & 0xFFu;
-                        const uint32_t ct = L.cook_time(recipe_idx(o) & 15u);
-                        T* item = imgT + (uint32_t)le * (uint32_t)items_per_env * OC_NUM_LAYERS + s_ioff[c & 63u];
-                        enc_object_writes<T>(item, o, in_pot, tk, ct);
-                        enc_object_writes<T>(item + (uint32_t)cells_n * OC_NUM_LAYERS, o, in_pot, tk, ct);
-                    }
-                }
-            }
-        } else
-        // (an env of the sub-group holds more objects than a list takes) lane = (env, object dword)
+        // objects on the grid (mdp.py:2482-2534): lane = (env, object dword)
         for (int q = lane; q < ne * obj_dwords; q += 64) {
             const int le = q / obj_dwords, j = q - le * obj_dwords;
             const int l = ow * 64 + l0 + le;
