@@ -649,26 +649,41 @@ int oc_multi_agent_step(const OcBatch* b, void* d_state, const uint8_t* d_action
                     while (((env_bytes * unit) & 15u) != 0) unit *= 2;  // 1, 2 or 4 envs per template
                     const size_t fixed = (size_t)n_obj * BLOCK * 16 + env_bytes * unit + (size_t)4 * BLOCK * 16;
                     const size_t budget = 150 * 1024;
-                    int gmax = fixed < budget ? (int)((budget - fixed) / (8 * env_bytes)) : 0;
-                    if (gmax > 64) gmax = 64;
+                    // wavefronts per workgroup: 16 (4 owners, 4 helpers, 8 encoders; round 6) for u8 observations whose private images
+                    // still hold >= 6 envs then (cramped_room-sized grids: the encode loop there is bound by what the wavefronts of a
+                    // CU can issue, not by bytes), else 8
 #ifdef OC_AMD_TUNING
+                    static const int forced_w = []() { const char* e = getenv("OC_TRAIN_OBS_WAVES"); return e ? atoi(e) : 0; }();
                     static const int forced_g = []() { const char* e = getenv("OC_TRAIN_OBS_G"); return e ? atoi(e) : 0; }();
-                    if (forced_g > 0 && forced_g < gmax) gmax = forced_g;
+#else
+                    constexpr int forced_w = 0, forced_g = 0;
 #endif
-                    gmax -= gmax % unit;
-                    if (gmax >= unit && gmax >= 2) {  // (one env per image — 9x5 f32 — measured slower than the two kernels: 123-127 vs 116-122 us)
-                        const size_t smem_o = fixed + (size_t)8 * gmax * env_bytes;
-#define GOTO(MP, T)                                                                                                     \
+                    int nwv = 0, gmax = 0;
+                    for (int w : {16, 8}) {
+                        if (forced_w && w != forced_w) continue;
+                        if (!forced_w && w == 16 && obs_dtype != OC_OBS_U8) continue;
+                        int g = fixed < budget ? (int)((budget - fixed) / ((size_t)w * env_bytes)) : 0;
+                        if (g > 64) g = 64;
+                        if (forced_g > 0 && forced_g < g) g = forced_g;
+                        g -= g % unit;
+                        if (w == 16 && g < 6 && !forced_w) continue;  // (measured: 7-env images 22.0 -> 19.5 us, 3-env images 31.8 -> 37.6)
+                        if (g >= unit && g >= 2) { nwv = w; gmax = g; break; }
+                    }
+                    if (nwv) {  // (one env per image — 9x5 f32 — measured slower than the two kernels: 123-127 vs 116-122 us)
+                        const size_t smem_o = fixed + (size_t)nwv * gmax * env_bytes;
+#define GOTO(MP, T, NW)                                                                                                 \
     do {                                                                                                                \
-        if (!want_lds(k_train_step_obs<MP, T>, smem_o)) break;                                                          \
-        hipLaunchKernelGGL((k_train_step_obs<MP, T>), grid, dim3(2 * BLOCK), smem_o, (hipStream_t)stream, b->d_layouts, \
+        if (!want_lds(k_train_step_obs<MP, T, NW>, smem_o)) break;                                                      \
+        hipLaunchKernelGGL((k_train_step_obs<MP, T, NW>), grid, dim3(NW * 64), smem_o, (hipStream_t)stream, b->d_layouts, \
                            (uint4*)d_state, d_actions, (float4*)d_rewards, d_flags, (float4*)d_ep_returns,              \
                            (float4*)d_ep_returns_out, d_plan_blob, d_plan_off, d_phi_tables, d_phi_next, d_phi_cur,     \
                            d_phi_start, reward_shaping_factor, d_shaped, d_done, (uint8_t*)d_obs, b->n_envs, b->width,  \
                            b->height, n_obj, horizon, unit, gmax, sa);                                                  \
     } while (0)
-                        if (obs_dtype == OC_OBS_U8) { if (b->max_pots == 1) GOTO(1, uint8_t); else GOTO(2, uint8_t); }
-                        else { if (b->max_pots == 1) GOTO(1, float); else GOTO(2, float); }
+#define GOTOW(MP, T) do { if (nwv == 16) GOTO(MP, T, 16); else GOTO(MP, T, 8); } while (0)
+                        if (obs_dtype == OC_OBS_U8) { if (b->max_pots == 1) GOTOW(1, uint8_t); else GOTOW(2, uint8_t); }
+                        else { if (b->max_pots == 1) GOTOW(1, float); else GOTOW(2, float); }
+#undef GOTOW
 #undef GOTO
                         return check_launch("oc_multi_agent_step");
                     }
@@ -1377,6 +1392,12 @@ int oc_mailbox_step(OcMailbox* m) {
     return OC_OK;
 }
 
+#ifdef OC_AMD_TUNING
+// tuning builds: the phase stamps of the last k_train_step_obs launch (train_obs.hpp: g_obs_dbg), n_words u32
+int oc_debug_train_obs(uint32_t* out, int n_words) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_obs_dbg), (size_t)n_words * 4, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef OC_AMD_TUNING
 // tuning builds: n back-to-back oc_mailbox_step calls from C (no Python / ctypes between them) -> microseconds per call
 double oc_mailbox_bench(OcMailbox* m, int n) {

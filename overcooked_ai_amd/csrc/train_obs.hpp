@@ -44,8 +44,23 @@ __device__ __forceinline__ uint4 phi_record(const Env3<MAXP>& s, uint32_t fl, ui
     return r;
 }
 
-template <int MAXP, typename T>
-__global__ __launch_bounds__(2 * BLOCK) void k_train_step_obs(
+#ifdef OC_AMD_TUNING
+// tuning builds: where a wavefront's time goes, in 10 ns ticks — [workgroup][wavefront][8]: kernel start -> second barrier passed,
+// barrier -> first claim (the helpers' potentials), then sums over its sub-groups: template copy, players, objects (+ urgency), stream;
+// [6] sub-groups taken, [7] kernel start -> this wavefront done
+__device__ uint32_t g_obs_dbg[4096 * 8 * 8];
+#define OBS_T(var) const uint64_t var = mb_now()
+#else
+#define OBS_T(var)
+#endif
+
+// NWV wavefronts per workgroup: 0..3 owners, 4..7 helpers (the potentials), 8.. (NWV = 16, round 6) ENCODERS that own nothing and
+// compute nothing but sub-groups.  tools/obs_phases.py (tuning build, stamps per phase) showed what the u8 observation of a small
+// grid costs: not bytes — 3.5 us until the second barrier, then per 14-env sub-group ~1 us of template copy, 0.4 players, 1.6
+// objects, 0.7 stream on a wavefront that shares its SIMD with ONE other (an instruction every ~8 clocks); a SIMD issues from up
+// to ~5 wavefronts at that latency, so more wavefronts per CU with smaller private images, not fewer instructions, is the lever.
+template <int MAXP, typename T, int NWV>
+__global__ __launch_bounds__(NWV * 64) void k_train_step_obs(
     const OcLayout* __restrict__ g_layouts, uint4* st, const uint8_t* __restrict__ actions, float4* __restrict__ rewards,
     uint8_t* __restrict__ flags, float4* ep_returns, float4* __restrict__ ep_out, const uint8_t* __restrict__ plan_blob,
     const uint32_t* __restrict__ plan_off, const uint8_t* __restrict__ phi_tables, double* __restrict__ phi_next,
@@ -53,6 +68,7 @@ __global__ __launch_bounds__(2 * BLOCK) void k_train_step_obs(
     uint8_t* __restrict__ done, uint8_t* __restrict__ obs_bytes, int64_t n, int W, int H, int n_obj, int horizon, int unit,
     int group_envs, StartArgs sa) {
 #pragma clang fp contract(off)
+    OBS_T(tm_start);
     extern __shared__ __attribute__((aligned(16))) uint4 s_dyn[];  // rows | template | header | records | rewards | images
     __shared__ uint4 s_lay[16];
     __shared__ uint2 s_lut[2 * LUT_ENTRIES];
@@ -84,11 +100,11 @@ __global__ __launch_bounds__(2 * BLOCK) void k_train_step_obs(
     OneIn in;
     double phi_before = 0.0;
     if (owner) in = one_load(st, actions, ep_returns, n, el, n_obj);
-    else if (phi_tables) phi_before = phi_cur[el];
-    for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += 2 * BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
+    else if (wave < 8 && phi_tables) phi_before = phi_cur[el];
+    for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += NWV * 64) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
     if (threadIdx.x < 16) s_lay[threadIdx.x] = reinterpret_cast<const uint4*>(g_layouts)[threadIdx.x];
     if (threadIdx.x < 4) s_next[threadIdx.x] = 0u;
-    for (int i = threadIdx.x; i < unit_chunks; i += 2 * BLOCK) s_tmpl[i] = make_uint4(0, 0, 0, 0);
+    for (int i = threadIdx.x; i < unit_chunks; i += NWV * 64) s_tmpl[i] = make_uint4(0, 0, 0, 0);
     const uint32_t inv_w = 65536u / (uint32_t)W + 1u;
     if (threadIdx.x < 64) {
         const uint32_t c = threadIdx.x, y = (c * inv_w) >> 16, x = c - y * (uint32_t)W;
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(2 * BLOCK) void k_train_step_obs(
     __syncthreads();
     const Lay L{reinterpret_cast<const uint8_t*>(s_lay)};
     // static terrain layers (mdp.py:2449-2465) of `unit` envs, both views — read by nobody before the second barrier
-    for (int q = threadIdx.x; q < unit * cells_n; q += 2 * BLOCK) {
+    for (int q = threadIdx.x; q < unit * cells_n; q += NWV * 64) {
         const int u = q / cells_n;
         const uint32_t c = (uint32_t)(q - u * cells_n);
         const uint32_t type = L.terrain(c) & 7u;
@@ -150,7 +166,8 @@ __global__ __launch_bounds__(2 * BLOCK) void k_train_step_obs(
         if (ep_returns) ep_returns[e] = ep;
     }
     __syncthreads();  // the only barrier behind the staging one: rows, headers, records and the template are in LDS
-    if (!owner && active && phi_tables) {
+    OBS_T(tm_bar);
+    if (!owner && wave < 8 && active && phi_tables) {
         // ---- phi(s'), the shaped rewards, phi(s) of the next step (k_train_step1's arithmetic, from the records)
         const Phi Tb{phi_tables};
         const uint8_t* plan = plan_blob + plan_off[0];
@@ -178,6 +195,10 @@ __global__ __launch_bounds__(2 * BLOCK) void k_train_step_obs(
     const int obj_dwords = n_obj * 4;
     const uint4* whdr = s_hdr + ow * 64;
     const uint32_t tmpl_magic = 0xFFFFFFFFu / (uint32_t)unit_chunks + 1u;  // i / unit_chunks == mulhi(i, magic) for i < 2^16
+    OBS_T(tm_loop);
+#ifdef OC_AMD_TUNING
+    uint32_t acc_copy = 0, acc_pl = 0, acc_obj = 0, acc_str = 0, acc_n = 0;
+#endif
     for (;;) {
         uint32_t g = 0;
         if (lane == 0) g = atomicAdd(&s_next[ow], 1u);
@@ -186,6 +207,7 @@ __global__ __launch_bounds__(2 * BLOCK) void k_train_step_obs(
         const int l0 = (int)g * group_envs;
         const int ne = min(group_envs, n_wave - l0);
         const int n_units = (ne + unit - 1) / unit;
+        OBS_T(t0);
         // the image = n_units copies of the template back to back: chunk i <- template chunk i mod unit_chunks (every lane busy
         // in every round; a loop over the template's chunks leaves 63 lanes idle in its last round when unit_chunks = 65)
         {
@@ -196,6 +218,7 @@ __global__ __launch_bounds__(2 * BLOCK) void k_train_step_obs(
             }
         }
         wave_fence();
+        OBS_T(t1);
         // players (mdp.py:2468-2479, ordering 2423-2434) and what they hold: lane = (env, player)
         bool urgent = false;
         for (int t = lane; t < 2 * ne; t += 64) {
@@ -214,6 +237,7 @@ __global__ __launch_bounds__(2 * BLOCK) void k_train_step_obs(
                 if (held) { enc_object_writes<T>(own, held, false, 0u, 0u); enc_object_writes<T>(other, held, false, 0u, 0u); }
             }
         }
+        OBS_T(t2);
         // objects on the grid (mdp.py:2482-2534): lane = (env, object dword)
         for (int q = lane; q < ne * obj_dwords; q += 64) {
             const int le = q / obj_dwords, j = q - le * obj_dwords;
@@ -249,6 +273,7 @@ __global__ __launch_bounds__(2 * BLOCK) void k_train_step_obs(
             }
         }
         wave_fence();
+        OBS_T(t3);
         // stream the image out: contiguous 16-byte stores (a ragged tail in dwords)
         const size_t total = env_bytes * ne;
         uint8_t* gdst = obs_bytes + env_bytes * (size_t)(wave_e0 + l0);
@@ -267,5 +292,18 @@ __global__ __launch_bounds__(2 * BLOCK) void k_train_step_obs(
             reinterpret_cast<uint32_t*>(gdst + (size_t)n16 * 16)[lane] =
                 reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(img) + (size_t)n16 * 16)[lane];
         wave_fence();
+#ifdef OC_AMD_TUNING
+        {
+            const uint64_t t4 = wall_clock64();  // (not mb_now: the stores just issued are not waited for)
+            acc_copy += (uint32_t)(t1 - t0); acc_pl += (uint32_t)(t2 - t1); acc_obj += (uint32_t)(t3 - t2); acc_str += (uint32_t)(t4 - t3); ++acc_n;
+        }
+#endif
     }
+#ifdef OC_AMD_TUNING
+    if (lane == 0 && blockIdx.x < 4096) {
+        uint32_t* d = g_obs_dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+        d[0] = (uint32_t)(tm_bar - tm_start); d[1] = (uint32_t)(tm_loop - tm_bar); d[2] = acc_copy; d[3] = acc_pl; d[4] = acc_obj; d[5] = acc_str;
+        d[6] = acc_n; d[7] = (uint32_t)(wall_clock64() - tm_start);
+    }
+#endif
 }
