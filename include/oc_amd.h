@@ -517,6 +517,7 @@ int oc_mailbox_close(OcMailbox* mailbox);
  *                        oc_step_many's inputs and bench.py's round-trip measurement.  Host-synchronous; elapsed_ms (or NULL)
  *                        receives the client kernel's duration (HIP events on `stream`).
  *   oc_step_server_steps steps served so far (the host's count; exact after _play / _sync)
+ * One caller at a time: the entry points of a server are not thread-safe, and two clients must not play on it concurrently.
  */
 #define OC_SV_STOP 0x10000u
 typedef struct OcStepServer OcStepServer;

@@ -1209,6 +1209,7 @@ int oc_step_server_play(OcStepServer* m, const uint8_t* d_actions, float* d_rewa
     clock_gettime(CLOCK_MONOTONIC, &m->last_use);
     if (__atomic_load_n(m->h_ctl + m->grid + SV_ERR_CLIENT, __ATOMIC_ACQUIRE) != 0u) {
         (void)sv_stop(m);  // (the host's step count follows whatever the device got to)
+        (void)hipMemset(m->d_claims + 16, 0, 16 * sizeof(uint32_t));  // (a client that gave up did not hand its block claims back)
         return fail(OC_ELAUNCH, "oc_step_server_play: no answer from the resident kernel within 1 s");
     }
     m->seq += (uint32_t)n_steps;
