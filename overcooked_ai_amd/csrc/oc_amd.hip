@@ -999,7 +999,8 @@ struct OcStepServer {
     hipEvent_t ev0, ev1;
     uint64_t* d_req;         // [n_envs] request granules
     uint4* d_rsp;            // [n_envs][2] response granules
-    uint32_t* h_ctl;         // [grid + SV_ERR_WORDS] pinned, GPU-mapped: 1 per resident workgroup, then the error words
+    uint32_t* h_ctl;         // [4 grid + SV_ERR_WORDS] pinned, GPU-mapped: 1 per serving wavefront, then the error / keep-alive words
+    unsigned n_flags, n_serving;  // 4 grid; wavefronts with at least one env: ceil(n_envs / 64)
     uint32_t* d_ctl;         // its device address
     uint32_t* d_claims;      // [32] block claims per XCD: [0..8] the server's, [16..24] the client's (sv_claim_block)
     unsigned grid;
@@ -1031,13 +1032,13 @@ double sv_since(const struct timespec& t) {
     clock_gettime(CLOCK_MONOTONIC, &now);
     return (double)(now.tv_sec - t.tv_sec) + 1e-9 * (double)(now.tv_nsec - t.tv_nsec);
 }
-unsigned sv_resident(const OcStepServer* m) {
+unsigned sv_resident(const OcStepServer* m) {  // wavefronts that say they serve
     unsigned alive = 0;
-    for (unsigned i = 0; i < m->grid; ++i) alive += __atomic_load_n(m->h_ctl + i, __ATOMIC_ACQUIRE) != 0u;
+    for (unsigned i = 0; i < m->n_flags; ++i) alive += __atomic_load_n(m->h_ctl + i, __ATOMIC_ACQUIRE) != 0u;
     return alive;
 }
 void sv_mark(OcStepServer* m, uint32_t v) {
-    for (unsigned i = 0; i < m->grid; ++i) __atomic_store_n(m->h_ctl + i, v, __ATOMIC_RELEASE);
+    for (unsigned i = 0; i < m->n_flags; ++i) __atomic_store_n(m->h_ctl + i, v, __ATOMIC_RELEASE);
 }
 template <typename K>
 bool sv_fits(K kernel, const OcStepServer* m, size_t smem) {  // every workgroup must be resident at once: they all poll
@@ -1073,7 +1074,7 @@ int sv_launch(OcStepServer* m) {
     const OcBatch* b = &m->b;
     const size_t smem = (size_t)m->n_obj * 8 * BLOCK * sizeof(uint32_t);
     const bool uniform = b->n_layouts == 1, lds = b->n_layouts <= LDS_LAYOUT_MAX, small = b->max_pots >= 1 && b->max_pots <= 2;
-    sv_mark(m, 1u);
+    sv_mark(m, 0u);  // (every serving wavefront reports in by itself)
     hipLaunchKernelGGL(k_step_server_post, dim3(m->grid), dim3(BLOCK), 0, m->stream, m->d_req, b->n_envs, 0u, m->d_rsp, 0u);
     (void)hipMemsetAsync(m->d_claims, 0, 16 * sizeof(uint32_t), m->stream);
 #define GOSV(U, MP, LL)                                                                                              \
@@ -1095,6 +1096,15 @@ int sv_launch(OcStepServer* m) {
     if (rc) { sv_mark(m, 0u); return rc; }
     m->launched = true;
     clock_gettime(CLOCK_MONOTONIC, &m->last_use);
+    // the server is up when every wavefront that has envs has said so (its states loaded, its first look at the requests next)
+    while (sv_resident(m) != m->n_serving) {
+        if (sv_since(m->last_use) > 2.0) {
+            (void)sv_stop(m);
+            return fail(OC_ELAUNCH, "oc_step_server: the resident kernel did not come up within 2 s");
+        }
+        __builtin_ia32_pause();
+    }
+    clock_gettime(CLOCK_MONOTONIC, &m->last_use);
     return OC_OK;
 }
 // resident and fresh (no workgroup about to leave for idleness), or relaunched
@@ -1102,12 +1112,12 @@ int sv_ensure(OcStepServer* m) {
     if (m->launched) {
         // announce the caller FIRST (a workgroup about to leave for idleness or age looks at this word and stays), give a workgroup
         // that had already looked 20 us to say that it left, THEN count: whoever is counted is still there when the client arrives
-        __atomic_fetch_add(m->h_ctl + m->grid + SV_KEEPALIVE, 1u, __ATOMIC_RELEASE);
+        __atomic_fetch_add(m->h_ctl + m->n_flags + SV_KEEPALIVE, 1u, __ATOMIC_RELEASE);
         struct timespec t0;
         clock_gettime(CLOCK_MONOTONIC, &t0);
         while (sv_since(t0) < 20e-6) __builtin_ia32_pause();
     }
-    if (m->launched && sv_resident(m) == m->grid) return OC_OK;
+    if (m->launched && sv_resident(m) == m->n_serving) return OC_OK;
     if (int rc = sv_stop(m)) return rc;
     return sv_launch(m);
 }
@@ -1138,7 +1148,10 @@ int oc_step_server_open(const OcBatch* b, void* d_state, float* d_ep_returns, in
     memset(m, 0, sizeof(*m));
     m->b = *b; m->n_obj = n_obj; m->horizon = horizon; m->options = options; m->sa = sa; m->d_state = d_state; m->d_ep_returns = d_ep_returns;
     m->grid = grid_for(b->n_envs);
+    m->n_flags = m->grid * (BLOCK / 64);
+    m->n_serving = (unsigned)((b->n_envs + 63) / 64);
     if (idle_ms == 0.0) idle_ms = 20.0;
+    if (idle_ms < 0.2) idle_ms = 0.2;  // (a window the host's 20 us announcement always fits in)
     if (life_s == 0.0) life_s = 600.0;
     int khz = 0;
     bool ok = hipGetDevice(&m->device) == hipSuccess;
@@ -1147,7 +1160,7 @@ int oc_step_server_open(const OcBatch* b, void* d_state, float* d_ep_returns, in
     m->idle_ticks = (uint64_t)((double)khz * idle_ms);
     m->life_ticks = (uint64_t)((double)khz * 1000.0 * life_s);
     m->client_ticks = (uint64_t)khz * 1000;  // a client wavefront gives up after 1 s without its responses
-    const size_t ctl_bytes = ((size_t)m->grid + SV_ERR_WORDS) * sizeof(uint32_t);
+    const size_t ctl_bytes = ((size_t)m->n_flags + SV_ERR_WORDS) * sizeof(uint32_t);
     ok = ok && hipMalloc((void**)&m->d_req, (size_t)b->n_envs * 8) == hipSuccess;
     ok = ok && hipMalloc((void**)&m->d_rsp, (size_t)b->n_envs * 32) == hipSuccess;
     ok = ok && hipMalloc((void**)&m->d_claims, 32 * sizeof(uint32_t)) == hipSuccess;
@@ -1192,14 +1205,14 @@ int oc_step_server_play(OcStepServer* m, const uint8_t* d_actions, float* d_rewa
     SvDevice dev(m->device);
     if (int rc = sv_ensure(m)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    __atomic_store_n(m->h_ctl + m->grid + SV_ERR_CLIENT, 0u, __ATOMIC_RELEASE);
+    __atomic_store_n(m->h_ctl + m->n_flags + SV_ERR_CLIENT, 0u, __ATOMIC_RELEASE);
     uint32_t* dbg = nullptr;
 #ifdef OC_AMD_TUNING
     if (getenv("OC_SV_DEBUG")) (void)hipMalloc((void**)&dbg, (size_t)m->grid * 16);
 #endif
     (void)hipEventRecord(m->ev0, s);
     hipLaunchKernelGGL(k_step_client, dim3(m->grid), dim3(BLOCK), 0, s, m->d_req, m->d_rsp, d_actions, (float4*)d_rewards, d_flags,
-                       m->d_ctl + m->grid, m->d_claims + 16, m->b.n_envs, m->seq + 1u, n_steps, m->client_ticks, sv_knobs("OC_SV_CLIENT", 0x04000100u), dbg);
+                       m->d_ctl + m->n_flags, m->d_claims + 16, m->b.n_envs, m->seq + 1u, n_steps, m->client_ticks, sv_knobs("OC_SV_CLIENT", 0x04000100u), dbg);
     (void)hipEventRecord(m->ev1, s);
     if (int rc = check_launch("oc_step_server_play")) return rc;
     if (hipEventSynchronize(m->ev1) != hipSuccess) {
@@ -1207,7 +1220,7 @@ int oc_step_server_play(OcStepServer* m, const uint8_t* d_actions, float* d_rewa
         return fail(OC_ELAUNCH, "oc_step_server_play: the client kernel failed");
     }
     clock_gettime(CLOCK_MONOTONIC, &m->last_use);
-    if (__atomic_load_n(m->h_ctl + m->grid + SV_ERR_CLIENT, __ATOMIC_ACQUIRE) != 0u) {
+    if (__atomic_load_n(m->h_ctl + m->n_flags + SV_ERR_CLIENT, __ATOMIC_ACQUIRE) != 0u) {
         (void)sv_stop(m);  // (the host's step count follows whatever the device got to)
         (void)hipMemset(m->d_claims + 16, 0, 16 * sizeof(uint32_t));  // (a client that gave up did not hand its block claims back)
         return fail(OC_ELAUNCH, "oc_step_server_play: no answer from the resident kernel within 1 s");

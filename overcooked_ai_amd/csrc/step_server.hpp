@@ -42,7 +42,9 @@ __device__ __forceinline__ void sv_store16x2(void* p, sv_u32x4 a, sv_u32x4 b) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" : : "v"(p), "v"(a), "v"(b) : "memory");
 }
 
-// the host-visible control words (pinned, GPU-mapped host memory): [0 .. grid) 1 while workgroup b is resident; then
+// the host-visible control words (pinned, GPU-mapped host memory): [0 .. 4 grid) 1 while WAVEFRONT w of workgroup b serves — each
+// wavefront comes and goes by itself, so each reports by itself (round 6: with one word per workgroup a wavefront that had left
+// for idleness hid behind three siblings that saw the caller's keep-alive and stayed; found by the stress test) —; then
 // [grid + SV_ERR_CLIENT]: a client wavefront gave up waiting for its responses; [grid + SV_KEEPALIVE]: bumped by the host before it
 // launches a client (a workgroup about to leave looks at it first)
 enum { SV_ERR_CLIENT = 0, SV_KEEPALIVE = 1, SV_ERR_WORDS = 4 };
@@ -97,14 +99,12 @@ __global__ __launch_bounds__(BLOCK) void k_step_server(const OcLayout* __restric
     extern __shared__ __attribute__((aligned(16))) uint16_t s_cells3[];  // [n_obj * 16][BLOCK]
     __shared__ uint4 s_lay[LAY_LDS ? (UNIFORM ? 16 : LDS_LAYOUT_MAX * 16) : 1];
     __shared__ uint2 s_lut[2 * LUT_ENTRIES];
-    __shared__ uint32_t s_left;  // wavefronts of this workgroup that have left the loop
     __shared__ uint32_t s_blk;
     const uint32_t blk = sv_claim_block(claims, &s_blk);  // (contains a barrier)
     const uint32_t my_xcc = sv_xcc();
     const int64_t e = (int64_t)blk * BLOCK + threadIdx.x;
     const bool active = e < n;
     const int64_t el = active ? e : n - 1;
-    if (threadIdx.x == 0) s_left = 0u;
     for (int i = threadIdx.x; i < 2 * LUT_ENTRIES; i += BLOCK) s_lut[i] = reinterpret_cast<const uint2*>(&g_lut)[i];
     Lay L = stage_layouts<LAY_LDS>(g_layouts, n_layouts, layout_id, el, true, s_lay);  // contains the barrier
     uint16_t* cells = s_cells3 + threadIdx.x;
@@ -128,8 +128,11 @@ __global__ __launch_bounds__(BLOCK) void k_step_server(const OcLayout* __restric
     }
     const uint64_t born = wall_clock64();
     uint64_t last = born;
-    uint32_t keep = __hip_atomic_load(ctl + gridDim.x + SV_KEEPALIVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t* const words = ctl + (size_t)gridDim.x * (BLOCK / 64u);  // behind the wavefronts' flags: the error / keep-alive words
+    uint32_t keep = __hip_atomic_load(words + SV_KEEPALIVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const bool wave_serves = __ballot(active) != 0ull;  // (a wavefront wholly beyond the batch has nobody to answer)
+    uint32_t* const my_flag = ctl + (size_t)blockIdx.x * (BLOCK / 64u) + (threadIdx.x >> 6);
+    if (wave_serves && (threadIdx.x & 63u) == 0u) __hip_atomic_store(my_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // "serving"
     while (wave_serves) {
         // ---- the request: payload and tag in one load per lane
         sv_u32x2 q;
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(BLOCK) void k_step_server(const OcLayout* __restric
             // host-side caller has announced itself since the last look at the keep-alive word (oc_amd.hip: sv_ensure bumps it
             // BEFORE it checks who is resident, so a client launched after that check finds every workgroup it counted)
             if (now - last > idle_ticks || (now - born > life_ticks && now - last > 20000u)) {
-                const uint32_t k = __hip_atomic_load(ctl + gridDim.x + SV_KEEPALIVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const uint32_t k = __hip_atomic_load(words + SV_KEEPALIVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (k == keep) { leave = true; break; }
                 keep = k;
                 last = now;
@@ -201,10 +204,7 @@ __global__ __launch_bounds__(BLOCK) void k_step_server(const OcLayout* __restric
         store_env3<MAXP>(C, L, st, n, e, n_obj, s, cells);
         if (ep_returns) ep_returns[e] = ep;
     }
-    if ((threadIdx.x & 63u) == 0u) {
-        if (atomicAdd(&s_left, 1u) + 1u == BLOCK / 64u)  // the workgroup's last wavefront says so
-            __hip_atomic_store(ctl + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (wave_serves && (threadIdx.x & 63u) == 0u) __hip_atomic_store(my_flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // "gone"
 }
 
 // k_step_client: the caller's side of the protocol as a kernel — lane = env, K steps: post the request (the caller's action
