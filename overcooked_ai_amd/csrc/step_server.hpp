@@ -18,7 +18,7 @@
 // barrier, no counter, no fence in the loop; wavefronts serve their 64 envs independently of each other.
 // The kernel never outlives its usefulness (as k_mailbox): it leaves on SV_STOP, after idle_ticks of wall_clock64 without a
 // request, or after life_ticks in total — writing the states back, so that every other oc_* call finds them in d_state — and
-// says so in a host-visible word per workgroup; the host side (oc_amd.hip: oc_step_server_*) relaunches it when needed.
+// says so in a host-visible word per wavefront; the host side (oc_amd.hip: oc_step_server_*) relaunches it when needed.
 // Not served: event sinks (OcEventSink), OC_OPT_PREDICATE_INTERACT.
 // ==========================================================================================
 constexpr uint32_t SV_STOP = 0x10000u;  // command bit of a request: write the states back and leave (no response)
