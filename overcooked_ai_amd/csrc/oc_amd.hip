@@ -930,9 +930,13 @@ int oc_rollout_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions,
 #else
         constexpr int forced_nw = 0;
 #endif
+        // round 6: u8 observations take eight wavefronts down to 4-env images — a wavefront that is issuing its image's stores into a
+        // busy store path is not building the next one, and eight of them leave the path idle less often (65 536 envs, us per step,
+        // four vs eight: 9x5 29.2 -> 27.6-28.3, 8x5 26.1 -> 24.2, 5x5 16.1 -> 15.4; profiles/r06_rollout_encode_ablation.txt)
+        const int min_g8 = obs_dtype == OC_OBS_U8 ? 4 : 8;
         int nw = 8;
         int gmax = fixed < budget ? (int)((budget - fixed) / (nw * env_bytes)) : 0;
-        if (((gmax < 8 || gmax < unit) && forced_nw != 8) || forced_nw == 4) {
+        if (((gmax < min_g8 || gmax < unit) && forced_nw != 8) || forced_nw == 4) {
             nw = 4;
             gmax = fixed < budget ? (int)((budget - fixed) / (nw * env_bytes)) : 0;
         }
@@ -943,6 +947,10 @@ int oc_rollout_encode(const OcBatch* b, void* d_state, const uint8_t* d_actions,
             int g = (span + parts - 1) / parts;
             g = (g + unit - 1) / unit * unit;
             if (g > gmax) g = gmax / unit * unit;
+#ifdef OC_AMD_TUNING
+            static const int forced_reg = []() { const char* e = getenv("OC_ROLLOUT_ENCODE_G"); return e ? atoi(e) : 0; }();  // tuning builds
+            if (forced_reg > 0 && forced_reg <= g && forced_reg % unit == 0) g = forced_reg;
+#endif
             const size_t smem = fixed + (size_t)nw * g * env_bytes;
             const dim3 grid(grid_for(b->n_envs));
 #define GORE(FAST, T, NW)                                                                                              \
