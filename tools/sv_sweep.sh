@@ -1,3 +1,8 @@
+#!/bin/bash
+# round 6: the wait / placement knobs of the resident batched step (oc_amd.hip sv_knobs) on a tuning build —
+#   python tools/build_variants.py sv_tune=-DOC_AMD_TUNING ; gpurun -- 'bash tools/sv_sweep.sh'
+# knob word: bits 0..7 naps before the first look, 8..15 naps between looks, bit 16 light polls, bit 17 no looks through the L2,
+# bits 24..26 (client) XCD shift of its block claims; OC_SV_DEBUG=1 prints where a round trip goes.  Results: profiles/r06_step_server.txt
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r6sv
 export OC_AMD_LIB=$PWD/overcooked_ai_amd/sv_tune.so
