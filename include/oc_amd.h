@@ -518,6 +518,9 @@ int oc_mailbox_close(OcMailbox* mailbox);
  *                        receives the client kernel's duration (HIP events on `stream`).
  *   oc_step_server_steps steps served so far (the host's count; exact after _play / _sync)
  * One caller at a time: the entry points of a server are not thread-safe, and two clients must not play on it concurrently.
+ * The resident kernel reads d_state / d_ep_returns on a stream of its own whenever it is (re)launched — at _open, and at a _play /
+ * _resume that finds it gone: work of the caller's on those arrays must be complete by then (_play waits for `stream` before a
+ * relaunch; before _open and _resume the caller synchronises its stream itself).
  */
 #define OC_SV_STOP 0x10000u
 typedef struct OcStepServer OcStepServer;

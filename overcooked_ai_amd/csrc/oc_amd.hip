@@ -1116,7 +1116,9 @@ int sv_launch(OcStepServer* m) {
     return OC_OK;
 }
 // resident and fresh (no workgroup about to leave for idleness), or relaunched
-int sv_ensure(OcStepServer* m) {
+// (caller_stream: the stream the caller's work on d_state runs on — a relaunch reads d_state on the server's own stream, so whatever the
+//  caller enqueued there since the last sync must be complete first)
+int sv_ensure(OcStepServer* m, const hipStream_t* caller_stream = nullptr) {
     if (m->launched) {
         // announce the caller FIRST (a workgroup about to leave for idleness or age looks at this word and stays), give a workgroup
         // that had already looked 20 us to say that it left, THEN count: whoever is counted is still there when the client arrives
@@ -1127,6 +1129,10 @@ int sv_ensure(OcStepServer* m) {
     }
     if (m->launched && sv_resident(m) == m->n_serving) return OC_OK;
     if (int rc = sv_stop(m)) return rc;
+    if (caller_stream && hipStreamSynchronize(*caller_stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(OC_ELAUNCH, "oc_step_server: the caller's stream failed");
+    }
     return sv_launch(m);
 }
 struct SvDevice {  // the server's device current for the scope
@@ -1211,8 +1217,8 @@ int oc_step_server_play(OcStepServer* m, const uint8_t* d_actions, float* d_rewa
     if (elapsed_ms) *elapsed_ms = 0.f;
     if (n_steps == 0) return OC_OK;
     SvDevice dev(m->device);
-    if (int rc = sv_ensure(m)) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = sv_ensure(m, &s)) return rc;
     __atomic_store_n(m->h_ctl + m->n_flags + SV_ERR_CLIENT, 0u, __ATOMIC_RELEASE);
     uint32_t* dbg = nullptr;
 #ifdef OC_AMD_TUNING

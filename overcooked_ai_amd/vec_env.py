@@ -492,6 +492,7 @@ class StepServer:
         self.env = env
         self._h = ctypes.c_void_p()
         with torch.cuda.device(env.device):
+            torch.cuda.current_stream(env.device).synchronize()  # (the resident kernel reads env.state on a stream of its own)
             rc = env.lib.oc_step_server_open(env._bref, env._state_ptr, env._ep_ptr, env.horizon, _lib.OPT_AUTO_RESET if env.auto_reset else 0,
                                              env._start_spec() if env.auto_reset else None, float(idle_ms), float(life_s), ctypes.byref(self._h))
         _lib.check(rc, "oc_step_server_open")
@@ -523,6 +524,7 @@ class StepServer:
 
     def resume(self):
         """(Re)launch the resident kernel if it has left — for device-side callers, before a burst of requests."""
+        torch.cuda.current_stream(self.env.device).synchronize()  # (a relaunch reads env.state on the server's own stream)
         _lib.check(self.env.lib.oc_step_server_resume(self._h), "oc_step_server_resume")
 
     def sync(self):

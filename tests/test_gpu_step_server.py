@@ -127,3 +127,30 @@ def test_step_server_leaves_and_returns_around_its_idle_and_life_windows(gpu):
             time.sleep(float(rng.choice([0.0, 0.0005, 0.001, 0.002, 0.03])))
         assert sv.steps == total
     assert torch.equal(res.state, one.state) and torch.equal(res.ep_returns, one.ep_returns)
+
+
+def test_step_server_relaunch_sees_the_callers_pending_work_on_the_states(gpu):
+    """Between sync() and the next play the caller may change the states with asynchronous calls on its own stream (here: a reset
+    and a burst of ordinary steps): the relaunch inside play waits for that stream before the resident kernel loads them."""
+    n, horizon = 4096, 50
+    res = make_env("cramped_room", n, gpu, horizon=horizon, auto_reset=True)
+    one = make_env("cramped_room", n, gpu, horizon=horizon, auto_reset=True)
+    g = torch.Generator(device=gpu).manual_seed(4)
+    acts = torch.randint(0, 6, (60, n, 2), dtype=torch.uint8, device=gpu, generator=g)
+    rew = torch.zeros((60, n, 4), dtype=torch.float32, device=gpu)
+    fl = torch.zeros((60, n), dtype=torch.uint8, device=gpu)
+    with res.step_server(idle_ms=5.0) as sv:
+        sv.play(acts[:20], rew[:20], fl[:20])
+        sv.sync()
+        for env in (res, one):
+            if env is one:
+                for k in range(20):
+                    env.step(acts[k])
+            env.reset()
+            for k in range(20, 40):  # (no synchronisation between these launches and the play below)
+                env.step(acts[k])
+        sv.play(acts[40:], rew[40:], fl[40:])
+        for k in range(40, 60):
+            r1, f1 = one.step(acts[k])
+            assert torch.equal(r1, rew[k]) and torch.equal(f1, fl[k]), k
+    assert torch.equal(res.state, one.state) and torch.equal(res.ep_returns, one.ep_returns)
