@@ -39,3 +39,14 @@ def test_plan_applies_the_argument_checks_of_the_real_call():
     with pytest.raises(_lib.OcAmdError, match="horizon"):
         dispatch.rollout_plan(one, 65536, horizon=0)
     assert dispatch.rollout_plan(one, 0) == "nothing to launch (no envs or no steps)"
+
+
+def test_generated_terrain_tables_take_the_l2_table_instance_in_rounds():
+    """BASELINE configs[4]'s rank shape: a table of generated 9 x 5 terrains (more layouts than LDS stages), 131 072 envs."""
+    from overcooked_ai_amd.layout_gen import reference_generated_layouts
+
+    tab = layouts.LayoutTable(reference_generated_layouts(64))
+    p = dispatch.rollout_plan(tab, 131072, options=_lib.OPT_AUTO_RESET | _lib.OPT_FLAGS_TILED8)
+    assert p.startswith("k_rollout5<LAY_LDS=false, FT8=true, OLD=false, BIG=false, EV=false>") and "2 round(s)" in p
+    # 1 M envs: beyond eight rounds the one-wavefront instances serve the batch (one-pot tables keep their tiled-flags instance)
+    assert dispatch.rollout_plan(tab, 1 << 20).startswith("k_rollout4<UNIFORM=false")
