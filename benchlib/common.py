@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--parity-steps", type=int, default=0,
                     help="steps of the launch the parity check replays from reset (default: one whole --fuse launch at 1 GPU, "
                          "1 200 steps per rank otherwise)")
+    ap.add_argument("--general-leg", default="",
+                    help="(with --pmc-child) the general_path leg whose launch shape the child replays: one of benchlib.legs.GENERAL_CASES")
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not collect roofline.traffic with rocprofv3 --pmc child passes of this same launch shape")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",

@@ -87,6 +87,24 @@ def side_legs(args, torch, VecOvercookedEnv, sharding, dev):
         legs["3"]["roofline"]["traffic_source"] = {"how": "not collected", "why": repr(exc)[:200]}
     return legs
 
+def general_case(name):
+    """(LayoutTable, VecOvercookedEnv keyword arguments) of a general_path leg — shared with the --pmc child that replays it."""
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+
+    if name == "coordination_ring_old_dynamics":
+        return LayoutTable([spec_from_name("coordination_ring", old_dynamics=True)]), {}
+    if name == "asymmetric_advantages_old_dynamics":
+        return LayoutTable([spec_from_name("asymmetric_advantages", old_dynamics=True)]), {}
+    if name == "cramped_room_event_log":
+        return LayoutTable([spec_from_name("cramped_room")]), {"track_events": True}
+    if name == "marshmallow_experiment":
+        return LayoutTable([spec_from_name("marshmallow_experiment")]), {}
+    raise ValueError("unknown general_path leg %r" % name)
+
+
+GENERAL_CASES = ("coordination_ring_old_dynamics", "asymmetric_advantages_old_dynamics", "cramped_room_event_log", "marshmallow_experiment")
+
+
 def general_legs(args, torch, VecOvercookedEnv, sharding, dev):
     """The batches OUTSIDE "two players, <= 2 pots, <= 64 cells, new dynamics, no event log" (VERDICT r5 #3): old dynamics — what
     the reference's paper-reproduction runs use (human_aware_rl/ppo/run_experiments.sh:4-12; mdp.py:1517-1518, 1696-1701) —,
@@ -96,13 +114,9 @@ def general_legs(args, torch, VecOvercookedEnv, sharding, dev):
 
     legs = {}
     n, fuse = N_ENVS_PER_GPU, DEFAULT_FUSE
-    cases = (("coordination_ring_old_dynamics", lambda: LayoutTable([spec_from_name("coordination_ring", old_dynamics=True)]), {}),
-             ("asymmetric_advantages_old_dynamics", lambda: LayoutTable([spec_from_name("asymmetric_advantages", old_dynamics=True)]), {}),
-             ("cramped_room_event_log", lambda: LayoutTable([spec_from_name("cramped_room")]), {"track_events": True}),
-             ("marshmallow_experiment", lambda: LayoutTable([spec_from_name("marshmallow_experiment")]), {}))
-    for name, make_table, kw in cases:
+    for name in GENERAL_CASES:
         try:
-            table = make_table()
+            table, kw = general_case(name)
             wl = {"table": table, "specs": table.specs, "lid": None, "sbytes": 4 * ((table.n_planes * 16) // 4),
                   "workload": "%s x %d envs, random policy, horizon %d auto-reset, outputs every step" % (name, n, HORIZON)}
 
@@ -137,6 +151,11 @@ def general_legs(args, torch, VecOvercookedEnv, sharding, dev):
             legs[name] = leg
             del env, rew, fl
             torch.cuda.empty_cache()
+            if not getattr(args, "no_traffic", False):  # two --pmc child passes of this leg's launch shape, as for the configs legs
+                ca = argparse.Namespace(config=2, envs=n, fuse=fuse, layout="cramped_room", terrains=getattr(args, "terrains", 4096),
+                                        lane_pair=False, predicate_interact=False, one_wavefront=False)
+                leg["roofline"]["traffic"], leg["roofline"]["traffic_source"] = measure_traffic(
+                    ca, "k_rollout5|k_rollout4", tiled8, extra=["--general-leg", name])
         except Exception as exc:
             legs[name] = {"error": repr(exc)[:300]}
     return legs

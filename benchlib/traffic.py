@@ -61,9 +61,15 @@ def pmc_child(args, torch, VecOvercookedEnv, dev):
             env.rollout_encode(fuse, obs, rew, fl)
         torch.cuda.synchronize(dev)
         return
-    wl = make_workload(args, 0)
     n, fuse = args.envs, max(1, args.fuse)
-    env = rollout_workload_env(args, wl, n, 0, dev, VecOvercookedEnv)()
+    if getattr(args, "general_leg", ""):  # a general_path leg: its own table and env options (benchlib.legs.general_case)
+        from benchlib.legs import general_case
+
+        table, kw = general_case(args.general_leg)
+        env = VecOvercookedEnv(table, n, horizon=HORIZON, device=dev, auto_reset=True, seed=0, **kw)
+    else:
+        wl = make_workload(args, 0)
+        env = rollout_workload_env(args, wl, n, 0, dev, VecOvercookedEnv)()
     rew = torch.zeros((fuse, n, 4), dtype=torch.float32, device=dev)
     fl = torch.zeros((fuse, n), dtype=torch.uint8, device=dev)
     tiled8 = args.flags_layout == "tiled8"  # (decided by the parent, which has tried it)
@@ -74,7 +80,7 @@ def pmc_child(args, torch, VecOvercookedEnv, dev):
             env.rollout_random(fuse, rew, fl)
     torch.cuda.synchronize(dev)
 
-def measure_traffic(args, kernel, tiled8=False):
+def measure_traffic(args, kernel, tiled8=False, extra=None):
     """roofline.traffic measured by THIS run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE — they do not fit one
     pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots') over a child of this same command that runs 3 launches of the timed
     shape.  KiB -> bytes; FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 B, same
@@ -92,6 +98,7 @@ def measure_traffic(args, kernel, tiled8=False):
     child = [sys.executable, BENCH_PY, "--pmc-child", "--config", str(args.config), "--envs", str(args.envs),
              "--fuse", str(args.fuse), "--layout", args.layout, "--terrains", str(args.terrains),
              "--flags-layout", "tiled8" if tiled8 else "step"]  # (the child takes the parent's decision: no probe launch in the counters)
+    child += list(extra or [])
     for flag, on in (("--lane-pair", args.lane_pair), ("--predicate-interact", args.predicate_interact),
                      ("--one-wavefront", args.one_wavefront)):
         if on:
