@@ -9,7 +9,7 @@ src = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 names = ["r06_driver_cmd_bench.json", "r06_driver_cmd_rocprof.txt", "r06_pmc_rollout.txt", "r06_pmc_rollout_config4.txt", "r06_sq_counters_config4.json",
          "r06_pytest_gpu.log", "r06_bench_config3.json", "r06_bench_config4.json", "r06_bench_config5.json", "r06_bench_1M_envs.json",
-         "r06_force_dist_nccl_1rank.json", "r06_single_process_2shards_1gpu.json", "r06_single_env_final.txt", "r06_soak.log",
+         "r06_force_dist_nccl_1rank.json", "r06_single_process_2shards_1gpu.json", "r06_single_env_final.txt",  # (r06_soak.log: the 300-seed run is kept)
          "r06_two_ranks_one_gpu_gloo.json", "sq_counters.json", "r06_soak_step_server.log"]
 for n in names:
     p = os.path.join(src, n)
