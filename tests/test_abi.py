@@ -211,3 +211,16 @@ def test_no_kernel_keeps_a_stack_object_or_reads_the_dispatch_packet(tmp_path):
             assert not (props & 0x6), "%s reads the dispatch packet / queue (kernel_code_properties %#x)" % (sym, props)
             checked += 1
     assert len(cos) == 4 and seen > 80 and checked > 80  # four translation units (oc_amd.hip + rollout4.hip x 3)
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md (the binding a maintainer of the reference would write) mentions every exported function."""
+    from overcooked_ai_amd import _lib
+
+    with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
+        doc = f.read()
+    names = set(re.findall(r"\boc_[a-z_0-9]+\b", doc))
+    for prefix, tails in re.findall(r"`(oc_[a-z_]+?)_[a-z]+ ((?:/ _[a-z_]+ ?)+)", doc):  # "`oc_mailbox_open / _buffer / _step`"
+        names |= {prefix + t.strip() for t in tails.split("/") if t.strip()}
+    missing = [e for e in _lib.EXPORTS if e not in names]
+    assert not missing, missing
