@@ -154,3 +154,27 @@ def test_step_server_relaunch_sees_the_callers_pending_work_on_the_states(gpu):
             r1, f1 = one.step(acts[k])
             assert torch.equal(r1, rew[k]) and torch.equal(f1, fl[k]), k
     assert torch.equal(res.state, one.state) and torch.equal(res.ep_returns, one.ep_returns)
+
+
+def test_step_server_on_a_table_read_through_l2_with_layout_redraws(gpu):
+    """More layouts than LDS stages (the general instance reads the records through L2), every restart on a re-drawn layout
+    (regen_layout): the resident kernel against consecutive oc_step calls, layout ids included."""
+    from overcooked_ai_amd.layout_gen import reference_generated_layouts
+    from overcooked_ai_amd.layouts import LayoutTable
+
+    table = LayoutTable(reference_generated_layouts(40))
+    n, horizon, K = 1000, 7, 30
+    lid = (np.arange(n) * 7 % 40).astype(np.uint16)
+    kw = dict(horizon=horizon, auto_reset=True, layout_id=lid, regen_layout=True, seed=3)
+    res = make_env(table, n, gpu, **kw)
+    one = make_env(table, n, gpu, **kw)
+    acts = torch.randint(0, 6, (K, n, 2), dtype=torch.uint8, device=gpu, generator=torch.Generator(device=gpu).manual_seed(8))
+    rew = torch.zeros((K, n, 4), dtype=torch.float32, device=gpu)
+    fl = torch.zeros((K, n), dtype=torch.uint8, device=gpu)
+    with res.step_server(idle_ms=5.0) as sv:
+        sv.play(acts, rew, fl)
+    for k in range(K):
+        r1, f1 = one.step(acts[k])
+        assert torch.equal(r1, rew[k]) and torch.equal(f1, fl[k]), k
+    assert torch.equal(res.state, one.state) and np.array_equal(res.layout_ids(), one.layout_ids())
+    assert (fl & 4).any() and not np.array_equal(res.layout_ids(), lid)
