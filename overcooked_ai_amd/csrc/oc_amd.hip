@@ -420,6 +420,7 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         c.uniform = uniform; c.lds = lds; c.small = small; c.events = ev_on(ea);
         c.old_dyn = (b->batch_flags & OC_BATCH_NEW_DYNAMICS) == 0;  // some layout may use old dynamics
         c.out = d_rewards != nullptr && d_flags != nullptr;
+        c.noout = d_rewards == nullptr && d_flags == nullptr;  // (a rollout run for its final states / returns / event counters)
         // big batches (more than ~1.5 wavefronts per SIMD) hide latency with the other wavefronts: no one-step-ahead reads
 #ifdef OC_AMD_TUNING
         static const int forced_pipe = []() { const char* e = getenv("OC_ROLLOUT_PIPE"); return e ? atoi(e) : -1; }();  // tuning builds
@@ -440,7 +441,8 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
         //  CU's LDS beside the cell words: grids of up to 48 cells)
         const bool ev_ok = !c.events || (ea.events == nullptr && lds && n_cells <= 64 &&
                                          oc_detail::rollout5_lds_bytes(true, false, true, n_obj) <= (size_t)160 * 1024);
-        const bool terrain_ok = two && c.out && small && shaping_uniform && (n_cells <= 64 || (n_cells <= 128 && lds)) && ev_ok && !no_mode2;
+        const bool terrain_shape = two && small && shaping_uniform && (n_cells <= 64 || (n_cells <= 128 && lds)) && ev_ok && !no_mode2;
+        const bool terrain_ok = terrain_shape && c.out;
         const bool mode2 = !c.joint && terrain_ok && !c.old_dyn && n_cells <= 64 && !c.events;
         // k_rollout5 (step_duo5.hpp): the step split between mover and interact wavefronts — whole workgroups of envs (every
         // wavefront meets every barrier) and whole 8-step blocks; a workgroup's 127-154 KB of LDS leave room for one per CU.
@@ -456,7 +458,7 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
 #endif
         const int64_t per_round = (simd_count() / 4) * BLOCK;
         const int64_t max_rounds = forced_rounds > 0 ? forced_rounds : 8;
-        c.duo = terrain_ok && n_steps >= 8 && !(options & OC_OPT_ONE_WAVEFRONT) && b->n_envs % BLOCK == 0 &&
+        c.duo = (terrain_ok || (terrain_shape && c.noout)) && n_steps >= 8 && !(options & OC_OPT_ONE_WAVEFRONT) && b->n_envs % BLOCK == 0 &&
                 b->n_envs <= per_round * max_rounds && (t0 & 7) == 0 && (n_steps & 7) == 0;
         c.tiled8 = tiled8;
         if (tiled8) {  // which instances write the tiled flags array: the pipelined joint-table one, the per-env-terrain ones of

@@ -52,17 +52,19 @@ constexpr size_t lds4_bytes(size_t cell_rows) {
 #define GO5(LL, FT8F) do { if (c.old_dyn) GO5X(LL, FT8F, true, false, false); else GO5X(LL, FT8F, false, false, false); } while (0)
 #define GO5BIG(FT8F) do { if (c.old_dyn) GO5X(true, FT8F, true, true, false); else GO5X(true, FT8F, false, true, false); } while (0)
 #define GO5EV(FT8F) do { if (c.old_dyn) GO5X(true, FT8F, true, false, true); else GO5X(true, FT8F, false, false, true); } while (0)
-#define GO5X(LL, FT8F, OLDF, BIGF, EVF)                                                                             \
+// ... for launches without output arrays (NOOUT; the flags layout does not matter there)
+#define GO5N(LL, BIGF, EVF) do { if (c.old_dyn) GO5X(LL, false, true, BIGF, EVF, true); else GO5X(LL, false, false, BIGF, EVF, true); } while (0)
+#define GO5X(LL, FT8F, OLDF, BIGF, EVF, ...)                                                                           \
     do {                                                                                                            \
         const size_t smem5 = rollout5_lds_bytes(LL, BIGF, EVF, c.n_obj);                                            \
         if (oc_detail::g_describe) {                                                                                \
             snprintf(oc_detail::g_describe, 256, "k_rollout5<LAY_LDS=" #LL ", FT8=" #FT8F ", OLD=" #OLDF ", BIG=" #BIGF ", EV=" #EVF \
-                     "> mover + interact wavefronts, %d round(s), %zu B LDS",                                       \
+                     "%s> mover + interact wavefronts, %d round(s), %zu B LDS", sizeof(#__VA_ARGS__) > 1 ? ", NOOUT=" #__VA_ARGS__ : "",                                       \
                      (int)((b->n_envs + (simd_count() / 4) * BLOCK - 1) / ((simd_count() / 4) * BLOCK)), smem5);    \
             break;                                                                                                  \
         }                                                                                                           \
-        if (!want_lds(k_rollout5<LL, FT8F, OLDF, BIGF, EVF>, smem5)) break;                                         \
-        hipLaunchKernelGGL((k_rollout5<LL, FT8F, OLDF, BIGF, EVF>), grid4, dim3(2 * BLOCK), smem5, c.stream, b->d_layouts, b->n_layouts, \
+        if (!want_lds(k_rollout5<LL, FT8F, OLDF, BIGF, EVF, ##__VA_ARGS__>, smem5)) break;                          \
+        hipLaunchKernelGGL((k_rollout5<LL, FT8F, OLDF, BIGF, EVF, ##__VA_ARGS__>), grid4, dim3(2 * BLOCK), smem5, c.stream, b->d_layouts, b->n_layouts, \
                            b->d_layout_id, (uint4*)c.d_state, (float4*)c.d_rewards, c.d_flags, (float4*)c.d_ep_returns, \
                            b->n_envs, b->width, c.n_obj, c.horizon, c.options, (uint32_t)c.seed, (uint32_t)(c.seed >> 32), \
                            c.env_offset, c.t0, c.n_steps, c.sa, c.ea);                                              \
@@ -115,6 +117,13 @@ void launch_rollout4_mode2(const Rollout4Call& c) {
         if (c.pipe) GO4(U, MP, LL, 2, true, false, 0, false, true, RUF, 4); else GO4(U, MP, LL, 2, true, false, 0, false, false, RUF); \
     } while (0)
     if (c.duo) {  // whole workgroups of envs, whole 8-step blocks, at most one workgroup per CU: mover + interact wavefronts
+        if (c.noout) {  // no output arrays: the same kernels without their two stores
+            if (c.events) GO5N(true, false, true);
+            else if (b->width * b->height > 64) GO5N(true, true, false);
+            else if (c.lds) GO5N(true, false, false);
+            else GO5N(false, false, false);
+            return;
+        }
         if (c.events) { if (c.tiled8) GO5EV(true); else GO5EV(false); }  // (event counters: tables in LDS, at most 64 cells)
         else if (b->width * b->height > 64) { if (c.tiled8) GO5BIG(true); else GO5BIG(false); }  // (65..128 cells: tables in LDS only)
         else if (c.lds) { if (c.tiled8) GO5(true, true); else GO5(true, false); }

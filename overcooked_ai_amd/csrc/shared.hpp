@@ -60,6 +60,7 @@ struct Rollout4Call {
     // what oc_rollout_random derived from the batch and the call
     bool uniform, lds, small, joint, old_dyn, out, pipe, events;
     bool tiled8;  // OC_OPT_FLAGS_TILED8: d_flags is [n_steps / 8][n_envs][8]
+    bool noout;   // neither d_rewards nor d_flags: k_rollout5 runs its store-free instances
     bool duo;     // MODE 3: the per-env-terrain step split between mover and interact wavefronts (step_lut4.hpp)
 };
 OC_HIDDEN void launch_rollout4_joint_events(const Rollout4Call& c);  // rollout4.hip, OC_R4_PART 0

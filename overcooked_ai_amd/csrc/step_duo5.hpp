@@ -166,7 +166,9 @@ struct Cw5 {
 // BIG: grids of 65..128 cells (16-bit cell words, a 128-bit floor mask in the mover)
 // EV: per-episode event counters (OcEventSink.d_counts / d_counts_done: env.py:382-401 game_stats) — [1 + N_EVENT_TYPES][BLOCK]
 //     u32 in LDS behind the cell words for the launch (row 0 takes what is not an event), logged with ds_add
-template <bool LAY_LDS, bool FT8, bool OLD = false, bool BIG = false, bool EV = false>
+// NOOUT: the launch has no output arrays (rewards and flags both NULL: a rollout run for its final states, episode returns or event
+//     counters) — the same step without the two stores (round 6: these launches used to fall to the general one-wavefront path)
+template <bool LAY_LDS, bool FT8, bool OLD = false, bool BIG = false, bool EV = false, bool NOOUT = false>
 __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_rollout5(
     const OcLayout* __restrict__ g_layouts, int n_layouts, const uint16_t* layout_id, uint4* st, float4* __restrict__ rewards,
     uint8_t* __restrict__ flags, float4* __restrict__ ep_returns, int64_t n, int W, int n_obj, int horizon, uint32_t options,
@@ -302,14 +304,15 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
                         O0 = L.u8(L_START_OR); O1 = L.u8(L_START_OR + 1);
                     }
                 }
-                if (FT8) {
+                if (NOOUT) {
+                } else if (FT8) {
                     uint32_t& half = (k8 & 4) ? tile_hi : tile_lo;
                     half = (k8 & 3) == 0 ? fl : (half | (fl << (8 * (k8 & 3))));
                 } else {
                     store_flag_byte(flg_k, flg_off[k8], fl);
                 }
             }
-            if (FT8) {
+            if (FT8 && !NOOUT) {
                 const uint64_t tile = ((uint64_t)tile_hi << 32) | tile_lo;
                 asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lane * 8u), "v"(tile), "s"(flg_k) : "memory");
             }
@@ -422,7 +425,9 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)
     auto flush = [&](const Pend& p, int k8) __attribute__((always_inline)) {
         typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
         const u64x2 q = {p.lo, p.hi};
-        if (FT8) {  // (beside flag tiles the quads keep plain stores, beside [step][env] flag bytes they stream: k_rollout4, round 5)
+        if (NOOUT) {  // (no reward array: only the episode's shaped returns take the quad's upper half)
+            asm volatile("v_pk_add_f32 %0, %0, %1\n\ts_nop 0" : "+v"(epsh) : "v"(p.hi));
+        } else if (FT8) {  // (beside flag tiles the quads keep plain stores, beside [step][env] flag bytes they stream: k_rollout4, round 5)
             asm volatile("global_store_dwordx4 %1, %2, %4\n\tv_pk_add_f32 %0, %0, %3\n\ts_nop 0"
                          : "+v"(epsh) : "v"(rew_off[k8 & 7]), "v"(q), "v"(p.hi), "s"(rew_k) : "memory");
         } else {

@@ -39,6 +39,7 @@ SHAPES = (
     ("1 048 576 envs x 4 000 steps", dict(n_envs=1 << 20)),
     ("65 536 envs, per-episode event counters", dict(n_envs=65536, event_sink=1)),
     ("100 envs x 5 steps", dict(n_envs=100, n_steps=5)),
+    ("65 536 envs x 4 000 steps, no output arrays", dict(n_envs=65536, with_outputs=False)),
 )
 
 

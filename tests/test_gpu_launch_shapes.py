@@ -408,3 +408,31 @@ def test_mover_interact_event_log_against_oracle(layouts, gpu):
         gd = env.event_counts_done.cpu().numpy().astype(np.int64)
         assert np.array_equal(np.stack([gd & 0xFFFF, (gd >> 16) & 0xFFFF], -1), done_counts), "published counters after %d steps" % steps
     assert done_counts.sum() > 0 and done_counts[:, 1].sum() + done_counts[:, 6].sum() > 0  # useful pick-ups were logged
+
+
+def test_rollouts_without_output_arrays_equal_the_ones_with(gpu):
+    """A launch without rewards / flags arrays (a rollout run for its final states, returns or event counters) takes the mover /
+    interact kernel's store-free instances (round 6; before: the general one-wavefront path): states, episode returns and the
+    per-episode event counters equal those of the same launch WITH output arrays — new and old dynamics, a 65-cell grid, a table
+    read through L2, the event log."""
+    from overcooked_ai_amd.layout_gen import reference_generated_layouts
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+    from overcooked_ai_amd.vec_env import VecOvercookedEnv
+
+    n, T = 4096, 808
+    cases = [(LayoutTable([spec_from_name("cramped_room")]), None, {}),
+             (LayoutTable([spec_from_name("coordination_ring", old_dynamics=True)]), None, {}),
+             (LayoutTable([spec_from_name("marshmallow_experiment")]), None, {}),
+             (LayoutTable(reference_generated_layouts(40)), (np.arange(n) * 3 % 40).astype(np.uint16), {}),
+             (LayoutTable([spec_from_name("asymmetric_advantages")]), None, {"track_events": True})]
+    for ci, (table, lid, kw) in enumerate(cases):
+        a = VecOvercookedEnv(table, n, horizon=100, device=gpu, auto_reset=True, seed=2, layout_id=lid, **kw)
+        b = VecOvercookedEnv(table, n, horizon=100, device=gpu, auto_reset=True, seed=2, layout_id=lid, **kw)
+        rew = torch.zeros((T, n, 4), dtype=torch.float32, device=gpu)
+        fl = torch.zeros((T, n), dtype=torch.uint8, device=gpu)
+        a.rollout_random(T)
+        b.rollout_random(T, rew, fl)
+        assert torch.equal(a.state, b.state) and torch.equal(a.ep_returns, b.ep_returns), ci
+        if kw:
+            assert torch.equal(a.event_counts, b.event_counts) and torch.equal(a.event_counts_done, b.event_counts_done)
+            assert int(a.event_counts_done.sum()) > 0
