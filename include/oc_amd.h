@@ -288,6 +288,9 @@ int oc_step_many(const OcBatch* batch, void* d_state, const uint8_t* d_actions, 
  * Same transition function as oc_step; state stays on chip between the fused steps.  A launch costs ~16 us outside its
  * step loop (table staging, state load / store, dispatch): 12 % of a 400-step launch of 65 536 envs, 1.5 % of a 4 000-step
  * one (207 vs 244 G env-steps/s on MI355X) — prefer few long launches.
+ * Launch shape and speed: the mover / interact kernel works in whole 8-step blocks of whole 256-env workgroups; a long call off that
+ * step grid (t0 or n_steps not a multiple of 8) is split inside the call — head and tail steps through the one-wavefront kernels —, a
+ * ragged batch takes the one-wavefront kernels altogether (oc_rollout_plan says which instance a call takes).
  *   d_rewards  [n_steps][n_envs][4] or NULL;  d_flags [n_steps][n_envs] or NULL ([n_steps / 8][n_envs][8] with OC_OPT_FLAGS_TILED8)
  *   env_offset global index of local env 0 (multi-GPU shards draw disjoint streams)
  *   t0         global step index of the first fused step

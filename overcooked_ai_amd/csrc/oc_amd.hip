@@ -458,8 +458,39 @@ int oc_rollout_random(const OcBatch* b, void* d_state, float* d_rewards, uint8_t
 #endif
         const int64_t per_round = (simd_count() / 4) * BLOCK;
         const int64_t max_rounds = forced_rounds > 0 ? forced_rounds : 8;
-        c.duo = (terrain_ok || (terrain_shape && c.noout)) && n_steps >= 8 && !(options & OC_OPT_ONE_WAVEFRONT) && b->n_envs % BLOCK == 0 &&
-                b->n_envs <= per_round * max_rounds && (t0 & 7) == 0 && (n_steps & 7) == 0;
+        const bool duo_batch = (terrain_ok || (terrain_shape && c.noout)) && !(options & OC_OPT_ONE_WAVEFRONT) && b->n_envs % BLOCK == 0 &&
+                               b->n_envs <= per_round * max_rounds;
+        // A long launch that is not made of whole 8-step blocks (t0 or n_steps not a multiple of 8 — e.g. every call after one
+        // rollout of 150 steps): the steps up to the next block boundary and the last < 8 steps go through the one-wavefront
+        // instances, the whole blocks between them through the mover / interact kernel — three launches on the stream, the same
+        // results (the state lives in d_state between them, every random draw is keyed by the global step)
+        if (duo_batch && !tiled8 && (((t0 & 7) != 0) || ((n_steps & 7) != 0))) {
+            const int head = (int)((8 - (t0 & 7)) & 7);
+            const int bulk = head < n_steps ? ((n_steps - head) & ~7) : 0;
+            if (bulk >= 256) {
+                const int lens[3] = {head, bulk, n_steps - head - bulk};
+                int off = 0;
+                for (int part = 0; part < 3; ++part) {
+                    const int len = lens[part];
+                    if (len > 0 && !(oc_detail::g_describe && part != 1)) {
+                        OcStartSpec sk;
+                        if (start) { sk = *start; sk.epoch = start->epoch + (uint32_t)off; }  // a restart at step k draws from epoch + k
+                        const int rc = oc_rollout_random(b, d_state, d_rewards ? d_rewards + (int64_t)off * b->n_envs * 4 : nullptr,
+                                                         d_flags ? d_flags + (int64_t)off * b->n_envs : nullptr, d_ep_returns, horizon,
+                                                         options | (part == 1 ? 0u : (uint32_t)OC_OPT_ONE_WAVEFRONT), seed, env_offset, t0 + off, len,
+                                                         start ? &sk : nullptr, events, stream);
+                        if (rc) return rc;
+                    }
+                    off += len;
+                }
+                if (oc_detail::g_describe) {
+                    const size_t used = strlen(oc_detail::g_describe);
+                    snprintf(oc_detail::g_describe + used, 256 - used, "; %d + %d steps around the whole blocks: one-wavefront launches", lens[0], lens[2]);
+                }
+                return OC_OK;
+            }
+        }
+        c.duo = duo_batch && n_steps >= 8 && (t0 & 7) == 0 && (n_steps & 7) == 0;
         c.tiled8 = tiled8;
         if (tiled8) {  // which instances write the tiled flags array: the pipelined joint-table one, the per-env-terrain ones of
                        // mixed tables in LDS (pipelined) and of one-pot tables in HBM

@@ -436,3 +436,34 @@ def test_rollouts_without_output_arrays_equal_the_ones_with(gpu):
         if kw:
             assert torch.equal(a.event_counts, b.event_counts) and torch.equal(a.event_counts_done, b.event_counts_done)
             assert int(a.event_counts_done.sum()) > 0
+
+
+def test_long_launches_off_the_eight_step_grid_split_around_whole_blocks(gpu):
+    """A launch whose first step or length is not a multiple of 8 runs its whole 8-step blocks on the mover / interact kernel and
+    the few steps around them on the one-wavefront instances (three launches inside one call): rewards, flags, states, returns,
+    event counters and layout re-draws equal the same calls served by the one-wavefront instances alone (OC_OPT_ONE_WAVEFRONT) —
+    drawn start states and per-episode layout re-draws included, whose draws are keyed by the step's epoch."""
+    from overcooked_ai_amd.layout_gen import reference_generated_layouts
+    from overcooked_ai_amd.layouts import LayoutTable, spec_from_name
+    from overcooked_ai_amd.vec_env import VecOvercookedEnv
+
+    n = 2048
+    gen = LayoutTable(reference_generated_layouts(24))
+    cases = [(LayoutTable([spec_from_name("asymmetric_advantages")]), None, dict(random_start_pos=True, rnd_obj_prob_thresh=0.3)),
+             (LayoutTable([spec_from_name("cramped_room")]), None, dict(track_events=True)),
+             (gen, (np.arange(n) * 5 % 24).astype(np.uint16), dict(regen_layout=True, random_start_pos=True))]
+    for ci, (table, lid, kw) in enumerate(cases):
+        a = VecOvercookedEnv(table, n, horizon=37, device=gpu, auto_reset=True, seed=6, layout_id=lid, **kw)
+        b = VecOvercookedEnv(table, n, horizon=37, device=gpu, auto_reset=True, seed=6, layout_id=lid, **kw)
+        b.one_wavefront = True
+        for T in (3, 1000, 13, 407, 800):  # first steps 0, 3, 1003, 1016, 1423: off the grid from the second call on
+            ra, fa = torch.zeros((T, n, 4), dtype=torch.float32, device=gpu), torch.zeros((T, n), dtype=torch.uint8, device=gpu)
+            rb, fb = torch.zeros_like(ra), torch.zeros_like(fa)
+            a.rollout_random(T, ra, fa)
+            b.rollout_random(T, rb, fb)
+            assert torch.equal(ra, rb) and torch.equal(fa, fb), (ci, T)
+            assert torch.equal(a.state, b.state) and torch.equal(a.ep_returns, b.ep_returns), (ci, T)
+        if "track_events" in kw:
+            assert torch.equal(a.event_counts, b.event_counts) and torch.equal(a.event_counts_done, b.event_counts_done)
+        if "regen_layout" in kw:
+            assert np.array_equal(a.layout_ids(), b.layout_ids())
